@@ -1,0 +1,108 @@
+"""Oracle vs the reference's golden .pco assets (decode pins + encode pins).
+
+Expected arrays restate the deterministic generators of
+/root/reference/pco/src/tests/compatibility.rs:71-303.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_assets")
+
+
+def asset(name):
+    with open(os.path.join(ASSETS, name), "rb") as f:
+        return f.read()
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    u = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(u), b.view(u))
+
+
+def pseudorandom_f16s():
+    # compatibility.rs:129-143 (f32 arithmetic, then f16::from_f32 = round to nearest even)
+    num = np.float32(0.1); out = []
+    for _ in range(2000):
+        num = np.float32(np.fmod(np.float32(np.float32(num * np.float32(77.7)) + np.float32(0.1)), np.float32(2.0)))
+        out.append(np.float32(-1.0) - num if num < np.float32(1.0) else num)
+    return np.array(out, dtype=np.float32).astype(np.float16)
+
+
+def expected_arrays():
+    e = {}
+    e["v0_0_0_classic.pco"] = np.concatenate([np.arange(0, 1000), np.arange(2000, 3000)]).astype(np.int32)
+    x = np.arange(2000, dtype=np.float32); x[1337] += np.float32(1.001)
+    e["v0_0_0_delta_float_mult.pco"] = x
+    x = (np.arange(2000) * 1000).astype(np.int32); x[1337] -= 1
+    e["v0_1_0_delta_int_mult.pco"] = x
+    e["v0_1_1_standalone_versioned.pco"] = np.zeros(0, np.float32)
+    h = pseudorandom_f16s()
+    e["v0_3_0_f16.pco"] = h
+    f = h.astype(np.float32)
+    bump = np.abs(f) < np.float32(1.1)
+    fb = f.view(np.uint32).copy(); fb[bump] += 1
+    e["v0_3_0_float_quant.pco"] = fb.view(np.float32)
+    e["v0_4_0_lookback_delta.pco"] = np.tile(np.array(
+        [1121827092, 729032807, 3968137854, 2875434067, 3775328080, 431649926, 1048116090, 1906978350, 14752788,
+         1180462487], dtype=np.uint32), 100)
+    e["v0_4_5_uniform_type.pco"] = np.array([1, 2, 3, 4, 5], np.uint32)
+    e["v0_4_8_minor_version.pco"] = np.array([1, 2, 3, 4, 5], np.uint32)
+    e["v1_0_0_u8.pco"] = np.concatenate([np.arange(0, 65), np.arange(192, 256)]).astype(np.uint8)
+    e["v1_0_0_i8.pco"] = np.concatenate([np.arange(-128, -63), np.arange(64, 128)]).astype(np.int8)
+    return e
+
+
+EXPECTED = expected_arrays()
+
+
+@pytest.mark.parametrize("name", sorted(EXPECTED))
+def test_oracle_decodes_reference_asset(name):
+    exp = EXPECTED[name]
+    got = O.simple_decompress(asset(name), exp.dtype)
+    assert bits_equal(got, exp), name
+
+
+@pytest.mark.parametrize("name", ["v1_0_0_dict.pco", "v1_0_0_conv1.pco"])
+def test_out_of_scope_assets_are_reported_unsupported(name):
+    with pytest.raises(O.OracleError) as ei:
+        O.simple_decompress(asset(name), np.uint64 if "dict" in name else np.int32)
+    assert ei.value.kind == O.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name", ["v1_0_0_u8.pco", "v1_0_0_i8.pco"])
+def test_oracle_reencodes_v1_assets_byte_for_byte(name):
+    # written by simple_compress(nums, ChunkConfig::default().with_enable_8_bit(true)),
+    # compatibility.rs:281-303: Auto mode, Auto delta, level 8, no uniform type
+    enc = O.simple_compress(EXPECTED[name], O.make_config(), uniform_type=False)
+    assert enc == asset(name)
+
+
+def test_oracle_reencodes_older_assets_chunk_bytes():
+    # Older standalone/format headers (8 bytes: magic, standalone v2, varint n_hint, format
+    # version) vs ours (10 bytes: + uniform-type byte, + minor version), but the chunk encoding is
+    # unchanged since: the bytes from the chunk's dtype byte onward must be identical.
+    for name, cfg, hdr_old, hdr_new in [
+        ("v0_4_0_lookback_delta.pco", O.make_config(delta=O.DELTA_TRY_LOOKBACK), 8, 10),
+        ("v0_4_8_minor_version.pco", O.make_config(), 8, 10),
+    ]:
+        gold = asset(name)
+        enc = O.simple_compress(EXPECTED[name], cfg)
+        assert enc[hdr_new:] == gold[hdr_old:], name
+
+
+def test_asset_metadata_matches_survey():
+    info, bins = O.inspect_first_chunk(asset("v1_0_0_u8.pco"))
+    assert (info.standalone_version, info.fmt_major, info.fmt_minor, info.n_hint, info.n) == (3, 4, 1, 129, 129)
+    assert info.mode_kind == 0 and info.delta_kind == 1 and info.delta_order == 1
+    assert info.ans_size_log[1] == 7
+    assert bins[1].tolist() == [[1, 0, 0], [127, 129, 0]]
+    assert info.meta_end_byte == 23
+    info, bins = O.inspect_first_chunk(asset("v0_4_0_lookback_delta.pco"))
+    assert info.delta_kind == 2 and info.window_n_log == 10 and info.state_n_log == 0
+    assert info.ans_size_log[0] == 7 and bins[0].tolist() == [[1, 1, 4], [127, 10, 0]]
+    assert info.ans_size_log[1] == 8 and len(bins[1]) == 3
