@@ -1,0 +1,215 @@
+/*
+ * pco_gfx.h -- C ABI of libpco_gfx.so, the MI355X-native (gfx950, HIP) implementation of
+ * pcodec's chunk encode / decode hot path.
+ *
+ * The library is a drop-in for that path only.  Section 1 is byte-compatible with the
+ * reference's own C ABI (pco_c/include/cpcodec_generated.h, pco_c/include/cpcodec.h);
+ * sections 2-4 are the entry points a `pco` FFI for this path would bind in addition:
+ * the explicit mode/delta specs the reference C struct cannot express, a batched
+ * many-chunk form operating on buffers already resident in HBM, and the wrapped
+ * ChunkCompressor / ChunkDecompressor surface.  No torch / HIP types appear in any signature:
+ * plain pointers and sizes only.  A `stream` argument is an opaque hipStream_t (NULL = the
+ * default stream).
+ *
+ * Thread-safety: every function is re-entrant; the library keeps one lazily grown device
+ * workspace per (thread, device) and no other state (cf. pco_c/src/lib.rs:57-70).
+ */
+#ifndef PCO_GFX_H
+#define PCO_GFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * 1. The reference C ABI, unchanged (replaces pco_c/src/lib.rs:128,146,178).
+ * ---------------------------------------------------------------------------------------- */
+
+/* number type bytes: pco_c/include/cpcodec.h:10-20, docs/format.md:205-217 */
+#define PCO_TYPE_U32 1
+#define PCO_TYPE_U64 2
+#define PCO_TYPE_I32 3
+#define PCO_TYPE_I64 4
+#define PCO_TYPE_F32 5
+#define PCO_TYPE_F64 6
+#define PCO_TYPE_U16 7
+#define PCO_TYPE_I16 8
+#define PCO_TYPE_F16 9
+#define PCO_TYPE_U8 10
+#define PCO_TYPE_I8 11
+
+typedef enum PcoError { /* pco_c/src/lib.rs:12-19 */
+  PcoSuccess,
+  PcoInvalidType,
+  PcoCompressionError,
+  PcoDecompressionError,
+} PcoError;
+
+typedef struct PcoChunkConfig { /* pco_c/src/lib.rs:21-32 */
+  unsigned int compression_level; /* 0-12, default 8 */
+  size_t max_page_n;              /* 0 => 2^18 */
+} PcoChunkConfig;
+
+/* pco_c/src/lib.rs:128-141 -> standalone/guarantee.rs:29-37 */
+size_t pco_standalone_guarantee_file_size(size_t n, unsigned char dtype);
+
+/* pco_c/src/lib.rs:146-173 -> standalone::simple_compress_into (standalone/simple.rs:22-48).
+ * `nums` and `dst` are HOST buffers.  Config NULL => level 8, Auto mode, Auto delta,
+ * enable_8_bit (pco_c/src/lib.rs:34-55). */
+enum PcoError pco_standalone_simple_compress_into(const void* nums, size_t n, unsigned char dtype,
+                                                  const struct PcoChunkConfig* config, void* dst,
+                                                  size_t dst_cap, size_t* n_written);
+
+/* pco_c/src/lib.rs:178-199 -> standalone::simple_decompress (standalone/simple.rs:149-152).
+ * `dst_cap` and `*n_written` are in ELEMENTS.  A too-small dst is an error
+ * (pco_c/src/lib.rs:110-112). */
+enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size_t compressed_len,
+                                                    unsigned char dtype, void* dst, size_t dst_cap,
+                                                    size_t* n_written);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Extended config: everything pco::ChunkConfig can say (chunk_config.rs:13-125,191-235).
+ * ---------------------------------------------------------------------------------------- */
+
+enum PcoModeSpecKind { /* chunk_config.rs:13-51 */
+  PCO_MODE_AUTO = 0,
+  PCO_MODE_CLASSIC = 1,
+  PCO_MODE_TRY_FLOAT_MULT = 2,  /* mode_f64 = base */
+  PCO_MODE_TRY_FLOAT_QUANT = 3, /* mode_u64 = k */
+  PCO_MODE_TRY_INT_MULT = 4,    /* mode_u64 = base */
+  PCO_MODE_TRY_DICT = 5,        /* not implemented (out of scope): PcoCompressionError */
+};
+enum PcoDeltaSpecKind { /* chunk_config.rs:61-109 */
+  PCO_DELTA_AUTO = 0,
+  PCO_DELTA_NOOP = 1,
+  PCO_DELTA_TRY_CONSECUTIVE = 2, /* delta_order = order (0..7) */
+  PCO_DELTA_TRY_LOOKBACK = 3,
+  PCO_DELTA_TRY_CONV1 = 4,       /* not implemented (out of scope): PcoCompressionError */
+};
+typedef struct PcoChunkConfigEx {
+  uint32_t compression_level; /* 0-12 */
+  uint32_t mode_kind;         /* enum PcoModeSpecKind */
+  double mode_f64;
+  uint64_t mode_u64;
+  uint32_t delta_kind;        /* enum PcoDeltaSpecKind */
+  uint32_t delta_order;
+  uint64_t max_page_n;        /* PagingSpec::EqualPagesUpTo; 0 => 2^18 */
+  uint32_t enable_8_bit;
+  uint32_t reserved;
+} PcoChunkConfigEx;
+
+/* Detailed status of the last failing call on this thread (errors.rs:8-24). */
+enum PcoGfxStatus {
+  PCO_GFX_OK = 0,
+  PCO_GFX_CORRUPTION = 1,
+  PCO_GFX_INSUFFICIENT_DATA = 2,
+  PCO_GFX_INVALID_ARGUMENT = 3,
+  PCO_GFX_UNSUPPORTED = 4,   /* feature outside the hot-path scope (Dict, Conv1, f16 arithmetic) */
+  PCO_GFX_DEVICE_ERROR = 5,  /* no GPU / HIP failure: the product has no CPU fallback */
+};
+int pco_gfx_last_status(void);
+const char* pco_gfx_last_error(void);
+/* Number of visible HIP devices (0 => every compute entry point fails with DEVICE_ERROR). */
+int pco_gfx_device_count(void);
+
+/* standalone::simple_compress / simple_compress_into with a full ChunkConfig.
+ * `uniform_type` != 0 writes the uniform dtype byte (simple_compress_into, simple.rs:27-29);
+ * 0 leaves it 0 (simple_compress, simple.rs:65).  HOST buffers. */
+enum PcoError pco_gfx_simple_compress_into_ex(const void* nums, size_t n, unsigned char dtype,
+                                              const PcoChunkConfigEx* config, int uniform_type,
+                                              void* dst, size_t dst_cap, size_t* n_written);
+size_t pco_gfx_guarantee_file_size(size_t n, unsigned char dtype, uint64_t max_page_n);
+/* standalone/guarantee.rs:21-23: bound for one standalone chunk of n numbers */
+size_t pco_gfx_guarantee_chunk_size(size_t n, unsigned char dtype);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. Batched chunk codec on DEVICE buffers (one chunk per workgroup; what a many-chunk
+ *    caller -- pco_cli bench, a columnar file writer -- would call once per row group).
+ *
+ *    A "standalone chunk" is exactly what standalone::ChunkCompressor::write emits
+ *    (standalone/compressor.rs:191-203): dtype byte | 24-bit n-1 | ChunkMeta | one page.
+ *    A .pco file is header | chunks... | 0x00 (standalone/simple.rs:62-91); use
+ *    pco_gfx_write_standalone_header / _footer to frame device-produced chunks.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct PcoGfxEncodeTask {
+  const void* src;   /* DEVICE pointer to n numbers */
+  uint64_t n;        /* 1 ..= 2^24 */
+  void* dst;         /* DEVICE pointer, >= pco_gfx_guarantee_chunk_size(n) + 16 bytes */
+  uint64_t dst_cap;
+  uint32_t dtype;
+  uint32_t reserved;
+} PcoGfxEncodeTask;
+
+typedef struct PcoGfxDecodeTask {
+  const void* src;   /* DEVICE pointer to >= 1 standalone chunks; 16 readable bytes past src_len */
+  uint64_t src_len;
+  void* dst;         /* DEVICE pointer */
+  uint64_t dst_cap;  /* elements */
+  uint32_t dtype;
+  uint32_t flags;    /* PCO_GFX_TASK_HAS_FILE_HEADER: src is a whole .pco file */
+} PcoGfxDecodeTask;
+#define PCO_GFX_TASK_HAS_FILE_HEADER 1u
+
+typedef struct PcoGfxTaskResult {
+  uint64_t n_out;    /* encode: bytes written; decode: elements written */
+  uint64_t consumed; /* decode: bytes consumed from src */
+  uint32_t status;   /* enum PcoGfxStatus */
+  uint32_t aux;      /* encode: bit0 = fell back to the uncompressed-equivalent chunk */
+} PcoGfxTaskResult;
+
+/* `tasks` and `results` are HOST arrays of n_tasks entries (copied by the library; results are
+ * filled when the call returns, i.e. the call synchronises `stream`).  If `results` is NULL the
+ * call is asynchronous and `d_results` (DEVICE array, may be NULL otherwise) receives the
+ * results in stream order. */
+enum PcoError pco_gfx_compress_chunks(size_t n_tasks, const PcoGfxEncodeTask* tasks,
+                                      const PcoChunkConfigEx* config, PcoGfxTaskResult* results,
+                                      PcoGfxTaskResult* d_results, void* stream);
+enum PcoError pco_gfx_decompress_chunks(size_t n_tasks, const PcoGfxDecodeTask* tasks,
+                                        PcoGfxTaskResult* results, PcoGfxTaskResult* d_results,
+                                        void* stream);
+
+/* standalone/compressor.rs:85-105 and :157-162 (host-side framing, tiny) */
+size_t pco_gfx_write_standalone_header(void* dst, size_t dst_cap, uint64_t n_hint, unsigned char uniform_dtype);
+size_t pco_gfx_write_standalone_footer(void* dst, size_t dst_cap);
+
+/* Release this thread's device workspace. */
+void pco_gfx_release_workspace(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Wrapped surface (wrapped/chunk_compressor.rs:544-705, wrapped/file_decompressor.rs:24-52,
+ *    wrapped/chunk_decompressor.rs:74-80, wrapped/page_decompressor.rs:193-246), host buffers.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct PcoGfxChunkCompressor PcoGfxChunkCompressor;
+typedef struct PcoGfxChunkDecompressor PcoGfxChunkDecompressor;
+
+size_t pco_wrapped_write_header(void* dst, size_t dst_cap);                    /* file_compressor.rs:54 */
+enum PcoError pco_wrapped_read_header(const void* src, size_t len, size_t* consumed,
+                                      uint8_t* major, uint8_t* minor);          /* file_decompressor.rs:24 */
+enum PcoError pco_chunk_compressor_new(const void* nums, size_t n, unsigned char dtype,
+                                       const PcoChunkConfigEx* config,
+                                       PcoGfxChunkCompressor** out);            /* chunk_compressor.rs:442 */
+size_t pco_chunk_compressor_n_pages(const PcoGfxChunkCompressor*);
+size_t pco_chunk_compressor_page_n(const PcoGfxChunkCompressor*, size_t page_idx); /* n_per_page :544 */
+size_t pco_chunk_compressor_meta_size_hint(const PcoGfxChunkCompressor*);       /* :556 */
+size_t pco_chunk_compressor_page_size_hint(const PcoGfxChunkCompressor*, size_t page_idx); /* :599 */
+enum PcoError pco_chunk_compressor_write_meta(const PcoGfxChunkCompressor*, void* dst, size_t dst_cap, size_t* n_written);          /* :564 */
+enum PcoError pco_chunk_compressor_write_page(const PcoGfxChunkCompressor*, size_t page_idx, void* dst, size_t dst_cap, size_t* n_written); /* :659 */
+void pco_chunk_compressor_free(PcoGfxChunkCompressor*);
+
+enum PcoError pco_chunk_decompressor_new(const void* src, size_t len, unsigned char dtype,
+                                         uint8_t format_major, PcoGfxChunkDecompressor** out,
+                                         size_t* consumed);                     /* file_decompressor.rs:44 */
+/* PageDecompressor::read of one whole page of `page_n` numbers (page_decompressor.rs:242) */
+enum PcoError pco_chunk_decompressor_read_page(PcoGfxChunkDecompressor*, const void* src, size_t len,
+                                               size_t page_n, void* dst, size_t dst_cap,
+                                               size_t* n_processed, size_t* consumed);
+void pco_chunk_decompressor_free(PcoGfxChunkDecompressor*);
+
+#if defined(__cplusplus)
+}
+#endif
+#endif /* PCO_GFX_H */

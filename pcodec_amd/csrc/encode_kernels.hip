@@ -1,0 +1,1031 @@
+// encode_kernels.hip -- gfx950 chunk encoder.
+//
+// Replaces, for the device path, the reference's encode stack
+//   mode/{classic,int_mult,float_mult,float_quant}.rs split_latents            -> enc_split_kernel
+//   delta/consecutive.rs:19-33 encode_in_place (+ moments)                     -> enc_split_kernel
+//   histograms.rs + sort_utils.rs (exact equal-count quantile histogram)       -> enc_hist_kernel
+//   bin_optimization.rs, ans/encoding.rs:95-175, ans/spec.rs, ans/encoding.rs:28-63,
+//   wrapped/chunk_compressor.rs:38-99,502-541 (train_infos, should_fallback)   -> enc_train_kernel
+//   compression_table.rs:51-74, chunk_latent_compressor.rs:96-132,163-329,
+//   wrapped/chunk_compressor.rs:564-705, metadata/*.rs write_to,
+//   standalone/compressor.rs:191-203                                            -> enc_page_kernel
+//
+// Data layout in HBM (per chunk, strides fixed per launch): latents of each latent variable
+// (delta / primary / secondary) as dense arrays in a workspace, an u32 "dissect word" per latent
+// (tANS value | tANS bit count | symbol), two sort buffers, and a small per-chunk plan (bins, tANS
+// encoder tables).  Everything that is serial per chunk (the tANS chains, the bin DP, the bit cursor)
+// runs in one wave per chunk with its tables in LDS; everything elementwise is a coalesced stream.
+#include <type_traits>
+
+#include "pco_dev.h"
+
+namespace pcogfx {
+
+#ifndef PCO_LDS
+#define PCO_LDS __attribute__((address_space(3)))
+#endif
+
+constexpr uint32_t kMaxUnoptBinsLog = 8;            // device limit this round (compression_level <= 8 at n >= 2^12)
+constexpr uint32_t kMaxBins = 1u << kMaxUnoptBinsLog;
+constexpr uint32_t kMaxEncTableLog = 12;            // estimated_ans_size_log <= 12 (wrapped/chunk_compressor.rs:73-79)
+constexpr uint32_t kDirectHistRange = 4096;         // value-space histogram when max-min < this
+
+struct EncVar {
+  uint32_t present, latent_bits, n_lat, lat_start;
+  unsigned long long minv, maxv;
+  uint32_t n_hist, n_bins, ans_size_log, max_ob;
+  uint32_t is_trivial, needs_ans, hist_path, pad;
+};
+static_assert(sizeof(EncVar) == 64, "EncVar");
+struct EncChunk {
+  uint64_t n;
+  uint32_t dtype, status;
+  uint32_t mode_kind, mode_k;
+  uint64_t mode_base;   // IntMult: base; FloatMult: ordered latent of base
+  uint64_t mode_aux;    // FloatMult: bits of inv_base
+  uint64_t mode_aux2;   // FloatMult: bits of base
+  uint32_t delta_kind, delta_order, window_n_log, state_n_log;
+  uint32_t fallback, unopt_bins_log;
+  uint64_t moments[8];
+  EncVar v[3];
+};
+static_assert(sizeof(EncChunk) % 8 == 0, "EncChunk");
+
+// per (chunk, var) plan region
+struct EncPlanVar {
+  uint32_t hcount[kMaxBins]; uint64_t hlower[kMaxBins]; uint64_t hupper[kMaxBins];   // unoptimized histogram
+  uint32_t bweight[kMaxBins]; uint32_t bcount[kMaxBins]; uint64_t blower[kMaxBins]; uint8_t bob[kMaxBins];  // optimized bins
+  uint32_t syminfo[kMaxBins];                  // cutoff(14) | min_renorm_bits(4)<<14 | (ns_off - weight + 8192)(14)<<18
+  uint16_t next_states[1u << kMaxEncTableLog];
+};
+struct EncWorkspace {
+  EncChunk* chunks;
+  EncPlanVar* plans;        // [task][3]
+  uint8_t* lat;             // [task][n_slots][n_stride] 8-byte elements
+  uint8_t* sort;            // [task][2][n_stride] 8-byte elements
+  uint32_t* dissect;        // [task][n_slots][n_stride]
+  uint64_t n_stride;
+  uint32_t n_slots;         // latent slots allocated per task
+  uint32_t slot_of_var[3];  // slot index per var (0xffffffff = not allocated)
+};
+
+__device__ __forceinline__ uint8_t PCO_LDS* enc_lds_base() {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pco_lds[];
+  return (uint8_t PCO_LDS*)pco_lds;
+}
+__device__ __forceinline__ void enc_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <class L> __device__ __forceinline__ L PCO_GLOBAL* lat_ptr(const EncWorkspace& ws, uint32_t task, uint32_t var) {
+  return (L PCO_GLOBAL*)(ws.lat + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * ws.n_stride * 8);
+}
+__device__ __forceinline__ uint32_t PCO_GLOBAL* dissect_ptr(const EncWorkspace& ws, uint32_t task, uint32_t var) {
+  return (uint32_t PCO_GLOBAL*)(ws.dissect + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * ws.n_stride);
+}
+template <class L> __device__ __forceinline__ L PCO_GLOBAL* sort_ptr(const EncWorkspace& ws, uint32_t task, uint32_t which) {
+  return (L PCO_GLOBAL*)(ws.sort + ((uint64_t)task * 2 + which) * ws.n_stride * 8);
+}
+
+// wrapped/chunk_compressor.rs:362-371
+__host__ __device__ inline uint32_t choose_unoptimized_bins_log(uint32_t level, uint64_t n) {
+  const uint32_t log_n = 63u - (uint32_t)__builtin_clzll(n);
+  const uint32_t fast = log_n >= 4 ? log_n - 4 : 0;
+  if (level <= fast) return level;
+  return fast + (level - fast) / 2;
+}
+
+// =========================================================================================================
+// K0: initialise per-chunk state
+// =========================================================================================================
+struct EncModePlan {  // host-resolved mode / delta (explicit specs; Auto is resolved by the host driver)
+  uint32_t mode_kind, mode_k; uint64_t mode_base, mode_aux, mode_aux2;
+  uint32_t delta_kind, delta_order, window_n_log, state_n_log;
+};
+
+__global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, const EncModePlan* plans, uint32_t n_tasks, uint32_t level) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tasks) return;
+  const PcoGfxEncodeTask task = tasks[t];
+  const EncModePlan mp = plans[t];
+  EncChunk c{};
+  c.n = task.n; c.dtype = task.dtype; c.status = PCO_GFX_OK;
+  c.mode_kind = mp.mode_kind; c.mode_k = mp.mode_k; c.mode_base = mp.mode_base; c.mode_aux = mp.mode_aux; c.mode_aux2 = mp.mode_aux2;
+  c.delta_kind = mp.delta_kind; c.delta_order = mp.delta_order; c.window_n_log = mp.window_n_log; c.state_n_log = mp.state_n_log;
+  c.unopt_bins_log = choose_unoptimized_bins_log(level, task.n);
+  const uint32_t lbits = (uint32_t)dtype_bits(task.dtype);
+  const uint32_t nlps = mp.delta_kind == kDeltaConsecutive ? mp.delta_order : (mp.delta_kind == kDeltaLookback ? (1u << mp.state_n_log) : 0u);
+  const uint64_t n = task.n;
+  for (int v = 0; v < 3; v++) { c.v[v].minv = ~0ull; c.v[v].maxv = 0; }
+  c.v[0].present = mp.delta_kind == kDeltaLookback; c.v[0].latent_bits = 32;
+  c.v[0].lat_start = 0; c.v[0].n_lat = (uint32_t)(n > nlps ? n - nlps : 0);
+  c.v[1].present = 1; c.v[1].latent_bits = lbits; c.v[1].lat_start = (uint32_t)(nlps < n ? nlps : n); c.v[1].n_lat = (uint32_t)(n - c.v[1].lat_start);
+  c.v[2].present = mp.mode_kind == kIntMult || mp.mode_kind == kFloatMult || mp.mode_kind == kFloatQuant;
+  c.v[2].latent_bits = lbits; c.v[2].lat_start = 0; c.v[2].n_lat = (uint32_t)n;
+  if (c.unopt_bins_log > kMaxUnoptBinsLog) c.status = PCO_GFX_UNSUPPORTED;
+  ws.chunks[t] = c;
+}
+
+// =========================================================================================================
+// K1: mode split + consecutive delta + min/max (elementwise, coalesced)
+// =========================================================================================================
+template <class L>
+__device__ __forceinline__ void split_one(uint32_t mode_kind, uint32_t num_kind, L mode_base, uint32_t mode_k, uint64_t aux_inv, uint64_t aux_base,
+                                          L bits, L& p, L& s) {
+  s = 0;
+  switch (mode_kind) {
+    case kClassic: p = to_latent_ordered<L>(bits, num_kind); break;
+    case kIntMult: { const L u = to_latent_ordered<L>(bits, num_kind); p = (L)(u / mode_base); s = (L)(u % mode_base); break; }
+    case kFloatQuant: {
+      const L num_ = to_latent_ordered<L>(bits, kFloat);
+      const L lowmax = (L)(((L)1 << mode_k) - 1);
+      p = (L)(num_ >> mode_k);
+      const L low = (L)(num_ & lowmax);
+      s = (bits & lmid<L>()) ? (L)(lowmax - low) : low;
+      break;
+    }
+    default: {  // kFloatMult (mode/float_mult.rs:38-60)
+      if constexpr (sizeof(L) >= 4) {
+        typedef typename FloatOf<L>::F F;
+        const F num = bits_to_float(bits);
+        const F inv_base = bits_to_float((L)aux_inv), base = bits_to_float((L)aux_base);
+        const F mult = round_half_away(num * inv_base);
+        p = int_float_to_latent<L>(mult);
+        s = (L)(to_latent_ordered<L>(bits, kFloat) - to_latent_ordered<L>(float_to_bits(mult * base), kFloat) + lmid<L>());
+      } else p = 0;
+    }
+  }
+}
+
+template <class L>
+__device__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& task, uint32_t t) {
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  const uint64_t n = task.n;
+  const uint32_t num_kind = dtype_kind(task.dtype);
+  const uint32_t mode_kind = ch->mode_kind, mode_k = ch->mode_k;
+  const L mode_base = (L)ch->mode_base; const uint64_t aux_inv = ch->mode_aux, aux_base = ch->mode_aux2;
+  const uint32_t order = ch->delta_kind == kDeltaConsecutive ? ch->delta_order : 0;
+  const bool has_sec = ch->v[2].present != 0;
+  const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)task.src;
+  L PCO_GLOBAL* lat1 = lat_ptr<L>(ws, t, 1);
+  L PCO_GLOBAL* lat2 = has_sec ? lat_ptr<L>(ws, t, 2) : nullptr;
+  L mn1 = (L)~(L)0, mx1 = 0, mn2 = (L)~(L)0, mx2 = 0;
+  const uint64_t base_i = (uint64_t)blockIdx.x * 1024;
+  for (int k = 0; k < 4; k++) {
+    const uint64_t i = base_i + (uint64_t)k * 256 + threadIdx.x;
+    if (i >= n) continue;
+    L w[8]; L s0 = 0;
+    const uint32_t o = i >= order ? order : 0;  // positions < order are junk (not stored)
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+      if (j <= o) { L p, s; split_one<L>(mode_kind, num_kind, mode_base, mode_k, aux_inv, aux_base, src[i - j], p, s); w[j] = p; if (j == 0) s0 = s; }
+      else w[j] = 0;
+    }
+    // k-th finite difference by repeated adjacent differences (wrapping; delta/consecutive.rs:3-33)
+#pragma unroll
+    for (uint32_t r = 1; r < 8; r++) {
+      if (r <= o) {
+#pragma unroll
+        for (uint32_t j = 0; j + r < 8; j++) if (j + r <= o) w[j] = (L)(w[j] - w[j + 1]);
+      }
+    }
+    L d = w[0];
+    if (order > 0) d = (L)(d + lmid<L>());
+    lat1[i] = d;
+    if (i >= order) { mn1 = d < mn1 ? d : mn1; mx1 = d > mx1 ? d : mx1; }
+    if (has_sec) { lat2[i] = s0; mn2 = s0 < mn2 ? s0 : mn2; mx2 = s0 > mx2 ? s0 : mx2; }
+    if (i == 0 && order > 0) {
+      // moments[o] = (delta^o p)[o]
+      L q[8];
+      for (uint32_t j = 0; j < 8; j++) {
+        if (j < order && j < n) { L p, s; split_one<L>(mode_kind, num_kind, mode_base, mode_k, aux_inv, aux_base, src[j], p, s); q[j] = p; } else q[j] = 0;
+      }
+      for (uint32_t oo = 0; oo < order; oo++) {
+        ch->moments[oo] = oo < n ? (uint64_t)q[0] : 0ull;  // an exhausted page yields L::ZERO moments
+        for (uint32_t j = 0; j + 1 < 8; j++) q[j] = (L)(q[j + 1] - q[j]);
+      }
+    }
+  }
+  // wave reduce min / max then one atomic per wave
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+    L o1 = shfl_idx(mn1, (int)(lane_id() ^ dlt)); mn1 = o1 < mn1 ? o1 : mn1;
+    L o2 = shfl_idx(mx1, (int)(lane_id() ^ dlt)); mx1 = o2 > mx1 ? o2 : mx1;
+    if (has_sec) {
+      L o3 = shfl_idx(mn2, (int)(lane_id() ^ dlt)); mn2 = o3 < mn2 ? o3 : mn2;
+      L o4 = shfl_idx(mx2, (int)(lane_id() ^ dlt)); mx2 = o4 > mx2 ? o4 : mx2;
+    }
+  }
+  if (lane_id() == 0) {
+    if (mn1 <= mx1) { atomicMin((unsigned long long*)&ws.chunks[t].v[1].minv, (unsigned long long)mn1); atomicMax((unsigned long long*)&ws.chunks[t].v[1].maxv, (unsigned long long)mx1); }
+    if (has_sec && mn2 <= mx2) { atomicMin((unsigned long long*)&ws.chunks[t].v[2].minv, (unsigned long long)mn2); atomicMax((unsigned long long*)&ws.chunks[t].v[2].maxv, (unsigned long long)mx2); }
+  }
+}
+
+__global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks) {
+  const uint32_t t = blockIdx.y;
+  const PcoGfxEncodeTask task = tasks[t];
+  if ((uint64_t)blockIdx.x * 1024 >= task.n) return;
+  if (ws.chunks[t].status != PCO_GFX_OK) return;
+  const int bits = dtype_bits(task.dtype);
+  if (bits == 64) enc_split_body<uint64_t>(ws, task, t);
+  else if (bits == 32) enc_split_body<uint32_t>(ws, task, t);
+  else if (bits == 16) enc_split_body<uint16_t>(ws, task, t);
+}
+
+// =========================================================================================================
+// K2: exact equal-count quantile histogram (histograms.rs).  The reference's quickselect output is a pure
+// function of the sorted multiset (verified against the literal algorithm in tests/test_oracle_kats.py):
+// walk bins b with end ranks c_count(b) = ceil((b+1)n/B); a run of equal values that straddles the end of
+// the bin containing its first rank is a "constant run" (histograms.rs:142-161), everything else merges
+// into the pending bin.  We therefore only need rank -> (value, run start, run end) queries:
+//   * direct path  (max-min < 4096): LDS counting histogram over value space + prefix sums;
+//   * sorted path  (otherwise): stable LSD radix sort (8-bit digits, significant digits only).
+// =========================================================================================================
+struct HistRec { uint32_t st, en; };
+
+template <class L>
+__device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins_log, L first_value,
+                                                   const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
+                                                   const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc,
+                                                   EncPlanVar PCO_GLOBAL* plan, uint32_t& n_hist_out) {
+  // sequential (one lane); at most 2 * 2^bins_log iterations
+  const uint64_t n = n_lat, B = (uint64_t)1 << bins_log;
+  auto bin_idx = [&](uint64_t pos) { return (uint32_t)((pos << bins_log) / n); };
+  auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n + B - 1) >> bins_log); };
+  uint32_t pos = 0; L pos_value = first_value;
+  bool pending = false; uint32_t pending_start = 0; L pending_lower = 0;
+  uint32_t next_avail = 0, n_hist = 0;
+  auto emit = [&](uint32_t start, uint32_t end, L lower, L upper) {
+    plan->hcount[n_hist] = end - start; plan->hlower[n_hist] = (uint64_t)lower; plan->hupper[n_hist] = (uint64_t)upper; n_hist++;
+  };
+  while (pos < n_lat) {
+    const uint32_t target = bin_idx(pos);
+    const uint32_t c = c_count(target);
+    const L v = rv[target]; const uint32_t st = rst[target], en = ren[target];
+    if (en <= c) {  // every run in [pos, c) fits: absorb and complete at c
+      if (!pending) { pending_start = pos; pending_lower = pos_value; }
+      emit(pending_start, c, pending_lower, v);
+      pending = false; next_avail = target + 1;
+      pos = c; pos_value = rnext[target];
+    } else {        // the run [st, en) of value v straddles c: constant run
+      if (st > pos && !pending) { pending = true; pending_start = pos; pending_lower = pos_value; }
+      const uint32_t mid = st + (en - st) / 2;
+      uint32_t b = bin_idx(mid);
+      if (b > next_avail) {
+        const uint32_t spare = b - 1;
+        if (pending) { emit(pending_start, st, pending_lower, rpred[target]); pending = false; next_avail = spare + 1; }
+        else b = spare;
+      }
+      if (!pending) { pending = true; pending_start = st; pending_lower = v; }
+      if (en >= c_count(b)) { emit(pending_start, en, pending_lower, v); pending = false; next_avail = b + 1; }
+      pos = en; pos_value = rsucc[target];
+    }
+  }
+  n_hist_out = n_hist;
+}
+
+// LDS layout of enc_hist_kernel
+constexpr uint32_t kHistLdsCounts = 0;                       // u32[4096 + 8] counts / prefix (direct path); radix counters (sorted path)
+constexpr uint32_t kHistLdsRecV = 16416;                     // u64[256] x4 + u32[256] x2
+constexpr uint32_t kHistLdsBytes = kHistLdsRecV + 4 * 2048 + 2 * 1024 + 2048;  // + block-scan scratch u32[512]
+
+template <class L>
+__device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log) {
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  EncVar PCO_GLOBAL* ev = &ch->v[var];
+  EncPlanVar PCO_GLOBAL* plan = (EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + var;
+  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+  const uint32_t n_lat = ev->n_lat;
+  if (n_lat == 0) { if (tid == 0) ev->n_hist = 0; return; }
+  const L minv = (L)ev->minv, maxv = (L)ev->maxv;
+  const L range = (L)(maxv - minv);
+  const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var) + ev->lat_start;
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  uint32_t PCO_LDS* counts = (uint32_t PCO_LDS*)(smem + kHistLdsCounts);
+  L PCO_LDS* rv = (L PCO_LDS*)(smem + kHistLdsRecV);
+  L PCO_LDS* rnext = (L PCO_LDS*)(smem + kHistLdsRecV + 2048);
+  L PCO_LDS* rpred = (L PCO_LDS*)(smem + kHistLdsRecV + 4096);
+  L PCO_LDS* rsucc = (L PCO_LDS*)(smem + kHistLdsRecV + 6144);
+  uint32_t PCO_LDS* rst = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 8192);
+  uint32_t PCO_LDS* ren = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 9216);
+  uint32_t PCO_LDS* scan = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 10240);
+  const uint32_t B = 1u << bins_log;
+  const uint64_t n64 = n_lat;
+  auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
+  __syncthreads();
+  if ((uint64_t)range < kDirectHistRange) {
+    // ---------------- direct path ----------------
+    for (uint32_t i = tid; i < kDirectHistRange + 8; i += 256) counts[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n_lat; i += 256) atomicAdd((uint32_t*)&counts[(uint32_t)(lat[i] - minv)], 1u);
+    __syncthreads();
+    // exclusive prefix over 4096 counters: 16 per thread + block scan
+    uint32_t loc[16]; uint32_t s = 0;
+    for (int k = 0; k < 16; k++) { loc[k] = counts[tid * 16 + k]; s += loc[k]; }
+    uint32_t incl = wave_incl_scan(s);
+    if (lane == 63) scan[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0; for (uint32_t w = 0; w < wave; w++) wbase += scan[w];
+    uint32_t run = wbase + incl - s;
+    for (int k = 0; k < 16; k++) { counts[tid * 16 + k] = run; run += loc[k]; }
+    if (tid == 255) counts[4096] = run;  // == n_lat
+    __syncthreads();
+    auto lookup = [&](uint32_t r, L& value, uint32_t& st, uint32_t& en) {
+      uint32_t lo = 0, hi = 4096;  // last v with P[v] <= r
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (counts[mid] <= r) lo = mid; else hi = mid; }
+      value = (L)(minv + (L)lo); st = counts[lo]; en = counts[lo + 1];
+    };
+    if (tid < B) {
+      const uint32_t c = c_count(tid);
+      L v; uint32_t st, en; lookup(c - 1, v, st, en);
+      rv[tid] = v; rst[tid] = st; ren[tid] = en;
+      L x; uint32_t a, b2;
+      if (c < n_lat) { lookup(c, x, a, b2); rnext[tid] = x; } else rnext[tid] = 0;
+      if (st > 0) { lookup(st - 1, x, a, b2); rpred[tid] = x; } else rpred[tid] = 0;
+      if (en < n_lat) { lookup(en, x, a, b2); rsucc[tid] = x; } else rsucc[tid] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) { uint32_t nh = 0; hist_state_machine<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, nh); ev->n_hist = nh; ev->hist_path = 0; }
+    __syncthreads();
+    return;
+  }
+  // ---------------- sorted path: stable LSD radix sort on key = x - min ----------------
+  const uint32_t sig_bits = bitlen<L>(range);
+  const uint32_t npass = (sig_bits + 7) / 8;
+  L PCO_GLOBAL* bufA = sort_ptr<L>(ws, t, 0);
+  L PCO_GLOBAL* bufB = sort_ptr<L>(ws, t, 1);
+  uint32_t PCO_LDS* cnt = counts;            // [4][256]
+  uint32_t PCO_LDS* cursor = counts + 1024;  // [4][256]
+  const uint32_t q = (n_lat + 3) / 4;        // per-wave contiguous quarter (keeps the scatter stable)
+  const uint32_t w_begin = wave * q < n_lat ? wave * q : n_lat;
+  const uint32_t w_end = (wave + 1) * q < n_lat ? (wave + 1) * q : n_lat;
+  for (uint32_t p = 0; p < npass; p++) {
+    const L PCO_GLOBAL* in = p == 0 ? lat : ((p & 1) ? bufA : bufB);
+    L PCO_GLOBAL* out = (p & 1) ? bufB : bufA;
+    const uint32_t shift = 8 * p;
+    for (uint32_t i = tid; i < 1024; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (uint32_t i = w_begin + lane; i < w_end; i += 64) {
+      const uint32_t d = (uint32_t)(((L)(in[i] - minv)) >> shift) & 255u;
+      atomicAdd((uint32_t*)&cnt[wave * 256 + d], 1u);
+    }
+    __syncthreads();
+    {  // thread = digit: exclusive scan over digits of the per-digit totals, then per-wave bases
+      const uint32_t c0 = cnt[tid], c1 = cnt[256 + tid], c2 = cnt[512 + tid], c3 = cnt[768 + tid];
+      const uint32_t tot = c0 + c1 + c2 + c3;
+      const uint32_t incl = wave_incl_scan(tot);
+      if (lane == 63) scan[wave] = incl;
+      __syncthreads();
+      uint32_t wbase = 0; for (uint32_t w = 0; w < wave; w++) wbase += scan[w];
+      const uint32_t excl = wbase + incl - tot;
+      cursor[tid] = excl; cursor[256 + tid] = excl + c0; cursor[512 + tid] = excl + c0 + c1; cursor[768 + tid] = excl + c0 + c1 + c2;
+    }
+    __syncthreads();
+    uint32_t PCO_LDS* mycur = cursor + wave * 256;
+    for (uint32_t i0 = w_begin; i0 < w_end; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const bool act = i < w_end;
+      const L x = act ? in[i] : (L)0;
+      const uint32_t d = act ? ((uint32_t)(((L)(x - minv)) >> shift) & 255u) : 0xffffffffu;
+      uint64_t m = __ballot(act);
+#pragma unroll
+      for (uint32_t bit = 0; bit < 8; bit++) { const uint64_t bm = __ballot((d >> bit) & 1); m &= ((d >> bit) & 1) ? bm : ~bm; }
+      const uint64_t lt = ((uint64_t)1 << lane) - 1;
+      const uint32_t rank = __popcll(m & lt), gcount = __popcll(m);
+      const uint32_t basec = act ? mycur[d] : 0;
+      enc_wave_sync();
+      if (act && rank == 0) mycur[d] = basec + gcount;
+      enc_wave_sync();
+      if (act) out[basec + rank] = x;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  const L PCO_GLOBAL* S = (npass & 1) ? bufA : bufB;
+  auto lookup_sorted = [&](uint32_t r, L& value, uint32_t& st, uint32_t& en) {
+    value = S[r];
+    uint32_t lo = 0, hi = r;   // first index with S[idx] >= value (S[r] == value)
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S[mid] < value) lo = mid + 1; else hi = mid; }
+    st = lo;
+    lo = r + 1; hi = n_lat;    // first index with S[idx] > value
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S[mid] <= value) lo = mid + 1; else hi = mid; }
+    en = lo;
+  };
+  if (tid < B) {
+    const uint32_t c = c_count(tid);
+    L v; uint32_t st, en; lookup_sorted(c - 1, v, st, en);
+    rv[tid] = v; rst[tid] = st; ren[tid] = en;
+    rnext[tid] = c < n_lat ? S[c] : (L)0;
+    rpred[tid] = st > 0 ? S[st - 1] : (L)0;
+    rsucc[tid] = en < n_lat ? S[en] : (L)0;
+  }
+  __syncthreads();
+  if (tid == 0) { uint32_t nh = 0; hist_state_machine<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, nh); ev->n_hist = nh; ev->hist_path = 1; }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void enc_hist_kernel(EncWorkspace ws, uint32_t n_tasks) {
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tasks) return;
+  const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (ch->status != PCO_GFX_OK) return;
+  const int bits = dtype_bits(ch->dtype);
+  const uint32_t ubl = ch->unopt_bins_log;
+  for (uint32_t var = 0; var < 3; var++) {
+    if (!ch->v[var].present) continue;
+    // secondary latents get fewer bins (wrapped/chunk_compressor.rs:238-248)
+    const uint32_t bl = var == 2 ? (ubl < 6 ? ubl : 6) : ubl;
+    if (var == 0) hist_var<uint32_t>(ws, t, var, bl);
+    else if (bits == 64) hist_var<uint64_t>(ws, t, var, bl);
+    else if (bits == 32) hist_var<uint32_t>(ws, t, var, bl);
+    else hist_var<uint16_t>(ws, t, var, bl);
+  }
+}
+
+// =========================================================================================================
+// K3: bin optimisation DP, weight quantisation, tANS encoder tables, fallback decision (one wave per chunk)
+// =========================================================================================================
+__device__ __forceinline__ float log2_approx_dev(float x) {  // bin_optimization.rs:19-43
+  constexpr float Z = 0.674f;
+  constexpr uint32_t SIGNIF_MASK = 0x7FFFFF;
+  const uint32_t Z_SIGNIF = __float_as_uint(Z) & SIGNIF_MASK;
+  constexpr float Bc = 2.0f / Z;
+  constexpr float Cc = -Bc / (6.0f * Z);
+  constexpr float Ac = -Bc - Cc;
+  const uint32_t bits = __float_as_uint(x);
+  const uint32_t exp = bits >> 23, signif = bits & SIGNIF_MASK;
+  const uint32_t high_bit = signif > Z_SIGNIF ? 1u : 0u;
+  const uint32_t log_int = exp + high_bit - 127u;
+  const float normalized = __uint_as_float(((0x7Fu ^ high_bit) << 23) | signif);
+  const float t0 = __fmul_rn(Cc, normalized);
+  const float t1 = __fadd_rn(Bc, t0);
+  const float t2 = __fmul_rn(normalized, t1);
+  const float t3 = __fadd_rn((float)log_int, Ac);
+  return __fadd_rn(t3, t2);
+}
+template <class L>
+__device__ __forceinline__ float bin_cost_dev(float meta, L lower, L upper, uint32_t count, float total_log2) {  // :46-57
+  const float countf = (float)count;
+  const float ans_cost = __fsub_rn(total_log2, log2_approx_dev(countf));
+  const float offset_cost = (float)bitlen<L>((L)(upper - lower));
+  return __fadd_rn(meta, __fmul_rn(__fadd_rn(ans_cost, offset_cost), countf));
+}
+
+constexpr uint32_t kTrainLdsCC = 0;                  // u32[257] cumulative counts
+constexpr uint32_t kTrainLdsBest = 1040;             // f32[257]
+constexpr uint32_t kTrainLdsLow = 2080;              // u64[256]
+constexpr uint32_t kTrainLdsUp = 2080 + 2048;        // u64[256]
+constexpr uint32_t kTrainLdsBj = 2080 + 4096;        // u16[256]
+constexpr uint32_t kTrainLdsPart = kTrainLdsBj + 512;  // u16[256][2] partition
+constexpr uint32_t kTrainLdsW = kTrainLdsPart + 1024;  // u32[256] weights, f32[256] float weights
+constexpr uint32_t kTrainLdsSym = kTrainLdsW + 2048;   // u16[4096] state symbols
+constexpr uint32_t kTrainLdsCum = kTrainLdsSym + 8192; // u32[257]
+constexpr uint32_t kTrainLdsBytes = kTrainLdsCum + 1040;
+
+template <class L>
+__device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  EncVar PCO_GLOBAL* ev = &ch->v[var];
+  EncPlanVar PCO_GLOBAL* plan = (EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + var;
+  const uint32_t lane = lane_id();
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  uint32_t PCO_LDS* cc = (uint32_t PCO_LDS*)(smem + kTrainLdsCC);
+  float PCO_LDS* best = (float PCO_LDS*)(smem + kTrainLdsBest);
+  L PCO_LDS* lows = (L PCO_LDS*)(smem + kTrainLdsLow);
+  L PCO_LDS* ups = (L PCO_LDS*)(smem + kTrainLdsUp);
+  uint16_t PCO_LDS* bj = (uint16_t PCO_LDS*)(smem + kTrainLdsBj);
+  uint16_t PCO_LDS* part = (uint16_t PCO_LDS*)(smem + kTrainLdsPart);
+  uint32_t PCO_LDS* wts = (uint32_t PCO_LDS*)(smem + kTrainLdsW);
+  float PCO_LDS* fw = (float PCO_LDS*)(smem + kTrainLdsW + 1024);
+  uint16_t PCO_LDS* ssym = (uint16_t PCO_LDS*)(smem + kTrainLdsSym);
+  uint32_t PCO_LDS* cum = (uint32_t PCO_LDS*)(smem + kTrainLdsCum);
+
+  const uint32_t n_lat = uni(ev->n_lat);
+  const uint32_t nb = uni(ev->n_hist);
+  if (n_lat == 0 || nb == 0) {  // train_infos: empty latents -> TrainedBins::default()
+    if (lane == 0) { ev->n_bins = 0; ev->ans_size_log = 0; ev->max_ob = 0; ev->is_trivial = 1; ev->needs_ans = 1; plan->next_states[0] = 1; }
+    return;
+  }
+  const uint32_t ubl = uni(ch->unopt_bins_log);
+  const uint32_t bins_log = var == 2 ? (ubl < 6 ? ubl : 6) : ubl;
+  const uint32_t n_log_ceil = n_lat <= 1 ? 0 : (32 - clz_u32(n_lat - 1));
+  uint32_t est = bins_log + 2; if (est > 12) est = 12; if (est > n_log_ceil) est = n_log_ceil;  // estimated_ans_size_log
+  // load histogram bins
+  enc_wave_sync();
+  for (uint32_t b = lane; b < nb; b += 64) { lows[b] = (L)plan->hlower[b]; ups[b] = (L)plan->hupper[b]; cc[b + 1] = plan->hcount[b]; }
+  if (lane == 0) { cc[0] = 0; best[0] = 0.0f; }
+  enc_wave_sync();
+  if (lane == 0) { uint32_t c = 0; for (uint32_t b = 0; b < nb; b++) { c += cc[b + 1]; cc[b + 1] = c; } }
+  enc_wave_sync();
+  const uint32_t total_count = cc[nb];
+  const float total_log2 = log2_approx_dev((float)total_count);
+  const float meta = (float)(est + LBits<L>::v + offset_bits_bits(LBits<L>::v));
+  // ---- DP (bin_optimization.rs:104-178): best[i+1] = min_j best[j] + cost(j..i); ties -> largest j ----
+  for (uint32_t i = 0; i < nb; i++) {
+    const L upper = ups[i]; const uint32_t cci = cc[i + 1];
+    float bc = 3.402823466e+38f; uint32_t bjv = 0xffffffffu;
+    for (int32_t j = (int32_t)i - (int32_t)lane; j >= 0; j -= 64) {
+      const float cost = __fadd_rn(best[j], bin_cost_dev<L>(meta, lows[j], upper, cci - cc[j], total_log2));
+      if (cost < bc) { bc = cost; bjv = (uint32_t)j; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float oc = __shfl_xor(bc, d, 64); const uint32_t oj = __shfl_xor(bjv, d, 64);
+      const bool take = oj != 0xffffffffu && (bjv == 0xffffffffu || oc < bc || (oc == bc && oj > bjv));
+      if (take) { bc = oc; bjv = oj; }
+    }
+    enc_wave_sync();
+    if (lane == 0) { best[i + 1] = bc; bj[i] = (uint16_t)bjv; }
+    enc_wave_sync();
+  }
+  // ---- partition choice + optimized bins + quantisation: sequential, tiny (lane 0) ----
+  uint32_t n_opt = 0, ans_size_log = 0;
+  if (lane == 0) {
+    const float best_cost = best[nb];
+    const float bias = __fmul_rn(0.1f, (float)total_count);
+    const float thr = __fadd_rn(best_cost, bias);
+    const float single = bin_cost_dev<L>(meta, lows[0], ups[nb - 1], total_count, total_log2);
+    bool done = false;
+    if (single < thr) { part[0] = 0; part[1] = (uint16_t)(nb - 1); n_opt = 1; done = true; }
+    if (!done) {
+      bool all_trivial = true;
+      for (uint32_t b = 0; b < nb; b++) if (lows[b] != ups[b]) { all_trivial = false; break; }
+      if (all_trivial) {
+        float cost = 0.0f;
+        for (uint32_t b = 0; b < nb; b++) cost = __fadd_rn(cost, bin_cost_dev<L>(meta, lows[b], ups[b], cc[b + 1] - cc[b], total_log2));
+        if (cost < thr) { for (uint32_t b = 0; b < nb; b++) { part[2 * b] = (uint16_t)b; part[2 * b + 1] = (uint16_t)b; } n_opt = nb; done = true; }
+      }
+    }
+    if (!done) {  // rewind_best_partitioning (built back to front, then reversed in place)
+      uint32_t cnt = 0; uint32_t i = nb - 1;
+      for (;;) { const uint32_t j = bj[i]; part[2 * cnt] = (uint16_t)j; part[2 * cnt + 1] = (uint16_t)i; cnt++; if (j > 0) i = j - 1; else break; }
+      for (uint32_t a = 0; a < cnt / 2; a++) {
+        const uint16_t j0 = part[2 * a], i0 = part[2 * a + 1];
+        part[2 * a] = part[2 * (cnt - 1 - a)]; part[2 * a + 1] = part[2 * (cnt - 1 - a) + 1];
+        part[2 * (cnt - 1 - a)] = j0; part[2 * (cnt - 1 - a) + 1] = i0;
+      }
+      n_opt = cnt;
+    }
+    // optimized bins (bin_optimization.rs:180-198)
+    uint32_t max_ob = 0;
+    for (uint32_t s = 0; s < n_opt; s++) {
+      const uint32_t j = part[2 * s], i = part[2 * s + 1];
+      const uint32_t count = cc[i + 1] - cc[j];
+      const L lower = lows[j], upper = ups[i];
+      const uint32_t ob = bitlen<L>((L)(upper - lower));
+      plan->bcount[s] = count; plan->blower[s] = (uint64_t)lower; plan->bob[s] = (uint8_t)ob;
+      wts[s] = count; max_ob = max_ob > ob ? max_ob : ob;
+    }
+    // quantize_weights (ans/encoding.rs:95-175)
+    if (n_opt == 1) { ans_size_log = 0; wts[0] = 1; }
+    else {
+      const uint32_t min_size_log = 32 - clz_u32(n_opt - 1);
+      uint32_t size_log = min_size_log > est ? min_size_log : est;
+      const uint32_t required = 1u << size_log;
+      const float multiplier = __fdiv_rn((float)required, (float)n_lat);
+      float desired_surplus = 0.0f;
+      for (uint32_t s = 0; s < n_opt; s++) {
+        float v = __fsub_rn(__fmul_rn((float)wts[s], multiplier), 1.0f);
+        v = v > 0.0f ? v : 0.0f;
+        fw[s] = v; desired_surplus = __fadd_rn(desired_surplus, v);
+      }
+      const uint32_t required_surplus = required - n_opt;
+      const float surplus_mult = desired_surplus == 0.0f ? 0.0f : __fdiv_rn((float)required_surplus, desired_surplus);
+      uint32_t weight_sum = 0;
+      for (uint32_t s = 0; s < n_opt; s++) {
+        const float f = __fadd_rn(1.0f, __fmul_rn(fw[s], surplus_mult));
+        fw[s] = f;
+        const float r = roundf(f);
+        uint32_t w = r <= 0.0f ? 0u : (r >= 4294967296.0f ? 0xffffffffu : (uint32_t)r);
+        wts[s] = w; weight_sum += w;
+      }
+      uint32_t i = 0;
+      while (weight_sum > required && i < n_opt) { if (wts[i] > 1 && (float)wts[i] > fw[i]) { wts[i]--; weight_sum--; } i++; }
+      i = 0;
+      while (weight_sum < required && i < n_opt) { if ((float)wts[i] < fw[i]) { wts[i]++; weight_sum++; } i++; }
+      if (weight_sum != required) ch->status = PCO_GFX_INVALID_ARGUMENT;  // the reference would panic (index out of bounds)
+      uint32_t pow2 = 32;
+      for (uint32_t s = 0; s < n_opt; s++) { const uint32_t tz = wts[s] == 0 ? 32u : (uint32_t)__builtin_ctz(wts[s]); pow2 = pow2 < tz ? pow2 : tz; }
+      size_log -= pow2;
+      for (uint32_t s = 0; s < n_opt; s++) wts[s] >>= pow2;
+      ans_size_log = size_log;
+    }
+    uint32_t c = 0;
+    for (uint32_t s = 0; s < n_opt; s++) { plan->bweight[s] = wts[s]; cum[s] = c; c += wts[s]; }
+    cum[n_opt] = c;
+    ev->n_bins = n_opt; ev->ans_size_log = ans_size_log; ev->max_ob = max_ob;
+    ev->is_trivial = (n_opt == 1 && plan->bob[0] == 0) ? 1u : 0u;
+    ev->needs_ans = n_opt != 1 ? 1u : 0u;
+  }
+  enc_wave_sync();
+  n_opt = uni(ev->n_bins); ans_size_log = uni(ev->ans_size_log);
+  // ---- tANS encoder tables (ans/spec.rs:37-59, ans/encoding.rs:28-63) ----
+  const uint32_t T = 1u << ans_size_log;
+  uint32_t stride = (3 * T) / 5; if ((stride & 1) == 0) stride += 1;
+  for (uint32_t tt = lane; tt < T; tt += 64) {
+    uint32_t lo = 0, hi = n_opt;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= tt) lo = mid; else hi = mid; }
+    ssym[(stride * tt) & (T - 1)] = (uint16_t)lo;
+  }
+  enc_wave_sync();
+  for (uint32_t s = lane; s < n_opt; s += 64) {
+    const uint32_t w = wts[s];
+    const uint32_t max_x_s = 2 * w - 1;
+    const uint32_t min_renorm_bits = ans_size_log - (31 - clz_u32(max_x_s));
+    const uint32_t cutoff = (2 * w) << min_renorm_bits;
+    const uint32_t adj = cum[s] - w + 8192u;  // next_states index = adj - 8192 + (state >> bits)
+    plan->syminfo[s] = cutoff | (min_renorm_bits << 14) | (adj << 18);
+  }
+  // next_states: states of symbol s in ascending state order -> T + state_idx; fill counters reuse wts[] (set to cum)
+  enc_wave_sync();
+  for (uint32_t s = lane; s < n_opt; s += 64) wts[s] = cum[s];
+  enc_wave_sync();
+  const uint32_t sym_bits = 32 - clz_u32(n_opt - 1 > 0 ? n_opt - 1 : 1);
+  for (uint32_t i0 = 0; i0 < T; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const bool act = i < T;
+    const uint32_t s = act ? (uint32_t)ssym[i] : 0xffffffffu;
+    uint64_t m = __ballot(act);
+    for (uint32_t bit = 0; bit < sym_bits; bit++) { const uint64_t bm = __ballot((s >> bit) & 1); m &= ((s >> bit) & 1) ? bm : ~bm; }
+    const uint64_t lt = ((uint64_t)1 << lane) - 1;
+    const uint32_t rank = __popcll(m & lt), gcount = __popcll(m);
+    const uint32_t basec = act ? wts[s] : 0;
+    enc_wave_sync();
+    if (act && rank == 0) wts[s] = basec + gcount;
+    enc_wave_sync();
+    if (act) plan->next_states[basec + rank] = (uint16_t)(T + i);
+  }
+  enc_wave_sync();
+}
+
+__global__ __launch_bounds__(64) void enc_train_kernel(EncWorkspace ws, uint32_t n_tasks) {
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tasks) return;
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (uni(ch->status) != PCO_GFX_OK) return;
+  const int bits = dtype_bits(uni(ch->dtype));
+  for (uint32_t var = 0; var < 3; var++) {
+    if (!uni(ch->v[var].present)) continue;
+    if (var == 0) train_var<uint32_t>(ws, t, var);
+    else if (bits == 64) train_var<uint64_t>(ws, t, var);
+    else if (bits == 32) train_var<uint32_t>(ws, t, var);
+    else train_var<uint16_t>(ws, t, var);
+    __threadfence_block();
+    enc_wave_sync();
+  }
+  // should_fallback (wrapped/chunk_compressor.rs:502-541)
+  if (lane_id() == 0) {
+    const uint32_t mode_kind = ch->mode_kind, delta_kind = ch->delta_kind;
+    uint32_t fallback = 0;
+    if (!(delta_kind == kDeltaNone && mode_kind == kClassic)) {
+      const uint64_t n = ch->n;
+      uint64_t worst_bits = 7;  // one page
+      uint64_t meta_bits = kBitsModeVariant + (mode_kind == kIntMult || mode_kind == kFloatMult ? (uint64_t)bits : (mode_kind == kFloatQuant ? kBitsQuantK : 0));
+      meta_bits += 4 + 5 + 5 + 64 + 32 * 32;  // DeltaEncoding::MAX_BIT_SIZE
+      uint64_t page_meta_bits = 0;
+      for (uint32_t var = 0; var < 3; var++) {
+        if (!ch->v[var].present) continue;
+        const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + var;
+        const uint32_t lb = ch->v[var].latent_bits, asl = ch->v[var].ans_size_log, nbv = ch->v[var].n_bins;
+        for (uint32_t s = 0; s < nbv; s++)
+          worst_bits += (uint64_t)plan->bcount[s] * (uint64_t)(plan->bob[s] + asl - (31 - clz_u32(plan->bweight[s])));
+        meta_bits += kBitsAnsSizeLog + kBitsNBins + (uint64_t)nbv * (asl + lb + offset_bits_bits(lb));
+        uint32_t nlps = 0;
+        if (var == 1) nlps = delta_kind == kDeltaConsecutive ? ch->delta_order : (delta_kind == kDeltaLookback ? (1u << ch->state_n_log) : 0u);
+        page_meta_bits += (uint64_t)asl * 4 + (uint64_t)lb * nlps;
+      }
+      const uint64_t worst = (meta_bits + 7) / 8 + (page_meta_bits + 7) / 8 + (worst_bits + 7) / 8;
+      const uint64_t base_meta_bits = kBitsModeVariant + (4 + 5 + 5 + 64 + 32 * 32) + kBitsAnsSizeLog + kBitsNBins + (uint64_t)bits + offset_bits_bits(bits);
+      const uint64_t baseline = (base_meta_bits + 7) / 8 + (n * (uint64_t)bits + 7) / 8;
+      fallback = worst > baseline ? 1u : 0u;
+    }
+    ch->fallback = fallback;
+  }
+}
+
+// =========================================================================================================
+// K4: dissect + reverse tANS + bit packing + metadata, one wave per chunk
+// =========================================================================================================
+constexpr uint32_t kStgDwords = 704;                       // staging for one section (<= 2048 B offsets + slack)
+constexpr uint32_t kPageLdsStg = 0;                        // u32[704]
+constexpr uint32_t kPageLdsSym = 2816;                     // u32[256] dissect words of the batch
+constexpr uint32_t kPageLdsVar = kPageLdsSym + 1024;       // per-var tables follow
+constexpr uint32_t kPageVarLow = 0;                        // u64[256] search lowers
+constexpr uint32_t kPageVarOb = 2048;                      // u8[256]
+constexpr uint32_t kPageVarInfo = 2048 + 256;              // u32[256] syminfo
+constexpr uint32_t kPageVarNs = 2048 + 256 + 1024;         // u16[T]
+__host__ __device__ constexpr uint32_t page_var_bytes(uint32_t table_log) { return 2048 + 256 + 1024 + (2u << table_log); }
+
+__device__ __forceinline__ void store_result(PcoGfxTaskResult PCO_GLOBAL* p, uint64_t n_out, uint32_t status, uint32_t aux) {
+  p->n_out = n_out; p->consumed = 0; p->status = status; p->aux = aux;
+}
+
+// Streaming bit sink: LSB-first fields into dst (bit_writer.rs:22-42 semantics), staged in LDS, flushed as dwords.
+struct BitSink {
+  uint32_t PCO_LDS* stg; uint32_t PCO_GLOBAL* dst; uint64_t dst_cap_bits; uint64_t outbit; uint32_t overflow;
+  __device__ __forceinline__ void init(uint32_t PCO_LDS* s, uint32_t PCO_GLOBAL* d, uint64_t cap_bytes) {
+    stg = s; dst = d; dst_cap_bits = cap_bytes * 8; outbit = 0; overflow = 0;
+    for (uint32_t i = lane_id(); i < kStgDwords; i += 64) stg[i] = 0;
+    enc_wave_sync();
+  }
+  // OR `nbits` (<= 64) of `val` at bit offset `rel` (relative to outbit)
+  __device__ __forceinline__ void put(uint32_t rel, uint64_t val, uint32_t nbits) {
+    if (nbits == 0) return;
+    if (nbits < 64) val &= ((uint64_t)1 << nbits) - 1;
+    const uint32_t pos = (uint32_t)(outbit & 31) + rel;
+    const uint32_t dw = pos >> 5, sh = pos & 31;
+    atomicOr((uint32_t*)&stg[dw], (uint32_t)(val << sh));
+    if (sh + nbits > 32) {
+      const uint64_t rest = sh ? (val >> (32 - sh)) : (val >> 32);
+      atomicOr((uint32_t*)&stg[dw + 1], (uint32_t)rest);
+      if (sh + nbits > 64) atomicOr((uint32_t*)&stg[dw + 2], (uint32_t)(rest >> 32));
+    }
+  }
+  // all lanes: finish a section of `total` bits
+  __device__ __forceinline__ void advance(uint32_t total) {
+    enc_wave_sync();
+    const uint64_t newbit = outbit + total;
+    if (newbit + 64 > dst_cap_bits) { overflow = 1; }
+    const uint64_t base_dw = outbit >> 5;
+    const uint32_t ncomplete = (uint32_t)((newbit >> 5) - base_dw);
+    const uint32_t lane = lane_id();
+    uint32_t last = 0;
+    if (!overflow) for (uint32_t i = lane; i < ncomplete; i += 64) dst[base_dw + i] = stg[i];
+    last = stg[ncomplete];
+    enc_wave_sync();
+    const uint32_t used = ncomplete + 1;
+    for (uint32_t i = lane; i < used && i < kStgDwords; i += 64) stg[i] = 0;
+    enc_wave_sync();
+    if (lane == 0) stg[0] = last;
+    enc_wave_sync();
+    outbit = newbit;
+  }
+  __device__ __forceinline__ void finish_byte() { const uint32_t pad = (uint32_t)((8 - (outbit & 7)) & 7); advance(pad); }
+  // write the trailing partial dword; returns total bytes
+  __device__ __forceinline__ uint64_t close() {
+    enc_wave_sync();
+    if (!overflow && lane_id() == 0 && (outbit & 31)) dst[outbit >> 5] = stg[0];
+    return (outbit + 7) >> 3;
+  }
+  // uniform single field written by lane 0
+  __device__ __forceinline__ void put_uniform(uint64_t val, uint32_t nbits) { if (lane_id() == 0) put(0, val, nbits); advance(nbits); }
+};
+
+template <class LV>
+__device__ __forceinline__ void page_load_var_tables(uint8_t PCO_LDS* vt, const EncPlanVar PCO_GLOBAL* plan, uint32_t n_bins, uint32_t asl) {
+  const uint32_t lane = lane_id();
+  LV PCO_LDS* low = (LV PCO_LDS*)(vt + kPageVarLow);
+  uint8_t PCO_LDS* ob = vt + kPageVarOb;
+  uint32_t PCO_LDS* info = (uint32_t PCO_LDS*)(vt + kPageVarInfo);
+  uint16_t PCO_LDS* ns = (uint16_t PCO_LDS*)(vt + kPageVarNs);
+  uint32_t padded = 1; while (padded < n_bins) padded <<= 1;
+  for (uint32_t b = lane; b < padded && b < 256; b += 64) {
+    low[b] = b < n_bins ? (LV)plan->blower[b] : (LV)~(LV)0;   // padded with L::MAX (compression_table.rs:22-26)
+    ob[b] = b < n_bins ? plan->bob[b] : 0;
+    info[b] = b < n_bins ? plan->syminfo[b] : 0;
+  }
+  const uint32_t T = 1u << asl;
+  for (uint32_t i = lane; i < T; i += 64) ns[i] = plan->next_states[i];
+}
+
+// Phase A1 for one variable: batches in reverse; binary search -> symbol; reverse tANS over 4 chains.
+template <class LV>
+__device__ void page_dissect_var(const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, uint32_t PCO_GLOBAL* dis, uint32_t n_lat,
+                                 uint32_t n_bins, uint32_t asl, uint32_t final_states[4]) {
+  const uint32_t lane = lane_id();
+  const LV PCO_LDS* low = (const LV PCO_LDS*)(vt + kPageVarLow);
+  const uint32_t PCO_LDS* info = (const uint32_t PCO_LDS*)(vt + kPageVarInfo);
+  const uint16_t PCO_LDS* ns = (const uint16_t PCO_LDS*)(vt + kPageVarNs);
+  uint32_t PCO_LDS* words = (uint32_t PCO_LDS*)(enc_lds_base() + kPageLdsSym);
+  uint32_t search_log = 0; while ((1u << search_log) < n_bins) search_log++;
+  uint32_t state = 1u << asl;  // lanes 0..3: chain states (ans/encoding.rs:89-91)
+  const uint32_t n_batches = (n_lat + kBatchN - 1) / kBatchN;
+  for (uint32_t b = n_batches; b-- > 0;) {
+    const uint32_t base = b * kBatchN;
+    const uint32_t cnt = n_lat - base < kBatchN ? n_lat - base : kBatchN;
+    // symbols: branch-free lower bound over padded search lowers (compression_table.rs:51-74)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = 4 * lane + k;
+      uint32_t sym = 0;
+      if (i < cnt) {
+        const LV x = lat[base + i];
+        for (uint32_t depth = 0; depth < search_log; depth++) {
+          const uint32_t bis = 1u << (search_log - 1 - depth);
+          if (x >= low[sym + bis]) sym += bis;
+        }
+        sym = sym < n_bins - 1 ? sym : n_bins - 1;
+      }
+      words[i] = sym << 16;
+    }
+    enc_wave_sync();
+    if (asl != 0 && lane < 4) {  // encode_ans_in_reverse (chunk_latent_compressor.rs:96-132)
+      const uint32_t steps = (cnt + 3) >> 2;
+      for (uint32_t g = steps; g-- > 0;) {
+        const uint32_t i = 4 * g + lane;
+        if (i < cnt) {
+          const uint32_t w = words[i];
+          const uint32_t si = info[w >> 16];
+          const uint32_t cutoff = si & 0x3fffu, minb = (si >> 14) & 15u, adj = si >> 18;
+          const uint32_t bits = minb + (state >= cutoff ? 1u : 0u);
+          const uint32_t val = state & ((1u << bits) - 1u);
+          words[i] = w | (bits << 12) | val;
+          state = ns[adj - 8192u + (state >> bits)];
+        }
+      }
+    }
+    enc_wave_sync();
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; if (i < cnt) dis[base + i] = words[i]; }
+    enc_wave_sync();
+  }
+  for (uint32_t j = 0; j < 4; j++) final_states[j] = __shfl(state, j, 64);
+}
+
+// Phase A2 for one variable's batch: pack 256 tANS fields then 256 offset fields.
+template <class LV>
+__device__ __forceinline__ void page_pack_batch(BitSink& sink, const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, const uint32_t PCO_GLOBAL* dis,
+                                                uint32_t base, uint32_t cnt, bool needs_ans, uint32_t max_ob, bool single_bin) {
+  const uint32_t lane = lane_id();
+  const LV PCO_LDS* low = (const LV PCO_LDS*)(vt + kPageVarLow);
+  const uint8_t PCO_LDS* obs = vt + kPageVarOb;
+  uint32_t w[4]; LV x[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t i = 4 * lane + k;
+    w[k] = (i < cnt && !single_bin) ? dis[base + i] : 0u;
+    x[k] = i < cnt ? lat[base + i] : (LV)0;
+  }
+  if (needs_ans) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) t += (4 * lane + k < cnt) ? ((w[k] >> 12) & 15u) : 0u;
+    const uint32_t incl = wave_incl_scan(t);
+    const uint32_t total = uni(shfl_idx(incl, 63));
+    uint32_t rel = incl - t;
+    uint64_t acc = 0; uint32_t accbits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (4 * lane + k < cnt) { const uint32_t nb = (w[k] >> 12) & 15u; acc |= (uint64_t)(w[k] & 0xfffu) << accbits; accbits += nb; }
+    }
+    sink.put(rel, acc, accbits);  // <= 48 bits
+    sink.advance(total);
+  }
+  if (max_ob != 0) {
+    uint32_t ob[4]; uint32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = 4 * lane + k;
+      const uint32_t sym = w[k] >> 16;
+      ob[k] = i < cnt ? (uint32_t)obs[sym] : 0u;
+      x[k] = (LV)(x[k] - low[sym]);
+      t += ob[k];
+    }
+    const uint32_t incl = wave_incl_scan(t);
+    const uint32_t total = uni(shfl_idx(incl, 63));
+    uint32_t rel = incl - t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { sink.put(rel, (uint64_t)x[k], ob[k]); rel += ob[k]; }
+    sink.advance(total);
+  }
+}
+
+template <class L>
+__device__ void page_chunk(const EncWorkspace& ws, const PcoGfxEncodeTask& task, uint32_t t, PcoGfxTaskResult PCO_GLOBAL* result, uint32_t lds_var_budget) {
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  const uint32_t lane = lane_id();
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  BitSink sink;
+  sink.init((uint32_t PCO_LDS*)(smem + kPageLdsStg), (uint32_t PCO_GLOBAL*)task.dst, task.dst_cap);
+  const uint32_t n = (uint32_t)uni((uint64_t)ch->n);
+  const uint32_t dtype = uni(ch->dtype);
+  constexpr uint32_t LB = LBits<L>::v;
+  const uint32_t fallback = uni(ch->fallback);
+  // standalone chunk preamble (standalone/compressor.rs:191-203)
+  sink.put_uniform(dtype, 8);
+  sink.put_uniform(n - 1, kBitsNEntries);
+  if (fallback) {
+    // fallback_chunk_compressor (wrapped/chunk_compressor.rs:396-438): Classic, NoOp, one bin {w 1, lower 0, offset_bits L::BITS}
+    sink.put_uniform(0, kBitsModeVariant); sink.put_uniform(0, kBitsDeltaVariant);
+    sink.put_uniform(0, kBitsAnsSizeLog); sink.put_uniform(1, kBitsNBins);
+    sink.put_uniform(0, 0); sink.put_uniform(0, LB); sink.put_uniform(LB, offset_bits_bits(LB));
+    sink.finish_byte();
+    // page meta: 4 x 0-bit states -> nothing; body: raw ordered latents
+    const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)task.src;
+    const uint32_t num_kind = dtype_kind(dtype);
+    for (uint32_t base = 0; base < n; base += kBatchN) {
+      const uint32_t cnt = n - base < kBatchN ? n - base : kBatchN;
+      uint32_t rel = 4 * lane * LB; uint32_t valid = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t i = 4 * lane + k;
+        if (i < cnt) { sink.put(rel, (uint64_t)to_latent_ordered<L>(src[base + i], num_kind), LB); valid++; }
+        rel += LB;
+      }
+      sink.advance(cnt * LB);
+    }
+    sink.finish_byte();
+    const uint64_t bytes = sink.close();
+    if (lane == 0) store_result(result, bytes, sink.overflow ? PCO_GFX_INVALID_ARGUMENT : PCO_GFX_OK, 1);
+    return;
+  }
+  // ---- per variable parameters ----
+  uint32_t present[3], n_bins[3], asl[3], max_ob[3], n_lat[3], lat_start[3], needs_ans[3], trivial[3], voff[3];
+  uint32_t off = kPageLdsVar;
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    present[v] = uni(ch->v[v].present); n_bins[v] = uni(ch->v[v].n_bins); asl[v] = uni(ch->v[v].ans_size_log); max_ob[v] = uni(ch->v[v].max_ob);
+    n_lat[v] = uni(ch->v[v].n_lat); lat_start[v] = uni(ch->v[v].lat_start); needs_ans[v] = uni(ch->v[v].needs_ans); trivial[v] = uni(ch->v[v].is_trivial);
+    voff[v] = off; if (present[v]) off += page_var_bytes(asl[v]);
+  }
+  (void)lds_var_budget;
+  const uint32_t mode_kind = uni(ch->mode_kind), delta_kind = uni(ch->delta_kind), delta_order = uni(ch->delta_order);
+  // ---- ChunkMeta (metadata/chunk.rs:176-189, mode.rs:169-195, delta_encoding.rs:204-254, chunk_latent_var.rs:55-71,158-168) ----
+  sink.put_uniform(mode_kind, kBitsModeVariant);
+  if (mode_kind == kIntMult || mode_kind == kFloatMult) sink.put_uniform(uni((uint64_t)ch->mode_base), LB);
+  else if (mode_kind == kFloatQuant) sink.put_uniform(uni(ch->mode_k), kBitsQuantK);
+  sink.put_uniform(delta_kind, kBitsDeltaVariant);
+  if (delta_kind == kDeltaConsecutive) { sink.put_uniform(delta_order, kBitsDeltaOrder); sink.put_uniform(0, 1); }
+  else if (delta_kind == kDeltaLookback) { sink.put_uniform(uni(ch->window_n_log) - 1, kBitsLookbackWindowLog); sink.put_uniform(uni(ch->state_n_log), kBitsLookbackStateLog); sink.put_uniform(0, 1); }
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    if (!present[v]) continue;
+    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    const uint32_t lb = v == 0 ? 32u : LB, obb = offset_bits_bits(lb);
+    sink.put_uniform(asl[v], kBitsAnsSizeLog); sink.put_uniform(n_bins[v], kBitsNBins);
+    const uint32_t bin_bits = asl[v] + lb + obb;
+    for (uint32_t b0 = 0; b0 < n_bins[v]; b0 += 64) {
+      const uint32_t b = b0 + lane;
+      const uint32_t nb = n_bins[v] - b0 < 64 ? n_bins[v] - b0 : 64;
+      if (b < n_bins[v]) {
+        const uint32_t rel = lane * bin_bits;
+        sink.put(rel, plan->bweight[b] - 1, asl[v]);
+        sink.put(rel + asl[v], plan->blower[b], lb);
+        sink.put(rel + asl[v] + lb, plan->bob[b], obb);
+      }
+      sink.advance(nb * bin_bits);
+    }
+  }
+  sink.finish_byte();
+  // ---- load tables, phase A1 (reverse dissect) ----
+  uint32_t fs[3][4];
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    for (int j = 0; j < 4; j++) fs[v][j] = 1u << asl[v];
+    if (!present[v] || trivial[v]) continue;
+    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    if (v == 0) page_load_var_tables<uint32_t>(smem + voff[v], plan, n_bins[v], asl[v]); else page_load_var_tables<L>(smem + voff[v], plan, n_bins[v], asl[v]);
+  }
+  enc_wave_sync();
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    if (!present[v] || trivial[v] || n_bins[v] <= 1) continue;
+    if (v == 0) page_dissect_var<uint32_t>(smem + voff[v], lat_ptr<uint32_t>(ws, t, 0) + lat_start[v], dissect_ptr(ws, t, 0), n_lat[v], n_bins[v], asl[v], fs[v]);
+    else page_dissect_var<L>(smem + voff[v], lat_ptr<L>(ws, t, v) + lat_start[v], dissect_ptr(ws, t, v), n_lat[v], n_bins[v], asl[v], fs[v]);
+  }
+  __threadfence_block();
+  enc_wave_sync();
+  // ---- page meta (metadata/page.rs:22-34, page_latent_var.rs:19-26) ----
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    if (!present[v]) continue;
+    if (v == 1) {
+      const uint32_t nlps = delta_kind == kDeltaConsecutive ? delta_order : 0u;
+      for (uint32_t i = 0; i < nlps; i++) sink.put_uniform(uni((uint64_t)ch->moments[i]), LB);
+    }
+    for (int j = 0; j < 4; j++) sink.put_uniform(fs[v][j] - (1u << asl[v]), asl[v]);
+  }
+  sink.finish_byte();
+  // ---- phase A2: pack batches forward (wrapped/chunk_compressor.rs:624-651) ----
+  for (uint32_t base = 0; base < n; base += kBatchN) {
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      if (!present[v] || trivial[v] || base >= n_lat[v]) continue;
+      const uint32_t cnt = n_lat[v] - base < kBatchN ? n_lat[v] - base : kBatchN;
+      if (v == 0) page_pack_batch<uint32_t>(sink, smem + voff[v], lat_ptr<uint32_t>(ws, t, 0) + lat_start[v], dissect_ptr(ws, t, 0), base, cnt, needs_ans[v] != 0, max_ob[v], n_bins[v] <= 1);
+      else page_pack_batch<L>(sink, smem + voff[v], lat_ptr<L>(ws, t, v) + lat_start[v], dissect_ptr(ws, t, v), base, cnt, needs_ans[v] != 0, max_ob[v], n_bins[v] <= 1);
+    }
+  }
+  sink.finish_byte();
+  const uint64_t bytes = sink.close();
+  if (lane == 0) store_result(result, bytes, sink.overflow ? PCO_GFX_INVALID_ARGUMENT : PCO_GFX_OK, 0);
+}
+
+__global__ __launch_bounds__(64) void enc_page_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, PcoGfxTaskResult* results, uint32_t n_tasks, uint32_t lds_var_budget) {
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tasks) return;
+  const PcoGfxEncodeTask task = tasks[t];
+  const uint32_t status = uni(ws.chunks[t].status);
+  if (status != PCO_GFX_OK) {
+    if (lane_id() == 0) store_result((PcoGfxTaskResult PCO_GLOBAL*)results + t, 0, status, 0);
+    return;
+  }
+  const int bits = dtype_bits(uni(task.dtype));
+  PcoGfxTaskResult PCO_GLOBAL* res = (PcoGfxTaskResult PCO_GLOBAL*)results + t;
+  if (bits == 64) page_chunk<uint64_t>(ws, task, t, res, lds_var_budget);
+  else if (bits == 32) page_chunk<uint32_t>(ws, task, t, res, lds_var_budget);
+  else page_chunk<uint16_t>(ws, task, t, res, lds_var_budget);
+}
+
+}  // namespace pcogfx

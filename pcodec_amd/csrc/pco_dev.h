@@ -1,0 +1,195 @@
+// pco_dev.h -- device-side helpers shared by the gfx950 decode and encode kernels.
+// Written for CDNA4 only: wavefront = 64 lanes, LDS staging, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pco_gfx.h"
+
+namespace pcogfx {
+
+// format constants (reference: pco/src/constants.rs:10-62, standalone/constants.rs:4-9)
+constexpr uint32_t kBatchN = 256;
+constexpr uint32_t kAnsInterleaving = 4;
+constexpr uint32_t kMaxAnsBits = 14;
+constexpr uint32_t kMaxEntries = 1u << 24;
+constexpr uint32_t kBitsAnsSizeLog = 4, kBitsModeVariant = 4, kBitsDeltaVariant = 4, kBitsDeltaOrder = 3;
+constexpr uint32_t kBitsLookbackWindowLog = 5, kBitsLookbackStateLog = 4, kBitsNBins = 15, kBitsQuantK = 8;
+constexpr uint32_t kBitsDictLen = 25, kBitsNEntries = 24, kBitsVarintPower = 6;
+constexpr uint32_t kMaxLookbackWindowLog = 24;
+constexpr uint32_t kWave = 64;
+
+enum ModeKind : uint32_t { kClassic = 0, kIntMult = 1, kFloatMult = 2, kFloatQuant = 3, kDict = 4 };
+enum DeltaKind : uint32_t { kDeltaNone = 0, kDeltaConsecutive = 1, kDeltaLookback = 2, kDeltaConv1 = 3 };
+enum NumKind : uint32_t { kUnsigned = 0, kSigned = 1, kFloat = 2 };
+
+__host__ __device__ inline int dtype_bits(uint32_t d) {
+  switch (d) {
+    case PCO_TYPE_U32: case PCO_TYPE_I32: case PCO_TYPE_F32: return 32;
+    case PCO_TYPE_U64: case PCO_TYPE_I64: case PCO_TYPE_F64: return 64;
+    case PCO_TYPE_U16: case PCO_TYPE_I16: case PCO_TYPE_F16: return 16;
+    case PCO_TYPE_U8: case PCO_TYPE_I8: return 8;
+  }
+  return 0;
+}
+__host__ __device__ inline uint32_t dtype_kind(uint32_t d) {
+  switch (d) {
+    case PCO_TYPE_I32: case PCO_TYPE_I64: case PCO_TYPE_I16: case PCO_TYPE_I8: return kSigned;
+    case PCO_TYPE_F32: case PCO_TYPE_F64: case PCO_TYPE_F16: return kFloat;
+    default: return kUnsigned;
+  }
+}
+__host__ __device__ inline uint32_t offset_bits_bits(int latent_bits) {  // bits.rs:24-26
+  return latent_bits == 8 ? 4 : latent_bits == 16 ? 5 : latent_bits == 32 ? 6 : 7;
+}
+
+template <class L> struct LBits;
+template <> struct LBits<uint16_t> { static constexpr uint32_t v = 16; };
+template <> struct LBits<uint32_t> { static constexpr uint32_t v = 32; };
+template <> struct LBits<uint64_t> { static constexpr uint32_t v = 64; };
+template <class L> __host__ __device__ constexpr L lmid() { return (L)((L)1 << (LBits<L>::v - 1)); }
+
+// order preserving bijections (data_types/unsigned.rs:155-161, signed.rs:46-52, float.rs:392-411)
+template <class L> __device__ __forceinline__ L to_latent_ordered(L bits, uint32_t kind) {
+  if (kind == kUnsigned) return bits;
+  if (kind == kSigned) return (L)(bits ^ lmid<L>());
+  return (bits & lmid<L>()) ? (L)~bits : (L)(bits ^ lmid<L>());
+}
+template <class L> __device__ __forceinline__ L from_latent_ordered(L l, uint32_t kind) {
+  if (kind == kUnsigned) return l;
+  if (kind == kSigned) return (L)(l ^ lmid<L>());
+  return (l & lmid<L>()) ? (L)(l ^ lmid<L>()) : (L)~l;
+}
+
+__device__ __forceinline__ uint32_t clz_u32(uint32_t x) { return x == 0 ? 32u : (uint32_t)__builtin_clz(x); }
+__device__ __forceinline__ uint32_t clz_u64(uint64_t x) { return x == 0 ? 64u : (uint32_t)__builtin_clzll(x); }
+template <class L> __device__ __forceinline__ uint32_t bitlen(L x) {
+  if constexpr (sizeof(L) == 8) return 64u - clz_u64((uint64_t)x);
+  else return 32u - clz_u32((uint32_t)x);
+}
+
+// ---- float <-> int-float latents (data_types/float.rs:208-244), f32/f64 only ----
+template <class L> struct FloatOf;
+template <> struct FloatOf<uint32_t> { typedef float F; static constexpr int kMantDigits = 24; };
+template <> struct FloatOf<uint64_t> { typedef double F; static constexpr int kMantDigits = 53; };
+__device__ __forceinline__ float bits_to_float(uint32_t b) { return __uint_as_float(b); }
+__device__ __forceinline__ double bits_to_float(uint64_t b) { return __longlong_as_double((long long)b); }
+__device__ __forceinline__ uint32_t float_to_bits(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ uint64_t float_to_bits(double f) { return (uint64_t)__double_as_longlong(f); }
+
+template <class L> __device__ __forceinline__ typename FloatOf<L>::F int_float_from_latent(L l) {
+  typedef typename FloatOf<L>::F F;
+  const L mid = lmid<L>();
+  const bool negative = l < mid;
+  const L abs_int = negative ? (L)(mid - 1 - l) : (L)(l - mid);
+  const L gpi = (L)1 << FloatOf<L>::kMantDigits;
+  F abs_float;
+  if (abs_int < gpi) abs_float = (F)abs_int;
+  else abs_float = bits_to_float((L)(float_to_bits((F)gpi) + (abs_int - gpi)));
+  return negative ? -abs_float : abs_float;
+}
+template <class L> __device__ __forceinline__ L int_float_to_latent(typename FloatOf<L>::F x) {
+  typedef typename FloatOf<L>::F F;
+  const L bits = float_to_bits(x);
+  const L abs_bits = (L)(bits & ~lmid<L>());
+  const F abs = bits_to_float(abs_bits);
+  const L gpi = (L)1 << FloatOf<L>::kMantDigits;
+  const F gpi_float = (F)gpi;
+  L abs_int;
+  if (abs < gpi_float) abs_int = (L)abs;  // exact: abs is an integer-valued float below 2^mant
+  else abs_int = (L)(gpi + (abs_bits - float_to_bits(gpi_float)));  // also NaN / inf
+  return (bits & lmid<L>()) ? (L)(lmid<L>() - 1 - abs_int) : (L)(lmid<L>() + abs_int);
+}
+// Rust f32::round / f64::round: half away from zero
+__device__ __forceinline__ float round_half_away(float x) { return roundf(x); }
+__device__ __forceinline__ double round_half_away(double x) { return round(x); }
+
+// ---- wave64 primitives ----
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+template <class T> __device__ __forceinline__ T shfl_up(T v, int d) {
+  if constexpr (sizeof(T) == 8) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)((uint64_t)v >> 32);
+    lo = __shfl_up(lo, d, 64); hi = __shfl_up(hi, d, 64);
+    return (T)(((uint64_t)hi << 32) | lo);
+  } else return (T)__shfl_up((uint32_t)v, d, 64);
+}
+template <class T> __device__ __forceinline__ T shfl_idx(T v, int src) {
+  if constexpr (sizeof(T) == 8) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)((uint64_t)v >> 32);
+    lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
+    return (T)(((uint64_t)hi << 32) | lo);
+  } else return (T)__shfl((uint32_t)v, src, 64);
+}
+// inclusive wave scan (wrapping add)
+template <class T> __device__ __forceinline__ T wave_incl_scan(T v) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = shfl_up(v, d);
+    if (lane >= (uint32_t)d) v = (T)(v + o);
+  }
+  return v;
+}
+template <class T> __device__ __forceinline__ T wave_sum(T v) { return shfl_idx(wave_incl_scan(v), 63); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(v, d, 64); v = v > o ? v : o; }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ---- explicit global address space (pointers loaded from task structs are generic/flat otherwise;
+//      flat loads would also tick lgkmcnt and serialise against the LDS traffic of the walkers) ----
+#define PCO_GLOBAL __attribute__((address_space(1)))
+typedef const uint8_t PCO_GLOBAL* gcptr_u8;
+typedef uint8_t PCO_GLOBAL* gptr_u8;
+template <class T> __device__ __forceinline__ const T PCO_GLOBAL* as_global(const T* p) { return (const T PCO_GLOBAL*)p; }
+template <class T> __device__ __forceinline__ T PCO_GLOBAL* as_global(T* p) { return (T PCO_GLOBAL*)p; }
+
+// ---- unaligned little-endian loads from global memory (amdhsa enables unaligned-access-mode) ----
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__device__ __forceinline__ uint64_t load_u64_le(gcptr_u8 p) { return *(const u64_unaligned PCO_GLOBAL*)p; }
+__device__ __forceinline__ uint32_t load_u32_le(gcptr_u8 p) { return *(const u32_unaligned PCO_GLOBAL*)p; }
+// bounds-safe: bytes at or beyond `len` read as zero
+__device__ __forceinline__ uint64_t load_u64_le_safe(gcptr_u8 base, uint64_t byte, uint64_t len) {
+  if (byte + 8 <= len) return load_u64_le(base + byte);
+  uint64_t v = 0;
+  for (int i = 0; i < 8; i++) if (byte + i < len) v |= (uint64_t)base[byte + i] << (8 * i);
+  return v;
+}
+// wave-uniform values: move to SGPRs so loops / branches on them are scalar
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni(uint64_t v) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
+// A slow, bounds-safe serial bit reader used for metadata (a few hundred fields per chunk).
+struct MetaReader {
+  gcptr_u8 src; uint64_t len; uint64_t bit;
+  __device__ __forceinline__ uint64_t peek(uint64_t at_bit, uint32_t n) const {  // n <= 64
+    if (n == 0) return 0;
+    const uint64_t byte = at_bit >> 3; const uint32_t sh = (uint32_t)(at_bit & 7);
+    uint64_t v = load_u64_le_safe(src, byte, len) >> sh;
+    if (sh + n > 64) v |= load_u64_le_safe(src, byte + 8, len) << (64 - sh);
+    if (n < 64) v &= ((uint64_t)1 << n) - 1;
+    return v;
+  }
+  __device__ __forceinline__ uint64_t read(uint32_t n) { uint64_t v = uni(peek(bit, n)); bit += n; return v; }
+  __device__ __forceinline__ bool in_bounds() const { return bit <= len * 8; }
+  // bit_reader.rs:237-247: returns false on non-zero padding
+  __device__ __forceinline__ bool drain_empty_byte() {
+    const uint32_t sh = (uint32_t)(bit & 7);
+    if (sh == 0) return true;
+    const uint64_t byte = bit >> 3;
+    const uint32_t b = byte < len ? src[byte] : 0;
+    bit += 8 - sh;
+    return (b >> sh) == 0;
+  }
+};
+
+}  // namespace pcogfx

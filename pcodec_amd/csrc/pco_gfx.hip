@@ -1,0 +1,212 @@
+// pco_gfx.hip -- the C ABI of libpco_gfx.so (see include/pco_gfx.h) and the launch logic.
+// One translation unit: the gfx950 kernels are included below.  There is NO CPU codec here: without a
+// HIP device every compute entry point fails with PCO_GFX_DEVICE_ERROR.
+#include "pco_host.h"
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+#include "decode_kernel.hip"
+#include "encode_kernels.hip"
+
+namespace pcogfx {
+
+static thread_local HostError g_err{PCO_GFX_OK, ""};
+void set_error(int status, const std::string& msg) { g_err.status = status; g_err.msg = msg; }
+void clear_error() { g_err.status = PCO_GFX_OK; g_err.msg.clear(); }
+
+struct WorkspaceHolder {
+  Workspace ws;
+  ~WorkspaceHolder() { /* process teardown: the driver reclaims device memory */ }
+};
+Workspace& workspace() {
+  static thread_local WorkspaceHolder h;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) throw HostError{PCO_GFX_DEVICE_ERROR, std::string("no HIP device: ") + hipGetErrorString(e)};
+  if (h.ws.device != dev) { h.ws.release_all(); h.ws.device = dev; }
+  return h.ws;
+}
+
+static void require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw HostError{PCO_GFX_DEVICE_ERROR, "libpco_gfx: no MI355X/HIP device visible; this library has no CPU fallback"};
+}
+
+// ---- guarantees (host arithmetic only) ----
+static size_t baseline_meta_max_size(int latent_bits) {  // wrapped/guarantee.rs:11-33 + metadata/chunk.rs:105-113
+  const size_t delta_max_bits = 4 + 5 + 5 + 64 + 32 * 32;  // DeltaEncoding::MAX_BIT_SIZE
+  const size_t var_bits = kBitsAnsSizeLog + kBitsNBins + (0 + (size_t)latent_bits + offset_bits_bits(latent_bits));
+  return (kBitsModeVariant + delta_max_bits + var_bits + 7) / 8;
+}
+size_t guarantee_wrapped_chunk_size(int latent_bits, size_t n) { return baseline_meta_max_size(latent_bits) + (n * (size_t)latent_bits + 7) / 8; }
+size_t guarantee_standalone_chunk_size(int latent_bits, size_t n) { return 1 + 3 + guarantee_wrapped_chunk_size(latent_bits, n); }
+size_t guarantee_standalone_header_size() { return 4 + 1 + (kBitsVarintPower + 64 + 8 + 7) / 8 + 2; }
+bool n_per_page(uint64_t max_page_n, size_t n, std::vector<size_t>& out) {
+  out.clear();
+  if (max_page_n == 0) max_page_n = 1u << 18;
+  if (n == 0) return true;
+  size_t n_pages = (n + max_page_n - 1) / max_page_n;
+  size_t low = n / n_pages, r = n % n_pages;
+  out.assign(n_pages, low);
+  for (size_t i = 0; i < r; i++) out[i] = low + 1;
+  return true;
+}
+
+static PcoError fail_with(const HostError& e, PcoError code) { set_error(e.status, e.msg); return code; }
+
+// ---------------------------------------------------------------------------------------------------------
+// decode launch
+// ---------------------------------------------------------------------------------------------------------
+static uint32_t g_decode_lds_bytes = 16 * 1024;  // dynamic LDS per wave (fixed area + tANS tables)
+
+static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results,
+                          PcoGfxTaskResult* d_results_user, hipStream_t stream) {
+  if (n_tasks == 0) return;
+  Workspace& ws = workspace();
+  // group task ids by number width: one kernel instantiation per width present in the batch
+  std::vector<uint32_t> ids[3];
+  bool any_bad = false;
+  for (size_t i = 0; i < n_tasks; i++) {
+    const int b = dtype_bits(tasks[i].dtype);
+    if (b == 64) ids[0].push_back((uint32_t)i); else if (b == 32) ids[1].push_back((uint32_t)i); else if (b == 16) ids[2].push_back((uint32_t)i); else any_bad = true;
+  }
+  if (any_bad) throw HostError{PCO_GFX_UNSUPPORTED, "decode: only 16/32/64-bit number types are implemented on the device"};
+  const size_t task_bytes = n_tasks * sizeof(PcoGfxDecodeTask);
+  uint8_t* d_base = (uint8_t*)ws.tasks.ensure(task_bytes + n_tasks * sizeof(uint32_t) + 64);
+  PcoGfxDecodeTask* d_tasks = (PcoGfxDecodeTask*)d_base;
+  uint32_t* d_ids = (uint32_t*)(d_base + ((task_bytes + 15) & ~(size_t)15));
+  PcoGfxTaskResult* d_results = d_results_user ? d_results_user : (PcoGfxTaskResult*)ws.results.ensure(n_tasks * sizeof(PcoGfxTaskResult));
+  PCO_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks, task_bytes, hipMemcpyHostToDevice, stream));
+  const bool mixed = (ids[0].size() != n_tasks) && (ids[1].size() != n_tasks) && (ids[2].size() != n_tasks);
+  std::vector<uint32_t> flat;
+  size_t id_off[3] = {0, 0, 0};
+  if (mixed) {
+    for (int g = 0; g < 3; g++) { id_off[g] = flat.size(); flat.insert(flat.end(), ids[g].begin(), ids[g].end()); }
+    PCO_HIP_CHECK(hipMemcpyAsync(d_ids, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  }
+  const uint32_t budget = g_decode_lds_bytes - kLdsFixed;
+  size_t max_grid = 0;
+  for (int g = 0; g < 3; g++) max_grid = std::max(max_grid, std::min<size_t>(ids[g].size(), 16384));
+  uint8_t* tbl = (uint8_t*)ws.tbl_ws.ensure(max_grid * kTblWsBytes);
+  for (int g = 0; g < 3; g++) {
+    if (ids[g].empty()) continue;
+    const uint32_t cnt = (uint32_t)ids[g].size();
+    const uint32_t grid = (uint32_t)std::min<size_t>(cnt, 16384);
+    const uint32_t* idp = mixed ? d_ids + id_off[g] : nullptr;
+    if (g == 0) hipLaunchKernelGGL(pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
+    else if (g == 1) hipLaunchKernelGGL(pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
+    else hipLaunchKernelGGL(pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
+    PCO_HIP_CHECK(hipGetLastError());
+  }
+  if (results) {
+    PCO_HIP_CHECK(hipMemcpyAsync(results, d_results, n_tasks * sizeof(PcoGfxTaskResult), hipMemcpyDeviceToHost, stream));
+    PCO_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+}
+
+}  // namespace pcogfx
+
+using namespace pcogfx;
+
+extern "C" {
+
+int pco_gfx_last_status(void) { return g_err.status; }
+const char* pco_gfx_last_error(void) { return g_err.msg.c_str(); }
+int pco_gfx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+void pco_gfx_release_workspace(void) { try { workspace().release_all(); } catch (...) {} }
+
+size_t pco_gfx_guarantee_file_size(size_t n, unsigned char dtype, uint64_t max_page_n) {
+  const int bits = dtype_bits(dtype);
+  if (!bits) return 0;
+  std::vector<size_t> pages;
+  n_per_page(max_page_n, n, pages);
+  size_t res = guarantee_standalone_header_size() + 1;
+  for (size_t p : pages) res += guarantee_standalone_chunk_size(bits, p);
+  return res;
+}
+size_t pco_standalone_guarantee_file_size(size_t n, unsigned char dtype) { return pco_gfx_guarantee_file_size(n, dtype, 0); }
+size_t pco_gfx_guarantee_chunk_size(size_t n, unsigned char dtype) {
+  const int bits = dtype_bits(dtype);
+  return bits ? guarantee_standalone_chunk_size(bits, n) : 0;
+}
+
+size_t pco_gfx_write_standalone_header(void* dst, size_t dst_cap, uint64_t n_hint, unsigned char uniform_dtype) {
+  // standalone/compressor.rs:12-16,85-105 + wrapped/file_compressor.rs:54-59
+  HostBitWriter w;
+  w.write(0x216f6370u, 32); w.write(3, 8); w.write(uniform_dtype, 8);
+  const uint32_t power = n_hint == 0 ? 1 : (64 - (uint32_t)__builtin_clzll(n_hint));
+  w.write(power - 1, kBitsVarintPower); w.write(n_hint, power); w.finish_byte();
+  w.write(4, 8); w.write(1, 8);
+  if (w.bytes() > dst_cap) return 0;
+  std::memcpy(dst, w.buf.data(), w.bytes());
+  return w.bytes();
+}
+size_t pco_gfx_write_standalone_footer(void* dst, size_t dst_cap) {
+  if (dst_cap < 1) return 0;
+  *(uint8_t*)dst = 0;
+  return 1;
+}
+size_t pco_wrapped_write_header(void* dst, size_t dst_cap) {
+  if (dst_cap < 2) return 0;
+  ((uint8_t*)dst)[0] = 4; ((uint8_t*)dst)[1] = 1;
+  return 2;
+}
+enum PcoError pco_wrapped_read_header(const void* src, size_t len, size_t* consumed, uint8_t* major, uint8_t* minor) {
+  clear_error();
+  const uint8_t* p = (const uint8_t*)src;
+  if (len < 1) { set_error(PCO_GFX_INSUFFICIENT_DATA, "empty header"); return PcoDecompressionError; }
+  uint8_t mj = p[0], mn = 0; size_t used = 1;
+  if (mj >= 4) { if (len < 2) { set_error(PCO_GFX_INSUFFICIENT_DATA, "short header"); return PcoDecompressionError; } mn = p[1]; used = 2; }
+  if (mj > 4) { set_error(PCO_GFX_CORRUPTION, "file's format version definitely cannot be decompressed"); return PcoDecompressionError; }
+  if (consumed) *consumed = used; if (major) *major = mj; if (minor) *minor = mn;
+  return PcoSuccess;
+}
+
+enum PcoError pco_gfx_decompress_chunks(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results,
+                                        PcoGfxTaskResult* d_results, void* stream) {
+  clear_error();
+  try {
+    require_device();
+    launch_decode(n_tasks, tasks, results, d_results, (hipStream_t)stream);
+    if (results) for (size_t i = 0; i < n_tasks; i++) if (results[i].status != PCO_GFX_OK) {
+      set_error((int)results[i].status, "decode task " + std::to_string(i) + " failed");
+      return PcoDecompressionError;
+    }
+    return PcoSuccess;
+  } catch (const HostError& e) { return fail_with(e, PcoDecompressionError); }
+}
+
+enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size_t compressed_len, unsigned char dtype,
+                                                    void* dst, size_t dst_cap, size_t* n_written) {
+  clear_error();
+  const int bits = dtype_bits(dtype);
+  if (!bits) { set_error(PCO_GFX_INVALID_ARGUMENT, "invalid dtype"); return PcoInvalidType; }
+  try {
+    require_device();
+    Workspace& ws = workspace();
+    uint8_t* d_in = (uint8_t*)ws.io_in.ensure(compressed_len + 64);
+    const size_t out_bytes = dst_cap * (size_t)(bits / 8);
+    uint8_t* d_out = (uint8_t*)ws.io_out.ensure(out_bytes + 64);
+    PCO_HIP_CHECK(hipMemsetAsync(d_in + compressed_len, 0, 64, 0));
+    if (compressed_len) PCO_HIP_CHECK(hipMemcpyAsync(d_in, compressed, compressed_len, hipMemcpyHostToDevice, 0));
+    PcoGfxDecodeTask task{d_in, compressed_len, d_out, dst_cap, dtype, PCO_GFX_TASK_HAS_FILE_HEADER};
+    PcoGfxTaskResult res{};
+    launch_decode(1, &task, &res, nullptr, 0);
+    if (res.status != PCO_GFX_OK) {
+      // a too-small dst is PcoDecompressionError, like pco_c/src/lib.rs:110-112
+      set_error((int)res.status, "decompression failed");
+      return PcoDecompressionError;
+    }
+    if (res.n_out) PCO_HIP_CHECK(hipMemcpy(dst, d_out, res.n_out * (size_t)(bits / 8), hipMemcpyDeviceToHost));
+    if (n_written) *n_written = res.n_out;
+    return PcoSuccess;
+  } catch (const HostError& e) { return fail_with(e, PcoDecompressionError); }
+}
+
+}  // extern "C"
+
+#include "pco_gfx_encode_api.inc"

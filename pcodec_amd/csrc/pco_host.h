@@ -1,0 +1,84 @@
+// pco_host.h -- host-side plumbing of libpco_gfx.so: error state, the per-thread device
+// workspace, and the host-side (tiny, O(metadata)) framing helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pco_gfx.h"
+
+namespace pcogfx {
+
+struct HostError {
+  int status;
+  std::string msg;
+};
+
+void set_error(int status, const std::string& msg);
+void clear_error();
+
+#define PCO_HIP_CHECK(expr)                                                                   \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) throw pcogfx::HostError{PCO_GFX_DEVICE_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e)}; \
+  } while (0)
+
+// A growable device buffer (never shrinks; freed by pco_gfx_release_workspace / thread exit).
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void* ensure(size_t bytes) {
+    if (bytes > cap) {
+      if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+      size_t want = bytes + bytes / 8 + 256;
+      hipError_t e = hipMalloc(&p, want);
+      if (e != hipSuccess) { p = nullptr; throw HostError{PCO_GFX_DEVICE_ERROR, std::string("hipMalloc failed: ") + hipGetErrorString(e)}; }
+      cap = want;
+    }
+    return p;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Workspace {
+  int device = -1;
+  DevBuf tasks, results, tbl_ws;          // decode
+  DevBuf io_in, io_out;                   // staging for the host-buffer entry points
+  DevBuf enc_state;                       // encode: per chunk plans etc. (see encode_kernels.hip)
+  DevBuf enc_lat, enc_sort, enc_ans, enc_small;
+  void release_all() {
+    tasks.release(); results.release(); tbl_ws.release(); io_in.release(); io_out.release();
+    enc_state.release(); enc_lat.release(); enc_sort.release(); enc_ans.release(); enc_small.release();
+  }
+};
+Workspace& workspace();
+
+// ---- host-side bit writer for framing / size computations (O(metadata) work only) ----
+struct HostBitWriter {
+  std::vector<uint8_t> buf;
+  uint64_t bit = 0;
+  void write(uint64_t v, uint32_t n) {
+    if (n == 0) return;
+    if (n < 64) v &= ((uint64_t)1 << n) - 1;
+    size_t need = (size_t)((bit + n + 7) >> 3) + 9;
+    if (buf.size() < need) buf.resize(need * 2, 0);
+    for (uint32_t i = 0; i < n;) {
+      size_t byte = (size_t)(bit >> 3); uint32_t sh = (uint32_t)(bit & 7);
+      uint32_t take = 8 - sh; if (take > n - i) take = n - i;
+      buf[byte] |= (uint8_t)(((v >> i) & ((1u << take) - 1)) << sh);
+      i += take; bit += take;
+    }
+  }
+  void finish_byte() { bit = (bit + 7) & ~(uint64_t)7; }
+  size_t bytes() const { return (size_t)((bit + 7) >> 3); }
+};
+
+// size guarantees (wrapped/guarantee.rs:11-37, standalone/guarantee.rs:11-37, metadata/chunk.rs:105-113)
+size_t guarantee_wrapped_chunk_size(int latent_bits, size_t n);
+size_t guarantee_standalone_chunk_size(int latent_bits, size_t n);
+size_t guarantee_standalone_header_size();
+bool n_per_page(uint64_t max_page_n, size_t n, std::vector<size_t>& out);  // chunk_config.rs:134-182
+
+}  // namespace pcogfx

@@ -1,0 +1,67 @@
+"""Helpers for the -m gpu tests: synthetic BASELINE configs, device buffers, batched calls."""
+import ctypes as C
+
+import numpy as np
+
+from pcodec_amd import _lib as G
+
+N18 = 1 << 18
+
+
+def cfg_pair(kind):
+    """(product config, oracle config) for a BASELINE.json config name."""
+    import oracle_lib as O
+    table = {
+        "c1": dict(mode=1, delta=1),                                    # Classic, NoOp
+        "c2": dict(mode=1, delta=2, delta_order=1),                     # Classic, TryConsecutive(1)
+        "c3": dict(mode=2, mode_f64=0.01, delta=1),                     # TryFloatMult(0.01), NoOp
+        "c3d": dict(mode=2, mode_f64=0.01, delta=2, delta_order=1),
+        "c4": dict(mode=1, delta=3),                                    # Classic, TryLookback
+        "auto": dict(),
+    }[kind]
+    return G.make_config(enable_8_bit=True, **table), O.make_config(**table)
+
+
+def synth(kind, n=N18, seed=None):
+    """SURVEY.md section 8(d) synthetic inputs."""
+    if kind == "c1":
+        return np.random.default_rng(1 if seed is None else seed).integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    if kind == "c2":
+        r = np.random.default_rng(2 if seed is None else seed)
+        return (np.uint64(1 << 40) + np.uint64(1000) * np.arange(n, dtype=np.uint64) + r.integers(0, 512, n).astype(np.uint64))
+    if kind in ("c3", "c3d"):
+        return np.random.default_rng(3 if seed is None else seed).integers(1000, 10000, n) / 100.0
+    if kind == "c4":
+        base = np.random.default_rng(40).integers(-(1 << 40), 1 << 40, 365)
+        return (base[np.arange(n) % 365] + np.random.default_rng(4 if seed is None else seed).integers(-3, 4, n)).astype(np.int64)
+    raise KeyError(kind)
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    u = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(u), b.view(u))
+
+
+def gpu_simple_decompress(data, np_dtype, cap):
+    L = G.lib()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    out = np.empty(max(cap, 1), dtype=np_dtype)
+    n = C.c_size_t(0)
+    code = L.pco_standalone_simple_decompress_into(buf.ctypes.data_as(C.c_void_p) if len(buf) else None, len(buf),
+                                                   G.DTYPE_BYTE[np.dtype(np_dtype).name], out.ctypes.data_as(C.c_void_p),
+                                                   cap, C.byref(n))
+    G.check(code)
+    return out[: n.value].copy()
+
+
+def gpu_simple_compress(arr, cfg, uniform_type=False):
+    L = G.lib()
+    arr = np.ascontiguousarray(arr)
+    dt = G.DTYPE_BYTE[arr.dtype.name]
+    cap = L.pco_gfx_guarantee_file_size(arr.size, dt, cfg.max_page_n) + 64
+    dst = np.empty(cap, np.uint8); n = C.c_size_t(0)
+    code = L.pco_gfx_simple_compress_into_ex(arr.ctypes.data_as(C.c_void_p), arr.size, dt, C.byref(cfg),
+                                             1 if uniform_type else 0, dst.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    G.check(code)
+    return dst[: n.value].tobytes()
