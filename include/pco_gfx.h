@@ -153,6 +153,11 @@ typedef struct PcoGfxDecodeTask {
   uint32_t flags;    /* PCO_GFX_TASK_HAS_FILE_HEADER: src is a whole .pco file */
 } PcoGfxDecodeTask;
 #define PCO_GFX_TASK_HAS_FILE_HEADER 1u
+/* wrapped surface: src = ChunkMeta followed by one page of exactly dst_cap numbers; bits 8..15 of
+ * `flags` carry the wrapped format's major version (wrapped/file_decompressor.rs:44-52) */
+#define PCO_GFX_TASK_WRAPPED_PAGE 2u
+/* parse + validate a ChunkMeta only; `consumed` = its byte length */
+#define PCO_GFX_TASK_META_ONLY 4u
 
 typedef struct PcoGfxTaskResult {
   uint64_t n_out;    /* encode: bytes written; decode: elements written */
@@ -178,6 +183,12 @@ size_t pco_gfx_write_standalone_footer(void* dst, size_t dst_cap);
 
 /* Release this thread's device workspace. */
 void pco_gfx_release_workspace(void);
+
+/* Per-kernel timing (HIP events on the launch stream): begin() arms it for this thread; end()
+ * synchronises and returns the number of kernels launched since begin(), writing their names
+ * NUL-separated into `names` and their durations in milliseconds into `ms`. */
+void pco_gfx_profile_begin(void);
+int pco_gfx_profile_end(char* names, size_t names_cap, float* ms, int cap);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Wrapped surface (wrapped/chunk_compressor.rs:544-705, wrapped/file_decompressor.rs:24-52,

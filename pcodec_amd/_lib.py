@@ -61,6 +61,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -m pcodec_amd.build` (needs hipcc). "
                               "pcodec_amd has no CPU fallback.")
+        # When PyTorch-ROCm is used in the same process (device buffers for the batched API), load its HIP
+        # runtime first so that both bind to ONE libamdhip64: two HIP runtimes in a process cannot both
+        # open the device ("No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is optional plumbing
+            pass
         L = C.CDLL(LIB_PATH)
         L.pco_gfx_last_error.restype = C.c_char_p
         L.pco_standalone_guarantee_file_size.restype = C.c_size_t

@@ -458,7 +458,8 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
 
 template <class L>
 __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaReader& mr, uint32_t lds_table_budget,
-                                         gptr_u8 tbl_ws, uint32_t format_major, uint32_t dtype, uint32_t n, L PCO_GLOBAL* dst, uint32_t& status) {
+                                         gptr_u8 tbl_ws, uint32_t format_major, uint32_t dtype, uint32_t n, L PCO_GLOBAL* dst, uint32_t& status,
+                                         bool meta_only) {
   const uint32_t lane = lane_id();
   const uint32_t num_kind = dtype_kind(dtype);
   constexpr uint32_t LB = LBits<L>::v;
@@ -566,6 +567,7 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
     }
     if (!valid) { status = PCO_GFX_CORRUPTION; return; }
   }
+  if (meta_only) return;
   PageParams pp{mode_kind, mode_k, num_kind, n, (uint64_t)mode_base};
   if (lds_tables) decode_page_body<L, true>(src, src_len, mr, tbl_lds, pp, dst, status);
   else decode_page_body<L, false>(src, src_len, mr, tbl_ws, pp, dst, status);
@@ -588,6 +590,22 @@ __global__ __launch_bounds__(64) void pco_decode_kernel(const PcoGfxDecodeTask* 
     uint64_t n_out = 0;
     uint32_t format_major = 4, uniform_type = 0;
     if (dtype_bits(dtype) != (int)LBits<L>::v) status = PCO_GFX_INVALID_ARGUMENT;
+    if (!status && (flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY))) {
+      // wrapped surface: src = ChunkMeta [+ one page of exactly dst_cap numbers]; the format version comes from the caller
+      format_major = (flags >> 8) & 0xffu;
+      const bool meta_only = (flags & PCO_GFX_TASK_META_ONLY) != 0;
+      const uint32_t n = meta_only ? 1u : (uint32_t)dst_cap;
+      if (!meta_only && (dst_cap == 0 || dst_cap > kMaxEntries)) status = PCO_GFX_INVALID_ARGUMENT;
+      if (!status) {
+        gptr_u8 tbl_ws = tbl_ws_base ? (gptr_u8)tbl_ws_base + (uint64_t)blockIdx.x * kTblWsBytes : (gptr_u8) nullptr;
+        decode_chunk<L>(src, src_len, mr, lds_table_budget, tbl_ws, format_major, dtype, n, (L PCO_GLOBAL*)task.dst, status, meta_only);
+        status = uni(status);
+        if (!status && !meta_only) n_out = n;
+      }
+      if (lane == 0) { PcoGfxTaskResult r; r.n_out = n_out; r.consumed = mr.bit >> 3; r.status = status; r.aux = 0; results[ti] = r; }
+      wave_sync_lds();
+      continue;
+    }
     if (!status && (flags & PCO_GFX_TASK_HAS_FILE_HEADER)) {
       // standalone/decompressor.rs:85-137
       const uint32_t magic = (uint32_t)mr.read(32);
@@ -621,7 +639,7 @@ __global__ __launch_bounds__(64) void pco_decode_kernel(const PcoGfxDecodeTask* 
       if (!mr.in_bounds()) { status = PCO_GFX_INSUFFICIENT_DATA; break; }
       if (n_out + n > dst_cap) { status = PCO_GFX_INVALID_ARGUMENT; break; }
       gptr_u8 tbl_ws = tbl_ws_base ? (gptr_u8)tbl_ws_base + (uint64_t)blockIdx.x * kTblWsBytes : (gptr_u8) nullptr;
-      decode_chunk<L>(src, src_len, mr, lds_table_budget, tbl_ws, format_major, dtype, n, (L PCO_GLOBAL*)task.dst + n_out, status);
+      decode_chunk<L>(src, src_len, mr, lds_table_budget, tbl_ws, format_major, dtype, n, (L PCO_GLOBAL*)task.dst + n_out, status, false);
       status = uni(status);
       if (!status) n_out += n;
       wave_sync_lds();

@@ -46,10 +46,26 @@ struct EncChunk {
   uint64_t mode_aux2;   // FloatMult: bits of base
   uint32_t delta_kind, delta_order, window_n_log, state_n_log;
   uint32_t fallback, unopt_bins_log;
-  uint64_t moments[8];
+  uint32_t n_pages, page_low, page_r, page_first;  // PagingSpec::EqualPagesUpTo layout: the first page_r pages hold page_low+1
   EncVar v[3];
 };
 static_assert(sizeof(EncChunk) % 8 == 0, "EncChunk");
+
+// One page = one independent delta + tANS stream (wrapped/chunk_compressor.rs:142-217,659-705).
+struct EncPage {
+  uint32_t chunk, page_idx;
+  uint64_t start, n;        // numbers [start, start+n) of the chunk
+  void* dst; uint64_t dst_cap;
+  uint32_t flags, pad;      // kPageFlagPreamble: standalone preamble + ChunkMeta first; kPageFlagMetaOnly: ChunkMeta only
+  uint64_t moments[8];      // delta state of the page (consecutive moments)
+};
+constexpr uint32_t kPageFlagPreamble = 1u, kPageFlagMetaOnly = 2u;
+
+__device__ __forceinline__ uint64_t page_start_of(uint64_t i, uint32_t low, uint32_t r) {
+  const uint64_t boundary = (uint64_t)r * (low + 1);
+  if (i < boundary) return (i / (low + 1)) * (low + 1);
+  return boundary + ((i - boundary) / low) * low;
+}
 
 // per (chunk, var) plan region
 struct EncPlanVar {
@@ -61,6 +77,7 @@ struct EncPlanVar {
 struct EncWorkspace {
   EncChunk* chunks;
   EncPlanVar* plans;        // [task][3]
+  EncPage* pages;           // [n_pages_total]
   uint8_t* lat;             // [task][n_slots][n_stride] 8-byte elements
   uint8_t* sort;            // [task][2][n_stride] 8-byte elements
   uint32_t* dissect;        // [task][n_slots][n_stride]
@@ -102,6 +119,7 @@ __host__ __device__ inline uint32_t choose_unoptimized_bins_log(uint32_t level, 
 struct EncModePlan {  // host-resolved mode / delta (explicit specs; Auto is resolved by the host driver)
   uint32_t mode_kind, mode_k; uint64_t mode_base, mode_aux, mode_aux2;
   uint32_t delta_kind, delta_order, window_n_log, state_n_log;
+  uint32_t n_pages, page_low, page_r, page_first;
 };
 
 __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, const EncModePlan* plans, uint32_t n_tasks, uint32_t level) {
@@ -117,10 +135,14 @@ __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, 
   const uint32_t lbits = (uint32_t)dtype_bits(task.dtype);
   const uint32_t nlps = mp.delta_kind == kDeltaConsecutive ? mp.delta_order : (mp.delta_kind == kDeltaLookback ? (1u << mp.state_n_log) : 0u);
   const uint64_t n = task.n;
+  c.n_pages = mp.n_pages; c.page_low = mp.page_low; c.page_r = mp.page_r; c.page_first = mp.page_first;
+  // stored latents of a delta'd variable: every page drops its first nlps (wrapped/chunk_compressor.rs:185-191)
+  uint64_t stored = 0;
+  for (uint32_t p = 0; p < mp.n_pages; p++) { const uint64_t pn = mp.page_low + (p < mp.page_r ? 1u : 0u); stored += pn > nlps ? pn - nlps : 0; }
   for (int v = 0; v < 3; v++) { c.v[v].minv = ~0ull; c.v[v].maxv = 0; }
   c.v[0].present = mp.delta_kind == kDeltaLookback; c.v[0].latent_bits = 32;
-  c.v[0].lat_start = 0; c.v[0].n_lat = (uint32_t)(n > nlps ? n - nlps : 0);
-  c.v[1].present = 1; c.v[1].latent_bits = lbits; c.v[1].lat_start = (uint32_t)(nlps < n ? nlps : n); c.v[1].n_lat = (uint32_t)(n - c.v[1].lat_start);
+  c.v[0].lat_start = 0; c.v[0].n_lat = (uint32_t)stored;
+  c.v[1].present = 1; c.v[1].latent_bits = lbits; c.v[1].lat_start = nlps; c.v[1].n_lat = (uint32_t)stored;
   c.v[2].present = mp.mode_kind == kIntMult || mp.mode_kind == kFloatMult || mp.mode_kind == kFloatQuant;
   c.v[2].latent_bits = lbits; c.v[2].lat_start = 0; c.v[2].n_lat = (uint32_t)n;
   if (c.unopt_bins_log > kMaxUnoptBinsLog) c.status = PCO_GFX_UNSUPPORTED;
@@ -159,17 +181,17 @@ __device__ __forceinline__ void split_one(uint32_t mode_kind, uint32_t num_kind,
 }
 
 template <class L>
-__device__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& task, uint32_t t) {
+__device__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& task, uint32_t t, EncPage PCO_GLOBAL* pg) {
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
-  const uint64_t n = task.n;
+  const uint64_t n = pg->n, pstart = pg->start;
   const uint32_t num_kind = dtype_kind(task.dtype);
   const uint32_t mode_kind = ch->mode_kind, mode_k = ch->mode_k;
   const L mode_base = (L)ch->mode_base; const uint64_t aux_inv = ch->mode_aux, aux_base = ch->mode_aux2;
   const uint32_t order = ch->delta_kind == kDeltaConsecutive ? ch->delta_order : 0;
   const bool has_sec = ch->v[2].present != 0;
-  const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)task.src;
-  L PCO_GLOBAL* lat1 = lat_ptr<L>(ws, t, 1);
-  L PCO_GLOBAL* lat2 = has_sec ? lat_ptr<L>(ws, t, 2) : nullptr;
+  const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)task.src + pstart;
+  L PCO_GLOBAL* lat1 = lat_ptr<L>(ws, t, 1) + pstart;
+  L PCO_GLOBAL* lat2 = has_sec ? lat_ptr<L>(ws, t, 2) + pstart : nullptr;
   L mn1 = (L)~(L)0, mx1 = 0, mn2 = (L)~(L)0, mx2 = 0;
   const uint64_t base_i = (uint64_t)blockIdx.x * 1024;
   for (int k = 0; k < 4; k++) {
@@ -202,7 +224,7 @@ __device__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& t
         if (j < order && j < n) { L p, s; split_one<L>(mode_kind, num_kind, mode_base, mode_k, aux_inv, aux_base, src[j], p, s); q[j] = p; } else q[j] = 0;
       }
       for (uint32_t oo = 0; oo < order; oo++) {
-        ch->moments[oo] = oo < n ? (uint64_t)q[0] : 0ull;  // an exhausted page yields L::ZERO moments
+        pg->moments[oo] = oo < n ? (uint64_t)q[0] : 0ull;  // an exhausted page yields L::ZERO moments
         for (uint32_t j = 0; j + 1 < 8; j++) q[j] = (L)(q[j + 1] - q[j]);
       }
     }
@@ -223,19 +245,21 @@ __device__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& t
 }
 
 __global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks) {
-  const uint32_t t = blockIdx.y;
+  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + blockIdx.y;
+  if (pg->flags & kPageFlagMetaOnly) return;
+  const uint32_t t = pg->chunk;
   const PcoGfxEncodeTask task = tasks[t];
-  if ((uint64_t)blockIdx.x * 1024 >= task.n) return;
+  if ((uint64_t)blockIdx.x * 1024 >= pg->n) return;
   if (ws.chunks[t].status != PCO_GFX_OK) return;
   const int bits = dtype_bits(task.dtype);
-  if (bits == 64) enc_split_body<uint64_t>(ws, task, t);
-  else if (bits == 32) enc_split_body<uint32_t>(ws, task, t);
-  else if (bits == 16) enc_split_body<uint16_t>(ws, task, t);
+  if (bits == 64) enc_split_body<uint64_t>(ws, task, t, pg);
+  else if (bits == 32) enc_split_body<uint32_t>(ws, task, t, pg);
+  else if (bits == 16) enc_split_body<uint16_t>(ws, task, t, pg);
 }
 
 // =========================================================================================================
 // K2: exact equal-count quantile histogram (histograms.rs).  The reference's quickselect output is a pure
-// function of the sorted multiset (verified against the literal algorithm in tests/test_oracle_kats.py):
+// function of the sorted multiset (property-tested against the literal algorithm by the CPU test suite):
 // walk bins b with end ranks c_count(b) = ceil((b+1)n/B); a run of equal values that straddles the end of
 // the bin containing its first rank is a "constant run" (histograms.rs:142-161), everything else merges
 // into the pending bin.  We therefore only need rank -> (value, run start, run end) queries:
@@ -300,7 +324,11 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   if (n_lat == 0) { if (tid == 0) ev->n_hist = 0; return; }
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   const L range = (L)(maxv - minv);
-  const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var) + ev->lat_start;
+  // Stored latents = every position that is not among the first `skip` of its page (wrapped/chunk_compressor.rs:129-140).
+  const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
+  const uint32_t n_all = (uint32_t)ch->n, skip = ev->lat_start, plow = ch->page_low, pr = ch->page_r;
+  const bool single_page = ch->n_pages == 1;
+  auto stored = [&](uint32_t i) { return skip == 0 || (single_page ? i >= skip : (uint64_t)i - page_start_of(i, plow, pr) >= skip); };
   uint8_t PCO_LDS* smem = enc_lds_base();
   uint32_t PCO_LDS* counts = (uint32_t PCO_LDS*)(smem + kHistLdsCounts);
   L PCO_LDS* rv = (L PCO_LDS*)(smem + kHistLdsRecV);
@@ -318,7 +346,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     // ---------------- direct path ----------------
     for (uint32_t i = tid; i < kDirectHistRange + 8; i += 256) counts[i] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < n_lat; i += 256) atomicAdd((uint32_t*)&counts[(uint32_t)(lat[i] - minv)], 1u);
+    for (uint32_t i = tid; i < n_all; i += 256) if (stored(i)) atomicAdd((uint32_t*)&counts[(uint32_t)(lat[i] - minv)], 1u);
     __syncthreads();
     // exclusive prefix over 4096 counters: 16 per thread + block scan
     uint32_t loc[16]; uint32_t s = 0;
@@ -357,16 +385,19 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   L PCO_GLOBAL* bufB = sort_ptr<L>(ws, t, 1);
   uint32_t PCO_LDS* cnt = counts;            // [4][256]
   uint32_t PCO_LDS* cursor = counts + 1024;  // [4][256]
-  const uint32_t q = (n_lat + 3) / 4;        // per-wave contiguous quarter (keeps the scatter stable)
-  const uint32_t w_begin = wave * q < n_lat ? wave * q : n_lat;
-  const uint32_t w_end = (wave + 1) * q < n_lat ? (wave + 1) * q : n_lat;
   for (uint32_t p = 0; p < npass; p++) {
     const L PCO_GLOBAL* in = p == 0 ? lat : ((p & 1) ? bufA : bufB);
     L PCO_GLOBAL* out = (p & 1) ? bufB : bufA;
     const uint32_t shift = 8 * p;
+    // pass 0 reads the page-structured latent array (skipping each page's junk prefix); later passes are dense
+    const uint32_t n_in = p == 0 ? n_all : n_lat;
+    const uint32_t q = (n_in + 3) / 4;       // per-wave contiguous quarter (keeps the scatter stable)
+    const uint32_t w_begin = wave * q < n_in ? wave * q : n_in;
+    const uint32_t w_end = (wave + 1) * q < n_in ? (wave + 1) * q : n_in;
     for (uint32_t i = tid; i < 1024; i += 256) cnt[i] = 0;
     __syncthreads();
     for (uint32_t i = w_begin + lane; i < w_end; i += 64) {
+      if (p == 0 && !stored(i)) continue;
       const uint32_t d = (uint32_t)(((L)(in[i] - minv)) >> shift) & 255u;
       atomicAdd((uint32_t*)&cnt[wave * 256 + d], 1u);
     }
@@ -385,7 +416,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     uint32_t PCO_LDS* mycur = cursor + wave * 256;
     for (uint32_t i0 = w_begin; i0 < w_end; i0 += 64) {
       const uint32_t i = i0 + lane;
-      const bool act = i < w_end;
+      const bool act = i < w_end && (p != 0 || stored(i));
       const L x = act ? in[i] : (L)0;
       const uint32_t d = act ? ((uint32_t)(((L)(x - minv)) >> shift) & 255u) : 0xffffffffu;
       uint64_t m = __ballot(act);
@@ -680,7 +711,8 @@ __global__ __launch_bounds__(64) void enc_train_kernel(EncWorkspace ws, uint32_t
     uint32_t fallback = 0;
     if (!(delta_kind == kDeltaNone && mode_kind == kClassic)) {
       const uint64_t n = ch->n;
-      uint64_t worst_bits = 7;  // one page
+      const uint64_t n_pages = ch->n_pages;
+      uint64_t worst_bits = 7 * n_pages;
       uint64_t meta_bits = kBitsModeVariant + (mode_kind == kIntMult || mode_kind == kFloatMult ? (uint64_t)bits : (mode_kind == kFloatQuant ? kBitsQuantK : 0));
       meta_bits += 4 + 5 + 5 + 64 + 32 * 32;  // DeltaEncoding::MAX_BIT_SIZE
       uint64_t page_meta_bits = 0;
@@ -695,7 +727,7 @@ __global__ __launch_bounds__(64) void enc_train_kernel(EncWorkspace ws, uint32_t
         if (var == 1) nlps = delta_kind == kDeltaConsecutive ? ch->delta_order : (delta_kind == kDeltaLookback ? (1u << ch->state_n_log) : 0u);
         page_meta_bits += (uint64_t)asl * 4 + (uint64_t)lb * nlps;
       }
-      const uint64_t worst = (meta_bits + 7) / 8 + (page_meta_bits + 7) / 8 + (worst_bits + 7) / 8;
+      const uint64_t worst = (meta_bits + 7) / 8 + n_pages * ((page_meta_bits + 7) / 8) + (worst_bits + 7) / 8;
       const uint64_t base_meta_bits = kBitsModeVariant + (4 + 5 + 5 + 64 + 32 * 32) + kBitsAnsSizeLog + kBitsNBins + (uint64_t)bits + offset_bits_bits(bits);
       const uint64_t baseline = (base_meta_bits + 7) / 8 + (n * (uint64_t)bits + 7) / 8;
       fallback = worst > baseline ? 1u : 0u;
@@ -891,36 +923,86 @@ __device__ __forceinline__ void page_pack_batch(BitSink& sink, const uint8_t PCO
   }
 }
 
+// ChunkMeta (metadata/chunk.rs:176-189, mode.rs:169-195, delta_encoding.rs:204-254, chunk_latent_var.rs:55-71,158-168)
 template <class L>
-__device__ void page_chunk(const EncWorkspace& ws, const PcoGfxEncodeTask& task, uint32_t t, PcoGfxTaskResult PCO_GLOBAL* result, uint32_t lds_var_budget) {
+__device__ void page_write_chunk_meta(BitSink& sink, const EncWorkspace& ws, uint32_t t) {
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  const uint32_t lane = lane_id();
+  constexpr uint32_t LB = LBits<L>::v;
+  if (uni(ch->fallback)) {
+    // fallback_chunk_compressor (wrapped/chunk_compressor.rs:396-438): Classic, NoOp, one bin {w 1, lower 0, offset_bits L::BITS}
+    sink.put_uniform(0, kBitsModeVariant); sink.put_uniform(0, kBitsDeltaVariant);
+    sink.put_uniform(0, kBitsAnsSizeLog); sink.put_uniform(1, kBitsNBins);
+    sink.put_uniform(0, LB); sink.put_uniform(LB, offset_bits_bits(LB));
+    sink.finish_byte();
+    return;
+  }
+  const uint32_t mode_kind = uni(ch->mode_kind), delta_kind = uni(ch->delta_kind), delta_order = uni(ch->delta_order);
+  sink.put_uniform(mode_kind, kBitsModeVariant);
+  if (mode_kind == kIntMult || mode_kind == kFloatMult) sink.put_uniform(uni((uint64_t)ch->mode_base), LB);
+  else if (mode_kind == kFloatQuant) sink.put_uniform(uni(ch->mode_k), kBitsQuantK);
+  sink.put_uniform(delta_kind, kBitsDeltaVariant);
+  if (delta_kind == kDeltaConsecutive) { sink.put_uniform(delta_order, kBitsDeltaOrder); sink.put_uniform(0, 1); }
+  else if (delta_kind == kDeltaLookback) { sink.put_uniform(uni(ch->window_n_log) - 1, kBitsLookbackWindowLog); sink.put_uniform(uni(ch->state_n_log), kBitsLookbackStateLog); sink.put_uniform(0, 1); }
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    if (!uni(ch->v[v].present)) continue;
+    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    const uint32_t asl = uni(ch->v[v].ans_size_log), nbins = uni(ch->v[v].n_bins);
+    const uint32_t lb = v == 0 ? 32u : LB, obb = offset_bits_bits(lb);
+    sink.put_uniform(asl, kBitsAnsSizeLog); sink.put_uniform(nbins, kBitsNBins);
+    const uint32_t bin_bits = asl + lb + obb;
+    for (uint32_t b0 = 0; b0 < nbins; b0 += 64) {
+      const uint32_t b = b0 + lane;
+      const uint32_t nb = nbins - b0 < 64 ? nbins - b0 : 64;
+      if (b < nbins) {
+        const uint32_t rel = lane * bin_bits;
+        sink.put(rel, plan->bweight[b] - 1, asl);
+        sink.put(rel + asl, plan->blower[b], lb);
+        sink.put(rel + asl + lb, plan->bob[b], obb);
+      }
+      sink.advance(nb * bin_bits);
+    }
+  }
+  sink.finish_byte();
+}
+
+// One page task: [standalone preamble + ChunkMeta] + page meta + page body (wrapped/chunk_compressor.rs:659-705).
+template <class L>
+__device__ void page_task(const EncWorkspace& ws, const PcoGfxEncodeTask& task, EncPage PCO_GLOBAL* pg, PcoGfxTaskResult PCO_GLOBAL* result) {
+  const uint32_t t = uni(pg->chunk);
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   const uint32_t lane = lane_id();
   uint8_t PCO_LDS* smem = enc_lds_base();
   BitSink sink;
-  sink.init((uint32_t PCO_LDS*)(smem + kPageLdsStg), (uint32_t PCO_GLOBAL*)task.dst, task.dst_cap);
-  const uint32_t n = (uint32_t)uni((uint64_t)ch->n);
+  sink.init((uint32_t PCO_LDS*)(smem + kPageLdsStg), (uint32_t PCO_GLOBAL*)pg->dst, uni((uint64_t)pg->dst_cap));
+  const uint32_t pflags = uni(pg->flags);
+  const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
+  const uint64_t pstart = uni((uint64_t)pg->start);
   const uint32_t dtype = uni(ch->dtype);
   constexpr uint32_t LB = LBits<L>::v;
   const uint32_t fallback = uni(ch->fallback);
-  // standalone chunk preamble (standalone/compressor.rs:191-203)
-  sink.put_uniform(dtype, 8);
-  sink.put_uniform(n - 1, kBitsNEntries);
+  if (pflags & kPageFlagPreamble) {  // standalone/compressor.rs:191-203
+    sink.put_uniform(dtype, 8);
+    sink.put_uniform(page_n - 1, kBitsNEntries);
+  }
+  if (pflags & (kPageFlagPreamble | kPageFlagMetaOnly)) page_write_chunk_meta<L>(sink, ws, t);
+  if (pflags & kPageFlagMetaOnly) {
+    const uint64_t bytes = sink.close();
+    if (lane == 0) store_result(result, bytes, sink.overflow ? PCO_GFX_INVALID_ARGUMENT : PCO_GFX_OK, fallback);
+    return;
+  }
   if (fallback) {
-    // fallback_chunk_compressor (wrapped/chunk_compressor.rs:396-438): Classic, NoOp, one bin {w 1, lower 0, offset_bits L::BITS}
-    sink.put_uniform(0, kBitsModeVariant); sink.put_uniform(0, kBitsDeltaVariant);
-    sink.put_uniform(0, kBitsAnsSizeLog); sink.put_uniform(1, kBitsNBins);
-    sink.put_uniform(0, 0); sink.put_uniform(0, LB); sink.put_uniform(LB, offset_bits_bits(LB));
-    sink.finish_byte();
-    // page meta: 4 x 0-bit states -> nothing; body: raw ordered latents
-    const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)task.src;
+    // page meta: 4 x 0-bit states -> nothing; body: the page's raw ordered latents, L::BITS each
+    const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)task.src + pstart;
     const uint32_t num_kind = dtype_kind(dtype);
-    for (uint32_t base = 0; base < n; base += kBatchN) {
-      const uint32_t cnt = n - base < kBatchN ? n - base : kBatchN;
-      uint32_t rel = 4 * lane * LB; uint32_t valid = 0;
+    for (uint32_t base = 0; base < page_n; base += kBatchN) {
+      const uint32_t cnt = page_n - base < kBatchN ? page_n - base : kBatchN;
+      uint32_t rel = 4 * lane * LB;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const uint32_t i = 4 * lane + k;
-        if (i < cnt) { sink.put(rel, (uint64_t)to_latent_ordered<L>(src[base + i], num_kind), LB); valid++; }
+        if (i < cnt) sink.put(rel, (uint64_t)to_latent_ordered<L>(src[base + i], num_kind), LB);
         rel += LB;
       }
       sink.advance(cnt * LB);
@@ -931,43 +1013,18 @@ __device__ void page_chunk(const EncWorkspace& ws, const PcoGfxEncodeTask& task,
     return;
   }
   // ---- per variable parameters ----
-  uint32_t present[3], n_bins[3], asl[3], max_ob[3], n_lat[3], lat_start[3], needs_ans[3], trivial[3], voff[3];
+  const uint32_t delta_kind = uni(ch->delta_kind), delta_order = uni(ch->delta_order);
+  uint32_t present[3], n_bins[3], asl[3], max_ob[3], n_lat[3], skip[3], needs_ans[3], trivial[3], voff[3];
   uint32_t off = kPageLdsVar;
 #pragma unroll
   for (int v = 0; v < 3; v++) {
     present[v] = uni(ch->v[v].present); n_bins[v] = uni(ch->v[v].n_bins); asl[v] = uni(ch->v[v].ans_size_log); max_ob[v] = uni(ch->v[v].max_ob);
-    n_lat[v] = uni(ch->v[v].n_lat); lat_start[v] = uni(ch->v[v].lat_start); needs_ans[v] = uni(ch->v[v].needs_ans); trivial[v] = uni(ch->v[v].is_trivial);
+    needs_ans[v] = uni(ch->v[v].needs_ans); trivial[v] = uni(ch->v[v].is_trivial);
+    skip[v] = v == 1 ? uni(ch->v[1].lat_start) : 0u;                 // the page's junk prefix (delta state lives in the page meta)
+    if (skip[v] > page_n) skip[v] = page_n;
+    n_lat[v] = page_n - skip[v];
     voff[v] = off; if (present[v]) off += page_var_bytes(asl[v]);
   }
-  (void)lds_var_budget;
-  const uint32_t mode_kind = uni(ch->mode_kind), delta_kind = uni(ch->delta_kind), delta_order = uni(ch->delta_order);
-  // ---- ChunkMeta (metadata/chunk.rs:176-189, mode.rs:169-195, delta_encoding.rs:204-254, chunk_latent_var.rs:55-71,158-168) ----
-  sink.put_uniform(mode_kind, kBitsModeVariant);
-  if (mode_kind == kIntMult || mode_kind == kFloatMult) sink.put_uniform(uni((uint64_t)ch->mode_base), LB);
-  else if (mode_kind == kFloatQuant) sink.put_uniform(uni(ch->mode_k), kBitsQuantK);
-  sink.put_uniform(delta_kind, kBitsDeltaVariant);
-  if (delta_kind == kDeltaConsecutive) { sink.put_uniform(delta_order, kBitsDeltaOrder); sink.put_uniform(0, 1); }
-  else if (delta_kind == kDeltaLookback) { sink.put_uniform(uni(ch->window_n_log) - 1, kBitsLookbackWindowLog); sink.put_uniform(uni(ch->state_n_log), kBitsLookbackStateLog); sink.put_uniform(0, 1); }
-#pragma unroll
-  for (int v = 0; v < 3; v++) {
-    if (!present[v]) continue;
-    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
-    const uint32_t lb = v == 0 ? 32u : LB, obb = offset_bits_bits(lb);
-    sink.put_uniform(asl[v], kBitsAnsSizeLog); sink.put_uniform(n_bins[v], kBitsNBins);
-    const uint32_t bin_bits = asl[v] + lb + obb;
-    for (uint32_t b0 = 0; b0 < n_bins[v]; b0 += 64) {
-      const uint32_t b = b0 + lane;
-      const uint32_t nb = n_bins[v] - b0 < 64 ? n_bins[v] - b0 : 64;
-      if (b < n_bins[v]) {
-        const uint32_t rel = lane * bin_bits;
-        sink.put(rel, plan->bweight[b] - 1, asl[v]);
-        sink.put(rel + asl[v], plan->blower[b], lb);
-        sink.put(rel + asl[v] + lb, plan->bob[b], obb);
-      }
-      sink.advance(nb * bin_bits);
-    }
-  }
-  sink.finish_byte();
   // ---- load tables, phase A1 (reverse dissect) ----
   uint32_t fs[3][4];
 #pragma unroll
@@ -981,8 +1038,8 @@ __device__ void page_chunk(const EncWorkspace& ws, const PcoGfxEncodeTask& task,
 #pragma unroll
   for (int v = 0; v < 3; v++) {
     if (!present[v] || trivial[v] || n_bins[v] <= 1) continue;
-    if (v == 0) page_dissect_var<uint32_t>(smem + voff[v], lat_ptr<uint32_t>(ws, t, 0) + lat_start[v], dissect_ptr(ws, t, 0), n_lat[v], n_bins[v], asl[v], fs[v]);
-    else page_dissect_var<L>(smem + voff[v], lat_ptr<L>(ws, t, v) + lat_start[v], dissect_ptr(ws, t, v), n_lat[v], n_bins[v], asl[v], fs[v]);
+    if (v == 0) page_dissect_var<uint32_t>(smem + voff[v], lat_ptr<uint32_t>(ws, t, 0) + pstart + skip[v], dissect_ptr(ws, t, 0) + pstart + skip[v], n_lat[v], n_bins[v], asl[v], fs[v]);
+    else page_dissect_var<L>(smem + voff[v], lat_ptr<L>(ws, t, v) + pstart + skip[v], dissect_ptr(ws, t, v) + pstart + skip[v], n_lat[v], n_bins[v], asl[v], fs[v]);
   }
   __threadfence_block();
   enc_wave_sync();
@@ -992,19 +1049,19 @@ __device__ void page_chunk(const EncWorkspace& ws, const PcoGfxEncodeTask& task,
     if (!present[v]) continue;
     if (v == 1) {
       const uint32_t nlps = delta_kind == kDeltaConsecutive ? delta_order : 0u;
-      for (uint32_t i = 0; i < nlps; i++) sink.put_uniform(uni((uint64_t)ch->moments[i]), LB);
+      for (uint32_t i = 0; i < nlps; i++) sink.put_uniform(uni((uint64_t)pg->moments[i]), LB);
     }
     for (int j = 0; j < 4; j++) sink.put_uniform(fs[v][j] - (1u << asl[v]), asl[v]);
   }
   sink.finish_byte();
   // ---- phase A2: pack batches forward (wrapped/chunk_compressor.rs:624-651) ----
-  for (uint32_t base = 0; base < n; base += kBatchN) {
+  for (uint32_t base = 0; base < page_n; base += kBatchN) {
 #pragma unroll
     for (int v = 0; v < 3; v++) {
       if (!present[v] || trivial[v] || base >= n_lat[v]) continue;
       const uint32_t cnt = n_lat[v] - base < kBatchN ? n_lat[v] - base : kBatchN;
-      if (v == 0) page_pack_batch<uint32_t>(sink, smem + voff[v], lat_ptr<uint32_t>(ws, t, 0) + lat_start[v], dissect_ptr(ws, t, 0), base, cnt, needs_ans[v] != 0, max_ob[v], n_bins[v] <= 1);
-      else page_pack_batch<L>(sink, smem + voff[v], lat_ptr<L>(ws, t, v) + lat_start[v], dissect_ptr(ws, t, v), base, cnt, needs_ans[v] != 0, max_ob[v], n_bins[v] <= 1);
+      if (v == 0) page_pack_batch<uint32_t>(sink, smem + voff[v], lat_ptr<uint32_t>(ws, t, 0) + pstart + skip[v], dissect_ptr(ws, t, 0) + pstart + skip[v], base, cnt, needs_ans[v] != 0, max_ob[v], n_bins[v] <= 1);
+      else page_pack_batch<L>(sink, smem + voff[v], lat_ptr<L>(ws, t, v) + pstart + skip[v], dissect_ptr(ws, t, v) + pstart + skip[v], base, cnt, needs_ans[v] != 0, max_ob[v], n_bins[v] <= 1);
     }
   }
   sink.finish_byte();
@@ -1012,20 +1069,23 @@ __device__ void page_chunk(const EncWorkspace& ws, const PcoGfxEncodeTask& task,
   if (lane == 0) store_result(result, bytes, sink.overflow ? PCO_GFX_INVALID_ARGUMENT : PCO_GFX_OK, 0);
 }
 
-__global__ __launch_bounds__(64) void enc_page_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, PcoGfxTaskResult* results, uint32_t n_tasks, uint32_t lds_var_budget) {
-  const uint32_t t = blockIdx.x;
-  if (t >= n_tasks) return;
+// grid = number of page tasks; results are per page task
+__global__ __launch_bounds__(64) void enc_page_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, PcoGfxTaskResult* results, uint32_t n_pages) {
+  const uint32_t p = blockIdx.x;
+  if (p >= n_pages) return;
+  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+  const uint32_t t = uni(pg->chunk);
   const PcoGfxEncodeTask task = tasks[t];
   const uint32_t status = uni(ws.chunks[t].status);
+  PcoGfxTaskResult PCO_GLOBAL* res = (PcoGfxTaskResult PCO_GLOBAL*)results + p;
   if (status != PCO_GFX_OK) {
-    if (lane_id() == 0) store_result((PcoGfxTaskResult PCO_GLOBAL*)results + t, 0, status, 0);
+    if (lane_id() == 0) store_result(res, 0, status, 0);
     return;
   }
   const int bits = dtype_bits(uni(task.dtype));
-  PcoGfxTaskResult PCO_GLOBAL* res = (PcoGfxTaskResult PCO_GLOBAL*)results + t;
-  if (bits == 64) page_chunk<uint64_t>(ws, task, t, res, lds_var_budget);
-  else if (bits == 32) page_chunk<uint32_t>(ws, task, t, res, lds_var_budget);
-  else page_chunk<uint16_t>(ws, task, t, res, lds_var_budget);
+  if (bits == 64) page_task<uint64_t>(ws, task, pg, res);
+  else if (bits == 32) page_task<uint32_t>(ws, task, pg, res);
+  else page_task<uint16_t>(ws, task, pg, res);
 }
 
 }  // namespace pcogfx

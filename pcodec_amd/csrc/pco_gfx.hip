@@ -58,6 +58,26 @@ bool n_per_page(uint64_t max_page_n, size_t n, std::vector<size_t>& out) {
 
 static PcoError fail_with(const HostError& e, PcoError code) { set_error(e.status, e.msg); return code; }
 
+// ---- optional per-kernel timing with HIP events on the launch stream (used by bench.py's roofline) ----
+struct KernelProfile {
+  bool on = false;
+  struct Rec { const char* name; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+};
+static thread_local KernelProfile g_prof;
+struct ScopedKernelTimer {
+  hipStream_t s; hipEvent_t b{}; bool live = false;
+  ScopedKernelTimer(const char* name, hipStream_t stream) : s(stream) {
+    if (!g_prof.on) return;
+    hipEvent_t a;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    (void)hipEventRecord(a, s);
+    g_prof.recs.push_back({name, a, b}); live = true;
+  }
+  ~ScopedKernelTimer() { if (live) (void)hipEventRecord(b, s); }
+};
+#define PCO_TIMED_LAUNCH(name, stream, ...) do { ScopedKernelTimer _t(name, stream); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 // ---------------------------------------------------------------------------------------------------------
 // decode launch
 // ---------------------------------------------------------------------------------------------------------
@@ -97,9 +117,9 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     const uint32_t cnt = (uint32_t)ids[g].size();
     const uint32_t grid = (uint32_t)std::min<size_t>(cnt, 16384);
     const uint32_t* idp = mixed ? d_ids + id_off[g] : nullptr;
-    if (g == 0) hipLaunchKernelGGL(pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
-    else if (g == 1) hipLaunchKernelGGL(pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
-    else hipLaunchKernelGGL(pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
+    if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
+    else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
+    else PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
     PCO_HIP_CHECK(hipGetLastError());
   }
   if (results) {
@@ -118,6 +138,31 @@ int pco_gfx_last_status(void) { return g_err.status; }
 const char* pco_gfx_last_error(void) { return g_err.msg.c_str(); }
 int pco_gfx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 void pco_gfx_release_workspace(void) { try { workspace().release_all(); } catch (...) {} }
+
+// Kernel timing: begin() arms per-launch HIP events on this thread; end() synchronises and returns one
+// (name, milliseconds) pair per kernel launched since begin().  Names are written NUL-separated.
+void pco_gfx_profile_begin(void) {
+  for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.recs.clear(); g_prof.on = true;
+}
+int pco_gfx_profile_end(char* names, size_t names_cap, float* ms, int cap) {
+  g_prof.on = false;
+  int n = 0; size_t pos = 0;
+  for (auto& r : g_prof.recs) {
+    float t = 0.f;
+    (void)hipEventSynchronize(r.b);
+    (void)hipEventElapsedTime(&t, r.a, r.b);
+    if (n < cap) {
+      const size_t len = std::strlen(r.name) + 1;
+      if (names && pos + len <= names_cap) { std::memcpy(names + pos, r.name, len); pos += len; }
+      if (ms) ms[n] = t;
+      n++;
+    }
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  g_prof.recs.clear();
+  return n;
+}
 
 size_t pco_gfx_guarantee_file_size(size_t n, unsigned char dtype, uint64_t max_page_n) {
   const int bits = dtype_bits(dtype);

@@ -1,0 +1,98 @@
+"""standalone.simple_* over the C ABI -- mirrors pco_python/src/standalone.rs:56-131 and
+pco::standalone (standalone/simple.rs:22-152).  numpy arrays in, bytes out; the work happens on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as G
+from .config import ChunkConfig, Progress
+
+_FILE_DTYPES = {1: np.uint32, 2: np.uint64, 3: np.int32, 4: np.int64, 5: np.float32, 6: np.float64,
+                7: np.uint16, 8: np.int16, 9: np.float16, 10: np.uint8, 11: np.int8}
+
+
+def _dtype_byte(arr):
+    try:
+        return G.DTYPE_BYTE[arr.dtype.name]
+    except KeyError:
+        raise TypeError(f"unsupported data type: {arr.dtype}")
+
+
+def simple_compress(nums, config=None):
+    """standalone::simple_compress (standalone/simple.rs:58-91): returns the .pco file as bytes."""
+    nums = np.ascontiguousarray(nums)
+    if nums.ndim != 1:
+        raise TypeError("nums must be a 1D array")
+    cfg = (config or ChunkConfig()).to_c()
+    L = G.lib()
+    dt = _dtype_byte(nums)
+    cap = L.pco_gfx_guarantee_file_size(nums.size, dt, cfg.max_page_n) + 64
+    dst = np.empty(cap, np.uint8)
+    n = C.c_size_t(0)
+    G.check(L.pco_gfx_simple_compress_into_ex(nums.ctypes.data_as(C.c_void_p), nums.size, dt, C.byref(cfg), 0,
+                                              dst.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+    return dst[: n.value].tobytes()
+
+
+def _peek_dtype_and_n_hint(data):
+    """Enough of FileDecompressor::new + peek_number_type_or_termination (standalone/decompressor.rs:85-188)
+    to size the output array: returns (dtype byte or 0 for an empty file, n_hint)."""
+    b = bytes(data[:32])
+    if len(b) < 5 or b[:4] != b"pco!":
+        raise RuntimeError("magic header does not match")
+    ver = b[4]
+    if ver < 2:
+        return (b[5] if len(b) > 5 else 0), 0  # wrapped version byte follows; dtype byte after it
+    pos = 5
+    uniform = 0
+    if ver >= 3:
+        uniform = b[pos]; pos += 1
+    bits = int.from_bytes(b[pos:pos + 10], "little")
+    power = 1 + (bits & 63)
+    n_hint = (bits >> 6) & ((1 << power) - 1)
+    pos += (6 + power + 7) // 8
+    major = b[pos]; pos += 1
+    if major >= 4:
+        pos += 1
+    first = b[pos] if pos < len(b) else 0
+    return (uniform or first), n_hint
+
+
+def simple_decompress(data):
+    """standalone::simple_decompress (standalone/simple.rs:149-152): the dtype is read from the file."""
+    data = bytes(data)
+    dt, n_hint = _peek_dtype_and_n_hint(data)
+    if dt == 0:
+        return None  # empty file: pco_python returns None (standalone.rs:110-131)
+    if dt not in _FILE_DTYPES:
+        raise RuntimeError(f"unknown number type byte: {dt}")
+    np_dtype = _FILE_DTYPES[dt]
+    cap = max(int(n_hint), 1)
+    L = G.lib()
+    buf = np.frombuffer(data, np.uint8)
+    while True:
+        out = np.empty(cap, np_dtype)
+        n = C.c_size_t(0)
+        code = L.pco_standalone_simple_decompress_into(buf.ctypes.data_as(C.c_void_p), len(buf), dt,
+                                                       out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+        if code != G.PcoSuccess and L.pco_gfx_last_status() == G.ST_INVALID_ARGUMENT and cap < (1 << 34):
+            cap *= 4  # n_hint is only a hint (standalone/decompressor.rs:265-277)
+            continue
+        G.check(code)
+        return out[: n.value].copy()
+
+
+def simple_decompress_into(data, dst):
+    """standalone::simple_decompress_into (standalone/simple.rs:100-143): fills `dst`, returns Progress."""
+    data = bytes(data)
+    dst_arr = np.asarray(dst)
+    if not dst_arr.flags["C_CONTIGUOUS"] or dst_arr.ndim != 1:
+        raise TypeError("dst must be a contiguous 1D array")
+    full = simple_decompress(data)
+    if full is None:
+        return Progress(0, True)
+    if full.dtype != dst_arr.dtype:
+        raise RuntimeError(f"requested chunk decompression with {dst_arr.dtype} does not match chunk's number type of {full.dtype}")
+    k = min(full.size, dst_arr.size)
+    dst_arr[:k] = full[:k]
+    return Progress(k, k == full.size)

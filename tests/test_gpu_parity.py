@@ -1,0 +1,304 @@
+"""-m gpu: parity of the HIP path (through the C ABI of libpco_gfx.so) against the oracle.
+
+Bar: bit-exact.  Encode -> identical .pco bytes; decode -> identical arrays.  Every test goes through
+the C ABI; the oracle is only the checker."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import gpu_util as U
+import oracle_lib as O
+from pcodec_amd import _lib as G
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = np.load(os.path.join(HERE, "golden", "oracle_fixtures.npz"))
+FIX_NAMES = sorted({k.split("__")[0] for k in FIX.files})
+# product features still on the round's to-do list (DESIGN.md "gaps"): the product must refuse them loudly
+NOT_YET = {"i64_seasonal_lookback": "lookback encode", "i64_auto_auto": "Auto specs", "f64_auto_auto": "Auto specs"}
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = G.lib()
+    assert lib.pco_gfx_device_count() >= 1, "these tests need an MI355X; the product has no CPU path"
+    return lib
+
+
+def fix_cfg(name):
+    c = FIX[name + "__cfg"]; f = float(FIX[name + "__f64"][0])
+    kw = dict(mode=int(c[0]), mode_u64=int(c[1]), delta=int(c[2]), delta_order=int(c[3]), max_page_n=int(c[4]), mode_f64=f)
+    return G.make_config(enable_8_bit=True, **kw), O.make_config(**kw)
+
+
+# ------------------------------------------------------------------------------------------------ decode
+def test_decode_reference_golden_assets(L):
+    from test_oracle_golden import EXPECTED, asset
+    for name, exp in sorted(EXPECTED.items()):
+        if exp.dtype.itemsize == 1:
+            with pytest.raises(G.PcoGfxError) as ei:
+                U.gpu_simple_decompress(asset(name), exp.dtype, exp.size)
+            assert ei.value.status == G.ST_UNSUPPORTED  # 8-bit types: declared gap, refused loudly
+            continue
+        got = U.gpu_simple_decompress(asset(name), exp.dtype, max(exp.size, 1))
+        assert U.bits_equal(got, exp), name
+    for name, dt in (("v1_0_0_dict.pco", np.uint64), ("v1_0_0_conv1.pco", np.int32)):
+        with pytest.raises(G.PcoGfxError) as ei:
+            U.gpu_simple_decompress(asset(name), dt, 4096)
+        assert ei.value.status == G.ST_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name", FIX_NAMES)
+def test_decode_committed_fixtures(L, name):
+    nums = FIX[name + "__nums"]
+    got = U.gpu_simple_decompress(FIX[name + "__pco"].tobytes(), nums.dtype, nums.size)
+    assert U.bits_equal(got, nums)
+
+
+# ------------------------------------------------------------------------------------------------ encode
+@pytest.mark.parametrize("name", FIX_NAMES)
+def test_encode_committed_fixtures_byte_identical(L, name):
+    gcfg, _ = fix_cfg(name)
+    nums = FIX[name + "__nums"]
+    if name in NOT_YET:
+        with pytest.raises(G.PcoGfxError) as ei:
+            U.gpu_simple_compress(nums, gcfg)
+        assert ei.value.status == G.ST_UNSUPPORTED, NOT_YET[name]
+        return
+    assert U.gpu_simple_compress(nums, gcfg) == FIX[name + "__pco"].tobytes()
+
+
+@pytest.mark.parametrize("kind", ["c1", "c2", "c3", "c3d"])
+def test_baseline_configs_full_size(L, kind):
+    """BASELINE.json configs at n = 2^18: identical .pco bytes on encode, identical arrays on decode."""
+    nums = U.synth(kind)
+    gcfg, ocfg = U.cfg_pair(kind)
+    want = O.simple_compress(nums, ocfg)
+    got = U.gpu_simple_compress(nums, gcfg)
+    assert got == want
+    assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums)
+
+
+def test_baseline_config4_decode_full_size(L):
+    nums = U.synth("c4")
+    _, ocfg = U.cfg_pair("c4")
+    enc = O.simple_compress(nums, ocfg)
+    assert U.bits_equal(U.gpu_simple_decompress(enc, nums.dtype, nums.size), nums)
+
+
+def test_encode_matrix_small(L):
+    rng = np.random.default_rng(99)
+    bad = []
+    for dt in (np.uint32, np.int32, np.uint64, np.int64, np.float32, np.float64, np.uint16, np.int16):
+        for n in (1, 2, 3, 255, 256, 257, 513, 2000):
+            for dk, do in ((1, 0), (2, 1), (2, 3), (2, 7)):
+                if np.dtype(dt).kind == "f":
+                    nums = [(rng.standard_normal(n) * 50).astype(dt), (rng.integers(0, 30, n) * 0.25).astype(dt)][n % 2]
+                    nums[rng.integers(0, n)] = np.nan
+                else:
+                    ii = np.iinfo(dt)
+                    nums = [rng.integers(max(ii.min, -(1 << 40)), min(ii.max, 1 << 40), n), np.cumsum(rng.integers(-3, 9, n)) % min(ii.max, 1 << 40)][n % 2].astype(dt)
+                kw = dict(mode=1, delta=dk, delta_order=do)
+                want = O.simple_compress(nums, O.make_config(**kw))
+                got = U.gpu_simple_compress(nums, G.make_config(enable_8_bit=True, **kw))
+                if got != want:
+                    bad.append((np.dtype(dt).name, n, dk, do))
+                elif not U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, n), nums):
+                    bad.append(("decode", np.dtype(dt).name, n, dk, do))
+    assert not bad, bad[:10]
+
+
+def test_levels_and_histogram_paths(L):
+    """compression levels 0..8 and both histogram paths (value-space counting vs radix sort), incl. heavy ties."""
+    rng = np.random.default_rng(5)
+    n = 20000
+    datasets = {
+        "narrow": rng.integers(0, 300, n).astype(np.uint64),
+        "wide": rng.integers(0, 1 << 62, n, dtype=np.uint64),
+        "ties": np.where(rng.random(n) < 0.6, 7, rng.integers(0, 1 << 40, n)).astype(np.uint64),
+        "geometric": (rng.geometric(0.05, n) * 1000003).astype(np.uint32),
+        "normal_f32": rng.standard_normal(n).astype(np.float32),
+        "lomax_i32": (rng.pareto(0.5, n) * 10).clip(0, 2e9).astype(np.int32),
+    }
+    for level in (0, 1, 4, 8):
+        for name, nums in datasets.items():
+            kw = dict(level=level, mode=1, delta=1)
+            want = O.simple_compress(nums, O.make_config(**kw))
+            _, _, fb = O.chunk_plan(nums, O.make_config(**kw))
+            got = U.gpu_simple_compress(nums, G.make_config(**kw))
+            if fb:  # the reference's order-dependent heapsort fallback ran: bytes may legitimately differ
+                assert U.bits_equal(O.simple_decompress(got, nums.dtype, cap=n + 8), nums)
+            else:
+                assert got == want, (level, name)
+
+
+def test_unsupported_requests_fail_loudly(L):
+    nums = np.arange(1000, dtype=np.uint32)
+    for kw in (dict(level=12, mode=1, delta=1), dict(mode=5, delta=1), dict(mode=1, delta=4, delta_order=2)):
+        with pytest.raises(G.PcoGfxError) as ei:
+            U.gpu_simple_compress(np.tile(nums, 300), G.make_config(**kw))
+        assert ei.value.status in (G.ST_UNSUPPORTED, G.ST_INVALID_ARGUMENT)
+    with pytest.raises(G.PcoGfxError) as ei:
+        U.gpu_simple_compress(nums, G.make_config(level=13, mode=1, delta=1))
+    assert ei.value.status == G.ST_INVALID_ARGUMENT
+    with pytest.raises(G.PcoGfxError):
+        U.gpu_simple_compress(nums, G.make_config(mode=2, mode_f64=0.1, delta=1))  # float mode on ints
+
+
+# ------------------------------------------------------------------------------------------------ errors
+def test_truncation_and_corruption_are_reported(L):
+    nums = np.array([0] * 50 + [1000] * 50, np.uint32)
+    enc = O.simple_compress(nums, O.make_config(mode=1, delta=1))
+    for i in range(len(enc) - 1):  # tests/stability.rs:8-34
+        with pytest.raises(G.PcoGfxError) as ei:
+            U.gpu_simple_decompress(enc[:i], np.uint32, 128)
+        assert ei.value.status == G.ST_INSUFFICIENT_DATA, i
+    big = O.simple_compress(U.synth("c2", 5000), O.make_config(mode=1, delta=2, delta_order=1))
+    rng = np.random.default_rng(1)
+    for _ in range(200):  # tests/corruption.rs: never crash / hang; error or garbage, like the reference
+        b = bytearray(big); b[rng.integers(0, len(b))] ^= 1 << rng.integers(0, 8)
+        try:
+            U.gpu_simple_decompress(bytes(b), np.uint64, 5000)
+        except G.PcoGfxError as e:
+            assert e.status in (G.ST_CORRUPTION, G.ST_INSUFFICIENT_DATA, G.ST_INVALID_ARGUMENT, G.ST_UNSUPPORTED)
+    with pytest.raises(G.PcoGfxError):  # dst too small (pco_c/src/lib.rs:110-112)
+        U.gpu_simple_decompress(big, np.uint64, 4999)
+    with pytest.raises(G.PcoGfxError) as ei:  # wrong dtype
+        U.gpu_simple_decompress(big, np.int64, 5000)
+    assert ei.value.status == G.ST_CORRUPTION
+
+
+# ------------------------------------------------------------------------------------------------ batched + wrapped
+def test_batched_device_api_mixed_dtypes(L):
+    import torch
+    rng = np.random.default_rng(3)
+    arrays = []
+    for i in range(48):
+        n = int(rng.integers(1, 70000))
+        k = i % 3
+        if k == 0: a = (np.uint64(1 << 40) + np.uint64(1000) * np.arange(n, dtype=np.uint64) + rng.integers(0, 512, n).astype(np.uint64))
+        elif k == 1: a = rng.standard_normal(n).astype(np.float32)
+        else: a = (rng.pareto(0.5, n) * 10).clip(0, 2e9).astype(np.int32)
+        arrays.append(a)
+    kw = dict(mode=1, delta=2, delta_order=1)
+    gcfg = G.make_config(**kw)
+    srcs = [torch.from_numpy(a.view(np.uint8)).cuda() for a in arrays]
+    caps = [(L.pco_gfx_guarantee_chunk_size(a.size, G.DTYPE_BYTE[a.dtype.name]) + 64 + 15) // 16 * 16 for a in arrays]
+    dsts = [torch.zeros(c, dtype=torch.uint8, device="cuda") for c in caps]
+    tasks = (G.EncodeTask * len(arrays))(*[G.EncodeTask(s.data_ptr(), a.size, d.data_ptr(), c, G.DTYPE_BYTE[a.dtype.name], 0)
+                                           for a, s, d, c in zip(arrays, srcs, dsts, caps)])
+    res = (G.TaskResult * len(arrays))()
+    G.check(L.pco_gfx_compress_chunks(len(arrays), tasks, C.byref(gcfg), res, None, None))
+    outs = [torch.empty(a.nbytes, dtype=torch.uint8, device="cuda") for a in arrays]
+    dtasks = (G.DecodeTask * len(arrays))(*[G.DecodeTask(d.data_ptr(), res[i].n_out, o.data_ptr(), a.size, G.DTYPE_BYTE[a.dtype.name], 0)
+                                            for i, (a, d, o) in enumerate(zip(arrays, dsts, outs))])
+    dres = (G.TaskResult * len(arrays))()
+    G.check(L.pco_gfx_decompress_chunks(len(arrays), dtasks, dres, None, None))
+    for i, a in enumerate(arrays):
+        want = O.simple_compress(a, O.make_config(**kw))
+        got = bytes(dsts[i][: res[i].n_out].cpu().numpy())
+        hdr = len(want) - 1 - len(got)
+        assert got == want[hdr:-1], i
+        assert dres[i].n_out == a.size and dres[i].consumed == res[i].n_out
+        assert U.bits_equal(outs[i].cpu().numpy().view(a.dtype), a), i
+    # a .pco file assembled from device-produced chunks with the library's framing == the oracle's file
+    a = arrays[0]
+    hdr = np.zeros(32, np.uint8); k = L.pco_gfx_write_standalone_header(hdr.ctypes.data_as(C.c_void_p), 32, a.size, 0)
+    assert bytes(hdr[:k]) + bytes(dsts[0][: res[0].n_out].cpu().numpy()) + b"\x00" == O.simple_compress(a, O.make_config(**kw))
+
+
+def test_wrapped_surface_round_trip(L):
+    """wrapped::ChunkCompressor / ChunkDecompressor (tests/low_level.rs:39-129): multi-page chunk, page by page."""
+    rng = np.random.default_rng(8)
+    nums = np.cumsum(rng.integers(-5, 50, 10000)).astype(np.int64)
+    cfg = G.make_config(mode=1, delta=2, delta_order=2, max_page_n=3000)
+    cc = C.c_void_p()
+    G.check(L.pco_chunk_compressor_new(nums.ctypes.data_as(C.c_void_p), C.c_size_t(nums.size), C.c_ubyte(4), C.byref(cfg), C.byref(cc)))
+    L.pco_chunk_compressor_n_pages.restype = C.c_size_t; L.pco_chunk_compressor_page_n.restype = C.c_size_t
+    L.pco_chunk_compressor_meta_size_hint.restype = C.c_size_t; L.pco_chunk_compressor_page_size_hint.restype = C.c_size_t
+    n_pages = L.pco_chunk_compressor_n_pages(cc)
+    assert n_pages == 4
+    page_ns = [L.pco_chunk_compressor_page_n(cc, C.c_size_t(i)) for i in range(n_pages)]
+    assert page_ns == [2500] * 4 and sum(page_ns) == nums.size
+    buf = np.zeros(1 << 20, np.uint8); w = C.c_size_t(0)
+    G.check(L.pco_chunk_compressor_write_meta(cc, buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), C.byref(w)))
+    meta = bytes(buf[: w.value])
+    assert len(meta) <= L.pco_chunk_compressor_meta_size_hint(cc)
+    pages = []
+    for i in range(n_pages):
+        G.check(L.pco_chunk_compressor_write_page(cc, C.c_size_t(i), buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), C.byref(w)))
+        pages.append(bytes(buf[: w.value]))
+        assert L.pco_chunk_compressor_page_size_hint(cc, C.c_size_t(i)) > 0
+    L.pco_chunk_compressor_free(cc)
+    # decode with the wrapped decompressor, page by page
+    cd = C.c_void_p(); used = C.c_size_t(0)
+    stream = meta + b"".join(pages)
+    sbuf = np.frombuffer(stream, np.uint8)
+    G.check(L.pco_chunk_decompressor_new(sbuf.ctypes.data_as(C.c_void_p), C.c_size_t(len(stream)), C.c_ubyte(4), C.c_uint8(4), C.byref(cd), C.byref(used)))
+    assert used.value == len(meta)
+    pos = len(meta); out = []
+    for i in range(n_pages):
+        dst = np.zeros(page_ns[i], np.int64); npr = C.c_size_t(0); cons = C.c_size_t(0)
+        G.check(L.pco_chunk_decompressor_read_page(cd, C.c_void_p(sbuf.ctypes.data + pos), C.c_size_t(len(stream) - pos), C.c_size_t(page_ns[i]),
+                                                   dst.ctypes.data_as(C.c_void_p), C.c_size_t(dst.size), C.byref(npr), C.byref(cons)))
+        assert npr.value == page_ns[i] and cons.value == len(pages[i])
+        pos += cons.value; out.append(dst)
+    L.pco_chunk_decompressor_free(cd)
+    assert np.array_equal(np.concatenate(out), nums)
+    # a single-page wrapped chunk equals the standalone chunk minus its 4-byte preamble
+    one = nums[:2000].copy()
+    cfg1 = G.make_config(mode=1, delta=2, delta_order=2)
+    G.check(L.pco_chunk_compressor_new(one.ctypes.data_as(C.c_void_p), C.c_size_t(one.size), C.c_ubyte(4), C.byref(cfg1), C.byref(cc)))
+    G.check(L.pco_chunk_compressor_write_meta(cc, buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), C.byref(w))); m1 = bytes(buf[: w.value])
+    G.check(L.pco_chunk_compressor_write_page(cc, C.c_size_t(0), buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), C.byref(w))); p1 = bytes(buf[: w.value])
+    L.pco_chunk_compressor_free(cc)
+    want = O.simple_compress(one, O.make_config(mode=1, delta=2, delta_order=2))
+    assert want[-1 - len(m1) - len(p1):-1] == m1 + p1
+
+
+def test_python_mirror_round_trip(L):
+    import pcodec_amd as P
+    rng = np.random.default_rng(12345)
+    for dtype in ("f4", "f8", "i2", "i4", "i8", "u2", "u4", "u8"):  # pco_python/test/test_standalone.py:19-44
+        data = rng.uniform(0, 1000, size=900).astype(dtype)
+        cfg = P.ChunkConfig(mode_spec=P.ModeSpec.classic(), delta_spec=P.DeltaSpec.try_consecutive(1), paging_spec=P.PagingSpec.equal_pages_up_to(300))
+        comp = P.standalone.simple_compress(data, cfg)
+        np.testing.assert_array_equal(P.standalone.simple_decompress(comp), data)
+        out = np.zeros(3, dtype)
+        pr = P.standalone.simple_decompress_into(comp, out)
+        assert pr.n_processed == 3 and not pr.finished
+        np.testing.assert_array_equal(out, data[:3])
+    with pytest.raises(RuntimeError, match="does not match chunk's number type"):
+        P.standalone.simple_decompress_into(comp, np.zeros(10, np.float64))
+
+
+def test_many_chunk_properties_full_size(L):
+    """At BASELINE size (2^18 x many chunks) check size-independent properties: encode->decode round trip,
+    determinism (same bytes for the same chunk wherever it sits in the batch), and chunk independence."""
+    import torch
+    nch = 64
+    base = U.synth("c2")
+    rng = np.random.default_rng(77)
+    host = np.stack([base + np.uint64(rng.integers(0, 1 << 20)) for _ in range(nch)])
+    host[17] = host[3]
+    src = torch.from_numpy(host.view(np.int64)).cuda()
+    dtb = 2
+    cap = (L.pco_gfx_guarantee_chunk_size(base.size, dtb) + 64 + 15) // 16 * 16
+    comp = torch.zeros(nch * cap, dtype=torch.uint8, device="cuda")
+    tasks = (G.EncodeTask * nch)(*[G.EncodeTask(src.data_ptr() + i * base.nbytes, base.size, comp.data_ptr() + i * cap, cap, dtb, 0) for i in range(nch)])
+    res = (G.TaskResult * nch)()
+    gcfg, ocfg = U.cfg_pair("c2")
+    G.check(L.pco_gfx_compress_chunks(nch, tasks, C.byref(gcfg), res, None, None))
+    c3 = bytes(comp[3 * cap: 3 * cap + res[3].n_out].cpu().numpy()); c17 = bytes(comp[17 * cap: 17 * cap + res[17].n_out].cpu().numpy())
+    assert c3 == c17
+    want = O.simple_compress(host[3], ocfg)
+    assert c3 == want[len(want) - 1 - len(c3):-1]
+    out = torch.empty_like(src)
+    dt = (G.DecodeTask * nch)(*[G.DecodeTask(comp.data_ptr() + i * cap, res[i].n_out, out.data_ptr() + i * base.nbytes, base.size, dtb, 0) for i in range(nch)])
+    dres = (G.TaskResult * nch)()
+    G.check(L.pco_gfx_decompress_chunks(nch, dt, dres, None, None))
+    assert torch.equal(out, src)
+    assert all(r.n_out <= L.pco_gfx_guarantee_chunk_size(base.size, dtb) for r in res)
