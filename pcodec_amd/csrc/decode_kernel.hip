@@ -574,8 +574,11 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
 }
 
 // One wave per task; a task is a stream of >= 1 standalone chunks of number width sizeof(L).
+#ifndef PCO_DEC_MIN_WAVES
+#define PCO_DEC_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for
+#endif
 template <class L>
-__global__ __launch_bounds__(64) void pco_decode_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids,
+__global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids,
                                                         uint32_t n_ids, uint32_t lds_table_budget, uint8_t* tbl_ws_base) {
   const uint32_t lane = lane_id();
   for (uint32_t bi = blockIdx.x; bi < n_ids; bi += gridDim.x) {

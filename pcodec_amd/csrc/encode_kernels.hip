@@ -141,7 +141,7 @@ __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, 
   for (uint32_t p = 0; p < mp.n_pages; p++) { const uint64_t pn = mp.page_low + (p < mp.page_r ? 1u : 0u); stored += pn > nlps ? pn - nlps : 0; }
   for (int v = 0; v < 3; v++) { c.v[v].minv = ~0ull; c.v[v].maxv = 0; }
   c.v[0].present = mp.delta_kind == kDeltaLookback; c.v[0].latent_bits = 32;
-  c.v[0].lat_start = 0; c.v[0].n_lat = (uint32_t)stored;
+  c.v[0].lat_start = nlps; c.v[0].n_lat = (uint32_t)stored;  // lookbacks live at the primary's index (page prefix unused)
   c.v[1].present = 1; c.v[1].latent_bits = lbits; c.v[1].lat_start = nlps; c.v[1].n_lat = (uint32_t)stored;
   c.v[2].present = mp.mode_kind == kIntMult || mp.mode_kind == kFloatMult || mp.mode_kind == kFloatQuant;
   c.v[2].latent_bits = lbits; c.v[2].lat_start = 0; c.v[2].n_lat = (uint32_t)n;
@@ -190,7 +190,9 @@ __device__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& t
   const uint32_t order = ch->delta_kind == kDeltaConsecutive ? ch->delta_order : 0;
   const bool has_sec = ch->v[2].present != 0;
   const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)task.src + pstart;
-  L PCO_GLOBAL* lat1 = lat_ptr<L>(ws, t, 1) + pstart;
+  const bool lookback = ch->delta_kind == kDeltaLookback;
+  // lookback: stage the un-delta'd primary in sort buffer A; enc_lookback_kernel turns it into lat[0] / lat[1]
+  L PCO_GLOBAL* lat1 = (lookback ? sort_ptr<L>(ws, t, 0) : lat_ptr<L>(ws, t, 1)) + pstart;
   L PCO_GLOBAL* lat2 = has_sec ? lat_ptr<L>(ws, t, 2) + pstart : nullptr;
   L mn1 = (L)~(L)0, mx1 = 0, mn2 = (L)~(L)0, mx2 = 0;
   const uint64_t base_i = (uint64_t)blockIdx.x * 1024;
@@ -215,7 +217,7 @@ __device__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& t
     L d = w[0];
     if (order > 0) d = (L)(d + lmid<L>());
     lat1[i] = d;
-    if (i >= order) { mn1 = d < mn1 ? d : mn1; mx1 = d > mx1 ? d : mx1; }
+    if (i >= order && !lookback) { mn1 = d < mn1 ? d : mn1; mx1 = d > mx1 ? d : mx1; }
     if (has_sec) { lat2[i] = s0; mn2 = s0 < mn2 ? s0 : mn2; mx2 = s0 > mx2 ? s0 : mx2; }
     if (i == 0 && order > 0) {
       // moments[o] = (delta^o p)[o]
@@ -255,6 +257,149 @@ __global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const P
   if (bits == 64) enc_split_body<uint64_t>(ws, task, t, pg);
   else if (bits == 32) enc_split_body<uint32_t>(ws, task, t, pg);
   else if (bits == 16) enc_split_body<uint16_t>(ws, task, t, pg);
+}
+
+// =========================================================================================================
+// K1b: lookback delta (delta/lookback.rs:22-185).  choose_lookbacks is a greedy, strictly element-ordered search
+// over 16 proposals (6 brute, 4 "repeating", 6 hashed), so one wave owns one page: each 64-element tile first
+// resolves all hash-table proposals in parallel (the table reads of a tile are independent of the choices; the
+// in-tile read-after-write hazards are patched with a 64-step broadcast), then lanes 0..15 score the 16
+// proposals element by element.  State: last-index hash tables in HBM (2 x 2^(w+1) u32), lookback counts in LDS
+// for lookbacks <= 8192 and in HBM beyond.
+// =========================================================================================================
+constexpr uint32_t kLbCountsLds = 8192;
+constexpr uint32_t kLbLdsCounts = 0;                       // u32[8192]
+constexpr uint32_t kLbLdsHp = kLbCountsLds * 4;            // u32[64][6] hash proposals of the tile
+constexpr uint32_t kLbLdsBytes = kLbLdsHp + 64 * 6 * 4;
+struct LookbackScratch { uint32_t* hash; uint32_t* counts; };  // per page: hash[2 << (wlog+1)], counts[1 << wlog]
+
+template <class L>
+__device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, uint32_t PCO_GLOBAL* hash_tbl, uint32_t PCO_GLOBAL* gcounts) {
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  const uint32_t lane = lane_id();
+  const uint32_t wlog = uni(ch->window_n_log), state_n = 1u << uni(ch->state_n_log);
+  const uint32_t window_n = 1u << wlog, hash_table_n = 2u << wlog, hash_mask = hash_table_n - 1;
+  const uint32_t n = (uint32_t)uni((uint64_t)pg->n); const uint64_t pstart = uni((uint64_t)pg->start);
+  const L PCO_GLOBAL* pre = sort_ptr<L>(ws, t, 0) + pstart;
+  uint32_t PCO_GLOBAL* lbs = lat_ptr<uint32_t>(ws, t, 0) + pstart;
+  L PCO_GLOBAL* out = lat_ptr<L>(ws, t, 1) + pstart;
+  uint32_t PCO_LDS* lcounts = (uint32_t PCO_LDS*)(enc_lds_base() + kLbLdsCounts);
+  uint32_t PCO_LDS* hp = (uint32_t PCO_LDS*)(enc_lds_base() + kLbLdsHp);
+  // delta state = the first state_n latents, right aligned (lookback.rs:179-181); state_n == 1 from this encoder
+  if (lane == 0) for (uint32_t i = 0; i < state_n && i < 8; i++) pg->moments[i] = i < n ? (uint64_t)pre[i] : 0ull;
+  if (n <= state_n) return;
+  const uint32_t n_counts = window_n < n ? window_n : n;
+  for (uint32_t i = lane; i < kLbCountsLds; i += 64) lcounts[i] = 1;
+  for (uint32_t i = kLbCountsLds + lane; i < n_counts; i += 64) gcounts[i] = 1;
+  for (uint32_t i = lane; i < 2 * hash_table_n; i += 64) hash_tbl[i] = 0;
+  __threadfence_block();
+  enc_wave_sync();
+  auto hash_fn = [&](uint64_t x) { x = (x ^ (x >> 32)) * 11400714819323197441ull; x = x ^ (x >> 32); return (uint32_t)x & hash_mask; };
+  uint32_t proposed = 1;            // lanes 0..15: proposed_lookbacks[lane] = min(lane+1, state_n) with state_n == 1
+  if (lane < 16) proposed = (lane + 1) < state_n ? (lane + 1) : state_n;
+  uint32_t best_lookback = 1, repeating_idx = 0;
+  L mn1 = (L)~(L)0, mx1 = 0; uint32_t mn0 = 0xffffffffu, mx0 = 0;
+  for (uint32_t i0 = state_n; i0 < n; i0 += 64) {
+    const uint32_t tile_n = n - i0 < 64 ? n - i0 : 64;
+    // ---- phase 1: hash proposals of the whole tile ----
+    const uint32_t ie = i0 + lane;
+    const bool act = lane < tile_n;
+    const uint64_t lv = act ? (uint64_t)pre[ie] : 0ull;
+    uint32_t slot[6], val[6];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const uint64_t bucket = lv >> (c == 0 ? 0 : 8);
+      slot[3 * c + 0] = c * hash_table_n + hash_fn(bucket - 1);
+      slot[3 * c + 1] = c * hash_table_n + hash_fn(bucket);
+      slot[3 * c + 2] = c * hash_table_n + hash_fn(bucket + 1);
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) val[r] = act ? __hip_atomic_load(&hash_tbl[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // L2-served: earlier tiles updated it with atomics
+    // in-tile hazards: an earlier element of the tile wrote its centre bucket (slot[1] / slot[4]) before we read
+    for (uint32_t j = 0; j < tile_n; j++) {
+      const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)slot[1], (int)j), c1 = (uint32_t)__builtin_amdgcn_readlane((int)slot[4], (int)j);
+      if (j < lane) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) { if (slot[r] == c0) val[r] = i0 + j; if (slot[3 + r] == c1) val[3 + r] = i0 + j; }
+      }
+    }
+    if (act) { atomicMax((uint32_t*)&hash_tbl[slot[1]], ie); atomicMax((uint32_t*)&hash_tbl[slot[4]], ie); }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const uint32_t lb = ie - val[r];
+      const uint32_t pidx = 10 + r;
+      hp[lane * 6 + r] = lb <= window_n ? lb : (pidx < ie ? pidx : ie);
+    }
+    enc_wave_sync();
+    // ---- phase 2: element by element, lanes 0..15 = the 16 proposals ----
+    for (uint32_t e = 0; e < tile_n; e++) {
+      const uint32_t i = i0 + e;
+      const L l = pre[i];   // uniform
+      const uint32_t new_brute = i < 16 ? i : 16;
+      if (lane == new_brute - 1) proposed = new_brute;
+      if (lane >= 10 && lane < 16) proposed = hp[e * 6 + (lane - 10)];
+      uint32_t key = 0;
+      if (lane < 16) {
+        const uint32_t lb = proposed;
+        const uint32_t cnt = lb - 1 < kLbCountsLds ? lcounts[lb - 1] : __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const L other = pre[i - lb];
+        const L d1 = (L)(l - other), d2 = (L)(other - l);
+        const L dlt = d1 < d2 ? d1 : d2;
+        const uint32_t lz = LBits<L>::v - bitlen<L>(dlt);
+        const uint32_t goodness = (32u - clz_u32(cnt)) + lz;
+        key = (goodness << 4) | (15u - lane);  // max key = max goodness, first proposal on ties (lookback.rs:88-96)
+      }
+#pragma unroll
+      for (int d = 8; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(key, d, 64); key = o > key ? o : key; }
+      const uint32_t best_p = 15u - (uni(key) & 15u);
+      const uint32_t new_best = (uint32_t)__builtin_amdgcn_readlane((int)proposed, (int)best_p);
+      if (new_best != best_lookback) repeating_idx++;
+      if (lane == 6 + (repeating_idx & 3u)) proposed = new_best;
+      best_lookback = new_best;
+      if (lane == 0) {
+        lbs[i] = new_best;
+        if (new_best - 1 < kLbCountsLds) lcounts[new_best - 1] += 1;
+        else { const uint32_t c = __hip_atomic_load(&gcounts[new_best - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&gcounts[new_best - 1], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      enc_wave_sync();
+    }
+    __threadfence_block();
+    enc_wave_sync();
+    // ---- apply (lookback.rs:166-185): l[i] -= l[i - lb], + MID; reads the un-delta'd copy so it is parallel ----
+    if (act) {
+      const uint32_t lb = lbs[ie];
+      const L d = (L)((L)lv - pre[ie - lb] + lmid<L>());
+      out[ie] = d;
+      mn1 = d < mn1 ? d : mn1; mx1 = d > mx1 ? d : mx1; mn0 = lb < mn0 ? lb : mn0; mx0 = lb > mx0 ? lb : mx0;
+    }
+  }
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+    L o1 = shfl_idx(mn1, (int)(lane ^ dlt)); mn1 = o1 < mn1 ? o1 : mn1;
+    L o2 = shfl_idx(mx1, (int)(lane ^ dlt)); mx1 = o2 > mx1 ? o2 : mx1;
+    uint32_t o3 = __shfl_xor(mn0, dlt, 64); mn0 = o3 < mn0 ? o3 : mn0;
+    uint32_t o4 = __shfl_xor(mx0, dlt, 64); mx0 = o4 > mx0 ? o4 : mx0;
+  }
+  if (lane == 0) {
+    atomicMin((unsigned long long*)&ws.chunks[t].v[1].minv, (unsigned long long)mn1); atomicMax((unsigned long long*)&ws.chunks[t].v[1].maxv, (unsigned long long)mx1);
+    atomicMin((unsigned long long*)&ws.chunks[t].v[0].minv, (unsigned long long)mn0); atomicMax((unsigned long long*)&ws.chunks[t].v[0].maxv, (unsigned long long)mx0);
+  }
+}
+
+__global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, uint32_t n_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32) {
+  const uint32_t p = blockIdx.x;
+  if (p >= n_pages) return;
+  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+  if (uni(pg->flags) & kPageFlagMetaOnly) return;
+  const uint32_t t = uni(pg->chunk);
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (uni(ch->status) != PCO_GFX_OK || uni(ch->delta_kind) != kDeltaLookback) return;
+  uint32_t PCO_GLOBAL* base = (uint32_t PCO_GLOBAL*)lb_scratch + (uint64_t)p * scratch_stride_u32;
+  const uint32_t wlog = uni(ch->window_n_log);
+  uint32_t PCO_GLOBAL* hash_tbl = base; uint32_t PCO_GLOBAL* gcounts = base + (4ull << wlog);
+  const int bits = dtype_bits(uni(ch->dtype));
+  if (bits == 64) lookback_page<uint64_t>(ws, t, pg, hash_tbl, gcounts);
+  else if (bits == 32) lookback_page<uint32_t>(ws, t, pg, hash_tbl, gcounts);
+  else lookback_page<uint16_t>(ws, t, pg, hash_tbl, gcounts);
 }
 
 // =========================================================================================================
@@ -1020,7 +1165,7 @@ __device__ void page_task(const EncWorkspace& ws, const PcoGfxEncodeTask& task, 
   for (int v = 0; v < 3; v++) {
     present[v] = uni(ch->v[v].present); n_bins[v] = uni(ch->v[v].n_bins); asl[v] = uni(ch->v[v].ans_size_log); max_ob[v] = uni(ch->v[v].max_ob);
     needs_ans[v] = uni(ch->v[v].needs_ans); trivial[v] = uni(ch->v[v].is_trivial);
-    skip[v] = v == 1 ? uni(ch->v[1].lat_start) : 0u;                 // the page's junk prefix (delta state lives in the page meta)
+    skip[v] = v == 2 ? 0u : uni(ch->v[v].lat_start);                 // the page's junk prefix (delta state lives in the page meta)
     if (skip[v] > page_n) skip[v] = page_n;
     n_lat[v] = page_n - skip[v];
     voff[v] = off; if (present[v]) off += page_var_bytes(asl[v]);
@@ -1048,7 +1193,7 @@ __device__ void page_task(const EncWorkspace& ws, const PcoGfxEncodeTask& task, 
   for (int v = 0; v < 3; v++) {
     if (!present[v]) continue;
     if (v == 1) {
-      const uint32_t nlps = delta_kind == kDeltaConsecutive ? delta_order : 0u;
+      const uint32_t nlps = delta_kind == kDeltaConsecutive ? delta_order : (delta_kind == kDeltaLookback ? (1u << uni(ch->state_n_log)) : 0u);
       for (uint32_t i = 0; i < nlps; i++) sink.put_uniform(uni((uint64_t)pg->moments[i]), LB);
     }
     for (int j = 0; j < 4; j++) sink.put_uniform(fs[v][j] - (1u << asl[v]), asl[v]);
@@ -1070,7 +1215,10 @@ __device__ void page_task(const EncWorkspace& ws, const PcoGfxEncodeTask& task, 
 }
 
 // grid = number of page tasks; results are per page task
-__global__ __launch_bounds__(64) void enc_page_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, PcoGfxTaskResult* results, uint32_t n_pages) {
+#ifndef PCO_PAGE_MIN_WAVES
+#define PCO_PAGE_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(64, PCO_PAGE_MIN_WAVES) void enc_page_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, PcoGfxTaskResult* results, uint32_t n_pages) {
   const uint32_t p = blockIdx.x;
   if (p >= n_pages) return;
   EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;

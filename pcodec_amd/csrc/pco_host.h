@@ -47,10 +47,10 @@ struct Workspace {
   DevBuf tasks, results, tbl_ws;          // decode
   DevBuf io_in, io_out;                   // staging for the host-buffer entry points
   DevBuf enc_state;                       // encode: per chunk plans etc. (see encode_kernels.hip)
-  DevBuf enc_lat, enc_sort, enc_ans, enc_small;
+  DevBuf enc_lat, enc_sort, enc_ans, enc_small, enc_lb;
   void release_all() {
     tasks.release(); results.release(); tbl_ws.release(); io_in.release(); io_out.release();
-    enc_state.release(); enc_lat.release(); enc_sort.release(); enc_ans.release(); enc_small.release();
+    enc_state.release(); enc_lat.release(); enc_sort.release(); enc_ans.release(); enc_small.release(); enc_lb.release();
   }
 };
 Workspace& workspace();

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = np.load(os.path.join(HERE, "golden", "oracle_fixtures.npz"))
 FIX_NAMES = sorted({k.split("__")[0] for k in FIX.files})
 # product features still on the round's to-do list (DESIGN.md "gaps"): the product must refuse them loudly
-NOT_YET = {"i64_seasonal_lookback": "lookback encode", "i64_auto_auto": "Auto specs", "f64_auto_auto": "Auto specs"}
+NOT_YET = {"i64_auto_auto": "Auto specs", "f64_auto_auto": "Auto specs"}
 
 
 @pytest.fixture(scope="module")
@@ -71,7 +71,7 @@ def test_encode_committed_fixtures_byte_identical(L, name):
     assert U.gpu_simple_compress(nums, gcfg) == FIX[name + "__pco"].tobytes()
 
 
-@pytest.mark.parametrize("kind", ["c1", "c2", "c3", "c3d"])
+@pytest.mark.parametrize("kind", ["c1", "c2", "c3", "c3d", "c4"])
 def test_baseline_configs_full_size(L, kind):
     """BASELINE.json configs at n = 2^18: identical .pco bytes on encode, identical arrays on decode."""
     nums = U.synth(kind)
@@ -82,11 +82,22 @@ def test_baseline_configs_full_size(L, kind):
     assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums)
 
 
-def test_baseline_config4_decode_full_size(L):
-    nums = U.synth("c4")
-    _, ocfg = U.cfg_pair("c4")
-    enc = O.simple_compress(nums, ocfg)
-    assert U.bits_equal(U.gpu_simple_decompress(enc, nums.dtype, nums.size), nums)
+def test_lookback_matrix(L):
+    """delta/lookback.rs encode + decode: periodic data, hash hits beyond the LDS count cache, tiny inputs."""
+    rng = np.random.default_rng(21)
+    cases = []
+    for dt in (np.uint32, np.int64, np.uint64):
+        for n in (1, 2, 3, 17, 64, 65, 100, 1000, 9000, 40000):
+            per = rng.integers(0, 1 << 30, 9 if n < 100 else 777)
+            cases.append((per[np.arange(n) % len(per)] + rng.integers(0, 3, n)).astype(dt))
+    far = rng.integers(0, 1 << 40, 12000); cases.append(np.tile(far, 3).astype(np.int64))   # lookbacks of 12000 > 8192
+    cases.append(np.arange(3000, dtype=np.uint32) % 9)                                     # tests/recovery.rs:404-420
+    for nums in cases:
+        kw = dict(mode=1, delta=3)
+        want = O.simple_compress(nums, O.make_config(**kw))
+        got = U.gpu_simple_compress(nums, G.make_config(**kw))
+        assert got == want, (nums.dtype, nums.size)
+        assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums)
 
 
 def test_encode_matrix_small(L):
