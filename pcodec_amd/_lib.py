@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpco_gfx.so")
+LIB_PATH = os.environ.get("PCO_GFX_LIB", os.path.join(HERE, "libpco_gfx.so"))  # override only for A/B experiments
 
 PcoSuccess, PcoInvalidType, PcoCompressionError, PcoDecompressionError = range(4)
 ST_OK, ST_CORRUPTION, ST_INSUFFICIENT_DATA, ST_INVALID_ARGUMENT, ST_UNSUPPORTED, ST_DEVICE_ERROR = range(6)

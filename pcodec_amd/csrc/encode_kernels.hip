@@ -120,6 +120,7 @@ struct EncModePlan {  // host-resolved mode / delta (explicit specs; Auto is res
   uint32_t mode_kind, mode_k; uint64_t mode_base, mode_aux, mode_aux2;
   uint32_t delta_kind, delta_order, window_n_log, state_n_log;
   uint32_t n_pages, page_low, page_r, page_first;
+  uint32_t ubl_override, pad;   // 0xffffffff = derive from (level, n); trials use the full chunk's value
 };
 
 __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, const EncModePlan* plans, uint32_t n_tasks, uint32_t level) {
@@ -131,7 +132,7 @@ __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, 
   c.n = task.n; c.dtype = task.dtype; c.status = PCO_GFX_OK;
   c.mode_kind = mp.mode_kind; c.mode_k = mp.mode_k; c.mode_base = mp.mode_base; c.mode_aux = mp.mode_aux; c.mode_aux2 = mp.mode_aux2;
   c.delta_kind = mp.delta_kind; c.delta_order = mp.delta_order; c.window_n_log = mp.window_n_log; c.state_n_log = mp.state_n_log;
-  c.unopt_bins_log = choose_unoptimized_bins_log(level, task.n);
+  c.unopt_bins_log = mp.ubl_override != 0xffffffffu ? mp.ubl_override : choose_unoptimized_bins_log(level, task.n);
   const uint32_t lbits = (uint32_t)dtype_bits(task.dtype);
   const uint32_t nlps = mp.delta_kind == kDeltaConsecutive ? mp.delta_order : (mp.delta_kind == kDeltaLookback ? (1u << mp.state_n_log) : 0u);
   const uint64_t n = task.n;
@@ -147,6 +148,39 @@ __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, 
   c.v[2].latent_bits = lbits; c.v[2].lat_start = 0; c.v[2].n_lat = (uint32_t)n;
   if (c.unopt_bins_log > kMaxUnoptBinsLog) c.status = PCO_GFX_UNSUPPORTED;
   ws.chunks[t] = c;
+}
+
+// gather: out[k] = src[idx[k]]  (Auto sampling: sampling.rs:27-100)
+struct GatherTask { const void* src; void* dst; const uint32_t* idx; uint32_t n_idx, elem_bytes; };
+__global__ __launch_bounds__(256) void gather_kernel(const GatherTask* tasks) {
+  const GatherTask g = tasks[blockIdx.y];
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= g.n_idx) return;
+  const uint32_t i = g.idx[k];
+  if (g.elem_bytes == 8) ((uint64_t*)g.dst)[k] = ((const uint64_t*)g.src)[i];
+  else if (g.elem_bytes == 4) ((uint32_t*)g.dst)[k] = ((const uint32_t*)g.src)[i];
+  else ((uint16_t*)g.dst)[k] = ((const uint16_t*)g.src)[i];
+}
+
+// compact per-task record of a trained plan, for the host-side size estimate of Auto delta trials
+struct TrialSummary {
+  uint32_t status, fallback;
+  uint32_t asl[2], n_bins[2], n_lat[2];
+  uint16_t w[2][kMaxBins];
+  uint8_t ob[2][kMaxBins];
+};
+__global__ __launch_bounds__(256) void enc_trial_summary_kernel(EncWorkspace ws, TrialSummary* out, uint32_t n_tasks) {
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tasks) return;
+  const EncChunk* ch = ws.chunks + t;
+  TrialSummary* o = out + t;
+  if (threadIdx.x == 0) { o->status = ch->status; o->fallback = ch->fallback; }
+  for (int v = 0; v < 2; v++) {
+    const EncPlanVar* plan = ws.plans + (uint64_t)t * 3 + v;
+    const uint32_t nb = ch->v[v].present ? ch->v[v].n_bins : 0;
+    if (threadIdx.x == 0) { o->asl[v] = ch->v[v].ans_size_log; o->n_bins[v] = nb; o->n_lat[v] = ch->v[v].present ? ch->v[v].n_lat : 0; }
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) { o->w[v][b] = (uint16_t)plan->bweight[b]; o->ob[v][b] = plan->bob[b]; }
+  }
 }
 
 // =========================================================================================================

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <memory>
 
+#include "pco_auto_host.inc"
 #include "decode_kernel.hip"
 #include "encode_kernels.hip"
 

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = np.load(os.path.join(HERE, "golden", "oracle_fixtures.npz"))
 FIX_NAMES = sorted({k.split("__")[0] for k in FIX.files})
 # product features still on the round's to-do list (DESIGN.md "gaps"): the product must refuse them loudly
-NOT_YET = {"i64_auto_auto": "Auto specs", "f64_auto_auto": "Auto specs"}
+NOT_YET = {}
 
 
 @pytest.fixture(scope="module")
@@ -98,6 +98,38 @@ def test_lookback_matrix(L):
         got = U.gpu_simple_compress(nums, G.make_config(**kw))
         assert got == want, (nums.dtype, nums.size)
         assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums)
+
+
+def test_auto_specs(L):
+    """ModeSpec::Auto / DeltaSpec::Auto (the reference's default ChunkConfig, and the NULL config of its C ABI)."""
+    rng = np.random.default_rng(31)
+    n = 30000
+    cases = {
+        "ramp_u64": U.synth("c2", n),
+        "decimals_f64": rng.integers(1000, 10000, n) / 100.0,
+        "decimals_f32": (rng.integers(1000, 10000, n) / 100.0).astype(np.float32),
+        "quantised_f64": (rng.standard_normal(n) * 100).astype(np.float32).astype(np.float64),
+        "intmult_i64": (rng.integers(-1000, 1000, n) * 8 - 1).astype(np.int64),
+        "walk_i32": np.cumsum(rng.integers(-50, 60, n)).astype(np.int32),
+        "smooth_i64": (np.cumsum(np.cumsum(rng.integers(-3, 4, n))) + (1 << 30)).astype(np.int64),
+        "seasonal_i64": U.synth("c4", n),
+        "uniform_u32": rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32),
+        "normal_f32": rng.standard_normal(n).astype(np.float32),
+        "tiny_u32": np.arange(9, dtype=np.uint32),
+        "small_i64": np.arange(300, dtype=np.int64) ** 2,
+    }
+    for name, nums in cases.items():
+        for kw in (dict(), dict(mode=1), dict(delta=1), dict(level=4)):
+            want = O.simple_compress(nums, O.make_config(**kw))
+            got = U.gpu_simple_compress(nums, G.make_config(**kw))
+            assert got == want, (name, kw)
+    # the reference C ABI with a NULL config: Auto/Auto, level 8, uniform dtype byte (pco_c/src/lib.rs:34-55, standalone/simple.rs:22-48)
+    nums = cases["decimals_f64"]
+    cap = L.pco_standalone_guarantee_file_size(nums.size, 6); dst = np.zeros(cap, np.uint8); w = C.c_size_t(0)
+    G.check(L.pco_standalone_simple_compress_into(nums.ctypes.data_as(C.c_void_p), nums.size, 6, None, dst.ctypes.data_as(C.c_void_p), cap, C.byref(w)))
+    assert bytes(dst[: w.value]) == O.simple_compress(nums, O.make_config(), uniform_type=True)
+    import pcodec_amd as P  # default ChunkConfig() round trip through the Python mirror
+    np.testing.assert_array_equal(P.standalone.simple_decompress(P.standalone.simple_compress(nums, P.ChunkConfig())), nums)
 
 
 def test_encode_matrix_small(L):
