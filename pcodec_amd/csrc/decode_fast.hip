@@ -1,0 +1,678 @@
+// decode_fast.hip -- two-kernel chunk decoder for the common case (one chunk per task, tANS tables that fit
+// a 5.5 KB LDS slice).  The single-kernel decoder in decode_kernel.hip stays as the general fallback.
+//
+// Why two kernels: profiling the one-wave-per-chunk kernel showed it is ISSUE-bound in the tANS walk -- the
+// four interleaved chains of a chunk occupy 4 of 64 lanes, so 64 steps x ~50 instructions per batch are paid
+// per chunk.  Here
+//   dec_walk_kernel   packs EIGHT chunks into one wave (8 groups of 8 lanes; lanes 0-3 of a group walk that
+//                     chunk's 4 tANS chains in lock-step with the other groups), parses all metadata, builds the
+//                     decoder tables in LDS and emits one u16 bin symbol per latent plus the bit position of
+//                     every batch's offset section (page_latent_decompressor.rs:89-177);
+//   dec_expand_kernel is the embarrassingly parallel rest, one wave per chunk: offsets unpack, delta scans,
+//                     join, coalesced stores (page_latent_decompressor.rs:15-44, delta/*.rs, mode/*.rs).
+// Extra HBM traffic versus the fused kernel: 2 B written + 2 B read per latent.
+#include "decode_kernel.hip"
+
+namespace pcogfx {
+
+constexpr uint32_t kWQ = 8;                      // chunks per wave in dec_walk_kernel: FOUR LANES (one per tANS chain) per chunk
+constexpr uint32_t kGrpWinOff = 0;               // u64[56] ANS window of the chunk's current batch
+constexpr uint32_t kGrpVarOff = 448;             // VarInfo[3]
+constexpr uint32_t kGrpTblOff = 640;             // per variable: entries u32[T] | offset_bits u8[n_bins]
+constexpr uint32_t kGrpTblBytes = 4272;
+constexpr uint32_t kGrpBytes = kGrpTblOff + kGrpTblBytes;   // 4912
+constexpr uint32_t kWalkTmpOff = kWQ * kGrpBytes;            // u32[264] scratch for the table build (one chunk at a time)
+constexpr uint32_t kWalkLdsBytes = kWalkTmpOff + 1056;       // 40352: four waves per CU
+constexpr uint32_t kFastMaxBins = 256;
+constexpr uint32_t kStatusRetryLegacy = 100;     // internal: hand the task to the single-kernel decoder
+static_assert(kGrpBytes % 16 == 0, "chunk slices must stay 16-byte aligned");
+static_assert(kWalkLdsBytes < 65536, "walk entries hold 16-bit LDS addresses");
+
+struct DecPlan {   // written by dec_walk_kernel, read by dec_expand_kernel
+  uint32_t status, n;
+  uint32_t mode_kind, mode_k;
+  uint64_t mode_base;
+  uint32_t num_kind, dtype;
+  uint32_t present[3], n_bins[3], max_ob[3], delta_kind[3], delta_order[3], nlps[3];
+  uint32_t window_n_log, state_n_log;
+  uint64_t moments[2][8];
+  uint64_t consumed;
+};
+constexpr uint64_t kBinsAreaPerVar = kFastMaxBins * 8 + kFastMaxBins;   // lowers (8 B stride) then offset bits
+constexpr uint64_t kBinsAreaPerTask = 3 * kBinsAreaPerVar;
+
+// walk entry (one u32 per tANS state): bits 0..15 LDS byte address of the entry of next_state_idx_base, 16..23 the bin
+// symbol, 24..31 bits_to_read.  The byte-aligned fields let the walker move them with v_perm_b32.
+__device__ __forceinline__ uint32_t make_wentry(uint32_t addr, uint32_t sym, uint32_t btr) { return addr | (sym << 16) | (btr << 24); }
+
+// Build one variable's walk table for chunk slot `q`: u32 entries and per-bin offset bits in LDS; lowers / offset bits
+// go to the global bins area for dec_expand_kernel.  All 64 lanes cooperate.  (ans/spec.rs:37-59, ans/decoding.rs:27-47)
+template <class LV>
+__device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader& mr, uint8_t PCO_GLOBAL* bins_out, uint32_t& status) {
+  const uint32_t lane = lane_id();
+  uint8_t PCO_LDS* grp = lds_base() + q * kGrpBytes;
+  VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(grp + kGrpVarOff) + vi;
+  const uint32_t asl = uni(vinfo->ans_size_log), n_bins = uni(vinfo->n_bins), latent_bits = uni(vinfo->latent_bits);
+  const uint32_t T = 1u << asl;
+  const uint32_t tbl_addr = (uint32_t)(uintptr_t)lds_base() + q * kGrpBytes + kGrpTblOff + uni(vinfo->off_nodes);   // absolute LDS byte address
+  uint32_t PCO_LDS* entries = (uint32_t PCO_LDS*)(grp + kGrpTblOff + uni(vinfo->off_nodes));
+  uint8_t PCO_LDS* obs = grp + kGrpTblOff + uni(vinfo->off_ob);
+  uint32_t PCO_LDS* cum = (uint32_t PCO_LDS*)(lds_base() + kWalkTmpOff);
+  uint64_t PCO_GLOBAL* g_low = (uint64_t PCO_GLOBAL*)(bins_out + (uint64_t)vi * kBinsAreaPerVar);
+  uint8_t PCO_GLOBAL* g_ob = bins_out + (uint64_t)vi * kBinsAreaPerVar + kFastMaxBins * 8;
+  const uint32_t obb = offset_bits_bits(latent_bits);
+  const uint32_t bin_bits = asl + latent_bits + obb;
+  const uint64_t bins_start = mr.bit;
+  uint32_t bad = 0, max_ob = 0, carry = 0;
+  for (uint32_t b0 = 0; b0 < n_bins; b0 += 64) {
+    const uint32_t b = b0 + lane;
+    uint32_t w = 0;
+    if (b < n_bins) {
+      const uint64_t at = bins_start + (uint64_t)b * bin_bits;
+      w = (uint32_t)mr.peek(at, asl) + 1;
+      const uint64_t lower = mr.peek(at + asl, latent_bits);
+      const uint32_t ob = (uint32_t)mr.peek(at + asl + latent_bits, obb);
+      if (ob > latent_bits) bad = 1;
+      g_low[b] = lower; g_ob[b] = (uint8_t)ob; obs[b] = (uint8_t)ob;
+      max_ob = max_ob > ob ? max_ob : ob;
+    }
+    const uint32_t incl = wave_incl_scan(w);
+    if (b < n_bins) cum[b] = carry + incl - w;
+    carry += uni(shfl_idx(incl, 63));
+  }
+  if (lane == 0) cum[n_bins] = carry;
+  mr.bit = bins_start + (uint64_t)n_bins * bin_bits;
+  max_ob = uni(wave_max_u32(max_ob));
+  if (lane == 0) vinfo->max_ob = max_ob;
+  if (!mr.in_bounds()) { status = PCO_GFX_INSUFFICIENT_DATA; return false; }
+  if (uni(wave_or_u32(bad))) { status = PCO_GFX_CORRUPTION; return false; }
+  if (n_bins == 0) { if (lane == 0) entries[0] = make_wentry(tbl_addr, 0, 0); wave_sync_lds(); return true; }
+  if (carry != T) { status = PCO_GFX_CORRUPTION; return false; }
+  wave_sync_lds();
+  uint32_t stride = (3 * T) / 5; if ((stride & 1) == 0) stride += 1;
+  for (uint32_t t = lane; t < T; t += 64) {
+    uint32_t lo = 0, hi = n_bins;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= t) lo = mid; else hi = mid; }
+    entries[(stride * t) & (T - 1)] = lo;   // pass 1: the spread symbol only
+  }
+  wave_sync_lds();
+  for (uint32_t b0 = 0; b0 < n_bins; b0 += 64) {
+    const uint32_t b = b0 + lane;
+    uint32_t w = 0;
+    if (b < n_bins) w = cum[b + 1] - cum[b];
+    wave_sync_lds();
+    if (b < n_bins) cum[b] = w;
+    wave_sync_lds();
+  }
+  const uint32_t sym_bits = 32 - clz_u32(n_bins - 1 > 0 ? n_bins - 1 : 1);
+  for (uint32_t i0 = 0; i0 < T; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const bool act = i < T;
+    const uint32_t s = act ? entries[i] : 0xffffffffu;
+    uint64_t m = __ballot(act);
+    for (uint32_t bit = 0; bit < sym_bits; bit++) { const uint64_t bm = __ballot((s >> bit) & 1); m &= ((s >> bit) & 1) ? bm : ~bm; }
+    const uint64_t lt = ((uint64_t)1 << lane) - 1;
+    const uint32_t rank = __popcll(m & lt), gcount = __popcll(m);
+    const uint32_t basec = act ? cum[s] : 0;
+    wave_sync_lds();
+    if (act && rank == 0) cum[s] = basec + gcount;
+    wave_sync_lds();
+    if (act) { const uint32_t x_s = basec + rank; const uint32_t btr = clz_u32(x_s) - clz_u32(T); entries[i] = make_wentry(tbl_addr + 4u * ((x_s << btr) - T), s, btr); }
+  }
+  wave_sync_lds();
+  return true;
+}
+
+struct FrontOut {
+  uint32_t status, n;
+  uint64_t bitpos;          // first bit of the page body
+  uint32_t states[3][4];
+};
+
+// Everything before the page body for one task, executed by the whole wave on behalf of group q.
+template <class L>
+__device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q, DecPlan PCO_GLOBAL* plan, uint8_t PCO_GLOBAL* bins_out, FrontOut& out) {
+  const uint32_t lane = lane_id();
+  gcptr_u8 src = (gcptr_u8)task.src;
+  const uint64_t src_len = uni((uint64_t)task.src_len);
+  const uint32_t dtype = uni(task.dtype), flags = uni(task.flags);
+  const uint64_t dst_cap = uni((uint64_t)task.dst_cap);
+  constexpr uint32_t LB = LBits<L>::v;
+  MetaReader mr{src, src_len, 0};
+  uint32_t status = PCO_GFX_OK, format_major = 4, uniform_type = 0;
+  out.status = PCO_GFX_OK; out.n = 0; out.bitpos = 0;
+  for (int v = 0; v < 3; v++) for (int j = 0; j < 4; j++) out.states[v][j] = 0;
+  VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(lds_base() + q * kGrpBytes + kGrpVarOff);
+  auto fail = [&](uint32_t s) { out.status = s; if (lane == 0) { plan->status = s; plan->consumed = mr.bit >> 3; plan->n = 0; } };
+  if (dtype_bits(dtype) != (int)LB) { fail(PCO_GFX_INVALID_ARGUMENT); return; }
+  if (flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY)) { fail(kStatusRetryLegacy); return; }
+  if (flags & PCO_GFX_TASK_HAS_FILE_HEADER) {  // standalone/decompressor.rs:85-137
+    const uint32_t magic = (uint32_t)mr.read(32);
+    if (!mr.in_bounds()) status = PCO_GFX_INSUFFICIENT_DATA; else if (magic != 0x216f6370u) status = PCO_GFX_CORRUPTION;
+    if (!status) {
+      const uint32_t sv = (uint32_t)mr.read(8);
+      if (sv < 2) mr.bit -= 8;
+      else {
+        if (sv >= 3) { const uint32_t ub = (uint32_t)mr.read(8); if (ub != 0) { if (dtype_bits(ub) == 0) status = PCO_GFX_CORRUPTION; uniform_type = ub; } }
+        if (!status) { const uint32_t power = 1 + (uint32_t)mr.read(kBitsVarintPower); mr.read(power); if (!mr.drain_empty_byte() && mr.in_bounds()) status = PCO_GFX_CORRUPTION; }
+      }
+      if (!status && !mr.in_bounds()) status = PCO_GFX_INSUFFICIENT_DATA;
+      if (!status && sv > 3) status = PCO_GFX_CORRUPTION;
+      if (!status) {
+        format_major = (uint32_t)mr.read(8);
+        if (format_major >= 4) mr.read(8);
+        if (format_major > 4) status = PCO_GFX_CORRUPTION; else if (!mr.in_bounds()) status = PCO_GFX_INSUFFICIENT_DATA;
+      }
+    }
+    if (status) { fail(status); return; }
+  } else if (src_len == 0) { fail(kStatusRetryLegacy); return; }  // empty stream: zero chunks
+  // chunk preamble (standalone/decompressor.rs:190-231)
+  const uint32_t tb = (uint32_t)mr.read(8);
+  if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
+  if (tb == 0) { fail(kStatusRetryLegacy); return; }  // empty file: the general path reports it
+  if ((uniform_type && uniform_type != tb) || tb != dtype) { fail(PCO_GFX_CORRUPTION); return; }
+  const uint32_t n = (uint32_t)mr.read(kBitsNEntries) + 1;
+  if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
+  if (n > dst_cap) { fail(PCO_GFX_INVALID_ARGUMENT); return; }
+  const uint32_t num_kind = dtype_kind(dtype);
+  // ChunkMeta (metadata/chunk.rs:127-174), as in decode_kernel.hip::decode_chunk
+  const uint32_t mode_kind = (uint32_t)mr.read(kBitsModeVariant);
+  L mode_base = 0; uint32_t mode_k = 0;
+  if (mode_kind == kIntMult) { if (format_major == 0) { fail(PCO_GFX_CORRUPTION); return; } mode_base = (L)mr.read(LB); }
+  else if (mode_kind == kFloatMult) mode_base = (L)mr.read(LB);
+  else if (mode_kind == kFloatQuant) mode_k = (uint32_t)mr.read(kBitsQuantK);
+  else if (mode_kind == kDict) { fail(mr.in_bounds() ? PCO_GFX_UNSUPPORTED : PCO_GFX_INSUFFICIENT_DATA); return; }
+  else if (mode_kind != kClassic) { fail(mr.in_bounds() ? PCO_GFX_CORRUPTION : PCO_GFX_INSUFFICIENT_DATA); return; }
+  if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
+  uint32_t dkind = kDeltaNone, dorder = 0, wlog = 0, slog = 0; bool sec_uses_delta = false;
+  if (format_major < 3) { dorder = (uint32_t)mr.read(kBitsDeltaOrder); if (dorder) dkind = kDeltaConsecutive; }
+  else {
+    const uint32_t variant = (uint32_t)mr.read(kBitsDeltaVariant);
+    if (variant == 1) { dorder = (uint32_t)mr.read(kBitsDeltaOrder); if (dorder == 0) { fail(PCO_GFX_CORRUPTION); return; } dkind = kDeltaConsecutive; sec_uses_delta = mr.read(1) != 0; }
+    else if (variant == 2) {
+      wlog = 1 + (uint32_t)mr.read(kBitsLookbackWindowLog); slog = (uint32_t)mr.read(kBitsLookbackStateLog);
+      if (wlog > kMaxLookbackWindowLog || slog > wlog) { fail(PCO_GFX_CORRUPTION); return; }
+      dkind = kDeltaLookback; sec_uses_delta = mr.read(1) != 0;
+    } else if (variant == 3) { fail(mr.in_bounds() ? PCO_GFX_UNSUPPORTED : PCO_GFX_INSUFFICIENT_DATA); return; }
+    else if (variant != 0) { fail(PCO_GFX_CORRUPTION); return; }
+  }
+  if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
+  const uint32_t present[3] = {dkind == kDeltaLookback ? 1u : 0u, 1u, (mode_kind == kIntMult || mode_kind == kFloatMult || mode_kind == kFloatQuant) ? 1u : 0u};
+  uint32_t total_tbl = 0; bool too_big = false;
+  {
+    MetaReader peek = mr;
+#pragma unroll
+    for (int vi = 0; vi < 3; vi++) {
+      VarInfo v{};
+      v.present = present[vi]; v.latent_bits = vi == 0 ? 32u : LB;
+      if (vi == 1 || (vi == 2 && sec_uses_delta)) { v.delta_kind = dkind; v.delta_order = dorder; v.window_n_log = wlog; v.state_n_log = slog; }
+      if (present[vi]) {
+        const uint32_t a = (uint32_t)peek.read(kBitsAnsSizeLog), nb = (uint32_t)peek.read(kBitsNBins);
+        if (!peek.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
+        if ((1u << a) < nb || (nb == 1 && a > 0) || a > kMaxAnsBits) { fail(PCO_GFX_CORRUPTION); return; }
+        v.ans_size_log = a; v.n_bins = nb;
+        v.off_nodes = total_tbl; v.off_lower = 0; v.off_ob = total_tbl + (4u << a);
+        total_tbl += (4u << a) + ((nb + 7u) & ~7u);
+        total_tbl = (total_tbl + 7u) & ~7u;
+        if (nb > kFastMaxBins || a > 12) too_big = true;
+        peek.bit += (uint64_t)nb * (a + v.latent_bits + offset_bits_bits(v.latent_bits));
+      }
+      if (lane == 0) { uint32_t PCO_LDS* p = (uint32_t PCO_LDS*)(vinfo + vi); const uint32_t* qq = (const uint32_t*)&v; for (int w = 0; w < 16; w++) p[w] = qq[w]; }
+    }
+  }
+  wave_sync_lds();
+  if (too_big || total_tbl > kGrpTblBytes) { fail(kStatusRetryLegacy); return; }
+  if (dkind == kDeltaLookback && (mode_kind != kClassic || sec_uses_delta)) { fail(kStatusRetryLegacy); return; }  // the general path reports it
+#pragma unroll
+  for (int vi = 0; vi < 3; vi++) {
+    if (!present[vi]) continue;
+    mr.bit += kBitsAnsSizeLog + kBitsNBins;
+    const bool ok = vi == 0 ? fast_build_var<uint32_t>(q, vi, mr, bins_out, status) : fast_build_var<L>(q, vi, mr, bins_out, status);
+    if (!ok) { fail(status); return; }
+  }
+  if (!mr.drain_empty_byte()) { if (mr.in_bounds()) { fail(PCO_GFX_CORRUPTION); return; } }
+  if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
+  if (dkind == kDeltaLookback) {  // metadata/chunk.rs:38-57
+    const uint32_t nb0 = uni(vinfo[0].n_bins);
+    const uint64_t PCO_GLOBAL* lw = (const uint64_t PCO_GLOBAL*)bins_out;
+    uint32_t bad = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    for (uint32_t b = lane; b < nb0; b += 64) { const uint64_t x = __hip_atomic_load(&lw[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (x < 1 || x > (1ull << wlog)) bad = 1; }
+    if (uni(wave_or_u32(bad))) { fail(PCO_GFX_CORRUPTION); return; }
+  }
+  {  // mode validity (data_types/unsigned.rs:65-71, float.rs:377-390)
+    bool valid = true;
+    if (mode_kind == kIntMult) valid = num_kind != kFloat && mode_base > 0;
+    else if (mode_kind == kFloatQuant) { const uint32_t prec = LB == 64 ? 52 : (LB == 32 ? 23 : 10); valid = num_kind == kFloat && mode_k > 0 && mode_k <= prec; }
+    else if (mode_kind == kFloatMult) {
+      if (num_kind != kFloat) valid = false;
+      else if constexpr (sizeof(L) >= 4) { typedef typename FloatOf<L>::F F; const F b = bits_to_float(from_latent_ordered<L>(mode_base, kFloat)); valid = isfinite(b) && b != (F)0; }
+      else { fail(PCO_GFX_UNSUPPORTED); return; }
+    }
+    if (!valid) { fail(PCO_GFX_CORRUPTION); return; }
+  }
+  // page meta (metadata/page.rs:36-57, page_latent_var.rs:28-49)
+  uint32_t nlps[3];
+#pragma unroll
+  for (int vi = 0; vi < 3; vi++) {
+    const uint32_t dk = uni(vinfo[vi].delta_kind);
+    nlps[vi] = dk == kDeltaConsecutive ? uni(vinfo[vi].delta_order) : (dk == kDeltaLookback ? (1u << uni(vinfo[vi].state_n_log)) : 0u);
+  }
+  L PCO_GLOBAL* dst = (L PCO_GLOBAL*)task.dst;
+#pragma unroll
+  for (int vi = 0; vi < 3; vi++) {
+    if (!present[vi]) continue;
+    const uint32_t lbits = vi == 0 ? 32u : LB;
+    const uint32_t dk = uni(vinfo[vi].delta_kind);
+    for (uint32_t i = 0; i < nlps[vi]; i++) {
+      const L x = (L)mr.read(lbits);
+      if (dk == kDeltaConsecutive) { if (lane == 0 && i < 8) plan->moments[vi == 2 ? 1 : 0][i] = (uint64_t)x; }
+      else if (vi == 1 && i < n && mr.in_bounds()) { if (lane == 0) dst[i] = from_latent_ordered<L>(x, num_kind); }
+    }
+    const uint32_t asl = uni(vinfo[vi].ans_size_log);
+    for (uint32_t j = 0; j < 4; j++) out.states[vi][j] = (uint32_t)mr.read(asl);
+  }
+  if (!mr.drain_empty_byte()) { if (mr.in_bounds()) { fail(PCO_GFX_CORRUPTION); return; } }
+  if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
+  const uint32_t n_in_body = n > nlps[1] ? n - nlps[1] : 0;
+  if (n_in_body > 0) for (int vi = 0; vi < 3; vi++) if (present[vi] && uni(vinfo[vi].n_bins) == 0) { fail(PCO_GFX_CORRUPTION); return; }
+  if (lane == 0) {
+    plan->status = PCO_GFX_OK; plan->n = n; plan->mode_kind = mode_kind; plan->mode_k = mode_k; plan->mode_base = (uint64_t)mode_base;
+    plan->num_kind = num_kind; plan->dtype = dtype; plan->window_n_log = wlog; plan->state_n_log = slog; plan->consumed = 0;
+    for (int vi = 0; vi < 3; vi++) {
+      plan->present[vi] = present[vi]; plan->n_bins[vi] = vinfo[vi].n_bins; plan->max_ob[vi] = vinfo[vi].max_ob;
+      plan->delta_kind[vi] = vinfo[vi].delta_kind; plan->delta_order[vi] = vinfo[vi].delta_order; plan->nlps[vi] = nlps[vi];
+    }
+  }
+  out.n = n; out.bitpos = mr.bit;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dec_walk_kernel: kWQ chunks per wave, four lanes per chunk (lane 4c+j walks tANS chain j of chunk slot c).
+//
+// The walk is a serial chain of n/4 steps per chunk, so the kernel is LATENCY-bound by construction; everything in
+// walk_step() is arranged around its critical path
+//   ds_read entry -> v_perm (bits_to_read into byte j) -> 2 quad DPP adds -> and + v_sad_u8 (bit position)
+//   -> v_alignbit / 2 v_cndmask (window extract) -> v_bfe -> v_lshl_add (next entry address).
+// The chunk's bit window lives in registers (w0..w5, refilled from the LDS copy of the batch's ANS section) so no
+// second LDS round trip sits on that path.  Symbols leave in 16-element blocks: dword j of a block holds chain j's
+// symbols of four consecutive steps (dec_expand_kernel undoes this).
+// ---------------------------------------------------------------------------------------------------------
+struct WalkRegs {
+  uint32_t saddr;                    // LDS byte address of the current state's entry
+  uint32_t w0, w1, w2, w3, w4, w5;   // 192-bit window; bit `rel` of (w1:w0) is the next unread bit
+  uint32_t rel, wq_addr;             // wq_addr: LDS address of the qword currently in (w5:w4)
+  uint32_t obsum, symacc;
+};
+
+template <int K, bool kTail>
+__device__ __forceinline__ void walk_step(WalkRegs& r, uint32_t sel_bb, uint32_t lowmask, uint32_t obs_addr, bool chain_on) {
+  const uint32_t e = *(const uint32_t PCO_LDS*)(uintptr_t)r.saddr;
+  uint32_t bb = __builtin_amdgcn_perm(e, 0u, sel_bb);
+  if (kTail) bb = chain_on ? bb : 0u;
+  uint32_t P = bb + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bb, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  P = P + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x4E, 0xf, 0xf, false);               // quad_perm [2,3,0,1]
+  const uint32_t h = __builtin_amdgcn_sad_u8(P & lowmask, 0u, r.rel);
+  const uint32_t rel2 = __builtin_amdgcn_sad_u8(P, 0u, r.rel);
+  const uint32_t c0 = __builtin_amdgcn_alignbit(r.w1, r.w0, h), c1 = __builtin_amdgcn_alignbit(r.w2, r.w1, h);
+  const uint32_t c2 = __builtin_amdgcn_alignbit(r.w3, r.w2, h), c3 = __builtin_amdgcn_alignbit(r.w4, r.w3, h);
+  const uint32_t c01 = h < 32 ? c0 : c1, c23 = h < 96 ? c2 : c3;
+  const uint32_t vraw = h < 64 ? c01 : c23;
+  const uint32_t btr = e >> 24;
+  const uint32_t v = __builtin_amdgcn_ubfe(vraw, 0u, btr);
+  const uint32_t next = ((e & 0xffffu) + (v << 2));
+  if (kTail) r.saddr = chain_on ? next : r.saddr; else r.saddr = next;
+  // off the critical path: symbol, offset bits, window advance
+  constexpr uint32_t sel_sym = K == 0 ? 0x03020106u : (K == 1 ? 0x03020600u : (K == 2 ? 0x03060100u : 0x06020100u));
+  r.symacc = __builtin_amdgcn_perm(e, r.symacc, sel_sym);
+  const uint32_t ob = *(const uint8_t PCO_LDS*)(uintptr_t)(obs_addr + ((e >> 16) & 0xffu));
+  if (kTail) r.obsum += chain_on ? ob : 0u; else r.obsum += ob;
+  const bool adv = rel2 >= 64;
+  r.w0 = adv ? r.w2 : r.w0; r.w1 = adv ? r.w3 : r.w1; r.w2 = adv ? r.w4 : r.w2; r.w3 = adv ? r.w5 : r.w3;
+  r.wq_addr += adv ? 8u : 0u;
+  r.rel = rel2 & 63u;
+  const uint64_t nq = *(const uint64_t PCO_LDS*)(uintptr_t)r.wq_addr;
+  r.w4 = (uint32_t)nq; r.w5 = (uint32_t)(nq >> 32);
+}
+
+template <class L>
+__global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
+                                                      uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride) {
+  const uint32_t lane = lane_id();
+  const uint32_t slot = lane >> 2, j = lane & 3;
+  // ---- phase 0: metadata + tables, one task at a time with the whole wave; slot q belongs to lanes 4q..4q+3 ----
+  uint32_t my_ti = 0xffffffffu, my_active = 0, my_front_ok = 0, my_n = 0, my_flags = 0;
+  uint32_t st0 = 0, st1 = 0, st2 = 0;   // this lane's chain state per variable, as an entry address
+  uint64_t my_bitpos = 0, my_len = 0;
+  gcptr_u8 my_src = nullptr;
+  for (uint32_t q = 0; q < kWQ; q++) {
+    const uint32_t bi = blockIdx.x * kWQ + q;
+    if (bi >= n_ids) break;
+    const uint32_t ti = task_ids ? task_ids[bi] : bi;
+    const PcoGfxDecodeTask task = tasks[ti];
+    FrontOut fo;
+    fast_front<L>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);
+    if (slot == q) {
+      my_ti = ti; my_active = fo.status == PCO_GFX_OK ? 1u : 0u; my_front_ok = my_active; my_n = fo.n; my_bitpos = fo.bitpos;
+      my_len = task.src_len; my_flags = task.flags; my_src = (gcptr_u8)task.src;
+      st0 = j == 0 ? fo.states[0][0] : (j == 1 ? fo.states[0][1] : (j == 2 ? fo.states[0][2] : fo.states[0][3]));
+      st1 = j == 0 ? fo.states[1][0] : (j == 1 ? fo.states[1][1] : (j == 2 ? fo.states[1][2] : fo.states[1][3]));
+      st2 = j == 0 ? fo.states[2][0] : (j == 1 ? fo.states[2][1] : (j == 2 ? fo.states[2][2] : fo.states[2][3]));
+    }
+    wave_sync_lds();
+  }
+  const uint32_t slice = (slot < kWQ ? slot : 0u) * kGrpBytes;   // LDS byte offset of this chunk's slice
+  uint8_t PCO_LDS* gbase = lds_base() + slice;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds_base();
+  uint64_t PCO_LDS* win = (uint64_t PCO_LDS*)(gbase + kGrpWinOff);
+  VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(gbase + kGrpVarOff);
+  // ---- phase 1: rounds; in each round every active chunk handles its next (batch, variable) item ----
+  uint32_t n_rem = my_n, batch = 0, cur_v = 0, status = PCO_GFX_OK, present_mask = 0, nlps1 = 0;
+  if (my_active) {
+    present_mask = (vinfo[0].present ? 1u : 0u) | 2u | (vinfo[2].present ? 4u : 0u);
+    nlps1 = vinfo[1].delta_kind == kDeltaConsecutive ? vinfo[1].delta_order : (vinfo[1].delta_kind == kDeltaLookback ? (1u << vinfo[1].state_n_log) : 0u);
+    cur_v = (present_mask & 1u) ? 0u : 1u;
+    if (n_rem == 0) my_active = 0;
+    // states -> entry addresses
+    st0 = lds0 + slice + kGrpTblOff + vinfo[0].off_nodes + 4u * st0;
+    st1 = lds0 + slice + kGrpTblOff + vinfo[1].off_nodes + 4u * st1;
+    st2 = lds0 + slice + kGrpTblOff + vinfo[2].off_nodes + 4u * st2;
+  }
+  const uint32_t sel_bb = j == 0 ? 0x0c0c0c07u : (j == 1 ? 0x0c0c070cu : (j == 2 ? 0x0c070c0cu : 0x070c0c0cu));
+  const uint32_t lowmask = (1u << (8 * j)) - 1u;
+  while (__any(my_active != 0)) {
+    uint32_t cnt = 0, nb = 0, asl = 0, off_ob = 0;
+    bool walk = false;
+    if (my_active) {
+      const VarInfo PCO_LDS* vi = vinfo + cur_v;
+      nb = vi->n_bins; asl = vi->ans_size_log; off_ob = vi->off_ob;
+      const uint32_t batch_n = n_rem < kBatchN ? n_rem : kBatchN;
+      if (cur_v == 0) { const uint32_t lim = n_rem > nlps1 ? n_rem - nlps1 : 0; cnt = lim < batch_n ? lim : batch_n; }
+      else {
+        const uint32_t nl = cur_v == 1 ? nlps1 : (vi->delta_kind == kDeltaConsecutive ? vi->delta_order : (vi->delta_kind == kDeltaLookback ? (1u << vi->state_n_log) : 0u));
+        const uint32_t rem = n_rem > nl ? n_rem - nl : 0; cnt = rem < kBatchN ? rem : kBatchN;
+      }
+      walk = cnt > 0 && nb > 1;
+    }
+    const uint64_t q0 = my_bitpos >> 6;   // first qword of the window, in qwords from src
+    WalkRegs r;
+    r.saddr = cur_v == 0 ? st0 : (cur_v == 1 ? st1 : st2);
+    r.rel = (uint32_t)(my_bitpos & 63); r.obsum = 0; r.symacc = 0;
+    r.w0 = r.w1 = r.w2 = r.w3 = r.w4 = r.w5 = 0; r.wq_addr = lds0 + slice + kGrpWinOff + 16;
+    if (walk) {  // stage the batch's ANS section: the chunk's 4 lanes copy qword pairs, all loads in flight at once
+      const uint32_t nq = ((r.rel + cnt * asl + 63u) >> 6) + 3u;   // <= 53
+      uint64_t lo[7], hi[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        const uint32_t qi = 2 * j + 8 * k;
+        lo[k] = 0; hi[k] = 0;
+        if (qi < nq) { lo[k] = load_u64_le_safe(my_src, (q0 + qi) * 8, my_len + 16); hi[k] = load_u64_le_safe(my_src, (q0 + qi + 1) * 8, my_len + 16); }
+      }
+#pragma unroll
+      for (int k = 0; k < 7; k++) { const uint32_t qi = 2 * j + 8 * k; if (qi < nq) { win[qi] = lo[k]; win[qi + 1] = hi[k]; } }
+    }
+    wave_sync_lds();
+    const uint32_t obs_addr = lds0 + slice + kGrpTblOff + off_ob;
+    uint8_t PCO_GLOBAL* sym_out = (uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)(my_ti == 0xffffffffu ? 0u : my_ti) * 3 + cur_v) * sym_stride + (uint64_t)batch * kBatchN + 4 * j;
+    if (walk) {
+      const uint64_t a = win[0], b = win[1], c = win[2];
+      r.w0 = (uint32_t)a; r.w1 = (uint32_t)(a >> 32); r.w2 = (uint32_t)b; r.w3 = (uint32_t)(b >> 32); r.w4 = (uint32_t)c; r.w5 = (uint32_t)(c >> 32);
+      if (__all(!walk || cnt == kBatchN)) {   // (lanes outside `walk` are masked off here anyway)
+        for (uint32_t blk = 0; blk < 16; blk++) {
+          walk_step<0, false>(r, sel_bb, lowmask, obs_addr, true);
+          walk_step<1, false>(r, sel_bb, lowmask, obs_addr, true);
+          walk_step<2, false>(r, sel_bb, lowmask, obs_addr, true);
+          walk_step<3, false>(r, sel_bb, lowmask, obs_addr, true);
+          *(uint32_t PCO_GLOBAL*)(sym_out + 16 * blk) = r.symacc;
+        }
+      } else {
+        const uint32_t steps = (cnt + 3) >> 2;
+        for (uint32_t blk = 0; blk * 4 < steps; blk++) {
+          const uint32_t g = blk * 4;
+          if (g + 0 < steps) walk_step<0, true>(r, sel_bb, lowmask, obs_addr, 4 * (g + 0) + j < cnt);
+          if (g + 1 < steps) walk_step<1, true>(r, sel_bb, lowmask, obs_addr, 4 * (g + 1) + j < cnt);
+          if (g + 2 < steps) walk_step<2, true>(r, sel_bb, lowmask, obs_addr, 4 * (g + 2) + j < cnt);
+          if (g + 3 < steps) walk_step<3, true>(r, sel_bb, lowmask, obs_addr, 4 * (g + 3) + j < cnt);
+          *(uint32_t PCO_GLOBAL*)(sym_out + 16 * blk) = r.symacc;
+        }
+      }
+      if (cur_v == 0) st0 = r.saddr; else if (cur_v == 1) st1 = r.saddr; else st2 = r.saddr;
+    }
+    if (my_active) {
+      // the four chains' offset-bit sums -> the chunk total (quad butterfly)
+      uint32_t obq = r.obsum;
+      obq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)obq, 0xB1, 0xf, 0xf, false);
+      obq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)obq, 0x4E, 0xf, 0xf, false);
+      const uint64_t ans_end = walk ? ((q0 << 6) + (uint64_t)((r.wq_addr - (lds0 + slice + kGrpWinOff + 16)) >> 3) * 64 + r.rel) : my_bitpos;
+      uint64_t ob_total = 0;
+      if (cnt > 0) ob_total = walk ? (uint64_t)obq : (nb == 1 ? (uint64_t)cnt * *(const uint8_t PCO_LDS*)(uintptr_t)obs_addr : 0ull);
+      if (cnt > 0 && j == 0) offpos_area[((uint64_t)my_ti * 3 + cur_v) * offpos_stride + batch] = ans_end;
+      my_bitpos = ans_end + ob_total;
+      if (my_bitpos > my_len * 8) { status = PCO_GFX_INSUFFICIENT_DATA; my_active = 0; }
+      uint32_t nv = cur_v + 1;
+      while (nv < 3 && !((present_mask >> nv) & 1u)) nv++;
+      if (nv >= 3) {
+        const uint32_t batch_n = n_rem < kBatchN ? n_rem : kBatchN;
+        n_rem -= batch_n; batch++;
+        nv = (present_mask & 1u) ? 0u : 1u;
+        if (n_rem == 0) my_active = 0;
+      }
+      cur_v = nv;
+    }
+    wave_sync_lds();
+  }
+  // ---- page end (page_decompressor.rs:184-188) and stream end ----
+  if (my_ti != 0xffffffffu && j == 0 && slot < kWQ) {
+    DecPlan PCO_GLOBAL* plan = (DecPlan PCO_GLOBAL*)plans + my_ti;
+    if (my_front_ok) {
+      uint64_t bit = my_bitpos;
+      if (status == PCO_GFX_OK) {
+        const uint32_t sh = (uint32_t)(bit & 7);
+        if (sh) { const uint64_t byte = bit >> 3; const uint32_t b = byte < my_len ? my_src[byte] : 0u; if ((b >> sh) != 0) status = PCO_GFX_CORRUPTION; bit += 8 - sh; }
+        if (bit > my_len * 8) status = PCO_GFX_INSUFFICIENT_DATA;
+      }
+      if (status == PCO_GFX_OK) {
+        uint64_t byte = bit >> 3;
+        if (my_flags & PCO_GFX_TASK_HAS_FILE_HEADER) {
+          if (byte >= my_len) status = PCO_GFX_INSUFFICIENT_DATA;
+          else if (my_src[byte] != 0) status = kStatusRetryLegacy;  // another chunk follows: general path
+          else byte += 1;
+        } else if (byte < my_len) status = kStatusRetryLegacy;
+        plan->consumed = byte;
+      }
+      plan->status = status;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dec_expand_kernel: one wave per chunk, everything after the tANS walk
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kExpLowOff = 0;                         // u64[3][256] lowers
+constexpr uint32_t kExpObOff = 3 * 2048;                   // u8[3][256]
+constexpr uint32_t kExpMomOff = kExpObOff + 768;           // u64[2][8]
+constexpr uint32_t kExpDlatOff = kExpMomOff + 128;         // u32[256]
+constexpr uint32_t kExpScratchOff = kExpDlatOff + 1024;    // u64[256]
+constexpr uint32_t kExpParentOff = kExpScratchOff + 2048;  // u32[256]
+constexpr uint32_t kExpLdsBytes = kExpParentOff + 1024;    // 11136
+
+template <class LV>
+__device__ __forceinline__ uint64_t expand_offsets(gcptr_u8 src, uint64_t src_len, uint64_t bitpos, uint32_t cnt, const uint8_t PCO_GLOBAL* syms,
+                                                    const uint64_t PCO_LDS* lowers, const uint8_t PCO_LDS* obs, bool single_bin, LV out[4]) {
+  const uint32_t lane = lane_id();
+  uint32_t ob[4]; LV low[4];
+  uint32_t s4[4] = {0, 0, 0, 0};
+  if (!single_bin) {
+    // dec_walk_kernel's block layout: dword j of 16-byte block (lane >> 2) holds chain j's symbols of steps 4*(lane>>2)..+3
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 blk = *(const u32x4 PCO_GLOBAL*)(syms + 16 * (lane >> 2));
+    const uint32_t sh = 8 * (lane & 3);
+    s4[0] = (blk.x >> sh) & 0xff; s4[1] = (blk.y >> sh) & 0xff; s4[2] = (blk.z >> sh) & 0xff; s4[3] = (blk.w >> sh) & 0xff;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const bool act = 4 * lane + k < cnt;
+    const uint32_t s = act ? s4[k] : 0u;
+    ob[k] = act ? (uint32_t)obs[s] : 0u;
+    low[k] = act ? (LV)lowers[s] : (LV)0;
+  }
+  const uint32_t t = ob[0] + ob[1] + ob[2] + ob[3];
+  const uint32_t incl = wave_incl_scan(t);
+  const uint32_t total = uni(shfl_idx(incl, 63));
+  uint64_t b = bitpos + (incl - t);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint64_t val = 0;
+    if (ob[k] != 0) {
+      const uint64_t byte = b >> 3; const uint32_t sh = (uint32_t)(b & 7);
+      val = load_u64_le_safe(src, byte, src_len + 16) >> sh;
+      if (sh + ob[k] > 64) val |= load_u64_le_safe(src, byte + 8, src_len + 16) << (64 - sh);
+      if (ob[k] < 64) val &= ((uint64_t)1 << ob[k]) - 1;
+    }
+    out[k] = (LV)(low[k] + (LV)val);
+    b += ob[k];
+  }
+  return bitpos + total;
+}
+
+template <class L>
+__global__ __launch_bounds__(64) void dec_expand_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids, uint32_t n_ids,
+                                                        const DecPlan* plans, const uint8_t* bins_area, const uint8_t* sym_area, uint64_t sym_stride,
+                                                        const uint64_t* offpos_area, uint64_t offpos_stride) {
+  const uint32_t lane = lane_id();
+  uint8_t PCO_LDS* smem = lds_base();
+  for (uint32_t bi = blockIdx.x; bi < n_ids; bi += gridDim.x) {
+    const uint32_t ti = task_ids ? task_ids[bi] : bi;
+    const DecPlan PCO_GLOBAL* plan = (const DecPlan PCO_GLOBAL*)plans + ti;
+    const uint32_t pstatus = uni(plan->status);
+    if (pstatus == kStatusRetryLegacy) continue;   // the single-kernel decoder finishes this task
+    if (pstatus != PCO_GFX_OK) {
+      if (lane == 0) { PcoGfxTaskResult r; r.n_out = 0; r.consumed = plan->consumed; r.status = pstatus; r.aux = 0; results[ti] = r; }
+      continue;
+    }
+    const PcoGfxDecodeTask task = tasks[ti];
+    gcptr_u8 src = (gcptr_u8)task.src;
+    const uint64_t src_len = uni((uint64_t)task.src_len);
+    L PCO_GLOBAL* dst = (L PCO_GLOBAL*)task.dst;
+    const uint32_t n = uni(plan->n), mode_kind = uni(plan->mode_kind), mode_k = uni(plan->mode_k), num_kind = uni(plan->num_kind);
+    const L mode_base = (L)uni((uint64_t)plan->mode_base);
+    uint32_t present[3], n_bins[3], max_ob[3], dk[3], dord[3], nlps[3];
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      present[v] = uni(plan->present[v]); n_bins[v] = uni(plan->n_bins[v]); max_ob[v] = uni(plan->max_ob[v]);
+      dk[v] = uni(plan->delta_kind[v]); dord[v] = uni(plan->delta_order[v]); nlps[v] = uni(plan->nlps[v]);
+    }
+    const uint32_t window_n_log = uni(plan->window_n_log);
+    const uint32_t state_n = dk[1] == kDeltaLookback ? nlps[1] : 0u;
+    uint64_t PCO_LDS* lowers = (uint64_t PCO_LDS*)(smem + kExpLowOff);
+    uint8_t PCO_LDS* obs = smem + kExpObOff;
+    uint64_t PCO_LDS* mom64 = (uint64_t PCO_LDS*)(smem + kExpMomOff);
+    uint32_t PCO_LDS* dlat = (uint32_t PCO_LDS*)(smem + kExpDlatOff);
+    L PCO_LDS* scratch = (L PCO_LDS*)(smem + kExpScratchOff);
+    uint32_t PCO_LDS* parent = (uint32_t PCO_LDS*)(smem + kExpParentOff);
+    L PCO_LDS* moments0 = (L PCO_LDS*)mom64; L PCO_LDS* moments1 = (L PCO_LDS*)(mom64 + 8);
+    wave_sync_lds();
+    const uint8_t PCO_GLOBAL* bins = (const uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      if (!present[v]) continue;
+      const uint64_t PCO_GLOBAL* gl = (const uint64_t PCO_GLOBAL*)(bins + (uint64_t)v * kBinsAreaPerVar);
+      const uint8_t PCO_GLOBAL* go = bins + (uint64_t)v * kBinsAreaPerVar + kFastMaxBins * 8;
+      for (uint32_t b = lane; b < n_bins[v]; b += 64) { lowers[v * 256 + b] = gl[b]; obs[v * 256 + b] = go[b]; }
+    }
+    if (lane < 8) { moments0[lane] = (L)plan->moments[0][lane]; moments1[lane] = (L)plan->moments[1][lane]; }
+    wave_sync_lds();
+    uint32_t n_remaining = n, lb_oob = 0, status = PCO_GFX_OK;
+    uint32_t batch = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += kBatchN, batch++) {
+      const uint32_t batch_n = n_remaining < kBatchN ? n_remaining : kBatchN;
+      L prim[4] = {0, 0, 0, 0}, sec[4] = {0, 0, 0, 0};
+      uint32_t prim_cnt = 0;
+#pragma unroll
+      for (int v = 0; v < 3; v++) {
+        if (!present[v]) continue;
+        uint32_t cnt;
+        if (v == 0) { const uint32_t lim = n_remaining > nlps[1] ? n_remaining - nlps[1] : 0; cnt = lim < batch_n ? lim : batch_n; }
+        else { const uint32_t rem = n_remaining > nlps[v] ? n_remaining - nlps[v] : 0; cnt = rem < kBatchN ? rem : kBatchN; }
+        if (cnt > 0) {
+          const bool single_bin = n_bins[v] <= 1;
+          const uint8_t PCO_GLOBAL* syms = (const uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)ti * 3 + v) * sym_stride + (uint64_t)batch * kBatchN;
+          const uint64_t off_start = uni(offpos_area[((uint64_t)ti * 3 + v) * offpos_stride + batch]);
+          if (v == 0) {
+            uint32_t tmp[4];
+            if (max_ob[0] != 0 || !single_bin) expand_offsets<uint32_t>(src, src_len, off_start, cnt, syms, lowers, obs, single_bin, tmp);
+            else { const uint32_t l0 = (uint32_t)lowers[0]; for (int k = 0; k < 4; k++) tmp[k] = l0; }
+            for (int k = 0; k < 4; k++) dlat[4 * lane + k] = 4 * lane + k < cnt ? tmp[k] : 0u;
+          } else {
+            L tmp[4];
+            if (max_ob[v] != 0 || !single_bin) expand_offsets<L>(src, src_len, off_start, cnt, syms, lowers + v * 256, obs + v * 256, single_bin, tmp);
+            else { const L l0 = (L)lowers[v * 256]; for (int k = 0; k < 4; k++) tmp[k] = 4 * lane + k < cnt ? l0 : (L)0; }
+            if (v == 1) { for (int k = 0; k < 4; k++) prim[k] = tmp[k]; prim_cnt = cnt; } else { for (int k = 0; k < 4; k++) sec[k] = tmp[k]; }
+          }
+        }
+        if (v >= 1 && dk[v] == kDeltaConsecutive) { if (v == 1) consecutive_decode<L>(prim, dord[1], moments0); else consecutive_decode<L>(sec, dord[2], moments1); }
+      }
+      if (dk[1] == kDeltaLookback) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t window_n = 1u << window_n_log;
+        const uint64_t kbase = (uint64_t)j0;
+        for (int k = 0; k < 4; k++) {
+          const uint32_t i = 4 * lane + k;
+          L val = (L)(prim[k] + lmid<L>());
+          uint32_t par = 0xffffffffu;
+          if (i < prim_cnt) {
+            uint32_t lb = dlat[i];
+            if (lb > window_n) { lb_oob = 1; lb = 1; }
+            if (lb == 0) { }
+            else if (lb <= i) par = i - lb;
+            else {
+              const int64_t jsrc = (int64_t)(state_n + kbase + i) - (int64_t)lb;
+              if (jsrc >= 0) val = (L)(val + to_latent_ordered<L>(__hip_atomic_load(&dst[jsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), num_kind));
+            }
+          }
+          scratch[i] = val; parent[i] = par;
+        }
+        wave_sync_lds();
+        for (int round = 0; round < 8; round++) {
+          L nv[4]; uint32_t np[4];
+          for (int k = 0; k < 4; k++) {
+            const uint32_t i = 4 * lane + k; const uint32_t p = parent[i];
+            nv[k] = scratch[i]; np[k] = p;
+            if (p != 0xffffffffu) { nv[k] = (L)(nv[k] + scratch[p]); np[k] = parent[p]; }
+          }
+          wave_sync_lds();
+          for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; scratch[i] = nv[k]; parent[i] = np[k]; }
+          wave_sync_lds();
+        }
+        for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; if (i < prim_cnt) dst[state_n + kbase + i] = from_latent_ordered<L>(scratch[i], num_kind); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        L outv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) outv[k] = join_one<L>(mode_kind, num_kind, mode_base, mode_k, prim[k], sec[k]);
+        const uint32_t i0 = 4 * lane;
+        L PCO_GLOBAL* o = dst + j0 + i0;
+        if (i0 + 4 <= batch_n && (((uintptr_t)o) & 15) == 0) {
+          if constexpr (sizeof(L) == 8) {
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            u64x2 PCO_GLOBAL* p = (u64x2 PCO_GLOBAL*)o;
+            u64x2 a; a.x = outv[0]; a.y = outv[1]; u64x2 b; b.x = outv[2]; b.y = outv[3];
+            p[0] = a; p[1] = b;
+          } else if constexpr (sizeof(L) == 4) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 a; a.x = outv[0]; a.y = outv[1]; a.z = outv[2]; a.w = outv[3];
+            *(u32x4 PCO_GLOBAL*)o = a;
+          } else { for (int k = 0; k < 4; k++) o[k] = outv[k]; }
+        } else { for (int k = 0; k < 4; k++) if (i0 + k < batch_n) o[k] = outv[k]; }
+      }
+      n_remaining -= batch_n;
+    }
+    if (uni(wave_or_u32(lb_oob))) status = PCO_GFX_CORRUPTION;
+    if (lane == 0) { PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? n : 0; r.consumed = plan->consumed; r.status = status; r.aux = 0; results[ti] = r; }
+    wave_sync_lds();
+  }
+}
+
+}  // namespace pcogfx

@@ -15,6 +15,7 @@
 // run the delta scan with wave shuffles, join and store 32 contiguous bytes per lane.  All
 // metadata is parsed on the device, so a many-chunk decode is a single launch with no host
 // round trip.
+#pragma once
 #include <type_traits>
 
 #include "pco_dev.h"
@@ -579,10 +580,13 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
 #endif
 template <class L>
 __global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids,
-                                                        uint32_t n_ids, uint32_t lds_table_budget, uint8_t* tbl_ws_base) {
+                                                        uint32_t n_ids, uint32_t lds_table_budget, uint8_t* tbl_ws_base,
+                                                        const uint32_t* only_if_status, uint32_t status_stride_u32, uint32_t status_value) {
   const uint32_t lane = lane_id();
   for (uint32_t bi = blockIdx.x; bi < n_ids; bi += gridDim.x) {
     const uint32_t ti = task_ids ? task_ids[bi] : bi;
+    // when chained after the two-kernel fast path: only finish the tasks it handed over
+    if (only_if_status && uni(only_if_status[(uint64_t)ti * status_stride_u32]) != status_value) continue;
     const PcoGfxDecodeTask task = tasks[ti];
     gcptr_u8 src = (gcptr_u8)task.src;
     const uint64_t src_len = uni((uint64_t)task.src_len);

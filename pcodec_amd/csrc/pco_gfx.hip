@@ -4,11 +4,13 @@
 #include "pco_host.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
 #include "pco_auto_host.inc"
 #include "decode_kernel.hip"
+#include "decode_fast.hip"
 #include "encode_kernels.hip"
 
 namespace pcogfx {
@@ -83,6 +85,7 @@ struct ScopedKernelTimer {
 // decode launch
 // ---------------------------------------------------------------------------------------------------------
 static uint32_t g_decode_lds_bytes = 16 * 1024;  // dynamic LDS per wave (fixed area + tANS tables)
+static bool g_decode_fast = std::getenv("PCO_GFX_NO_FAST_DECODE") == nullptr;  // A/B switch for the two-kernel path
 
 static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results,
                           PcoGfxTaskResult* d_results_user, hipStream_t stream) {
@@ -113,19 +116,58 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
   size_t max_grid = 0;
   for (int g = 0; g < 3; g++) max_grid = std::max(max_grid, std::min<size_t>(ids[g].size(), 16384));
   uint8_t* tbl = (uint8_t*)ws.tbl_ws.ensure(max_grid * kTblWsBytes);
+  // Fast path (decode_fast.hip): walk 8 chunks per wave, then expand one chunk per wave; whatever it cannot take
+  // (multi-chunk streams, big tANS tables, wrapped pages, ...) is finished by the single-kernel decoder.
+  uint64_t max_cap = 0; bool plain = true;
+  for (size_t i = 0; i < n_tasks; i++) { max_cap = std::max<uint64_t>(max_cap, tasks[i].dst_cap); if (tasks[i].flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY)) plain = false; }
+  const uint64_t sym_stride = ((max_cap + 255) & ~(uint64_t)255) + 256, offpos_stride = sym_stride / 256 + 2;
+  const bool fast = g_decode_fast && plain && n_tasks * 3 * sym_stride <= ((size_t)48 << 30);
+  DecPlan* d_plans = nullptr; uint8_t* d_bins = nullptr; uint8_t* d_sym = nullptr; uint64_t* d_offpos = nullptr;
+  if (fast) {
+    d_plans = (DecPlan*)ws.dec_plans.ensure(n_tasks * sizeof(DecPlan));
+    d_bins = (uint8_t*)ws.dec_bins.ensure(n_tasks * kBinsAreaPerTask);
+    d_sym = (uint8_t*)ws.dec_sym.ensure(n_tasks * 3 * sym_stride + 64);
+    d_offpos = (uint64_t*)ws.dec_offpos.ensure(n_tasks * 3 * offpos_stride * 8);
+  }
+  if (fast) {  // the walker keeps kWQ chunks' tables in one wave's LDS: opt in to more than 64 KB of dynamic LDS, once
+    static const bool walk_lds_ok = [] {
+      return hipFuncSetAttribute((const void*)dec_walk_kernel<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsBytes) == hipSuccess &&
+             hipFuncSetAttribute((const void*)dec_walk_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsBytes) == hipSuccess &&
+             hipFuncSetAttribute((const void*)dec_walk_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsBytes) == hipSuccess;
+    }();
+    if (!walk_lds_ok) throw HostError{PCO_GFX_DEVICE_ERROR, "cannot reserve LDS for dec_walk_kernel"};
+  }
   for (int g = 0; g < 3; g++) {
     if (ids[g].empty()) continue;
     const uint32_t cnt = (uint32_t)ids[g].size();
     const uint32_t grid = (uint32_t)std::min<size_t>(cnt, 16384);
     const uint32_t* idp = mixed ? d_ids + id_off[g] : nullptr;
-    if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
-    else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
-    else PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl);
+    const uint32_t* filt = fast ? (const uint32_t*)d_plans : nullptr;
+    const uint32_t fstride = (uint32_t)(sizeof(DecPlan) / 4);
+    if (fast) {
+      const uint32_t wgrid = (cnt + kWQ - 1) / kWQ;
+      if (g == 0) { PCO_TIMED_LAUNCH("dec_walk_kernel<u64>", stream, dec_walk_kernel<uint64_t>, dim3(wgrid), dim3(64), kWalkLdsBytes, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
+                    PCO_TIMED_LAUNCH("dec_expand_kernel<u64>", stream, dec_expand_kernel<uint64_t>, dim3(grid), dim3(64), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
+      else if (g == 1) { PCO_TIMED_LAUNCH("dec_walk_kernel<u32>", stream, dec_walk_kernel<uint32_t>, dim3(wgrid), dim3(64), kWalkLdsBytes, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
+                         PCO_TIMED_LAUNCH("dec_expand_kernel<u32>", stream, dec_expand_kernel<uint32_t>, dim3(grid), dim3(64), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
+      else { PCO_TIMED_LAUNCH("dec_walk_kernel<u16>", stream, dec_walk_kernel<uint16_t>, dim3(wgrid), dim3(64), kWalkLdsBytes, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
+             PCO_TIMED_LAUNCH("dec_expand_kernel<u16>", stream, dec_expand_kernel<uint16_t>, dim3(grid), dim3(64), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
+    }
+    if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
+    else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
+    else PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
     PCO_HIP_CHECK(hipGetLastError());
   }
   if (results) {
     PCO_HIP_CHECK(hipMemcpyAsync(results, d_results, n_tasks * sizeof(PcoGfxTaskResult), hipMemcpyDeviceToHost, stream));
     PCO_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  if (const char* dump = std::getenv("PCO_GFX_DEBUG_DUMP")) if (fast) {  // TEMP debug aid
+    PCO_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<uint8_t> syms(3 * sym_stride); std::vector<uint64_t> op(3 * offpos_stride);
+    PCO_HIP_CHECK(hipMemcpy(syms.data(), d_sym, syms.size(), hipMemcpyDeviceToHost));
+    PCO_HIP_CHECK(hipMemcpy(op.data(), d_offpos, op.size() * 8, hipMemcpyDeviceToHost));
+    FILE* f = fopen(dump, "wb"); uint64_t hdr[2] = {sym_stride, offpos_stride}; fwrite(hdr, 8, 2, f); fwrite(syms.data(), 1, syms.size(), f); fwrite(op.data(), 8, op.size(), f); fclose(f);
   }
 }
 
