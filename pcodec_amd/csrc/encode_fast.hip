@@ -1,0 +1,586 @@
+// encode_fast.hip -- the page encoder of the common case, split by what bounds each part:
+//
+//   enc_dissect_kernel  (HBM-bound)      latent -> bin symbol (u8) + per-batch offset-bit totals
+//                                        (compression_table.rs:51-74, chunk_latent_compressor.rs:60-94)
+//   enc_walk_kernel     (latency-bound)  the reverse tANS walk: 8 (page, variable) items per wave, four lanes per
+//                                        item, one lane per interleaved chain; emits (bits, value) per symbol and
+//                                        the final states (chunk_latent_compressor.rs:96-132, ans/encoding.rs:65-91)
+//   enc_scan_kernel     (tiny)           bit position of every run of kRunBatches batches, page size, overflow check
+//   enc_pack_kernel     (HBM-bound)      metadata + tANS fields + offset fields of one run per wave, joined to its
+//                                        neighbours with atomicOr on the boundary dwords
+//                                        (wrapped/chunk_compressor.rs:624-705, bit_writer.rs:22-42)
+//
+// enc_page_kernel (encode_kernels.hip) remains the general path: fallback chunks, ChunkMeta-only tasks and tANS
+// tables beyond kFastEncMaxAsl.  Both produce the same bytes.
+//
+// Symbol / field scratch layout ("quad-transposed", shared with the decoder's symbol scratch): within every block
+// of 16 consecutive latents of a page variable, unit j (a dword of 4 symbols, or 4 u16 fields) holds chain j's
+// entries of the block's four steps, i.e. latents 16B+j, 16B+4+j, 16B+8+j, 16B+12+j.
+#pragma once
+
+namespace pcogfx {
+
+constexpr uint32_t kRunBatches = 16;          // batches per dissect block / pack run
+
+struct EncFast {
+  uint8_t* sym;         // [task][slot][n_stride] bin symbols, quad-transposed per page variable
+  uint16_t* answ;       // [task][slot][n_stride] bits << 12 | value, quad-transposed
+  uint32_t* bat;        // [page][3][bat_stride][2]: offset bits, tANS bits of the batch
+  uint64_t* run_start;  // [page][run_stride] first bit of the run, relative to the page task's dst
+  uint32_t* fstate;     // [page][3][4] final tANS states
+  uint32_t bat_stride, run_stride;
+  uint32_t runs_per_page, pad;   // 1-D grids of dissect / pack: block = page * runs_per_page + run
+  uint64_t stride;               // elements per (task, slot) in sym / answ: n_stride + 16 per page, so that the 16-latent
+                                 // blocks of neighbouring pages never overlap (see fast_at)
+};
+// first scratch index of a page variable: its latent index plus 16 slots per preceding page
+__device__ __forceinline__ uint64_t fast_at(const EncPage PCO_GLOBAL* pg, uint32_t skip) { return uni((uint64_t)pg->start) + skip + 16ull * uni(pg->page_idx); }
+
+__device__ __forceinline__ uint8_t PCO_GLOBAL* fsym_ptr(const EncWorkspace& ws, const EncFast& fx, uint32_t task, uint32_t var) {
+  return (uint8_t PCO_GLOBAL*)fx.sym + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * fx.stride;
+}
+__device__ __forceinline__ uint16_t PCO_GLOBAL* fansw_ptr(const EncWorkspace& ws, const EncFast& fx, uint32_t task, uint32_t var) {
+  return (uint16_t PCO_GLOBAL*)fx.answ + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * fx.stride;
+}
+
+template <int CTRL> __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+// 4x4 byte transpose across the four lanes of a quad: lane j ends up with byte j of every lane's dword
+__device__ __forceinline__ uint32_t quad_transpose_u8(uint32_t d, uint32_t j) {
+  const uint32_t d0 = quad_dpp<0x00>(d), d1 = quad_dpp<0x55>(d), d2 = quad_dpp<0xAA>(d), d3 = quad_dpp<0xFF>(d);
+  const uint32_t sel = 0x0c0c0000u | ((4u + j) << 8) | j;
+  const uint32_t lo = __builtin_amdgcn_perm(d1, d0, sel), hi = __builtin_amdgcn_perm(d3, d2, sel);
+  return lo | (hi << 16);
+}
+// 4x4 u16 transpose: each lane holds (a: entries 0,1 | b: entries 2,3); lane j ends up with entry j of every lane
+__device__ __forceinline__ void quad_transpose_u16(uint32_t& a, uint32_t& b, uint32_t j) {
+  const uint32_t a0 = quad_dpp<0x00>(a), a1 = quad_dpp<0x55>(a), a2 = quad_dpp<0xAA>(a), a3 = quad_dpp<0xFF>(a);
+  const uint32_t b0 = quad_dpp<0x00>(b), b1 = quad_dpp<0x55>(b), b2 = quad_dpp<0xAA>(b), b3 = quad_dpp<0xFF>(b);
+  const bool lo = j < 2;
+  const uint32_t x0 = lo ? a0 : b0, x1 = lo ? a1 : b1, x2 = lo ? a2 : b2, x3 = lo ? a3 : b3;
+  const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+  a = __builtin_amdgcn_perm(x1, x0, sel); b = __builtin_amdgcn_perm(x3, x2, sel);
+}
+
+// The page's view of one variable (as in page_task)
+struct PageVar { uint32_t present, n_bins, asl, max_ob, needs_ans, trivial, skip, n_lat; };
+__device__ __forceinline__ PageVar page_var(const EncChunk PCO_GLOBAL* ch, uint32_t v, uint32_t page_n) {
+  PageVar r;
+  r.present = uni(ch->v[v].present); r.n_bins = uni(ch->v[v].n_bins); r.asl = uni(ch->v[v].ans_size_log); r.max_ob = uni(ch->v[v].max_ob);
+  r.needs_ans = uni(ch->v[v].needs_ans); r.trivial = uni(ch->v[v].is_trivial);
+  r.skip = v == 2 ? 0u : uni(ch->v[v].lat_start);
+  if (r.skip > page_n) r.skip = page_n;
+  r.n_lat = page_n - r.skip;
+  return r;
+}
+
+// =========================================================================================================
+// dissect
+// =========================================================================================================
+constexpr uint32_t kDisVarBytes = 2048 + 256;    // search lowers (8 B stride) + offset bits
+constexpr uint32_t kDisLdsBytes = 3 * kDisVarBytes;
+
+template <class LV>
+__device__ __forceinline__ void dissect_batch(const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, uint8_t PCO_GLOBAL* sym_out, uint32_t PCO_GLOBAL* ob_bits_out,
+                                              uint32_t cnt, uint32_t n_bins, uint32_t search_log) {
+  const uint32_t lane = lane_id();
+  const LV PCO_LDS* low = (const LV PCO_LDS*)vt;
+  const uint8_t PCO_LDS* obs = vt + 2048;
+  uint32_t packed = 0, t = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t i = 4 * lane + k;
+    uint32_t sym = 0;
+    if (i < cnt) {
+      const LV x = lat[i];
+      for (uint32_t depth = 0; depth < search_log; depth++) {  // branch-free lower bound over padded lowers (compression_table.rs:51-74)
+        const uint32_t bis = 1u << (search_log - 1 - depth);
+        if (x >= low[sym + bis]) sym += bis;
+      }
+      sym = sym < n_bins - 1 ? sym : n_bins - 1;
+      t += obs[sym];
+    }
+    packed |= sym << (8 * k);
+  }
+  const uint32_t tr = quad_transpose_u8(packed, lane & 3);
+  if (4 * lane < ((cnt + 15u) & ~15u)) *(u32_unaligned PCO_GLOBAL*)(sym_out + 4 * lane) = tr;   // whole 16-latent blocks
+  const uint32_t total = wave_sum(t);
+  if (lane == 0) *ob_bits_out = total;
+}
+
+template <class L>
+__device__ void dissect_block(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run, EncPage PCO_GLOBAL* pg, EncChunk PCO_GLOBAL* ch) {
+  const uint32_t t = uni(pg->chunk);
+  const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
+  const uint64_t pstart = uni((uint64_t)pg->start);
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  PageVar pv[3];
+  bool any = false;
+#pragma unroll
+  for (int v = 0; v < 3; v++) { pv[v] = page_var(ch, v, page_n); if (pv[v].present && pv[v].n_bins > 1 && (uint64_t)run * kRunBatches * kBatchN < pv[v].n_lat) any = true; }
+  if (!any) return;
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    if (!pv[v].present || pv[v].n_bins <= 1) continue;
+    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    const uint32_t b = threadIdx.x;  // 256 threads: one padded bin each
+    if (v == 0) ((uint32_t PCO_LDS*)(smem + v * kDisVarBytes))[b] = b < pv[v].n_bins ? (uint32_t)plan->blower[b] : 0xffffffffu;
+    else ((L PCO_LDS*)(smem + v * kDisVarBytes))[b] = b < pv[v].n_bins ? (L)plan->blower[b] : (L)~(L)0;
+    (smem + v * kDisVarBytes + 2048)[b] = b < pv[v].n_bins ? plan->bob[b] : 0;
+  }
+  __syncthreads();
+  const uint32_t wave = threadIdx.x >> 6;
+  for (uint32_t bb = wave; bb < kRunBatches; bb += 4) {
+    const uint32_t batch = run * kRunBatches + bb;
+    const uint32_t base = batch * kBatchN;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      if (!pv[v].present || pv[v].n_bins <= 1 || base >= pv[v].n_lat) continue;
+      const uint32_t cnt = pv[v].n_lat - base < kBatchN ? pv[v].n_lat - base : kBatchN;
+      uint32_t search_log = 0; while ((1u << search_log) < pv[v].n_bins) search_log++;
+      const uint64_t at = pstart + pv[v].skip + base, fat = fast_at(pg, pv[v].skip) + base;
+      uint32_t PCO_GLOBAL* ob_out = (uint32_t PCO_GLOBAL*)fx.bat + (((uint64_t)p * 3 + v) * fx.bat_stride + batch) * 2;
+      if (v == 0) dissect_batch<uint32_t>(smem + v * kDisVarBytes, lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, ob_out, cnt, pv[v].n_bins, search_log);
+      else dissect_batch<L>(smem + v * kDisVarBytes, lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, ob_out, cnt, pv[v].n_bins, search_log);
+    }
+  }
+}
+
+// grid pages * runs_per_page, 256 threads
+__global__ __launch_bounds__(256) void enc_dissect_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+  const uint32_t p = blockIdx.x / fx.runs_per_page, run = blockIdx.x % fx.runs_per_page;
+  if (p >= n_pages) return;
+  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + uni(pg->chunk);
+  if (!page_is_fast(ch, pg)) return;
+  const int bits = dtype_bits(uni(ch->dtype));
+  if (bits == 64) dissect_block<uint64_t>(ws, fx, p, run, pg, ch);
+  else if (bits == 32) dissect_block<uint32_t>(ws, fx, p, run, pg, ch);
+  else dissect_block<uint16_t>(ws, fx, p, run, pg, ch);
+}
+
+// =========================================================================================================
+// reverse tANS walk
+// =========================================================================================================
+constexpr uint32_t kEwQ = 8;                       // (page, variable) items per wave
+constexpr uint32_t kEwNsOff = 0;                   // u16[1024] next states
+constexpr uint32_t kEwInfoOff = 2048;              // u64[256]: cutoff | min_renorm_bits << 16, LDS address of the symbol's next-state row
+constexpr uint32_t kEwSymOff = 4096;               // u8[2][256] symbols of the current / next batch
+constexpr uint32_t kEwSlotBytes = 4608;
+constexpr uint32_t kEwLdsBytes = kEwQ * kEwSlotBytes;
+
+// one reverse step of one chain: (ans/encoding.rs:65-87)
+__device__ __forceinline__ uint32_t ew_step(uint32_t& state, uint32_t& bits_acc, uint64_t info) {
+  const uint32_t lo = (uint32_t)info, row = (uint32_t)(info >> 32);
+  const uint32_t cutoff = lo & 0xffffu, minb = lo >> 16;
+  const uint32_t bits = minb + (state >= cutoff ? 1u : 0u);
+  const uint32_t val = __builtin_amdgcn_ubfe(state, 0u, bits);
+  state = *(const uint16_t PCO_LDS*)(uintptr_t)(row + ((state >> bits) << 1));
+  bits_acc += bits;
+  return (bits << 12) | val;
+}
+
+__global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+  const uint32_t lane = lane_id();
+  const uint32_t slot = lane >> 2, j = lane & 3;
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t n_items = n_pages * ws.n_slots;
+  // ---- phase 0: tables of the wave's items into LDS (all lanes cooperate, one item at a time) ----
+  uint32_t my_n_lat = 0, my_T = 0, my_p = 0, my_v = 0;
+  uint64_t my_at = 0; uint32_t my_task = 0;
+  for (uint32_t q = 0; q < kEwQ; q++) {
+    const uint32_t item = blockIdx.x * kEwQ + q;
+    if (item >= n_items) break;
+    const uint32_t p = item / ws.n_slots, s = item % ws.n_slots;
+    const uint32_t v = ws.slot_of_var[0] == s ? 0u : (ws.slot_of_var[1] == s ? 1u : 2u);
+    EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+    const uint32_t t = uni(pg->chunk);
+    EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+    if (!page_is_fast(ch, pg)) continue;
+    const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
+    const PageVar pv = page_var(ch, v, page_n);
+    if (!pv.present || pv.n_bins <= 1 || pv.n_lat == 0) {
+      if (pv.present && lane < 4) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
+      continue;
+    }
+    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    uint8_t PCO_LDS* sl = smem + q * kEwSlotBytes;
+    const uint32_t T = 1u << pv.asl;
+    for (uint32_t i = lane; i < T; i += 64) ((uint16_t PCO_LDS*)(sl + kEwNsOff))[i] = plan->next_states[i];
+    for (uint32_t b = lane; b < pv.n_bins; b += 64) {
+      const uint32_t si = plan->syminfo[b];   // cutoff(14) | min_renorm_bits(4) << 14 | (row + 8192)(14) << 18
+      const uint32_t cutoff = si & 0x3fffu, minb = (si >> 14) & 15u, row = (si >> 18) - 8192u;   // row may be "negative": wraps mod 2^32 below
+      const uint32_t row_addr = lds0 + q * kEwSlotBytes + kEwNsOff + 2u * row;
+      ((uint64_t PCO_LDS*)(sl + kEwInfoOff))[b] = (uint64_t)(cutoff | (minb << 16)) | ((uint64_t)row_addr << 32);
+    }
+    if (slot == q) { my_n_lat = pv.n_lat; my_T = T; my_p = p; my_v = v; my_task = t; my_at = fast_at(pg, pv.skip); }
+  }
+  enc_wave_sync();
+  if (my_n_lat == 0) { if (__all(my_n_lat == 0)) return; }
+  // ---- phase 1: batches in reverse ----
+  const uint32_t slice = lds0 + (slot < kEwQ ? slot : 0u) * kEwSlotBytes;
+  const uint32_t info_addr = slice + kEwInfoOff, symbuf = slice + kEwSymOff;
+  const uint8_t PCO_GLOBAL* gsym = (const uint8_t PCO_GLOBAL*)fsym_ptr(ws, fx, my_task, my_v) + my_at;
+  uint16_t PCO_GLOBAL* gans = fansw_ptr(ws, fx, my_task, my_v) + my_at;
+  uint32_t PCO_GLOBAL* gbat = (uint32_t PCO_GLOBAL*)fx.bat + ((uint64_t)my_p * 3 + my_v) * fx.bat_stride * 2;
+  const uint32_t n_batches = (my_n_lat + kBatchN - 1) / kBatchN;
+  uint32_t state = my_T;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+  typedef uint64_t __attribute__((aligned(2))) u64_align2;
+  // the last (possibly partial) batch: staged directly, walked with per-step predicates
+  if (n_batches > 0) {
+    const uint32_t b = n_batches - 1, base = b * kBatchN, cnt = my_n_lat - base;
+    const uint32_t blocks_bytes = (cnt + 15u) & ~15u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t off = 64 * j + 16 * k;
+      if (off < blocks_bytes) *(u32x4 PCO_LDS*)(uintptr_t)(symbuf + (b & 1) * 256 + off) = *(const u32x4_unaligned PCO_GLOBAL*)(gsym + base + off);
+    }
+  }
+  enc_wave_sync();
+  if (n_batches > 0) {
+    const uint32_t b = n_batches - 1, base = b * kBatchN, cnt = my_n_lat - base;
+    const uint32_t steps = (cnt + 3) >> 2;
+    uint32_t bits_acc = 0;
+    for (uint32_t blk = (steps + 3) >> 2; blk-- > 0;) {
+      const uint32_t sd = *(const uint32_t PCO_LDS*)(uintptr_t)(symbuf + (b & 1) * 256 + 16 * blk + 4 * j);
+      uint64_t out = 0;
+#pragma unroll
+      for (int k = 3; k >= 0; k--) {
+        const uint32_t g = 4 * blk + k;
+        if (4 * g + j < cnt) {
+          const uint64_t info = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> (8 * k)) & 0xffu));
+          out |= (uint64_t)ew_step(state, bits_acc, info) << (16 * k);
+        }
+      }
+      *(u64_align2 PCO_GLOBAL*)(gans + base + 16 * blk + 4 * j) = out;
+    }
+    bits_acc += quad_dpp<0xB1>(bits_acc); bits_acc += quad_dpp<0x4E>(bits_acc);
+    if (j == 0) gbat[(uint64_t)b * 2 + 1] = bits_acc;
+  }
+  // full batches, newest first; the next batch's symbols are fetched while the current one is walked
+  const uint32_t n_full = n_batches > 0 ? n_batches - 1 : 0;
+  uint32_t max_full = n_full;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(max_full, d, 64); max_full = max_full > o ? max_full : o; }
+  max_full = uni(max_full);
+  u32x4 pre[4];
+  if (n_full > 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) pre[k] = *(const u32x4_unaligned PCO_GLOBAL*)(gsym + (uint64_t)(n_full - 1) * kBatchN + 64 * j + 16 * k);
+  }
+  for (uint32_t it = 0; it < max_full; it++) {
+    const bool act = it < n_full;
+    const uint32_t b = act ? n_full - 1 - it : 0u;
+    const uint32_t buf = symbuf + (b & 1) * 256;
+    if (act) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) *(u32x4 PCO_LDS*)(uintptr_t)(buf + 64 * j + 16 * k) = pre[k];
+    }
+    enc_wave_sync();
+    if (act && b > 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) pre[k] = *(const u32x4_unaligned PCO_GLOBAL*)(gsym + (uint64_t)(b - 1) * kBatchN + 64 * j + 16 * k);
+    }
+    if (act) {
+      uint32_t bits_acc = 0;
+      uint16_t PCO_GLOBAL* ga = gans + (uint64_t)b * kBatchN + 4 * j;
+      // software pipeline: the symbol dword and its four info words of block blk-1 are fetched while block blk is walked
+      uint32_t sd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * 15 + 4 * j);
+      uint64_t i0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (sd & 0xffu));
+      uint64_t i1 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> 8) & 0xffu));
+      uint64_t i2 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> 16) & 0xffu));
+      uint64_t i3 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (sd >> 24));
+      for (uint32_t blk = 16; blk-- > 0;) {
+        const uint32_t nblk = blk > 0 ? blk - 1 : 0;
+        const uint32_t nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * nblk + 4 * j);
+        const uint64_t n0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd & 0xffu));
+        const uint64_t n1 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((nsd >> 8) & 0xffu));
+        const uint64_t n2 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((nsd >> 16) & 0xffu));
+        const uint64_t n3 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd >> 24));
+        const uint32_t o3 = ew_step(state, bits_acc, i3);
+        const uint32_t o2 = ew_step(state, bits_acc, i2);
+        const uint32_t o1 = ew_step(state, bits_acc, i1);
+        const uint32_t o0 = ew_step(state, bits_acc, i0);
+        *(u64_align2 PCO_GLOBAL*)(ga + 16 * blk) = (uint64_t)(o0 | (o1 << 16)) | ((uint64_t)(o2 | (o3 << 16)) << 32);
+        i0 = n0; i1 = n1; i2 = n2; i3 = n3;
+      }
+      bits_acc += quad_dpp<0xB1>(bits_acc); bits_acc += quad_dpp<0x4E>(bits_acc);
+      if (j == 0) gbat[(uint64_t)b * 2 + 1] = bits_acc;
+    }
+    enc_wave_sync();
+  }
+  if (my_n_lat > 0 && slot < kEwQ) fx.fstate[((uint64_t)my_p * 3 + my_v) * 4 + j] = state;
+}
+
+// =========================================================================================================
+// scan: positions of the runs, page size
+// =========================================================================================================
+__device__ __forceinline__ uint64_t chunk_meta_bits_of(const EncChunk PCO_GLOBAL* ch, uint32_t LB) {  // page_write_chunk_meta, non-fallback
+  const uint32_t mode_kind = uni(ch->mode_kind), delta_kind = uni(ch->delta_kind);
+  uint64_t bits = kBitsModeVariant;
+  if (mode_kind == kIntMult || mode_kind == kFloatMult) bits += LB; else if (mode_kind == kFloatQuant) bits += kBitsQuantK;
+  bits += kBitsDeltaVariant;
+  if (delta_kind == kDeltaConsecutive) bits += kBitsDeltaOrder + 1;
+  else if (delta_kind == kDeltaLookback) bits += kBitsLookbackWindowLog + kBitsLookbackStateLog + 1;
+  for (int v = 0; v < 3; v++) {
+    if (!uni(ch->v[v].present)) continue;
+    const uint32_t lb = v == 0 ? 32u : LB;
+    bits += kBitsAnsSizeLog + kBitsNBins + (uint64_t)uni(ch->v[v].n_bins) * (uni(ch->v[v].ans_size_log) + lb + offset_bits_bits(lb));
+  }
+  return (bits + 7) & ~(uint64_t)7;
+}
+
+// grid pages, 64 threads
+__global__ __launch_bounds__(64) void enc_scan_kernel(EncWorkspace ws, EncFast fx, PcoGfxTaskResult* results, uint32_t n_pages) {
+  const uint32_t p = blockIdx.x;
+  if (p >= n_pages) return;
+  const uint32_t lane = lane_id();
+  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+  const uint32_t t = uni(pg->chunk);
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (!page_is_fast(ch, pg)) return;
+  const uint32_t LB = (uint32_t)dtype_bits(uni(ch->dtype));
+  const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
+  const uint32_t pflags = uni(pg->flags);
+  PageVar pv[3]; uint32_t ob0[3];
+  uint64_t head = 0;
+  if (pflags & kPageFlagPreamble) head += 8 + kBitsNEntries + chunk_meta_bits_of(ch, LB);
+  uint64_t page_meta = 0;
+  const uint32_t delta_kind = uni(ch->delta_kind);
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    pv[v] = page_var(ch, v, page_n);
+    ob0[v] = 0;
+    if (!pv[v].present) continue;
+    if (pv[v].n_bins == 1) ob0[v] = uni((uint32_t)((const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v)->bob[0]);
+    if (v == 1) page_meta += (uint64_t)LB * (delta_kind == kDeltaConsecutive ? uni(ch->delta_order) : (delta_kind == kDeltaLookback ? (1u << uni(ch->state_n_log)) : 0u));
+    page_meta += 4ull * pv[v].asl;
+  }
+  head += (page_meta + 7) & ~(uint64_t)7;
+  uint32_t PCO_GLOBAL* dst32 = (uint32_t PCO_GLOBAL*)pg->dst;
+  const uint64_t cap_bits = uni((uint64_t)pg->dst_cap) * 8;
+  const uint32_t n_batches = (page_n + kBatchN - 1) / kBatchN;
+  uint64_t carry = head;
+  // first pass: total size (so that nothing is written to a dst that is too small)
+  for (int pass = 0; pass < 2; pass++) {
+    carry = head;
+    for (uint32_t c0 = 0; c0 < n_batches; c0 += 64) {
+      const uint32_t b = c0 + lane;
+      uint64_t bits = 0;
+      if (b < n_batches) {
+        const uint32_t base = b * kBatchN;
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+          if (!pv[v].present || pv[v].trivial || base >= pv[v].n_lat) continue;
+          const uint32_t cnt = pv[v].n_lat - base < kBatchN ? pv[v].n_lat - base : kBatchN;
+          if (pv[v].n_bins > 1) { const uint32_t PCO_GLOBAL* r = (const uint32_t PCO_GLOBAL*)fx.bat + (((uint64_t)p * 3 + v) * fx.bat_stride + b) * 2; bits += (uint64_t)r[0] + r[1]; }
+          else bits += (uint64_t)cnt * ob0[v];
+        }
+      }
+      const uint64_t incl = wave_incl_scan(bits);
+      const uint64_t start = carry + incl - bits;
+      if (pass == 1 && b < n_batches && (b % kRunBatches) == 0) {
+        fx.run_start[(uint64_t)p * fx.run_stride + b / kRunBatches] = start;
+        dst32[start >> 5] = 0;   // the run's first dword is joined with atomicOr by its two writers
+      }
+      carry += uni(shfl_idx(incl, 63));
+    }
+    if (pass == 0) {
+      const uint64_t total = (carry + 7) & ~(uint64_t)7;
+      const bool overflow = total + 64 > cap_bits;
+      if (lane == 0) { pg->pad = overflow ? 1u : 0u; store_result((PcoGfxTaskResult PCO_GLOBAL*)results + p, overflow ? 0 : total >> 3, overflow ? PCO_GFX_INVALID_ARGUMENT : PCO_GFX_OK, 0); }
+      if (overflow) return;
+      if (lane == 0) { dst32[0] = 0; dst32[total >> 5] = 0; dst32[carry >> 5] = 0; }
+    }
+  }
+}
+
+// =========================================================================================================
+// pack
+// =========================================================================================================
+// BitSink whose run starts at an arbitrary bit of dst: the first and the last dword it touches are shared with the
+// neighbouring runs and are merged with atomicOr (enc_scan_kernel zeroed them); interior dwords are plain stores.
+struct RunSink : BitSink {
+  uint64_t first_dw;
+  __device__ __forceinline__ void init_at(uint32_t PCO_LDS* s, uint32_t PCO_GLOBAL* d, uint64_t cap_bytes, uint64_t start_bit) {
+    init(s, d, cap_bytes); outbit = start_bit; first_dw = start_bit >> 5;
+  }
+  __device__ __forceinline__ void advance_run(uint32_t total) {
+    enc_wave_sync();
+    const uint64_t newbit = outbit + total;
+    const uint64_t base_dw = outbit >> 5;
+    const uint32_t ncomplete = (uint32_t)((newbit >> 5) - base_dw);
+    const uint32_t lane = lane_id();
+    for (uint32_t i = lane; i < ncomplete; i += 64) {
+      if (base_dw + i == first_dw) atomicOr((uint32_t*)(dst + base_dw + i), stg[i]); else dst[base_dw + i] = stg[i];
+    }
+    const uint32_t last = stg[ncomplete];
+    enc_wave_sync();
+    const uint32_t used = ncomplete + 1;
+    for (uint32_t i = lane; i < used && i < kStgDwords; i += 64) stg[i] = 0;
+    enc_wave_sync();
+    if (lane == 0) stg[0] = last;
+    enc_wave_sync();
+    outbit = newbit;
+  }
+  __device__ __forceinline__ void put_uniform_run(uint64_t val, uint32_t nbits) { if (lane_id() == 0) put(0, val, nbits); advance_run(nbits); }
+  __device__ __forceinline__ void finish_byte_run() { advance_run((uint32_t)((8 - (outbit & 7)) & 7)); }
+  __device__ __forceinline__ void close_run() {
+    enc_wave_sync();
+    if (lane_id() == 0 && (outbit & 31)) atomicOr((uint32_t*)(dst + (outbit >> 5)), stg[0]);
+  }
+};
+
+constexpr uint32_t kPackLdsVar = kPageLdsStg + kStgDwords * 4;   // 2816: per-var (lowers u64[256] | offset bits u8[256])
+constexpr uint32_t kPackVarBytes = 2048 + 256;
+constexpr uint32_t kPackLdsBytes = kPackLdsVar + 3 * kPackVarBytes;
+
+template <class LV>
+__device__ __forceinline__ void pack_batch(RunSink& sink, const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, const uint8_t PCO_GLOBAL* sym,
+                                           const uint16_t PCO_GLOBAL* answ, uint32_t cnt, bool needs_ans, uint32_t max_ob, bool single_bin) {
+  const uint32_t lane = lane_id();
+  const LV PCO_LDS* low = (const LV PCO_LDS*)vt;
+  const uint8_t PCO_LDS* obs = vt + 2048;
+  const bool blk_on = 4 * lane < ((cnt + 15u) & ~15u);
+  uint32_t syms = 0;
+  if (!single_bin) { syms = blk_on ? *(const u32_unaligned PCO_GLOBAL*)(sym + 4 * lane) : 0u; syms = quad_transpose_u8(syms, lane & 3); }
+  if (needs_ans) {
+    typedef uint64_t __attribute__((aligned(2))) u64_align2;
+    const uint64_t w = blk_on ? *(const u64_align2 PCO_GLOBAL*)(answ + 4 * lane) : 0ull;
+    uint32_t a = (uint32_t)w, b = (uint32_t)(w >> 32);
+    quad_transpose_u16(a, b, lane & 3);
+    const uint32_t f[4] = {a & 0xffffu, a >> 16, b & 0xffffu, b >> 16};
+    uint64_t acc = 0; uint32_t accbits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (4 * lane + k < cnt) { const uint32_t nb = f[k] >> 12; acc |= (uint64_t)(f[k] & 0xfffu) << accbits; accbits += nb; }
+    const uint32_t incl = wave_incl_scan(accbits);
+    const uint32_t total = uni(shfl_idx(incl, 63));
+    sink.put(incl - accbits, acc, accbits);  // <= 48 bits
+    sink.advance_run(total);
+  }
+  if (max_ob != 0) {
+    uint32_t ob[4]; LV x[4]; uint32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = 4 * lane + k;
+      const uint32_t s = (syms >> (8 * k)) & 0xffu;
+      ob[k] = i < cnt ? (uint32_t)obs[s] : 0u;
+      x[k] = i < cnt ? (LV)(lat[i] - low[s]) : (LV)0;
+      t += ob[k];
+    }
+    const uint32_t incl = wave_incl_scan(t);
+    const uint32_t total = uni(shfl_idx(incl, 63));
+    uint32_t rel = incl - t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { sink.put(rel, (uint64_t)x[k], ob[k]); rel += ob[k]; }
+    sink.advance_run(total);
+  }
+}
+
+template <class L>
+__device__ void pack_run(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run, EncPage PCO_GLOBAL* pg, EncChunk PCO_GLOBAL* ch) {
+  const uint32_t t = uni(pg->chunk);
+  const uint32_t lane = lane_id();
+  constexpr uint32_t LB = LBits<L>::v;
+  const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
+  const uint64_t pstart = uni((uint64_t)pg->start);
+  if ((uint64_t)run * kRunBatches * kBatchN >= page_n) return;
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  PageVar pv[3];
+#pragma unroll
+  for (int v = 0; v < 3; v++) pv[v] = page_var(ch, v, page_n);
+  RunSink sink;
+  sink.init_at((uint32_t PCO_LDS*)(smem + kPageLdsStg), (uint32_t PCO_GLOBAL*)pg->dst, uni((uint64_t)pg->dst_cap), run == 0 ? 0ull : uni(fx.run_start[(uint64_t)p * fx.run_stride + run]));
+  if (run == 0) {
+    const uint32_t pflags = uni(pg->flags);
+    if (pflags & kPageFlagPreamble) {  // standalone/compressor.rs:191-203, then ChunkMeta
+      sink.put_uniform_run(uni(ch->dtype), 8);
+      sink.put_uniform_run(page_n - 1, kBitsNEntries);
+      // ChunkMeta (metadata/chunk.rs:176-189, mode.rs:169-195, delta_encoding.rs:204-254, chunk_latent_var.rs:55-71,158-168)
+      const uint32_t mode_kind = uni(ch->mode_kind), delta_kind = uni(ch->delta_kind), delta_order = uni(ch->delta_order);
+      sink.put_uniform_run(mode_kind, kBitsModeVariant);
+      if (mode_kind == kIntMult || mode_kind == kFloatMult) sink.put_uniform_run(uni((uint64_t)ch->mode_base), LB);
+      else if (mode_kind == kFloatQuant) sink.put_uniform_run(uni(ch->mode_k), kBitsQuantK);
+      sink.put_uniform_run(delta_kind, kBitsDeltaVariant);
+      if (delta_kind == kDeltaConsecutive) { sink.put_uniform_run(delta_order, kBitsDeltaOrder); sink.put_uniform_run(0, 1); }
+      else if (delta_kind == kDeltaLookback) { sink.put_uniform_run(uni(ch->window_n_log) - 1, kBitsLookbackWindowLog); sink.put_uniform_run(uni(ch->state_n_log), kBitsLookbackStateLog); sink.put_uniform_run(0, 1); }
+#pragma unroll
+      for (int v = 0; v < 3; v++) {
+        if (!pv[v].present) continue;
+        const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+        const uint32_t asl = pv[v].asl, nbins = pv[v].n_bins;
+        const uint32_t lb = v == 0 ? 32u : LB, obb = offset_bits_bits(lb);
+        sink.put_uniform_run(asl, kBitsAnsSizeLog); sink.put_uniform_run(nbins, kBitsNBins);
+        const uint32_t bin_bits = asl + lb + obb;
+        for (uint32_t b0 = 0; b0 < nbins; b0 += 64) {
+          const uint32_t b = b0 + lane;
+          const uint32_t nb = nbins - b0 < 64 ? nbins - b0 : 64;
+          if (b < nbins) {
+            const uint32_t rel = lane * bin_bits;
+            sink.put(rel, plan->bweight[b] - 1, asl);
+            sink.put(rel + asl, plan->blower[b], lb);
+            sink.put(rel + asl + lb, plan->bob[b], obb);
+          }
+          sink.advance_run(nb * bin_bits);
+        }
+      }
+      sink.finish_byte_run();
+    }
+    // page meta (metadata/page.rs:22-34, page_latent_var.rs:19-26)
+    const uint32_t delta_kind = uni(ch->delta_kind);
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      if (!pv[v].present) continue;
+      if (v == 1) {
+        const uint32_t nlps = delta_kind == kDeltaConsecutive ? uni(ch->delta_order) : (delta_kind == kDeltaLookback ? (1u << uni(ch->state_n_log)) : 0u);
+        for (uint32_t i = 0; i < nlps; i++) sink.put_uniform_run(uni((uint64_t)pg->moments[i]), LB);
+      }
+      for (int jj = 0; jj < 4; jj++) sink.put_uniform_run(uni(fx.fstate[((uint64_t)p * 3 + v) * 4 + jj]) - (1u << pv[v].asl), pv[v].asl);
+    }
+    sink.finish_byte_run();
+  }
+  // tables for the offsets
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    if (!pv[v].present || pv[v].trivial) continue;
+    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    uint8_t PCO_LDS* vt = smem + kPackLdsVar + v * kPackVarBytes;
+    for (uint32_t b = lane; b < pv[v].n_bins; b += 64) {
+      if (v == 0) ((uint32_t PCO_LDS*)vt)[b] = (uint32_t)plan->blower[b]; else ((L PCO_LDS*)vt)[b] = (L)plan->blower[b];
+      (vt + 2048)[b] = plan->bob[b];
+    }
+  }
+  enc_wave_sync();
+  for (uint32_t bb = 0; bb < kRunBatches; bb++) {
+    const uint32_t base = (run * kRunBatches + bb) * kBatchN;
+    if (base >= page_n) break;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      if (!pv[v].present || pv[v].trivial || base >= pv[v].n_lat) continue;
+      const uint32_t cnt = pv[v].n_lat - base < kBatchN ? pv[v].n_lat - base : kBatchN;
+      const uint64_t at = pstart + pv[v].skip + base, fat = fast_at(pg, pv[v].skip) + base;
+      const uint8_t PCO_LDS* vt = smem + kPackLdsVar + v * kPackVarBytes;
+      if (v == 0) pack_batch<uint32_t>(sink, vt, lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, fansw_ptr(ws, fx, t, 0) + fat, cnt, pv[v].needs_ans != 0, pv[v].max_ob, pv[v].n_bins <= 1);
+      else pack_batch<L>(sink, vt, lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, fansw_ptr(ws, fx, t, v) + fat, cnt, pv[v].needs_ans != 0, pv[v].max_ob, pv[v].n_bins <= 1);
+    }
+  }
+  if ((uint64_t)(run + 1) * kRunBatches * kBatchN >= page_n) sink.finish_byte_run();
+  sink.close_run();
+}
+
+// grid pages * runs_per_page, 64 threads
+__global__ __launch_bounds__(64) void enc_pack_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+  const uint32_t p = blockIdx.x / fx.runs_per_page, run = blockIdx.x % fx.runs_per_page;
+  if (p >= n_pages) return;
+  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + uni(pg->chunk);
+  if (!page_is_fast(ch, pg) || uni(pg->pad) != 0) return;
+  const int bits = dtype_bits(uni(ch->dtype));
+  if (bits == 64) pack_run<uint64_t>(ws, fx, p, run, pg, ch);
+  else if (bits == 32) pack_run<uint32_t>(ws, fx, p, run, pg, ch);
+  else pack_run<uint16_t>(ws, fx, p, run, pg, ch);
+}
+
+}  // namespace pcogfx

@@ -29,6 +29,7 @@ constexpr uint32_t kMaxUnoptBinsLog = 8;            // device limit this round (
 constexpr uint32_t kMaxBins = 1u << kMaxUnoptBinsLog;
 constexpr uint32_t kMaxEncTableLog = 12;            // estimated_ans_size_log <= 12 (wrapped/chunk_compressor.rs:73-79)
 constexpr uint32_t kDirectHistRange = 4096;         // value-space histogram when max-min < this
+constexpr uint32_t kFastEncMaxAsl = 10;             // larger tANS tables take the single-kernel page path
 
 struct EncVar {
   uint32_t present, latent_bits, n_lat, lat_start;
@@ -47,6 +48,7 @@ struct EncChunk {
   uint32_t delta_kind, delta_order, window_n_log, state_n_log;
   uint32_t fallback, unopt_bins_log;
   uint32_t n_pages, page_low, page_r, page_first;  // PagingSpec::EqualPagesUpTo layout: the first page_r pages hold page_low+1
+  uint32_t fast_ok, pad2;   // 1: the chunk's pages go through the dissect / walk / scan / pack kernels (encode_fast.hip)
   EncVar v[3];
 };
 static_assert(sizeof(EncChunk) % 8 == 0, "EncChunk");
@@ -912,6 +914,9 @@ __global__ __launch_bounds__(64) void enc_train_kernel(EncWorkspace ws, uint32_t
       fallback = worst > baseline ? 1u : 0u;
     }
     ch->fallback = fallback;
+    uint32_t fast_ok = fallback ? 0u : 1u;
+    for (uint32_t var = 0; var < 3; var++) if (ch->v[var].present && ch->v[var].ans_size_log > kFastEncMaxAsl) fast_ok = 0;
+    ch->fast_ok = fast_ok;
   }
 }
 
@@ -1248,17 +1253,22 @@ __device__ void page_task(const EncWorkspace& ws, const PcoGfxEncodeTask& task, 
   if (lane == 0) store_result(result, bytes, sink.overflow ? PCO_GFX_INVALID_ARGUMENT : PCO_GFX_OK, 0);
 }
 
+__device__ __forceinline__ bool page_is_fast(const EncChunk PCO_GLOBAL* ch, const EncPage PCO_GLOBAL* pg) {
+  return uni(ch->status) == PCO_GFX_OK && uni(ch->fast_ok) != 0 && !(uni(pg->flags) & kPageFlagMetaOnly);
+}
+
 // grid = number of page tasks; results are per page task
 #ifndef PCO_PAGE_MIN_WAVES
 #define PCO_PAGE_MIN_WAVES 4
 #endif
-__global__ __launch_bounds__(64, PCO_PAGE_MIN_WAVES) void enc_page_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, PcoGfxTaskResult* results, uint32_t n_pages) {
+__global__ __launch_bounds__(64, PCO_PAGE_MIN_WAVES) void enc_page_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, PcoGfxTaskResult* results, uint32_t n_pages, uint32_t skip_fast) {
   const uint32_t p = blockIdx.x;
   if (p >= n_pages) return;
   EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
   const uint32_t t = uni(pg->chunk);
   const PcoGfxEncodeTask task = tasks[t];
   const uint32_t status = uni(ws.chunks[t].status);
+  if (skip_fast && page_is_fast((const EncChunk PCO_GLOBAL*)ws.chunks + t, pg)) return;   // encode_fast.hip wrote this page
   PcoGfxTaskResult PCO_GLOBAL* res = (PcoGfxTaskResult PCO_GLOBAL*)results + p;
   if (status != PCO_GFX_OK) {
     if (lane_id() == 0) store_result(res, 0, status, 0);

@@ -12,6 +12,7 @@
 #include "decode_kernel.hip"
 #include "decode_fast.hip"
 #include "encode_kernels.hip"
+#include "encode_fast.hip"
 
 namespace pcogfx {
 
