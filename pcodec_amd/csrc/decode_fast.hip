@@ -488,13 +488,14 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
 // ---------------------------------------------------------------------------------------------------------
 // dec_expand_kernel: one wave per chunk, everything after the tANS walk
 // ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kExpWaves = 4;                          // waves per chunk: batch b is unpacked by wave b % 4
 constexpr uint32_t kExpLowOff = 0;                         // u64[3][256] lowers
 constexpr uint32_t kExpObOff = 3 * 2048;                   // u8[3][256]
-constexpr uint32_t kExpMomOff = kExpObOff + 768;           // u64[2][8]
-constexpr uint32_t kExpDlatOff = kExpMomOff + 128;         // u32[256]
-constexpr uint32_t kExpScratchOff = kExpDlatOff + 1024;    // u64[256]
-constexpr uint32_t kExpParentOff = kExpScratchOff + 2048;  // u32[256]
-constexpr uint32_t kExpLdsBytes = kExpParentOff + 1024;    // 11136
+constexpr uint32_t kExpMomOff = kExpObOff + 768;           // u64[2][8] delta moments, carried from batch to batch
+constexpr uint32_t kExpTurnOff = kExpMomOff + 128;         // u32 turn (next batch allowed into the ordered section), u32 lookback-oob flag
+constexpr uint32_t kExpWaveOff = kExpTurnOff + 16;         // per wave: dlat u32[256] | scratch u64[256] | parent u32[256]
+constexpr uint32_t kExpWaveBytes = 4096;
+constexpr uint32_t kExpLdsBytes = kExpWaveOff + kExpWaves * kExpWaveBytes;    // 23440
 
 template <class LV>
 __device__ __forceinline__ uint64_t expand_offsets(gcptr_u8 src, uint64_t src_len, uint64_t bitpos, uint32_t cnt, const uint8_t PCO_GLOBAL* syms,
@@ -535,11 +536,14 @@ __device__ __forceinline__ uint64_t expand_offsets(gcptr_u8 src, uint64_t src_le
   return bitpos + total;
 }
 
+// One workgroup of kExpWaves waves per chunk.  Unpacking a batch (symbols -> bins -> offsets) is independent of
+// every other batch and hides its HBM latency behind the other waves; only the delta decode is ordered: wave b % 4
+// enters it when `turn` reaches b, reads the moments the previous batch left in LDS, and passes the turn on.
 template <class L>
-__global__ __launch_bounds__(64) void dec_expand_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids, uint32_t n_ids,
-                                                        const DecPlan* plans, const uint8_t* bins_area, const uint8_t* sym_area, uint64_t sym_stride,
-                                                        const uint64_t* offpos_area, uint64_t offpos_stride) {
-  const uint32_t lane = lane_id();
+__global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids, uint32_t n_ids,
+                                                         const DecPlan* plans, const uint8_t* bins_area, const uint8_t* sym_area, uint64_t sym_stride,
+                                                         const uint64_t* offpos_area, uint64_t offpos_stride) {
+  const uint32_t lane = lane_id(), tid = threadIdx.x, wave = tid >> 6;
   uint8_t PCO_LDS* smem = lds_base();
   for (uint32_t bi = blockIdx.x; bi < n_ids; bi += gridDim.x) {
     const uint32_t ti = task_ids ? task_ids[bi] : bi;
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(64) void dec_expand_kernel(const PcoGfxDecodeTask* 
     const uint32_t pstatus = uni(plan->status);
     if (pstatus == kStatusRetryLegacy) continue;   // the single-kernel decoder finishes this task
     if (pstatus != PCO_GFX_OK) {
-      if (lane == 0) { PcoGfxTaskResult r; r.n_out = 0; r.consumed = plan->consumed; r.status = pstatus; r.aux = 0; results[ti] = r; }
+      if (tid == 0) { PcoGfxTaskResult r; r.n_out = 0; r.consumed = plan->consumed; r.status = pstatus; r.aux = 0; results[ti] = r; }
       continue;
     }
     const PcoGfxDecodeTask task = tasks[ti];
@@ -567,88 +571,103 @@ __global__ __launch_bounds__(64) void dec_expand_kernel(const PcoGfxDecodeTask* 
     uint64_t PCO_LDS* lowers = (uint64_t PCO_LDS*)(smem + kExpLowOff);
     uint8_t PCO_LDS* obs = smem + kExpObOff;
     uint64_t PCO_LDS* mom64 = (uint64_t PCO_LDS*)(smem + kExpMomOff);
-    uint32_t PCO_LDS* dlat = (uint32_t PCO_LDS*)(smem + kExpDlatOff);
-    L PCO_LDS* scratch = (L PCO_LDS*)(smem + kExpScratchOff);
-    uint32_t PCO_LDS* parent = (uint32_t PCO_LDS*)(smem + kExpParentOff);
+    uint32_t PCO_LDS* turn = (uint32_t PCO_LDS*)(smem + kExpTurnOff);
+    uint8_t PCO_LDS* wsm = smem + kExpWaveOff + wave * kExpWaveBytes;
+    uint32_t PCO_LDS* dlat = (uint32_t PCO_LDS*)wsm;
+    L PCO_LDS* scratch = (L PCO_LDS*)(wsm + 1024);
+    uint32_t PCO_LDS* parent = (uint32_t PCO_LDS*)(wsm + 3072);
     L PCO_LDS* moments0 = (L PCO_LDS*)mom64; L PCO_LDS* moments1 = (L PCO_LDS*)(mom64 + 8);
-    wave_sync_lds();
+    __syncthreads();   // the previous chunk's LDS state is dead
     const uint8_t PCO_GLOBAL* bins = (const uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask;
 #pragma unroll
     for (int v = 0; v < 3; v++) {
       if (!present[v]) continue;
       const uint64_t PCO_GLOBAL* gl = (const uint64_t PCO_GLOBAL*)(bins + (uint64_t)v * kBinsAreaPerVar);
       const uint8_t PCO_GLOBAL* go = bins + (uint64_t)v * kBinsAreaPerVar + kFastMaxBins * 8;
-      for (uint32_t b = lane; b < n_bins[v]; b += 64) { lowers[v * 256 + b] = gl[b]; obs[v * 256 + b] = go[b]; }
+      for (uint32_t b = tid; b < n_bins[v]; b += 256) { lowers[v * 256 + b] = gl[b]; obs[v * 256 + b] = go[b]; }
     }
-    if (lane < 8) { moments0[lane] = (L)plan->moments[0][lane]; moments1[lane] = (L)plan->moments[1][lane]; }
-    wave_sync_lds();
-    uint32_t n_remaining = n, lb_oob = 0, status = PCO_GFX_OK;
-    uint32_t batch = 0;
-    for (uint32_t j0 = 0; j0 < n; j0 += kBatchN, batch++) {
+    if (tid < 8) { moments0[tid] = (L)plan->moments[0][tid]; moments1[tid] = (L)plan->moments[1][tid]; }
+    if (tid == 0) { turn[0] = 0; turn[1] = 0; }
+    __syncthreads();
+    const bool ordered = dk[1] != kDeltaNone || (present[2] && dk[2] == kDeltaConsecutive);
+    const uint32_t n_batches = (n + kBatchN - 1) / kBatchN;
+    uint32_t lb_oob = 0;
+    for (uint32_t batch = wave; batch < n_batches; batch += kExpWaves) {
+      const uint32_t j0 = batch * kBatchN, n_remaining = n - j0;
       const uint32_t batch_n = n_remaining < kBatchN ? n_remaining : kBatchN;
       L prim[4] = {0, 0, 0, 0}, sec[4] = {0, 0, 0, 0};
       uint32_t prim_cnt = 0;
+      // ---- unordered: unpack every variable of the batch ----
 #pragma unroll
       for (int v = 0; v < 3; v++) {
         if (!present[v]) continue;
         uint32_t cnt;
         if (v == 0) { const uint32_t lim = n_remaining > nlps[1] ? n_remaining - nlps[1] : 0; cnt = lim < batch_n ? lim : batch_n; }
         else { const uint32_t rem = n_remaining > nlps[v] ? n_remaining - nlps[v] : 0; cnt = rem < kBatchN ? rem : kBatchN; }
-        if (cnt > 0) {
-          const bool single_bin = n_bins[v] <= 1;
-          const uint8_t PCO_GLOBAL* syms = (const uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)ti * 3 + v) * sym_stride + (uint64_t)batch * kBatchN;
-          const uint64_t off_start = uni(offpos_area[((uint64_t)ti * 3 + v) * offpos_stride + batch]);
-          if (v == 0) {
-            uint32_t tmp[4];
-            if (max_ob[0] != 0 || !single_bin) expand_offsets<uint32_t>(src, src_len, off_start, cnt, syms, lowers, obs, single_bin, tmp);
-            else { const uint32_t l0 = (uint32_t)lowers[0]; for (int k = 0; k < 4; k++) tmp[k] = l0; }
-            for (int k = 0; k < 4; k++) dlat[4 * lane + k] = 4 * lane + k < cnt ? tmp[k] : 0u;
-          } else {
-            L tmp[4];
-            if (max_ob[v] != 0 || !single_bin) expand_offsets<L>(src, src_len, off_start, cnt, syms, lowers + v * 256, obs + v * 256, single_bin, tmp);
-            else { const L l0 = (L)lowers[v * 256]; for (int k = 0; k < 4; k++) tmp[k] = 4 * lane + k < cnt ? l0 : (L)0; }
-            if (v == 1) { for (int k = 0; k < 4; k++) prim[k] = tmp[k]; prim_cnt = cnt; } else { for (int k = 0; k < 4; k++) sec[k] = tmp[k]; }
-          }
+        if (cnt == 0) continue;
+        const bool single_bin = n_bins[v] <= 1;
+        const uint8_t PCO_GLOBAL* syms = (const uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)ti * 3 + v) * sym_stride + (uint64_t)batch * kBatchN;
+        const uint64_t off_start = uni(offpos_area[((uint64_t)ti * 3 + v) * offpos_stride + batch]);
+        if (v == 0) {
+          uint32_t tmp[4];
+          if (max_ob[0] != 0 || !single_bin) expand_offsets<uint32_t>(src, src_len, off_start, cnt, syms, lowers, obs, single_bin, tmp);
+          else { const uint32_t l0 = (uint32_t)lowers[0]; for (int k = 0; k < 4; k++) tmp[k] = l0; }
+          for (int k = 0; k < 4; k++) dlat[4 * lane + k] = 4 * lane + k < cnt ? tmp[k] : 0u;
+        } else {
+          L tmp[4];
+          if (max_ob[v] != 0 || !single_bin) expand_offsets<L>(src, src_len, off_start, cnt, syms, lowers + v * 256, obs + v * 256, single_bin, tmp);
+          else { const L l0 = (L)lowers[v * 256]; for (int k = 0; k < 4; k++) tmp[k] = 4 * lane + k < cnt ? l0 : (L)0; }
+          if (v == 1) { for (int k = 0; k < 4; k++) prim[k] = tmp[k]; prim_cnt = cnt; } else { for (int k = 0; k < 4; k++) sec[k] = tmp[k]; }
         }
-        if (v >= 1 && dk[v] == kDeltaConsecutive) { if (v == 1) consecutive_decode<L>(prim, dord[1], moments0); else consecutive_decode<L>(sec, dord[2], moments1); }
       }
-      if (dk[1] == kDeltaLookback) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t window_n = 1u << window_n_log;
-        const uint64_t kbase = (uint64_t)j0;
-        for (int k = 0; k < 4; k++) {
-          const uint32_t i = 4 * lane + k;
-          L val = (L)(prim[k] + lmid<L>());
-          uint32_t par = 0xffffffffu;
-          if (i < prim_cnt) {
-            uint32_t lb = dlat[i];
-            if (lb > window_n) { lb_oob = 1; lb = 1; }
-            if (lb == 0) { }
-            else if (lb <= i) par = i - lb;
-            else {
-              const int64_t jsrc = (int64_t)(state_n + kbase + i) - (int64_t)lb;
-              if (jsrc >= 0) val = (L)(val + to_latent_ordered<L>(__hip_atomic_load(&dst[jsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), num_kind));
-            }
-          }
-          scratch[i] = val; parent[i] = par;
-        }
-        wave_sync_lds();
-        for (int round = 0; round < 8; round++) {
-          L nv[4]; uint32_t np[4];
+      // ---- ordered: delta decode, batch after batch ----
+      if (ordered) {
+        while (__hip_atomic_load((uint32_t*)turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != batch) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (dk[1] == kDeltaConsecutive) consecutive_decode<L>(prim, dord[1], moments0);
+        if (present[2] && dk[2] == kDeltaConsecutive) consecutive_decode<L>(sec, dord[2], moments1);
+        if (dk[1] == kDeltaLookback) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t window_n = 1u << window_n_log;
+          const uint64_t kbase = (uint64_t)j0;
           for (int k = 0; k < 4; k++) {
-            const uint32_t i = 4 * lane + k; const uint32_t p = parent[i];
-            nv[k] = scratch[i]; np[k] = p;
-            if (p != 0xffffffffu) { nv[k] = (L)(nv[k] + scratch[p]); np[k] = parent[p]; }
+            const uint32_t i = 4 * lane + k;
+            L val = (L)(prim[k] + lmid<L>());
+            uint32_t par = 0xffffffffu;
+            if (i < prim_cnt) {
+              uint32_t lb = dlat[i];
+              if (lb > window_n) { lb_oob = 1; lb = 1; }
+              if (lb == 0) { }
+              else if (lb <= i) par = i - lb;
+              else {
+                const int64_t jsrc = (int64_t)(state_n + kbase + i) - (int64_t)lb;
+                if (jsrc >= 0) val = (L)(val + to_latent_ordered<L>(__hip_atomic_load(&dst[jsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), num_kind));
+              }
+            }
+            scratch[i] = val; parent[i] = par;
           }
           wave_sync_lds();
-          for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; scratch[i] = nv[k]; parent[i] = np[k]; }
-          wave_sync_lds();
+          for (int round = 0; round < 8; round++) {
+            L nv[4]; uint32_t np[4];
+            for (int k = 0; k < 4; k++) {
+              const uint32_t i = 4 * lane + k; const uint32_t p = parent[i];
+              nv[k] = scratch[i]; np[k] = p;
+              if (p != 0xffffffffu) { nv[k] = (L)(nv[k] + scratch[p]); np[k] = parent[p]; }
+            }
+            wave_sync_lds();
+            for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; scratch[i] = nv[k]; parent[i] = np[k]; }
+            wave_sync_lds();
+          }
+          for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; if (i < prim_cnt) dst[state_n + kbase + i] = from_latent_ordered<L>(scratch[i], num_kind); }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          __builtin_amdgcn_wave_barrier();
         }
-        for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; if (i < prim_cnt) dst[state_n + kbase + i] = from_latent_ordered<L>(scratch[i], num_kind); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-      } else {
+        if (lane == 0) __hip_atomic_store((uint32_t*)turn, batch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (dk[1] != kDeltaLookback) {
         L outv[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) outv[k] = join_one<L>(mode_kind, num_kind, mode_base, mode_k, prim[k], sec[k]);
@@ -667,11 +686,13 @@ __global__ __launch_bounds__(64) void dec_expand_kernel(const PcoGfxDecodeTask* 
           } else { for (int k = 0; k < 4; k++) o[k] = outv[k]; }
         } else { for (int k = 0; k < 4; k++) if (i0 + k < batch_n) o[k] = outv[k]; }
       }
-      n_remaining -= batch_n;
     }
-    if (uni(wave_or_u32(lb_oob))) status = PCO_GFX_CORRUPTION;
-    if (lane == 0) { PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? n : 0; r.consumed = plan->consumed; r.status = status; r.aux = 0; results[ti] = r; }
-    wave_sync_lds();
+    if (uni(wave_or_u32(lb_oob)) && lane == 0) __hip_atomic_fetch_or((uint32_t*)(turn + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t status = turn[1] ? PCO_GFX_CORRUPTION : PCO_GFX_OK;
+      PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? n : 0; r.consumed = plan->consumed; r.status = status; r.aux = 0; results[ti] = r;
+    }
   }
 }
 

@@ -188,86 +188,130 @@ __global__ __launch_bounds__(256) void enc_trial_summary_kernel(EncWorkspace ws,
 // =========================================================================================================
 // K1: mode split + consecutive delta + min/max (elementwise, coalesced)
 // =========================================================================================================
-template <class L>
-__device__ __forceinline__ void split_one(uint32_t mode_kind, uint32_t num_kind, L mode_base, uint32_t mode_k, uint64_t aux_inv, uint64_t aux_base,
-                                          L bits, L& p, L& s) {
+template <class L, int MODE>
+__device__ __forceinline__ void split_one(uint32_t num_kind, L mode_base, uint32_t mode_k, uint64_t aux_inv, uint64_t aux_base, L bits, L& p, L& s) {
   s = 0;
-  switch (mode_kind) {
-    case kClassic: p = to_latent_ordered<L>(bits, num_kind); break;
-    case kIntMult: { const L u = to_latent_ordered<L>(bits, num_kind); p = (L)(u / mode_base); s = (L)(u % mode_base); break; }
-    case kFloatQuant: {
-      const L num_ = to_latent_ordered<L>(bits, kFloat);
-      const L lowmax = (L)(((L)1 << mode_k) - 1);
-      p = (L)(num_ >> mode_k);
-      const L low = (L)(num_ & lowmax);
-      s = (bits & lmid<L>()) ? (L)(lowmax - low) : low;
-      break;
-    }
-    default: {  // kFloatMult (mode/float_mult.rs:38-60)
-      if constexpr (sizeof(L) >= 4) {
-        typedef typename FloatOf<L>::F F;
-        const F num = bits_to_float(bits);
-        const F inv_base = bits_to_float((L)aux_inv), base = bits_to_float((L)aux_base);
-        const F mult = round_half_away(num * inv_base);
-        p = int_float_to_latent<L>(mult);
-        s = (L)(to_latent_ordered<L>(bits, kFloat) - to_latent_ordered<L>(float_to_bits(mult * base), kFloat) + lmid<L>());
-      } else p = 0;
-    }
+  if constexpr (MODE == kClassic) p = to_latent_ordered<L>(bits, num_kind);
+  else if constexpr (MODE == kIntMult) { const L u = to_latent_ordered<L>(bits, num_kind); p = (L)(u / mode_base); s = (L)(u % mode_base); }
+  else if constexpr (MODE == kFloatQuant) {
+    const L num_ = to_latent_ordered<L>(bits, kFloat);
+    const L lowmax = (L)(((L)1 << mode_k) - 1);
+    p = (L)(num_ >> mode_k);
+    const L low = (L)(num_ & lowmax);
+    s = (bits & lmid<L>()) ? (L)(lowmax - low) : low;
+  } else {  // kFloatMult (mode/float_mult.rs:38-60)
+    if constexpr (sizeof(L) >= 4) {
+      typedef typename FloatOf<L>::F F;
+      const F num = bits_to_float(bits);
+      const F inv_base = bits_to_float((L)aux_inv), base = bits_to_float((L)aux_base);
+      const F mult = round_half_away(num * inv_base);
+      p = int_float_to_latent<L>(mult);
+      s = (L)(to_latent_ordered<L>(bits, kFloat) - to_latent_ordered<L>(float_to_bits(mult * base), kFloat) + lmid<L>());
+    } else p = 0;
   }
 }
 
-template <class L>
-__device__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& task, uint32_t t, EncPage PCO_GLOBAL* pg) {
+// One thread owns kSplitE contiguous numbers (all of its loads are issued before anything is used), a block owns a
+// tile of kSplitTile.  The `order` preceding primaries a thread needs for the finite differences come from its left
+// neighbour through LDS; the block's halo (the 7 numbers before the tile) is split by threads 249..255.
+constexpr uint32_t kSplitE = 8, kSplitTile = 256 * kSplitE;
+constexpr uint32_t kSplitLdsPrev = 0;                       // L[257][7]: slot 0 = halo, slot t + 1 = thread t
+constexpr uint32_t kSplitLdsRed = 257 * 7 * 8;              // u64[4 waves][4]
+constexpr uint32_t kSplitLdsBytes = kSplitLdsRed + 128;
+
+template <class L, int MODE>
+__device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& task, uint32_t t, EncPage PCO_GLOBAL* pg, uint32_t tile) {
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
-  const uint64_t n = pg->n, pstart = pg->start;
-  const uint32_t num_kind = dtype_kind(task.dtype);
-  const uint32_t mode_kind = ch->mode_kind, mode_k = ch->mode_k;
-  const L mode_base = (L)ch->mode_base; const uint64_t aux_inv = ch->mode_aux, aux_base = ch->mode_aux2;
-  const uint32_t order = ch->delta_kind == kDeltaConsecutive ? ch->delta_order : 0;
-  const bool has_sec = ch->v[2].present != 0;
+  const uint64_t n = uni((uint64_t)pg->n), pstart = uni((uint64_t)pg->start);
+  const uint32_t num_kind = dtype_kind(uni(task.dtype));
+  const uint32_t mode_k = uni(ch->mode_k);
+  const L mode_base = (L)uni((uint64_t)ch->mode_base); const uint64_t aux_inv = uni((uint64_t)ch->mode_aux), aux_base = uni((uint64_t)ch->mode_aux2);
+  const uint32_t delta_kind = uni(ch->delta_kind);
+  const uint32_t order = delta_kind == kDeltaConsecutive ? uni(ch->delta_order) : 0;
+  constexpr bool has_sec = MODE != kClassic;
   const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)task.src + pstart;
-  const bool lookback = ch->delta_kind == kDeltaLookback;
+  const bool lookback = delta_kind == kDeltaLookback;
   // lookback: stage the un-delta'd primary in sort buffer A; enc_lookback_kernel turns it into lat[0] / lat[1]
   L PCO_GLOBAL* lat1 = (lookback ? sort_ptr<L>(ws, t, 0) : lat_ptr<L>(ws, t, 1)) + pstart;
   L PCO_GLOBAL* lat2 = has_sec ? lat_ptr<L>(ws, t, 2) + pstart : nullptr;
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  const uint32_t tid = threadIdx.x;
+  const uint64_t tile0 = (uint64_t)tile * kSplitTile;
+  const uint64_t e0 = tile0 + (uint64_t)tid * kSplitE;
+  L raw[kSplitE], a[7 + kSplitE], sec[kSplitE];
+  const bool full = e0 + kSplitE <= n;
+  if (full) {
+#pragma unroll
+    for (uint32_t k = 0; k < kSplitE; k++) raw[k] = src[e0 + k];
+  } else {
+#pragma unroll
+    for (uint32_t k = 0; k < kSplitE; k++) raw[k] = e0 + k < n ? src[e0 + k] : (L)0;
+  }
+  L halo_raw = 0;
+  const bool halo_on = order > 0 && tid >= 249 && tile0 + tid >= 256 && tile0 + tid - 256 < n;   // element tile0 - 7 + (tid - 249)
+  if (halo_on) halo_raw = src[tile0 + tid - 256];
+#pragma unroll
+  for (uint32_t k = 0; k < kSplitE; k++) split_one<L, MODE>(num_kind, mode_base, mode_k, aux_inv, aux_base, raw[k], a[7 + k], sec[k]);
+#pragma unroll
+  for (uint32_t jj = 0; jj < 7; jj++) a[jj] = 0;
+  if (order > 0) {  // (wrapping) k-th finite difference by repeated adjacent differences (delta/consecutive.rs:3-33)
+    L PCO_LDS* prevbuf = (L PCO_LDS*)(smem + kSplitLdsPrev);
+#pragma unroll
+    for (uint32_t jj = 0; jj < 7; jj++) if (jj + order >= 7) prevbuf[(tid + 1) * 7 + jj] = a[8 + jj];
+    if (tid >= 249) { L hp = 0, hs; if (halo_on) split_one<L, MODE>(num_kind, mode_base, mode_k, aux_inv, aux_base, halo_raw, hp, hs); prevbuf[tid - 249] = hp; }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t jj = 0; jj < 7; jj++) if (jj + order >= 7) a[jj] = prevbuf[tid * 7 + jj];
+    for (uint32_t r = 0; r < order; r++) {
+#pragma unroll
+      for (uint32_t idx = 6 + kSplitE; idx >= 1; idx--) a[idx] = (L)(a[idx] - a[idx - 1]);
+    }
+  }
   L mn1 = (L)~(L)0, mx1 = 0, mn2 = (L)~(L)0, mx2 = 0;
-  const uint64_t base_i = (uint64_t)blockIdx.x * 1024;
-  for (int k = 0; k < 4; k++) {
-    const uint64_t i = base_i + (uint64_t)k * 256 + threadIdx.x;
-    if (i >= n) continue;
-    L w[8]; L s0 = 0;
-    const uint32_t o = i >= order ? order : 0;  // positions < order are junk (not stored)
+  L d[kSplitE];
+  const L toggle = order > 0 ? lmid<L>() : (L)0;
+  if (full && e0 >= order) {
 #pragma unroll
-    for (uint32_t j = 0; j < 8; j++) {
-      if (j <= o) { L p, s; split_one<L>(mode_kind, num_kind, mode_base, mode_k, aux_inv, aux_base, src[i - j], p, s); w[j] = p; if (j == 0) s0 = s; }
-      else w[j] = 0;
+    for (uint32_t k = 0; k < kSplitE; k++) {
+      d[k] = (L)(a[7 + k] + toggle);
+      mn1 = d[k] < mn1 ? d[k] : mn1; mx1 = d[k] > mx1 ? d[k] : mx1;
+      if (has_sec) { mn2 = sec[k] < mn2 ? sec[k] : mn2; mx2 = sec[k] > mx2 ? sec[k] : mx2; }
     }
-    // k-th finite difference by repeated adjacent differences (wrapping; delta/consecutive.rs:3-33)
+  } else {
 #pragma unroll
-    for (uint32_t r = 1; r < 8; r++) {
-      if (r <= o) {
-#pragma unroll
-        for (uint32_t j = 0; j + r < 8; j++) if (j + r <= o) w[j] = (L)(w[j] - w[j + 1]);
-      }
-    }
-    L d = w[0];
-    if (order > 0) d = (L)(d + lmid<L>());
-    lat1[i] = d;
-    if (i >= order && !lookback) { mn1 = d < mn1 ? d : mn1; mx1 = d > mx1 ? d : mx1; }
-    if (has_sec) { lat2[i] = s0; mn2 = s0 < mn2 ? s0 : mn2; mx2 = s0 > mx2 ? s0 : mx2; }
-    if (i == 0 && order > 0) {
-      // moments[o] = (delta^o p)[o]
-      L q[8];
-      for (uint32_t j = 0; j < 8; j++) {
-        if (j < order && j < n) { L p, s; split_one<L>(mode_kind, num_kind, mode_base, mode_k, aux_inv, aux_base, src[j], p, s); q[j] = p; } else q[j] = 0;
-      }
-      for (uint32_t oo = 0; oo < order; oo++) {
-        pg->moments[oo] = oo < n ? (uint64_t)q[0] : 0ull;  // an exhausted page yields L::ZERO moments
-        for (uint32_t j = 0; j + 1 < 8; j++) q[j] = (L)(q[j + 1] - q[j]);
+    for (uint32_t k = 0; k < kSplitE; k++) {
+      d[k] = (L)(a[7 + k] + toggle);
+      const uint64_t i = e0 + k;
+      if (i < n) {
+        if (i >= order) { mn1 = d[k] < mn1 ? d[k] : mn1; mx1 = d[k] > mx1 ? d[k] : mx1; }   // positions < order are junk (not stored)
+        if (has_sec) { mn2 = sec[k] < mn2 ? sec[k] : mn2; mx2 = sec[k] > mx2 ? sec[k] : mx2; }
       }
     }
   }
-  // wave reduce min / max then one atomic per wave
+  if (lookback) { mn1 = (L)~(L)0; mx1 = 0; }   // enc_lookback_kernel owns the primary's range
+  if (full) {
+#pragma unroll
+    for (uint32_t k = 0; k < kSplitE; k++) lat1[e0 + k] = d[k];
+    if (has_sec) {
+#pragma unroll
+      for (uint32_t k = 0; k < kSplitE; k++) lat2[e0 + k] = sec[k];
+    }
+  } else {
+#pragma unroll
+    for (uint32_t k = 0; k < kSplitE; k++) if (e0 + k < n) { lat1[e0 + k] = d[k]; if (has_sec) lat2[e0 + k] = sec[k]; }
+  }
+  if (e0 == 0 && order > 0) {
+    // moments[o] = (delta^o p)[o]
+    L q[8];
+    for (uint32_t jj = 0; jj < 8; jj++) {
+      if (jj < order && jj < n) { L pp, ss; split_one<L, MODE>(num_kind, mode_base, mode_k, aux_inv, aux_base, src[jj], pp, ss); q[jj] = pp; } else q[jj] = 0;
+    }
+    for (uint32_t oo = 0; oo < order; oo++) {
+      pg->moments[oo] = oo < n ? (uint64_t)q[0] : 0ull;  // an exhausted page yields L::ZERO moments
+      for (uint32_t jj = 0; jj + 1 < 8; jj++) q[jj] = (L)(q[jj + 1] - q[jj]);
+    }
+  }
+  // min / max: wave reduce, block reduce through LDS, one atomic pair per block
   for (int dlt = 32; dlt >= 1; dlt >>= 1) {
     L o1 = shfl_idx(mn1, (int)(lane_id() ^ dlt)); mn1 = o1 < mn1 ? o1 : mn1;
     L o2 = shfl_idx(mx1, (int)(lane_id() ^ dlt)); mx1 = o2 > mx1 ? o2 : mx1;
@@ -276,23 +320,42 @@ __device__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& t
       L o4 = shfl_idx(mx2, (int)(lane_id() ^ dlt)); mx2 = o4 > mx2 ? o4 : mx2;
     }
   }
-  if (lane_id() == 0) {
-    if (mn1 <= mx1) { atomicMin((unsigned long long*)&ws.chunks[t].v[1].minv, (unsigned long long)mn1); atomicMax((unsigned long long*)&ws.chunks[t].v[1].maxv, (unsigned long long)mx1); }
-    if (has_sec && mn2 <= mx2) { atomicMin((unsigned long long*)&ws.chunks[t].v[2].minv, (unsigned long long)mn2); atomicMax((unsigned long long*)&ws.chunks[t].v[2].maxv, (unsigned long long)mx2); }
+  uint64_t PCO_LDS* red = (uint64_t PCO_LDS*)(smem + kSplitLdsRed);
+  if (lane_id() == 0) { const uint32_t w = tid >> 6; red[w * 4 + 0] = (uint64_t)mn1; red[w * 4 + 1] = (uint64_t)mx1; red[w * 4 + 2] = (uint64_t)mn2; red[w * 4 + 3] = (uint64_t)mx2; }
+  __syncthreads();
+  if (tid == 0) {
+    uint64_t m1 = ~0ull, x1 = 0, m2 = ~0ull, x2 = 0;
+    for (uint32_t w = 0; w < 4; w++) {
+      m1 = red[w * 4] < m1 ? red[w * 4] : m1; x1 = red[w * 4 + 1] > x1 ? red[w * 4 + 1] : x1;
+      m2 = red[w * 4 + 2] < m2 ? red[w * 4 + 2] : m2; x2 = red[w * 4 + 3] > x2 ? red[w * 4 + 3] : x2;
+    }
+    if (m1 <= x1) { atomicMin((unsigned long long*)&ws.chunks[t].v[1].minv, (unsigned long long)m1); atomicMax((unsigned long long*)&ws.chunks[t].v[1].maxv, (unsigned long long)x1); }
+    if (has_sec && m2 <= x2) { atomicMin((unsigned long long*)&ws.chunks[t].v[2].minv, (unsigned long long)m2); atomicMax((unsigned long long*)&ws.chunks[t].v[2].maxv, (unsigned long long)x2); }
   }
 }
 
-__global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks) {
-  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + blockIdx.y;
-  if (pg->flags & kPageFlagMetaOnly) return;
-  const uint32_t t = pg->chunk;
+template <class L>
+__device__ __forceinline__ void enc_split_mode(const EncWorkspace& ws, const PcoGfxEncodeTask& task, uint32_t t, EncPage PCO_GLOBAL* pg, uint32_t tile, uint32_t mode_kind) {
+  if (mode_kind == kClassic) enc_split_body<L, kClassic>(ws, task, t, pg, tile);
+  else if (mode_kind == kIntMult) enc_split_body<L, kIntMult>(ws, task, t, pg, tile);
+  else if (mode_kind == kFloatQuant) enc_split_body<L, kFloatQuant>(ws, task, t, pg, tile);
+  else enc_split_body<L, kFloatMult>(ws, task, t, pg, tile);
+}
+
+// grid pages * tiles_per_page, 256 threads
+__global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, uint32_t tiles_per_page) {
+  const uint32_t page = blockIdx.x / tiles_per_page, tile = blockIdx.x % tiles_per_page;
+  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + page;
+  if (uni(pg->flags) & kPageFlagMetaOnly) return;
+  const uint32_t t = uni(pg->chunk);
   const PcoGfxEncodeTask task = tasks[t];
-  if ((uint64_t)blockIdx.x * 1024 >= pg->n) return;
-  if (ws.chunks[t].status != PCO_GFX_OK) return;
-  const int bits = dtype_bits(task.dtype);
-  if (bits == 64) enc_split_body<uint64_t>(ws, task, t, pg);
-  else if (bits == 32) enc_split_body<uint32_t>(ws, task, t, pg);
-  else if (bits == 16) enc_split_body<uint16_t>(ws, task, t, pg);
+  if ((uint64_t)tile * kSplitTile >= uni((uint64_t)pg->n)) return;
+  if (uni(ws.chunks[t].status) != PCO_GFX_OK) return;
+  const int bits = dtype_bits(uni(task.dtype));
+  const uint32_t mode_kind = uni(ws.chunks[t].mode_kind);
+  if (bits == 64) enc_split_mode<uint64_t>(ws, task, t, pg, tile, mode_kind);
+  else if (bits == 32) enc_split_mode<uint32_t>(ws, task, t, pg, tile, mode_kind);
+  else if (bits == 16) enc_split_mode<uint16_t>(ws, task, t, pg, tile, mode_kind);
 }
 
 // =========================================================================================================

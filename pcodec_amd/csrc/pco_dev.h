@@ -50,15 +50,22 @@ template <> struct LBits<uint64_t> { static constexpr uint32_t v = 64; };
 template <class L> __host__ __device__ constexpr L lmid() { return (L)((L)1 << (LBits<L>::v - 1)); }
 
 // order preserving bijections (data_types/unsigned.rs:155-161, signed.rs:46-52, float.rs:392-411)
+// Branch-free: `kind` is wave-uniform, the masks below stay in SGPRs.
+template <class L> struct SignedOf;
+template <> struct SignedOf<uint16_t> { typedef int16_t T; };
+template <> struct SignedOf<uint32_t> { typedef int32_t T; };
+template <> struct SignedOf<uint64_t> { typedef int64_t T; };
 template <class L> __device__ __forceinline__ L to_latent_ordered(L bits, uint32_t kind) {
-  if (kind == kUnsigned) return bits;
-  if (kind == kSigned) return (L)(bits ^ lmid<L>());
-  return (bits & lmid<L>()) ? (L)~bits : (L)(bits ^ lmid<L>());
+  typedef typename SignedOf<L>::T S;
+  const L neg = (L)((S)bits >> (LBits<L>::v - 1));                     // all ones for a set sign bit
+  const L m = (L)((kind == kFloat ? neg : (L)0) | (kind == kUnsigned ? (L)0 : lmid<L>()));
+  return (L)(bits ^ m);   // unsigned: x; signed: x ^ MID; float: sign ? !x : x ^ MID
 }
 template <class L> __device__ __forceinline__ L from_latent_ordered(L l, uint32_t kind) {
-  if (kind == kUnsigned) return l;
-  if (kind == kSigned) return (L)(l ^ lmid<L>());
-  return (l & lmid<L>()) ? (L)(l ^ lmid<L>()) : (L)~l;
+  typedef typename SignedOf<L>::T S;
+  const L pos = (L)((S)(L)~l >> (LBits<L>::v - 1));                    // all ones for a clear top bit
+  const L m = (L)((kind == kFloat ? pos : (L)0) | (kind == kUnsigned ? (L)0 : lmid<L>()));
+  return (L)(l ^ m);      // unsigned: l; signed: l ^ MID; float: top ? l ^ MID : !l
 }
 
 __device__ __forceinline__ uint32_t clz_u32(uint32_t x) { return x == 0 ? 32u : (uint32_t)__builtin_clz(x); }

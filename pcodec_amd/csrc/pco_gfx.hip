@@ -148,11 +148,11 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     if (fast) {
       const uint32_t wgrid = (cnt + kWQ - 1) / kWQ;
       if (g == 0) { PCO_TIMED_LAUNCH("dec_walk_kernel<u64>", stream, dec_walk_kernel<uint64_t>, dim3(wgrid), dim3(64), kWalkLdsBytes, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
-                    PCO_TIMED_LAUNCH("dec_expand_kernel<u64>", stream, dec_expand_kernel<uint64_t>, dim3(grid), dim3(64), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
+                    PCO_TIMED_LAUNCH("dec_expand_kernel<u64>", stream, dec_expand_kernel<uint64_t>, dim3(grid), dim3(256), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
       else if (g == 1) { PCO_TIMED_LAUNCH("dec_walk_kernel<u32>", stream, dec_walk_kernel<uint32_t>, dim3(wgrid), dim3(64), kWalkLdsBytes, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
-                         PCO_TIMED_LAUNCH("dec_expand_kernel<u32>", stream, dec_expand_kernel<uint32_t>, dim3(grid), dim3(64), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
+                         PCO_TIMED_LAUNCH("dec_expand_kernel<u32>", stream, dec_expand_kernel<uint32_t>, dim3(grid), dim3(256), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
       else { PCO_TIMED_LAUNCH("dec_walk_kernel<u16>", stream, dec_walk_kernel<uint16_t>, dim3(wgrid), dim3(64), kWalkLdsBytes, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
-             PCO_TIMED_LAUNCH("dec_expand_kernel<u16>", stream, dec_expand_kernel<uint16_t>, dim3(grid), dim3(64), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
+             PCO_TIMED_LAUNCH("dec_expand_kernel<u16>", stream, dec_expand_kernel<uint16_t>, dim3(grid), dim3(256), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
     }
     if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
     else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);

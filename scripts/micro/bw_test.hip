@@ -1,0 +1,64 @@
+// HBM copy micro-benchmark: access-pattern calibration for the streaming kernels (debug aid, not part of the product)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef unsigned long long u64;
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void copy8(const u64* __restrict__ s, u64* __restrict__ d, size_t n) {
+  size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  u64 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = s[base + k * 256];
+#pragma unroll
+  for (int k = 0; k < 4; k++) d[base + k * 256] = v[k] + 1;
+}
+__global__ __launch_bounds__(256) void copy8_serial(const u64* __restrict__ s, u64* __restrict__ d, size_t n) {
+  size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  for (int k = 0; k < 4; k++) { u64 v = s[base + k * 256]; __builtin_amdgcn_s_waitcnt(0); d[base + k * 256] = v + 1; }
+}
+template <int R>
+__global__ __launch_bounds__(256) void copy16(const u64x2* __restrict__ s, u64x2* __restrict__ d, size_t n2) {
+  size_t base = (size_t)blockIdx.x * (256 * R) + threadIdx.x;
+  u64x2 v[R];
+#pragma unroll
+  for (int k = 0; k < R; k++) v[k] = s[base + k * 256];
+#pragma unroll
+  for (int k = 0; k < R; k++) { v[k].x += 1; d[base + k * 256] = v[k]; }
+}
+__global__ __launch_bounds__(256) void copy64c(const u64x2* __restrict__ s, u64x2* __restrict__ d, size_t n2) {
+  size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  u64x2 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = s[base + k];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { v[k].x += 1; d[base + k] = v[k]; }
+}
+__global__ __launch_bounds__(256) void read16(const u64x2* __restrict__ s, u64* __restrict__ d, size_t n2) {
+  size_t base = (size_t)blockIdx.x * 2048 + threadIdx.x;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { u64x2 v = s[base + k * 256]; acc += v.x ^ v.y; }
+  if (acc == 0x1234567) d[0] = acc;
+}
+int main() {
+  size_t n = (size_t)1 << 30;  // 8 GiB in, 8 GiB out
+  u64 *s, *d; hipMalloc(&s, n * 8); hipMalloc(&d, n * 8);
+  hipMemset(s, 1, n * 8); hipMemset(d, 0, n * 8);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto run = [&](const char* name, auto launch, double bytes) {
+    launch(); hipDeviceSynchronize();
+    hipEventRecord(e0); for (int i = 0; i < 3; i++) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    printf("%-14s %.3f ms  %.2f TB/s\n", name, ms, bytes / ms / 1e9);
+  };
+  run("copy8", [&] { copy8<<<n / 1024, 256>>>(s, d, n); }, 16.0 * n);
+  run("copy8_serial", [&] { copy8_serial<<<n / 1024, 256>>>(s, d, n); }, 16.0 * n);
+  run("copy16x1", [&] { copy16<1><<<n / 2 / 256, 256>>>((u64x2*)s, (u64x2*)d, n / 2); }, 16.0 * n);
+  run("copy16x4", [&] { copy16<4><<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, n / 2); }, 16.0 * n);
+  run("copy16x8", [&] { copy16<8><<<n / 2 / 2048, 256>>>((u64x2*)s, (u64x2*)d, n / 2); }, 16.0 * n);
+  run("copy64c", [&] { copy64c<<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, n / 2); }, 16.0 * n);
+  run("read16x8", [&] { read16<<<n / 2 / 2048, 256>>>((u64x2*)s, d, n / 2); }, 8.0 * n);
+  run("memset", [&] { hipMemsetAsync(d, 0, n * 8); }, 8.0 * n);
+  run("memcpyD2D", [&] { hipMemcpyAsync(d, s, n * 8, hipMemcpyDeviceToDevice); }, 16.0 * n);
+  return 0;
+}
