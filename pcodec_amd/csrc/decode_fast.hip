@@ -78,7 +78,7 @@ __device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader&
     }
     const uint32_t incl = wave_incl_scan(w);
     if (b < n_bins) cum[b] = carry + incl - w;
-    carry += uni(shfl_idx(incl, 63));
+    carry += wave_last(incl);
   }
   if (lane == 0) cum[n_bins] = carry;
   mr.bit = bins_start + (uint64_t)n_bins * bin_bits;
@@ -519,7 +519,7 @@ __device__ __forceinline__ uint64_t expand_offsets(gcptr_u8 src, uint64_t src_le
   }
   const uint32_t t = ob[0] + ob[1] + ob[2] + ob[3];
   const uint32_t incl = wave_incl_scan(t);
-  const uint32_t total = uni(shfl_idx(incl, 63));
+  const uint32_t total = wave_last(incl);
   uint64_t b = bitpos + (incl - t);
 #pragma unroll
   for (int k = 0; k < 4; k++) {

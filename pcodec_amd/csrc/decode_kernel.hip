@@ -97,7 +97,7 @@ __device__ __noinline__ bool build_var_tables(tptr<kLds, uint8_t> tbl, uint32_t 
     }
     const uint32_t incl = wave_incl_scan(w);
     if (b < n_bins) cum[b] = carry + incl - w;
-    carry += uni(shfl_idx(incl, 63));
+    carry += wave_last(incl);
   }
   if (lane == 0) { cum[n_bins] = carry; }
   mr.bit = bins_start + (uint64_t)n_bins * bin_bits;
@@ -228,7 +228,7 @@ __device__ __forceinline__ uint64_t unpack_offsets(gcptr_u8 src, uint64_t src_le
   }
   const uint32_t t = ob[0] + ob[1] + ob[2] + ob[3];
   const uint32_t incl = wave_incl_scan(t);
-  const uint32_t total = uni(shfl_idx(incl, 63));
+  const uint32_t total = wave_last(incl);
   uint64_t b = bitpos + (incl - t);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -258,7 +258,7 @@ __device__ __forceinline__ void consecutive_decode(L x[4], uint32_t order, L PCO
     const L incl = wave_incl_scan(t);
     const L base = (L)(mom + (L)(incl - t));
     x[0] = base; x[1] = (L)(base + e1); x[2] = (L)(base + e2); x[3] = (L)(base + e3);
-    const L total = shfl_idx(incl, 63);
+    const L total = wave_last(incl);
     wave_sync_lds();
     if (lane == 0) moments[m] = (L)(mom + total);
     wave_sync_lds();

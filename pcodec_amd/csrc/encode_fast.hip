@@ -108,7 +108,7 @@ __device__ __forceinline__ void dissect_batch(const uint8_t PCO_LDS* vt, const L
 }
 
 template <class L>
-__device__ void dissect_block(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run, EncPage PCO_GLOBAL* pg, EncChunk PCO_GLOBAL* ch) {
+__device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run, EncPage PCO_GLOBAL* pg, EncChunk PCO_GLOBAL* ch) {
   const uint32_t t = uni(pg->chunk);
   const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
   const uint64_t pstart = uni((uint64_t)pg->start);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64) void enc_scan_kernel(EncWorkspace ws, EncFast f
         fx.run_start[(uint64_t)p * fx.run_stride + b / kRunBatches] = start;
         dst32[start >> 5] = 0;   // the run's first dword is joined with atomicOr by its two writers
       }
-      carry += uni(shfl_idx(incl, 63));
+      carry += wave_last(incl);
     }
     if (pass == 0) {
       const uint64_t total = (carry + 7) & ~(uint64_t)7;
@@ -400,16 +400,33 @@ __global__ __launch_bounds__(64) void enc_scan_kernel(EncWorkspace ws, EncFast f
 // =========================================================================================================
 // pack
 // =========================================================================================================
-// BitSink whose run starts at an arbitrary bit of dst: the first and the last dword it touches are shared with the
-// neighbouring runs and are merged with atomicOr (enc_scan_kernel zeroed them); interior dwords are plain stores.
-struct RunSink : BitSink {
-  uint64_t first_dw;
-  __device__ __forceinline__ void init_at(uint32_t PCO_LDS* s, uint32_t PCO_GLOBAL* d, uint64_t cap_bytes, uint64_t start_bit) {
-    init(s, d, cap_bytes); outbit = start_bit; first_dw = start_bit >> 5;
-  }
-  __device__ __forceinline__ void advance_run(uint32_t total) {
+// Bit sink of one run.  Fields are OR-ed into an LDS staging area (atomics: neighbouring lanes share dwords) that is
+// written to dst only when it fills up, so small sections cost no flush.  The run starts at an arbitrary bit of dst:
+// the first and the last dword it touches are shared with the neighbouring runs and are merged with atomicOr
+// (enc_scan_kernel zeroed them); interior dwords are plain stores.  (bit_writer.rs:22-42 semantics.)
+struct PackSink {
+  uint32_t PCO_LDS* stg; uint32_t PCO_GLOBAL* dst; uint64_t outbit, first_dw; uint32_t pend;   // pend: staged bits after outbit
+  __device__ __forceinline__ void init_at(uint32_t PCO_LDS* s, uint32_t PCO_GLOBAL* d, uint64_t start_bit) {
+    stg = s; dst = d; outbit = start_bit; first_dw = start_bit >> 5; pend = 0;
+    for (uint32_t i = lane_id(); i < kStgDwords; i += 64) stg[i] = 0;
     enc_wave_sync();
-    const uint64_t newbit = outbit + total;
+  }
+  __device__ __forceinline__ void put(uint32_t rel, uint64_t val, uint32_t nbits) {   // nbits <= 64 of val at bit `rel` after the staged bits
+    if (nbits == 0) return;
+    if (nbits < 64) val &= ((uint64_t)1 << nbits) - 1;
+    const uint32_t pos = (uint32_t)(outbit & 31) + pend + rel;
+    const uint32_t dw = pos >> 5, sh = pos & 31;
+    atomicOr((uint32_t*)&stg[dw], (uint32_t)(val << sh));
+    if (sh + nbits > 32) {
+      const uint64_t rest = sh ? (val >> (32 - sh)) : (val >> 32);
+      atomicOr((uint32_t*)&stg[dw + 1], (uint32_t)rest);
+      if (sh + nbits > 64) atomicOr((uint32_t*)&stg[dw + 2], (uint32_t)(rest >> 32));
+    }
+  }
+  __device__ __forceinline__ void commit(uint32_t total) { pend += total; }
+  __device__ __forceinline__ void flush() {
+    enc_wave_sync();
+    const uint64_t newbit = outbit + pend;
     const uint64_t base_dw = outbit >> 5;
     const uint32_t ncomplete = (uint32_t)((newbit >> 5) - base_dw);
     const uint32_t lane = lane_id();
@@ -418,69 +435,93 @@ struct RunSink : BitSink {
     }
     const uint32_t last = stg[ncomplete];
     enc_wave_sync();
-    const uint32_t used = ncomplete + 1;
-    for (uint32_t i = lane; i < used && i < kStgDwords; i += 64) stg[i] = 0;
+    for (uint32_t i = lane; i <= ncomplete; i += 64) stg[i] = 0;
     enc_wave_sync();
     if (lane == 0) stg[0] = last;
     enc_wave_sync();
-    outbit = newbit;
+    outbit = newbit; pend = 0;
   }
-  __device__ __forceinline__ void put_uniform_run(uint64_t val, uint32_t nbits) { if (lane_id() == 0) put(0, val, nbits); advance_run(nbits); }
-  __device__ __forceinline__ void finish_byte_run() { advance_run((uint32_t)((8 - (outbit & 7)) & 7)); }
-  __device__ __forceinline__ void close_run() {
-    enc_wave_sync();
+  // make room for `bits` more staged bits (plus the 64-bit reach of put)
+  __device__ __forceinline__ void reserve(uint32_t bits) { if ((uint32_t)(outbit & 31) + pend + bits + 96 > kStgDwords * 32) flush(); }
+  __device__ __forceinline__ void put_uniform(uint64_t val, uint32_t nbits) { reserve(64); if (lane_id() == 0) put(0, val, nbits); commit(nbits); }
+  __device__ __forceinline__ void finish_byte() { commit((uint32_t)((8 - ((outbit + pend) & 7)) & 7)); }
+  __device__ __forceinline__ void close() {
+    flush();
     if (lane_id() == 0 && (outbit & 31)) atomicOr((uint32_t*)(dst + (outbit >> 5)), stg[0]);
   }
 };
 
-constexpr uint32_t kPackLdsVar = kPageLdsStg + kStgDwords * 4;   // 2816: per-var (lowers u64[256] | offset bits u8[256])
+constexpr uint32_t kPackLdsVar = kPageLdsStg + kStgDwords * 4;   // 2816: per latent slot (lowers u64[256] | offset bits u8[256])
 constexpr uint32_t kPackVarBytes = 2048 + 256;
-constexpr uint32_t kPackLdsBytes = kPackLdsVar + 3 * kPackVarBytes;
+__host__ __device__ constexpr uint32_t pack_lds_bytes(uint32_t n_slots) { return kPackLdsVar + n_slots * kPackVarBytes; }
+
+// what one lane holds of one (batch, variable) item: 4 symbols, 4 tANS fields, 4 latents
+struct PackItem { uint32_t syms, a, b; uint64_t x[4]; };
 
 template <class LV>
-__device__ __forceinline__ void pack_batch(RunSink& sink, const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, const uint8_t PCO_GLOBAL* sym,
-                                           const uint16_t PCO_GLOBAL* answ, uint32_t cnt, bool needs_ans, uint32_t max_ob, bool single_bin) {
+__device__ __forceinline__ void pack_load(PackItem& it, const LV PCO_GLOBAL* lat, const uint8_t PCO_GLOBAL* sym, const uint16_t PCO_GLOBAL* answ,
+                                          uint32_t cnt, bool needs_ans, bool single_bin, bool has_offsets) {
   const uint32_t lane = lane_id();
-  const LV PCO_LDS* low = (const LV PCO_LDS*)vt;
-  const uint8_t PCO_LDS* obs = vt + 2048;
+  typedef uint64_t __attribute__((aligned(2))) u64_align2;
   const bool blk_on = 4 * lane < ((cnt + 15u) & ~15u);
-  uint32_t syms = 0;
-  if (!single_bin) { syms = blk_on ? *(const u32_unaligned PCO_GLOBAL*)(sym + 4 * lane) : 0u; syms = quad_transpose_u8(syms, lane & 3); }
+  it.syms = (!single_bin && blk_on) ? *(const u32_unaligned PCO_GLOBAL*)(sym + 4 * lane) : 0u;
+  uint64_t w = 0;
+  if (needs_ans && blk_on) w = *(const u64_align2 PCO_GLOBAL*)(answ + 4 * lane);
+  it.a = (uint32_t)w; it.b = (uint32_t)(w >> 32);
+  if (!has_offsets) { it.x[0] = it.x[1] = it.x[2] = it.x[3] = 0; return; }
+  if (cnt == kBatchN) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) it.x[k] = (uint64_t)lat[4 * lane + k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) it.x[k] = 4 * lane + k < cnt ? (uint64_t)lat[4 * lane + k] : 0ull;
+  }
+}
+
+// pack one item: its tANS fields, then its offset fields (chunk_latent_compressor.rs:134-169)
+__device__ __forceinline__ void pack_item(PackSink& sink, const uint8_t PCO_LDS* vt, const PackItem& it, uint32_t cnt, uint32_t asl, bool needs_ans, uint32_t max_ob, bool single_bin) {
+  const uint32_t lane = lane_id();
+  const uint64_t PCO_LDS* low = (const uint64_t PCO_LDS*)vt;
+  const uint8_t PCO_LDS* obs = vt + 2048;
+  sink.reserve((needs_ans ? cnt * asl : 0u) + cnt * max_ob);
+  const uint32_t syms = single_bin ? 0u : quad_transpose_u8(it.syms, lane & 3);
   if (needs_ans) {
-    typedef uint64_t __attribute__((aligned(2))) u64_align2;
-    const uint64_t w = blk_on ? *(const u64_align2 PCO_GLOBAL*)(answ + 4 * lane) : 0ull;
-    uint32_t a = (uint32_t)w, b = (uint32_t)(w >> 32);
+    uint32_t a = it.a, b = it.b;
     quad_transpose_u16(a, b, lane & 3);
     const uint32_t f[4] = {a & 0xffffu, a >> 16, b & 0xffffu, b >> 16};
     uint64_t acc = 0; uint32_t accbits = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) if (4 * lane + k < cnt) { const uint32_t nb = f[k] >> 12; acc |= (uint64_t)(f[k] & 0xfffu) << accbits; accbits += nb; }
     const uint32_t incl = wave_incl_scan(accbits);
-    const uint32_t total = uni(shfl_idx(incl, 63));
     sink.put(incl - accbits, acc, accbits);  // <= 48 bits
-    sink.advance_run(total);
+    sink.commit(wave_last(incl));
   }
   if (max_ob != 0) {
-    uint32_t ob[4]; LV x[4]; uint32_t t = 0;
+    uint32_t ob[4]; uint64_t x[4]; uint32_t t = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const uint32_t i = 4 * lane + k;
       const uint32_t s = (syms >> (8 * k)) & 0xffu;
-      ob[k] = i < cnt ? (uint32_t)obs[s] : 0u;
-      x[k] = i < cnt ? (LV)(lat[i] - low[s]) : (LV)0;
+      ob[k] = 4 * lane + k < cnt ? (uint32_t)obs[s] : 0u;
+      x[k] = it.x[k] - low[s];
       t += ob[k];
     }
     const uint32_t incl = wave_incl_scan(t);
-    const uint32_t total = uni(shfl_idx(incl, 63));
     uint32_t rel = incl - t;
+    if (max_ob <= 16) {  // the lane's four fields fit one 64-bit word: one put
+      uint64_t acc = 0; uint32_t sh = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { sink.put(rel, (uint64_t)x[k], ob[k]); rel += ob[k]; }
-    sink.advance_run(total);
+      for (int k = 0; k < 4; k++) { acc |= (x[k] & (((uint64_t)1 << ob[k]) - 1)) << sh; sh += ob[k]; }
+      sink.put(rel, acc, t);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) { sink.put(rel, x[k], ob[k]); rel += ob[k]; }
+    }
+    sink.commit(wave_last(incl));
   }
 }
 
 template <class L>
-__device__ void pack_run(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run, EncPage PCO_GLOBAL* pg, EncChunk PCO_GLOBAL* ch) {
+__device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run, EncPage PCO_GLOBAL* pg, EncChunk PCO_GLOBAL* ch) {
   const uint32_t t = uni(pg->chunk);
   const uint32_t lane = lane_id();
   constexpr uint32_t LB = LBits<L>::v;
@@ -491,42 +532,43 @@ __device__ void pack_run(const EncWorkspace& ws, const EncFast& fx, uint32_t p, 
   PageVar pv[3];
 #pragma unroll
   for (int v = 0; v < 3; v++) pv[v] = page_var(ch, v, page_n);
-  RunSink sink;
-  sink.init_at((uint32_t PCO_LDS*)(smem + kPageLdsStg), (uint32_t PCO_GLOBAL*)pg->dst, uni((uint64_t)pg->dst_cap), run == 0 ? 0ull : uni(fx.run_start[(uint64_t)p * fx.run_stride + run]));
+  PackSink sink;
+  sink.init_at((uint32_t PCO_LDS*)(smem + kPageLdsStg), (uint32_t PCO_GLOBAL*)pg->dst, run == 0 ? 0ull : uni(fx.run_start[(uint64_t)p * fx.run_stride + run]));
   if (run == 0) {
     const uint32_t pflags = uni(pg->flags);
     if (pflags & kPageFlagPreamble) {  // standalone/compressor.rs:191-203, then ChunkMeta
-      sink.put_uniform_run(uni(ch->dtype), 8);
-      sink.put_uniform_run(page_n - 1, kBitsNEntries);
+      sink.put_uniform(uni(ch->dtype), 8);
+      sink.put_uniform(page_n - 1, kBitsNEntries);
       // ChunkMeta (metadata/chunk.rs:176-189, mode.rs:169-195, delta_encoding.rs:204-254, chunk_latent_var.rs:55-71,158-168)
       const uint32_t mode_kind = uni(ch->mode_kind), delta_kind = uni(ch->delta_kind), delta_order = uni(ch->delta_order);
-      sink.put_uniform_run(mode_kind, kBitsModeVariant);
-      if (mode_kind == kIntMult || mode_kind == kFloatMult) sink.put_uniform_run(uni((uint64_t)ch->mode_base), LB);
-      else if (mode_kind == kFloatQuant) sink.put_uniform_run(uni(ch->mode_k), kBitsQuantK);
-      sink.put_uniform_run(delta_kind, kBitsDeltaVariant);
-      if (delta_kind == kDeltaConsecutive) { sink.put_uniform_run(delta_order, kBitsDeltaOrder); sink.put_uniform_run(0, 1); }
-      else if (delta_kind == kDeltaLookback) { sink.put_uniform_run(uni(ch->window_n_log) - 1, kBitsLookbackWindowLog); sink.put_uniform_run(uni(ch->state_n_log), kBitsLookbackStateLog); sink.put_uniform_run(0, 1); }
+      sink.put_uniform(mode_kind, kBitsModeVariant);
+      if (mode_kind == kIntMult || mode_kind == kFloatMult) sink.put_uniform(uni((uint64_t)ch->mode_base), LB);
+      else if (mode_kind == kFloatQuant) sink.put_uniform(uni(ch->mode_k), kBitsQuantK);
+      sink.put_uniform(delta_kind, kBitsDeltaVariant);
+      if (delta_kind == kDeltaConsecutive) { sink.put_uniform(delta_order, kBitsDeltaOrder); sink.put_uniform(0, 1); }
+      else if (delta_kind == kDeltaLookback) { sink.put_uniform(uni(ch->window_n_log) - 1, kBitsLookbackWindowLog); sink.put_uniform(uni(ch->state_n_log), kBitsLookbackStateLog); sink.put_uniform(0, 1); }
 #pragma unroll
       for (int v = 0; v < 3; v++) {
         if (!pv[v].present) continue;
         const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
         const uint32_t asl = pv[v].asl, nbins = pv[v].n_bins;
         const uint32_t lb = v == 0 ? 32u : LB, obb = offset_bits_bits(lb);
-        sink.put_uniform_run(asl, kBitsAnsSizeLog); sink.put_uniform_run(nbins, kBitsNBins);
+        sink.put_uniform(asl, kBitsAnsSizeLog); sink.put_uniform(nbins, kBitsNBins);
         const uint32_t bin_bits = asl + lb + obb;
         for (uint32_t b0 = 0; b0 < nbins; b0 += 64) {
           const uint32_t b = b0 + lane;
           const uint32_t nb = nbins - b0 < 64 ? nbins - b0 : 64;
+          sink.reserve(64 * bin_bits);
           if (b < nbins) {
             const uint32_t rel = lane * bin_bits;
             sink.put(rel, plan->bweight[b] - 1, asl);
             sink.put(rel + asl, plan->blower[b], lb);
             sink.put(rel + asl + lb, plan->bob[b], obb);
           }
-          sink.advance_run(nb * bin_bits);
+          sink.commit(nb * bin_bits);
         }
       }
-      sink.finish_byte_run();
+      sink.finish_byte();
     }
     // page meta (metadata/page.rs:22-34, page_latent_var.rs:19-26)
     const uint32_t delta_kind = uni(ch->delta_kind);
@@ -535,39 +577,52 @@ __device__ void pack_run(const EncWorkspace& ws, const EncFast& fx, uint32_t p, 
       if (!pv[v].present) continue;
       if (v == 1) {
         const uint32_t nlps = delta_kind == kDeltaConsecutive ? uni(ch->delta_order) : (delta_kind == kDeltaLookback ? (1u << uni(ch->state_n_log)) : 0u);
-        for (uint32_t i = 0; i < nlps; i++) sink.put_uniform_run(uni((uint64_t)pg->moments[i]), LB);
+        for (uint32_t i = 0; i < nlps; i++) sink.put_uniform(uni((uint64_t)pg->moments[i]), LB);
       }
-      for (int jj = 0; jj < 4; jj++) sink.put_uniform_run(uni(fx.fstate[((uint64_t)p * 3 + v) * 4 + jj]) - (1u << pv[v].asl), pv[v].asl);
+      for (int jj = 0; jj < 4; jj++) sink.put_uniform(uni(fx.fstate[((uint64_t)p * 3 + v) * 4 + jj]) - (1u << pv[v].asl), pv[v].asl);
     }
-    sink.finish_byte_run();
+    sink.finish_byte();
   }
-  // tables for the offsets
+  // tables for the offsets: lowers widened to u64 (differences wrap the same way once masked to offset_bits)
+  bool on[3];
 #pragma unroll
   for (int v = 0; v < 3; v++) {
-    if (!pv[v].present || pv[v].trivial) continue;
+    on[v] = pv[v].present && !pv[v].trivial;
+    if (!on[v]) continue;
     const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
-    uint8_t PCO_LDS* vt = smem + kPackLdsVar + v * kPackVarBytes;
-    for (uint32_t b = lane; b < pv[v].n_bins; b += 64) {
-      if (v == 0) ((uint32_t PCO_LDS*)vt)[b] = (uint32_t)plan->blower[b]; else ((L PCO_LDS*)vt)[b] = (L)plan->blower[b];
-      (vt + 2048)[b] = plan->bob[b];
-    }
+    uint8_t PCO_LDS* vt = smem + kPackLdsVar + ws.slot_of_var[v] * kPackVarBytes;
+    for (uint32_t b = lane; b < pv[v].n_bins; b += 64) { ((uint64_t PCO_LDS*)vt)[b] = plan->blower[b]; (vt + 2048)[b] = plan->bob[b]; }
   }
   enc_wave_sync();
+  // batches of the run; the next batch's loads are issued before the current one is packed
+  PackItem cur[3], nxt[3];
+  auto load_batch = [&](uint32_t bb, PackItem (&dstv)[3]) {
+    const uint32_t base = (run * kRunBatches + bb) * kBatchN;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      if (!on[v] || base >= pv[v].n_lat) continue;
+      const uint32_t cnt = pv[v].n_lat - base < kBatchN ? pv[v].n_lat - base : kBatchN;
+      const uint64_t at = pstart + pv[v].skip + base, fat = fast_at(pg, pv[v].skip) + base;
+      if (v == 0) pack_load<uint32_t>(dstv[v], lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, fansw_ptr(ws, fx, t, 0) + fat, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
+      else pack_load<L>(dstv[v], lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, fansw_ptr(ws, fx, t, v) + fat, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
+    }
+  };
+  load_batch(0, cur);
   for (uint32_t bb = 0; bb < kRunBatches; bb++) {
     const uint32_t base = (run * kRunBatches + bb) * kBatchN;
     if (base >= page_n) break;
+    if (bb + 1 < kRunBatches && base + kBatchN < page_n) load_batch(bb + 1, nxt);
 #pragma unroll
     for (int v = 0; v < 3; v++) {
-      if (!pv[v].present || pv[v].trivial || base >= pv[v].n_lat) continue;
+      if (!on[v] || base >= pv[v].n_lat) continue;
       const uint32_t cnt = pv[v].n_lat - base < kBatchN ? pv[v].n_lat - base : kBatchN;
-      const uint64_t at = pstart + pv[v].skip + base, fat = fast_at(pg, pv[v].skip) + base;
-      const uint8_t PCO_LDS* vt = smem + kPackLdsVar + v * kPackVarBytes;
-      if (v == 0) pack_batch<uint32_t>(sink, vt, lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, fansw_ptr(ws, fx, t, 0) + fat, cnt, pv[v].needs_ans != 0, pv[v].max_ob, pv[v].n_bins <= 1);
-      else pack_batch<L>(sink, vt, lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, fansw_ptr(ws, fx, t, v) + fat, cnt, pv[v].needs_ans != 0, pv[v].max_ob, pv[v].n_bins <= 1);
+      pack_item(sink, smem + kPackLdsVar + ws.slot_of_var[v] * kPackVarBytes, cur[v], cnt, pv[v].asl, pv[v].needs_ans != 0, pv[v].max_ob, pv[v].n_bins <= 1);
     }
+#pragma unroll
+    for (int v = 0; v < 3; v++) cur[v] = nxt[v];
   }
-  if ((uint64_t)(run + 1) * kRunBatches * kBatchN >= page_n) sink.finish_byte_run();
-  sink.close_run();
+  if ((uint64_t)(run + 1) * kRunBatches * kBatchN >= page_n) sink.finish_byte();
+  sink.close();
 }
 
 // grid pages * runs_per_page, 64 threads

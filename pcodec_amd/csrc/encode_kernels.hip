@@ -1141,7 +1141,7 @@ __device__ __forceinline__ void page_pack_batch(BitSink& sink, const uint8_t PCO
 #pragma unroll
     for (int k = 0; k < 4; k++) t += (4 * lane + k < cnt) ? ((w[k] >> 12) & 15u) : 0u;
     const uint32_t incl = wave_incl_scan(t);
-    const uint32_t total = uni(shfl_idx(incl, 63));
+    const uint32_t total = wave_last(incl);
     uint32_t rel = incl - t;
     uint64_t acc = 0; uint32_t accbits = 0;
 #pragma unroll
@@ -1162,7 +1162,7 @@ __device__ __forceinline__ void page_pack_batch(BitSink& sink, const uint8_t PCO
       t += ob[k];
     }
     const uint32_t incl = wave_incl_scan(t);
-    const uint32_t total = uni(shfl_idx(incl, 63));
+    const uint32_t total = wave_last(incl);
     uint32_t rel = incl - t;
 #pragma unroll
     for (int k = 0; k < 4; k++) { sink.put(rel, (uint64_t)x[k], ob[k]); rel += ob[k]; }

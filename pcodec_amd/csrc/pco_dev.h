@@ -127,17 +127,28 @@ template <class T> __device__ __forceinline__ T shfl_idx(T v, int src) {
     return (T)(((uint64_t)hi << 32) | lo);
   } else return (T)__shfl((uint32_t)v, src, 64);
 }
-// inclusive wave scan (wrapping add)
+// inclusive wave scan (wrapping add) on the DPP network: 4 row_shr steps inside each row of 16 lanes, then row_bcast:15
+// into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Lanes that have no source read 0.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true); }
+template <int CTRL, int ROW_MASK, class T> __device__ __forceinline__ T dpp0_t(T v) {
+  if constexpr (sizeof(T) == 8) return (T)(((uint64_t)dpp0<CTRL, ROW_MASK>((uint32_t)((uint64_t)v >> 32)) << 32) | dpp0<CTRL, ROW_MASK>((uint32_t)v));
+  else return (T)dpp0<CTRL, ROW_MASK>((uint32_t)v);
+}
 template <class T> __device__ __forceinline__ T wave_incl_scan(T v) {
-  const uint32_t lane = lane_id();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    T o = shfl_up(v, d);
-    if (lane >= (uint32_t)d) v = (T)(v + o);
-  }
+  v = (T)(v + dpp0_t<0x111, 0xf>(v));
+  v = (T)(v + dpp0_t<0x112, 0xf>(v));
+  v = (T)(v + dpp0_t<0x114, 0xf>(v));
+  v = (T)(v + dpp0_t<0x118, 0xf>(v));
+  v = (T)(v + dpp0_t<0x142, 0xa>(v));
+  v = (T)(v + dpp0_t<0x143, 0xc>(v));
   return v;
 }
-template <class T> __device__ __forceinline__ T wave_sum(T v) { return shfl_idx(wave_incl_scan(v), 63); }
+// value of lane 63, wave-uniform
+template <class T> __device__ __forceinline__ T wave_last(T v) {
+  if constexpr (sizeof(T) == 8) return (T)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63));
+  else return (T)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+}
+template <class T> __device__ __forceinline__ T wave_sum(T v) { return wave_last(wave_incl_scan(v)); }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(v, d, 64); v = v > o ? v : o; }
