@@ -497,43 +497,82 @@ constexpr uint32_t kExpWaveOff = kExpTurnOff + 16;         // per wave: dlat u32
 constexpr uint32_t kExpWaveBytes = 4096;
 constexpr uint32_t kExpLdsBytes = kExpWaveOff + kExpWaves * kExpWaveBytes;    // 23440
 
-template <class LV>
-__device__ __forceinline__ uint64_t expand_offsets(gcptr_u8 src, uint64_t src_len, uint64_t bitpos, uint32_t cnt, const uint8_t PCO_GLOBAL* syms,
-                                                    const uint64_t PCO_LDS* lowers, const uint8_t PCO_LDS* obs, bool single_bin, LV out[4]) {
+// What one lane prefetches of one (batch, variable) item: its symbol dword and 32 bytes of the offsets section.
+struct ExpPre { uint32_t syms; uint32_t sec[8]; };
+constexpr uint32_t kExpStgDwords = 528;   // 2048 B of section + the dwords a 64-bit field may reach into
+
+// Issue the loads of an item.  The section is fetched from its dword-aligned start: lane l takes bytes [32 l, 32 l + 32).
+__device__ __forceinline__ void expand_prefetch(ExpPre& pre, gcptr_u8 src, uint64_t src_len, uint64_t start_bit, uint32_t need_bits,
+                                                const uint8_t PCO_GLOBAL* syms, uint32_t cnt, bool single_bin) {
   const uint32_t lane = lane_id();
-  uint32_t ob[4]; LV low[4];
-  uint32_t s4[4] = {0, 0, 0, 0};
-  if (!single_bin) {
-    // dec_walk_kernel's block layout: dword j of 16-byte block (lane >> 2) holds chain j's symbols of steps 4*(lane>>2)..+3
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 blk = *(const u32x4 PCO_GLOBAL*)(syms + 16 * (lane >> 2));
-    const uint32_t sh = 8 * (lane & 3);
-    s4[0] = (blk.x >> sh) & 0xff; s4[1] = (blk.y >> sh) & 0xff; s4[2] = (blk.z >> sh) & 0xff; s4[3] = (blk.w >> sh) & 0xff;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+  pre.syms = (!single_bin && 4 * lane < ((cnt + 15u) & ~15u)) ? *(const uint32_t PCO_GLOBAL*)(syms + 4 * lane) : 0u;
+  const uint64_t byte0 = (start_bit >> 5) * 4;
+  const uint32_t need_bytes = need_bits == 0 ? 0u : (((uint32_t)(start_bit & 31) + need_bits + 31u) / 32u) * 4u + 8u;
+  const uint32_t off = 32 * lane;
+#pragma unroll
+  for (int k = 0; k < 8; k++) pre.sec[k] = 0;
+  if (off < need_bytes) {
+    if (byte0 + off + 32 <= src_len + 16) {
+      const u32x4 a = *(const u32x4_unaligned PCO_GLOBAL*)(src + byte0 + off), b = *(const u32x4_unaligned PCO_GLOBAL*)(src + byte0 + off + 16);
+      pre.sec[0] = a.x; pre.sec[1] = a.y; pre.sec[2] = a.z; pre.sec[3] = a.w; pre.sec[4] = b.x; pre.sec[5] = b.y; pre.sec[6] = b.z; pre.sec[7] = b.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const uint64_t w = load_u64_le_safe(src, byte0 + off + 8 * k, src_len + 16); pre.sec[2 * k] = (uint32_t)w; pre.sec[2 * k + 1] = (uint32_t)(w >> 32); }
+    }
   }
+}
+
+// Turn a prefetched item into latents: bins from the symbols, offsets from the staged section (page_latent_decompressor.rs:15-44,179-213).
+template <class LV>
+__device__ __forceinline__ void expand_item(const ExpPre& pre, uint32_t PCO_LDS* stg, gcptr_u8 src, uint64_t src_len, uint64_t start_bit, uint32_t need_bits, uint32_t cnt,
+                                            const uint64_t PCO_LDS* lowers, const uint8_t PCO_LDS* obs, bool single_bin, LV out[4]) {
+  const uint32_t lane = lane_id();
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  if (need_bits != 0) {
+    const uint32_t need_bytes = (((uint32_t)(start_bit & 31) + need_bits + 31u) / 32u) * 4u + 8u;
+    if (32 * lane < need_bytes) {
+      u32x4 a, b; a.x = pre.sec[0]; a.y = pre.sec[1]; a.z = pre.sec[2]; a.w = pre.sec[3]; b.x = pre.sec[4]; b.y = pre.sec[5]; b.z = pre.sec[6]; b.w = pre.sec[7];
+      *(u32x4 PCO_LDS*)(stg + 8 * lane) = a; *(u32x4 PCO_LDS*)(stg + 8 * lane + 4) = b;
+    }
+    if (need_bytes > 2048 && lane < 2) {   // only 64-bit offsets at the maximum width reach past 64 x 32 bytes: fetched here, not prefetched
+      const uint64_t w = load_u64_le_safe(src, (start_bit >> 5) * 4 + 2048 + 8 * lane, src_len + 16);
+      stg[512 + 2 * lane] = (uint32_t)w; stg[513 + 2 * lane] = (uint32_t)(w >> 32);
+    }
+  }
+  wave_sync_lds();
+  const uint32_t syms = single_bin ? 0u : quad_transpose_u8(pre.syms, lane & 3);
+  uint32_t ob[4]; LV low[4]; uint32_t t = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const bool act = 4 * lane + k < cnt;
-    const uint32_t s = act ? s4[k] : 0u;
+    const uint32_t s = (syms >> (8 * k)) & 0xffu;
     ob[k] = act ? (uint32_t)obs[s] : 0u;
     low[k] = act ? (LV)lowers[s] : (LV)0;
+    t += ob[k];
   }
-  const uint32_t t = ob[0] + ob[1] + ob[2] + ob[3];
   const uint32_t incl = wave_incl_scan(t);
-  const uint32_t total = wave_last(incl);
-  uint64_t b = bitpos + (incl - t);
+  uint32_t r = (uint32_t)(start_bit & 31) + incl - t;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    uint64_t val = 0;
-    if (ob[k] != 0) {
-      const uint64_t byte = b >> 3; const uint32_t sh = (uint32_t)(b & 7);
-      val = load_u64_le_safe(src, byte, src_len + 16) >> sh;
-      if (sh + ob[k] > 64) val |= load_u64_le_safe(src, byte + 8, src_len + 16) << (64 - sh);
-      if (ob[k] < 64) val &= ((uint64_t)1 << ob[k]) - 1;
+    LV val = 0;
+    if (need_bits != 0) {
+      const uint32_t d = r >> 5;
+      const uint32_t w0 = stg[d], w1 = stg[d + 1];
+      if constexpr (sizeof(LV) == 8) {
+        const uint32_t w2 = stg[d + 2];
+        const uint64_t v64 = (uint64_t)__builtin_amdgcn_alignbit(w1, w0, r) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, r) << 32);
+        val = ob[k] >= 64 ? v64 : (v64 & (((uint64_t)1 << ob[k]) - 1));
+      } else {
+        val = (LV)__builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(w1, w0, r), 0u, ob[k]);   // offset_bits <= 32; width 32 keeps all bits
+        if (ob[k] >= 32) val = (LV)__builtin_amdgcn_alignbit(w1, w0, r);
+      }
     }
-    out[k] = (LV)(low[k] + (LV)val);
-    b += ob[k];
+    out[k] = (LV)(low[k] + val);
+    r += ob[k];
   }
-  return bitpos + total;
+  wave_sync_lds();   // the staging area is reused by the next item
 }
 
 // One workgroup of kExpWaves waves per chunk.  Unpacking a batch (symbols -> bins -> offsets) is independent of
@@ -576,6 +615,7 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
     uint32_t PCO_LDS* dlat = (uint32_t PCO_LDS*)wsm;
     L PCO_LDS* scratch = (L PCO_LDS*)(wsm + 1024);
     uint32_t PCO_LDS* parent = (uint32_t PCO_LDS*)(wsm + 3072);
+    uint32_t PCO_LDS* stg = (uint32_t PCO_LDS*)(wsm + 1024);   // section staging; shares scratch / parent, which only the ordered lookback part uses
     L PCO_LDS* moments0 = (L PCO_LDS*)mom64; L PCO_LDS* moments1 = (L PCO_LDS*)(mom64 + 8);
     __syncthreads();   // the previous chunk's LDS state is dead
     const uint8_t PCO_GLOBAL* bins = (const uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask;
@@ -592,34 +632,74 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
     const bool ordered = dk[1] != kDeltaNone || (present[2] && dk[2] == kDeltaConsecutive);
     const uint32_t n_batches = (n + kBatchN - 1) / kBatchN;
     uint32_t lb_oob = 0;
-    for (uint32_t batch = wave; batch < n_batches; batch += kExpWaves) {
+    // per-variable latent count of a batch
+    auto cnt_of = [&](uint32_t batch, int v) -> uint32_t {
+      const uint32_t n_remaining = n - batch * kBatchN;
+      const uint32_t batch_n = n_remaining < kBatchN ? n_remaining : kBatchN;
+      if (v == 0) { const uint32_t lim = n_remaining > nlps[1] ? n_remaining - nlps[1] : 0; return lim < batch_n ? lim : batch_n; }
+      const uint32_t rem = n_remaining > nlps[v] ? n_remaining - nlps[v] : 0; return rem < kBatchN ? rem : kBatchN;
+    };
+    // software pipeline over this wave's batches: the loads of the next batch (symbols, offset sections) are in flight
+    // while the current one is expanded; section starts are fetched one batch further ahead.  At most two variables
+    // are live on this path (lookback implies classic mode, see fast_front): slot 0 = variable 0 or 2, slot 1 = the primary.
+    const int other = present[0] ? 0 : 2;
+    const bool has_other = present[0] || present[2];
+    const uint32_t wave_u = uni(wave);
+    ExpPre pre[2], nxt[2];
+    uint64_t st_cur[2] = {0, 0}, st_nxt[2] = {0, 0}, st_raw[2] = {0, 0};
+    auto var_of = [&](int slot) -> int { return slot == 1 ? 1 : other; };
+    auto issue_starts = [&](uint32_t batch, uint64_t (&st)[2]) {   // plain per-lane loads; made uniform only when they are needed
+#pragma unroll
+      for (int sl = 0; sl < 2; sl++) {
+        const int v = var_of(sl);
+        st[sl] = ((sl == 1 || has_other) && batch < n_batches && cnt_of(batch, v) > 0) ? offpos_area[((uint64_t)ti * 3 + v) * offpos_stride + batch] : 0ull;
+      }
+    };
+    auto prefetch = [&](uint32_t batch, const uint64_t (&st)[2], ExpPre (&dstp)[2]) {
+#pragma unroll
+      for (int sl = 0; sl < 2; sl++) {
+        const int v = var_of(sl);
+        if (sl == 0 && !has_other) continue;
+        const uint32_t cnt = cnt_of(batch, v);
+        if (cnt == 0) continue;
+        const uint8_t PCO_GLOBAL* syms = (const uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)ti * 3 + v) * sym_stride + (uint64_t)batch * kBatchN;
+        expand_prefetch(dstp[sl], src, src_len, st[sl], cnt * max_ob[v], syms, cnt, n_bins[v] <= 1);
+      }
+    };
+    if (wave_u < n_batches) {
+      issue_starts(wave_u, st_cur); issue_starts(wave_u + kExpWaves, st_nxt);
+      for (int sl = 0; sl < 2; sl++) { st_cur[sl] = uni(st_cur[sl]); st_nxt[sl] = uni(st_nxt[sl]); }
+      prefetch(wave_u, st_cur, pre);
+    }
+    for (uint32_t batch = wave_u; batch < n_batches; batch += kExpWaves) {
       const uint32_t j0 = batch * kBatchN, n_remaining = n - j0;
       const uint32_t batch_n = n_remaining < kBatchN ? n_remaining : kBatchN;
       L prim[4] = {0, 0, 0, 0}, sec[4] = {0, 0, 0, 0};
       uint32_t prim_cnt = 0;
+      issue_starts(batch + 2 * kExpWaves, st_raw);   // issued before the prefetch so that waiting for them does not wait for it
+      if (batch + kExpWaves < n_batches) prefetch(batch + kExpWaves, st_nxt, nxt);
       // ---- unordered: unpack every variable of the batch ----
 #pragma unroll
-      for (int v = 0; v < 3; v++) {
-        if (!present[v]) continue;
-        uint32_t cnt;
-        if (v == 0) { const uint32_t lim = n_remaining > nlps[1] ? n_remaining - nlps[1] : 0; cnt = lim < batch_n ? lim : batch_n; }
-        else { const uint32_t rem = n_remaining > nlps[v] ? n_remaining - nlps[v] : 0; cnt = rem < kBatchN ? rem : kBatchN; }
+      for (int sl = 0; sl < 2; sl++) {
+        if (sl == 0 && !has_other) continue;
+        const int v = var_of(sl);
+        const uint32_t cnt = cnt_of(batch, v);
         if (cnt == 0) continue;
         const bool single_bin = n_bins[v] <= 1;
-        const uint8_t PCO_GLOBAL* syms = (const uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)ti * 3 + v) * sym_stride + (uint64_t)batch * kBatchN;
-        const uint64_t off_start = uni(offpos_area[((uint64_t)ti * 3 + v) * offpos_stride + batch]);
         if (v == 0) {
           uint32_t tmp[4];
-          if (max_ob[0] != 0 || !single_bin) expand_offsets<uint32_t>(src, src_len, off_start, cnt, syms, lowers, obs, single_bin, tmp);
+          if (max_ob[0] != 0 || !single_bin) expand_item<uint32_t>(pre[0], stg, src, src_len, st_cur[0], cnt * max_ob[0], cnt, lowers, obs, single_bin, tmp);
           else { const uint32_t l0 = (uint32_t)lowers[0]; for (int k = 0; k < 4; k++) tmp[k] = l0; }
           for (int k = 0; k < 4; k++) dlat[4 * lane + k] = 4 * lane + k < cnt ? tmp[k] : 0u;
         } else {
           L tmp[4];
-          if (max_ob[v] != 0 || !single_bin) expand_offsets<L>(src, src_len, off_start, cnt, syms, lowers + v * 256, obs + v * 256, single_bin, tmp);
+          if (max_ob[v] != 0 || !single_bin) expand_item<L>(pre[sl], stg, src, src_len, st_cur[sl], cnt * max_ob[v], cnt, lowers + v * 256, obs + v * 256, single_bin, tmp);
           else { const L l0 = (L)lowers[v * 256]; for (int k = 0; k < 4; k++) tmp[k] = 4 * lane + k < cnt ? l0 : (L)0; }
           if (v == 1) { for (int k = 0; k < 4; k++) prim[k] = tmp[k]; prim_cnt = cnt; } else { for (int k = 0; k < 4; k++) sec[k] = tmp[k]; }
         }
       }
+#pragma unroll
+      for (int sl = 0; sl < 2; sl++) { pre[sl] = nxt[sl]; st_cur[sl] = st_nxt[sl]; st_nxt[sl] = uni(st_raw[sl]); }
       // ---- ordered: delta decode, batch after batch ----
       if (ordered) {
         while (__hip_atomic_load((uint32_t*)turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != batch) __builtin_amdgcn_s_sleep(1);

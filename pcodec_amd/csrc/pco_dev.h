@@ -149,6 +149,25 @@ template <class T> __device__ __forceinline__ T wave_last(T v) {
   else return (T)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
 }
 template <class T> __device__ __forceinline__ T wave_sum(T v) { return wave_last(wave_incl_scan(v)); }
+// ---- quad (4 consecutive lanes) helpers ----
+template <int CTRL> __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+// 4x4 byte transpose across the four lanes of a quad: lane j ends up with byte j of every lane's dword
+__device__ __forceinline__ uint32_t quad_transpose_u8(uint32_t d, uint32_t j) {
+  const uint32_t d0 = quad_dpp<0x00>(d), d1 = quad_dpp<0x55>(d), d2 = quad_dpp<0xAA>(d), d3 = quad_dpp<0xFF>(d);
+  const uint32_t sel = 0x0c0c0000u | ((4u + j) << 8) | j;
+  const uint32_t lo = __builtin_amdgcn_perm(d1, d0, sel), hi = __builtin_amdgcn_perm(d3, d2, sel);
+  return lo | (hi << 16);
+}
+// 4x4 u16 transpose: each lane holds (a: entries 0,1 | b: entries 2,3); lane j ends up with entry j of every lane
+__device__ __forceinline__ void quad_transpose_u16(uint32_t& a, uint32_t& b, uint32_t j) {
+  const uint32_t a0 = quad_dpp<0x00>(a), a1 = quad_dpp<0x55>(a), a2 = quad_dpp<0xAA>(a), a3 = quad_dpp<0xFF>(a);
+  const uint32_t b0 = quad_dpp<0x00>(b), b1 = quad_dpp<0x55>(b), b2 = quad_dpp<0xAA>(b), b3 = quad_dpp<0xFF>(b);
+  const bool lo = j < 2;
+  const uint32_t x0 = lo ? a0 : b0, x1 = lo ? a1 : b1, x2 = lo ? a2 : b2, x3 = lo ? a3 : b3;
+  const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+  a = __builtin_amdgcn_perm(x1, x0, sel); b = __builtin_amdgcn_perm(x3, x2, sel);
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(v, d, 64); v = v > o ? v : o; }
