@@ -554,11 +554,17 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
 }
 
 // LDS layout of enc_hist_kernel
-constexpr uint32_t kHistLdsCounts = 0;                       // u32[4096 + 8] counts / prefix (direct path); radix counters (sorted path)
-constexpr uint32_t kHistLdsRecV = 16416;                     // u64[256] x4 + u32[256] x2
-constexpr uint32_t kHistLdsBytes = kHistLdsRecV + 4 * 2048 + 2 * 1024 + 2048;  // + block-scan scratch u32[512]
+// records first (u64[256] x4, u32[256] x2, block-scan scratch u32[512]), then the counters: u32[R + 8] counts / prefix of
+// the direct path (R = 4096 in enc_hist_kernel, 32768 in enc_hist_wide_kernel) or the radix counters of the sorted path
+constexpr uint32_t kHistLdsRecV = 0;
+constexpr uint32_t kHistLdsCounts = 4 * 2048 + 2 * 1024 + 2048;
+constexpr uint32_t kWideHistRange = 32768;
+__host__ __device__ constexpr uint32_t hist_lds_bytes(uint32_t range) { return kHistLdsCounts + (range + 8) * 4; }
+constexpr uint32_t kHistLdsBytes = hist_lds_bytes(kDirectHistRange);
 
-template <class L>
+// T threads per block; R = value range handled by LDS counting.  kWide: only variables whose range lies in
+// [kDirectHistRange, R) are processed (enc_hist_wide_kernel); otherwise those are left to that kernel.
+template <class L, uint32_t T, uint32_t R, bool kWide>
 __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log) {
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   EncVar PCO_GLOBAL* ev = &ch->v[var];
@@ -568,6 +574,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   if (n_lat == 0) { if (tid == 0) ev->n_hist = 0; return; }
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   const L range = (L)(maxv - minv);
+  if (kWide ? ((uint64_t)range < kDirectHistRange || (uint64_t)range >= R) : ((uint64_t)range >= kDirectHistRange && (uint64_t)range < kWideHistRange)) return;
   // Stored latents = every position that is not among the first `skip` of its page (wrapped/chunk_compressor.rs:129-140).
   const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
   const uint32_t n_all = (uint32_t)ch->n, skip = ev->lat_start, plow = ch->page_low, pr = ch->page_r;
@@ -586,25 +593,36 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   const uint64_t n64 = n_lat;
   auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
   __syncthreads();
-  if ((uint64_t)range < kDirectHistRange) {
+  if ((uint64_t)range < R) {
     // ---------------- direct path ----------------
-    for (uint32_t i = tid; i < kDirectHistRange + 8; i += 256) counts[i] = 0;
+    constexpr uint32_t PER = R / T;   // counters per thread in the prefix pass
+    for (uint32_t i = tid; i < R + 8; i += T) counts[i] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < n_all; i += 256) if (stored(i)) atomicAdd((uint32_t*)&counts[(uint32_t)(lat[i] - minv)], 1u);
+    {  // counting: 8 loads in flight per thread
+      uint32_t base = 0;
+      for (; base + 8 * T <= n_all; base += 8 * T) {
+        L x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = lat[base + k * T + tid];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (stored(base + k * T + tid)) atomicAdd((uint32_t*)&counts[(uint32_t)(x[k] - minv)], 1u);
+      }
+      for (uint32_t i = base + tid; i < n_all; i += T) if (stored(i)) atomicAdd((uint32_t*)&counts[(uint32_t)(lat[i] - minv)], 1u);
+    }
     __syncthreads();
-    // exclusive prefix over 4096 counters: 16 per thread + block scan
-    uint32_t loc[16]; uint32_t s = 0;
-    for (int k = 0; k < 16; k++) { loc[k] = counts[tid * 16 + k]; s += loc[k]; }
+    // exclusive prefix over R counters: PER per thread + block scan
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < PER; k++) s += counts[tid * PER + k];
     uint32_t incl = wave_incl_scan(s);
     if (lane == 63) scan[wave] = incl;
     __syncthreads();
     uint32_t wbase = 0; for (uint32_t w = 0; w < wave; w++) wbase += scan[w];
     uint32_t run = wbase + incl - s;
-    for (int k = 0; k < 16; k++) { counts[tid * 16 + k] = run; run += loc[k]; }
-    if (tid == 255) counts[4096] = run;  // == n_lat
+    for (uint32_t k = 0; k < PER; k++) { const uint32_t c = counts[tid * PER + k]; counts[tid * PER + k] = run; run += c; }
+    if (tid == T - 1) counts[R] = run;  // == n_lat
     __syncthreads();
     auto lookup = [&](uint32_t r, L& value, uint32_t& st, uint32_t& en) {
-      uint32_t lo = 0, hi = 4096;  // last v with P[v] <= r
+      uint32_t lo = 0, hi = R;  // last v with P[v] <= r
       while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (counts[mid] <= r) lo = mid; else hi = mid; }
       value = (L)(minv + (L)lo); st = counts[lo]; en = counts[lo + 1];
     };
@@ -622,7 +640,9 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     __syncthreads();
     return;
   }
-  // ---------------- sorted path: stable LSD radix sort on key = x - min ----------------
+  if constexpr (kWide) return;
+  // ---------------- sorted path: stable LSD radix sort on key = x - min (256 threads) ----------------
+  if constexpr (!kWide) {
   const uint32_t sig_bits = bitlen<L>(range);
   const uint32_t npass = (sig_bits + 7) / 8;
   L PCO_GLOBAL* bufA = sort_ptr<L>(ws, t, 0);
@@ -698,24 +718,31 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   __syncthreads();
   if (tid == 0) { uint32_t nh = 0; hist_state_machine<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, nh); ev->n_hist = nh; ev->hist_path = 1; }
   __syncthreads();
+  }
 }
 
-__global__ __launch_bounds__(256) void enc_hist_kernel(EncWorkspace ws, uint32_t n_tasks) {
-  const uint32_t t = blockIdx.x;
-  if (t >= n_tasks) return;
+template <uint32_t T, uint32_t R, bool kWide>
+__device__ __forceinline__ void hist_chunk(const EncWorkspace& ws, uint32_t t) {
   const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
-  if (ch->status != PCO_GFX_OK) return;
-  const int bits = dtype_bits(ch->dtype);
-  const uint32_t ubl = ch->unopt_bins_log;
+  if (uni(ch->status) != PCO_GFX_OK) return;
+  const int bits = dtype_bits(uni(ch->dtype));
+  const uint32_t ubl = uni(ch->unopt_bins_log);
   for (uint32_t var = 0; var < 3; var++) {
-    if (!ch->v[var].present) continue;
+    if (!uni(ch->v[var].present)) continue;
     // secondary latents get fewer bins (wrapped/chunk_compressor.rs:238-248)
     const uint32_t bl = var == 2 ? (ubl < 6 ? ubl : 6) : ubl;
-    if (var == 0) hist_var<uint32_t>(ws, t, var, bl);
-    else if (bits == 64) hist_var<uint64_t>(ws, t, var, bl);
-    else if (bits == 32) hist_var<uint32_t>(ws, t, var, bl);
-    else hist_var<uint16_t>(ws, t, var, bl);
+    if (var == 0) hist_var<uint32_t, T, R, kWide>(ws, t, var, bl);
+    else if (bits == 64) hist_var<uint64_t, T, R, kWide>(ws, t, var, bl);
+    else if (bits == 32) hist_var<uint32_t, T, R, kWide>(ws, t, var, bl);
+    else hist_var<uint16_t, T, R, kWide>(ws, t, var, bl);
   }
+}
+__global__ __launch_bounds__(256) void enc_hist_kernel(EncWorkspace ws, uint32_t n_tasks) {
+  if (blockIdx.x < n_tasks) hist_chunk<256, kDirectHistRange, false>(ws, blockIdx.x);
+}
+// value ranges in [4096, 32768): LDS counting with one 1024-thread block (131 KB of counters) per chunk
+__global__ __launch_bounds__(1024) void enc_hist_wide_kernel(EncWorkspace ws, uint32_t n_tasks) {
+  if (blockIdx.x < n_tasks) hist_chunk<1024, kWideHistRange, true>(ws, blockIdx.x);
 }
 
 // =========================================================================================================
