@@ -146,17 +146,15 @@ def main():
         G.check(L.pco_gfx_decompress_chunks(nch, dec_tasks.ctypes.data, dec_res.ctypes.data, None, None))
 
     def gather_pages():
+        # optional: rank 0 collects every rank's compressed chunks, in chunk order, over RCCL (pcodec_amd/sharding.py)
         if world == 1:
             return
-        sizes = torch.tensor(enc_res["n_out"].astype(np.int64), device=device)
-        all_sizes = [torch.empty_like(sizes) for _ in range(world)]
-        dist.all_gather(all_sizes, sizes)  # 8 B per chunk
-        mine = comp.view(nch, cap)
-        if rank == 0:
-            bufs = [torch.empty_like(mine) for _ in range(world)]
-            dist.gather(mine, bufs, dst=0)
-        else:
-            dist.gather(mine, None, dst=0)
+        from pcodec_amd import sharding as S
+        sizes = torch.from_numpy(enc_res["n_out"].astype(np.int64)).to(device)
+        rows = comp.view(nch, cap)
+        keep = torch.arange(cap, device=device).unsqueeze(0) < sizes.unsqueeze(1)
+        payload = rows[keep]                       # chunks back to back
+        S.gather_pages(payload, sizes, dst=0)
 
     def step():
         encode()
@@ -237,8 +235,6 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.workload, cfg_kw)
-        elif not args.no_cpu_baseline:
-            line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

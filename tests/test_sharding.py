@@ -1,0 +1,94 @@
+"""N > 1 path on CPU: world-size-2 gloo run of the chunk sharding + page gather.
+The per-chunk codec here is the oracle (test infrastructure); on the GPU box bench.py --gather runs the same
+sharding code over RCCL with libpco_gfx as the codec."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import oracle_lib as O
+from pcodec_amd import sharding as S
+
+
+def test_shard_range_partitions_in_order():
+    for n in [0, 1, 5, 8, 1023, 1024]:
+        for world in [1, 2, 3, 8]:
+            seen = []
+            for r in range(world):
+                a, b = S.shard_range(n, r, world)
+                assert 0 <= a <= b <= n and b - a in (n // world, n // world + 1)
+                seen += list(range(a, b))
+                for c in range(a, b):
+                    assert S.shard_of_chunk(c, n, world) == r
+            assert seen == list(range(n))
+
+
+def _chunks(n_chunks, chunk_n):
+    rng = np.random.default_rng(11)
+    return [(np.uint64(1 << 40) + np.uint64(1000) * np.arange(chunk_n, dtype=np.uint64) + rng.integers(0, 512, chunk_n).astype(np.uint64)) for _ in range(n_chunks)]
+
+
+def _chunk_bytes(a, cfg):
+    whole = O.simple_compress(a, cfg)           # header | chunk | 0x00
+    _, _ = O.inspect_first_chunk(whole)
+    hdr = _header_len(whole)
+    return whole[hdr:-1]
+
+
+def _header_len(whole):
+    # "pco!" ver uniform varint(n_hint) pad fmt_major fmt_minor (standalone/compressor.rs:85-113)
+    assert whole[:4] == b"pco!" and whole[4] == 3
+    bits = int.from_bytes(whole[6:16], "little")
+    power = (bits & 63) + 1
+    return 6 + (6 + power + 7) // 8 + 2
+
+
+def _worker(rank, world, port, n_chunks, chunk_n, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = O.make_config(mode=1, delta=2, delta_order=1)
+        data = _chunks(n_chunks, chunk_n)
+        a, b = S.shard_range(n_chunks, rank, world)
+        mine = [_chunk_bytes(data[c], cfg) for c in range(a, b)]
+        payload, sizes = S.pack_chunks(mine)
+        bufs, all_sizes = S.gather_pages(torch.from_numpy(payload), torch.from_numpy(sizes), dst=0)
+        assert [int(s.numel()) for s in all_sizes] == [S.shard_range(n_chunks, r, world)[1] - S.shard_range(n_chunks, r, world)[0] for r in range(world)]
+        if rank == 0:
+            q.put([bytes(x.numpy()) for x in bufs])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_reassembles_the_file():
+    import torch.multiprocessing as mp
+    n_chunks, chunk_n, world = 5, 3000, 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_chunks, chunk_n, q)) for r in range(world)]
+    for p in procs: p.start()
+    per_rank = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120); assert p.exitcode == 0
+    # reference result: all chunks compressed by one process, in order
+    cfg = O.make_config(mode=1, delta=2, delta_order=1)
+    data = _chunks(n_chunks, chunk_n)
+    single = [_chunk_bytes(a, cfg) for a in data]
+    assert b"".join(per_rank) == b"".join(single)
+    # the assembled standalone file decodes to the concatenated input
+    from pcodec_amd import _lib as G
+    L = G.lib()
+    hdr = np.zeros(32, np.uint8)
+    k = L.pco_gfx_write_standalone_header(hdr.ctypes.data_as(C.c_void_p), 32, n_chunks * chunk_n, 0)
+    blob = S.assemble_standalone_file(bytes(hdr[:k]), per_rank)
+    back = O.simple_decompress(blob, np.uint64, cap=n_chunks * chunk_n + 8)
+    assert np.array_equal(back, np.concatenate(data))
