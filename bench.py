@@ -151,9 +151,8 @@ def main():
             return
         from pcodec_amd import sharding as S
         sizes = torch.from_numpy(enc_res["n_out"].astype(np.int64)).to(device)
-        rows = comp.view(nch, cap)
-        keep = torch.arange(cap, device=device).unsqueeze(0) < sizes.unsqueeze(1)
-        payload = rows[keep]                       # chunks back to back
+        n_out = enc_res["n_out"]
+        payload = torch.cat([comp[i * cap: i * cap + int(n_out[i])] for i in range(nch)])   # chunks back to back
         S.gather_pages(payload, sizes, dst=0)
 
     def step():
