@@ -58,31 +58,42 @@ __device__ __forceinline__ PageVar page_var(const EncChunk PCO_GLOBAL* ch, uint3
 // =========================================================================================================
 // dissect
 // =========================================================================================================
-constexpr uint32_t kDisVarBytes = 2048 + 256;    // search lowers (8 B stride) + offset bits
+constexpr uint32_t kDisVarBytes = 2048 + 256 + kDirectHistRange;    // search lowers (8 B stride) + offset bits + value -> bin table
 constexpr uint32_t kDisLdsBytes = 3 * kDisVarBytes;
 
-template <class LV>
+// One batch of one variable.  kLut: the variable's value range is below kDirectHistRange, so the bin of a latent is one
+// LDS table lookup away; otherwise the branch-free lower bound over the padded lowers (compression_table.rs:51-74),
+// with the four searches of a lane interleaved so that their LDS round trips overlap.
+template <class LV, bool kLut>
 __device__ __forceinline__ void dissect_batch(const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, uint8_t PCO_GLOBAL* sym_out, uint32_t PCO_GLOBAL* ob_bits_out,
-                                              uint32_t cnt, uint32_t n_bins, uint32_t search_log) {
+                                              uint32_t cnt, uint32_t n_bins, uint32_t search_log, LV minv) {
   const uint32_t lane = lane_id();
   const LV PCO_LDS* low = (const LV PCO_LDS*)vt;
   const uint8_t PCO_LDS* obs = vt + 2048;
+  const uint8_t PCO_LDS* lut = vt + 2048 + 256;
+  LV x[4]; uint32_t sym[4] = {0, 0, 0, 0};
+  if (cnt == kBatchN) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = lat[4 * lane + k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = 4 * lane + k < cnt ? lat[4 * lane + k] : minv;
+  }
+  if (kLut) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) sym[k] = lut[(uint32_t)(x[k] - minv)];
+  } else {
+    for (uint32_t depth = 0; depth < search_log; depth++) {
+      const uint32_t bis = 1u << (search_log - 1 - depth);
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (x[k] >= low[sym[k] + bis]) sym[k] += bis;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) sym[k] = sym[k] < n_bins - 1 ? sym[k] : n_bins - 1;
+  }
   uint32_t packed = 0, t = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t i = 4 * lane + k;
-    uint32_t sym = 0;
-    if (i < cnt) {
-      const LV x = lat[i];
-      for (uint32_t depth = 0; depth < search_log; depth++) {  // branch-free lower bound over padded lowers (compression_table.rs:51-74)
-        const uint32_t bis = 1u << (search_log - 1 - depth);
-        if (x >= low[sym + bis]) sym += bis;
-      }
-      sym = sym < n_bins - 1 ? sym : n_bins - 1;
-      t += obs[sym];
-    }
-    packed |= sym << (8 * k);
-  }
+  for (int k = 0; k < 4; k++) { if (4 * lane + k < cnt) t += obs[sym[k]]; else sym[k] = 0; packed |= sym[k] << (8 * k); }
   const uint32_t tr = quad_transpose_u8(packed, lane & 3);
   if (4 * lane < ((cnt + 15u) & ~15u)) *(u32_unaligned PCO_GLOBAL*)(sym_out + 4 * lane) = tr;   // whole 16-latent blocks
   const uint32_t total = wave_sum(t);
@@ -100,14 +111,36 @@ __device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncF
 #pragma unroll
   for (int v = 0; v < 3; v++) { pv[v] = page_var(ch, v, page_n); if (pv[v].present && pv[v].n_bins > 1 && (uint64_t)run * kRunBatches * kBatchN < pv[v].n_lat) any = true; }
   if (!any) return;
+  bool use_lut[3]; uint64_t minv[3];
 #pragma unroll
   for (int v = 0; v < 3; v++) {
+    use_lut[v] = false; minv[v] = 0;
     if (!pv[v].present || pv[v].n_bins <= 1) continue;
     const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    minv[v] = uni((uint64_t)ch->v[v].minv);
+    const uint64_t range = uni((uint64_t)ch->v[v].maxv) - minv[v];
+    use_lut[v] = range < kDirectHistRange;
+    uint8_t PCO_LDS* vt = smem + v * kDisVarBytes;
     const uint32_t b = threadIdx.x;  // 256 threads: one padded bin each
-    if (v == 0) ((uint32_t PCO_LDS*)(smem + v * kDisVarBytes))[b] = b < pv[v].n_bins ? (uint32_t)plan->blower[b] : 0xffffffffu;
-    else ((L PCO_LDS*)(smem + v * kDisVarBytes))[b] = b < pv[v].n_bins ? (L)plan->blower[b] : (L)~(L)0;
-    (smem + v * kDisVarBytes + 2048)[b] = b < pv[v].n_bins ? plan->bob[b] : 0;
+    if (v == 0) ((uint32_t PCO_LDS*)vt)[b] = b < pv[v].n_bins ? (uint32_t)plan->blower[b] : 0xffffffffu;
+    else ((L PCO_LDS*)vt)[b] = b < pv[v].n_bins ? (L)plan->blower[b] : (L)~(L)0;
+    (vt + 2048)[b] = b < pv[v].n_bins ? plan->bob[b] : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < 3; v++) {   // value -> bin table: each thread fills 16 consecutive values (one search, then a walk over the sorted lowers)
+    if (!use_lut[v]) continue;
+    uint8_t PCO_LDS* vt = smem + v * kDisVarBytes;
+    auto lower_of = [&](uint32_t b) -> uint64_t { return v == 0 ? (uint64_t)((const uint32_t PCO_LDS*)vt)[b] : (uint64_t)((const L PCO_LDS*)vt)[b]; };
+    const uint32_t u0 = threadIdx.x * (kDirectHistRange / 256);
+    const uint64_t x0 = minv[v] + u0;
+    uint32_t sym = 0;
+    { uint32_t lo = 0, hi = pv[v].n_bins; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lower_of(mid) <= x0) lo = mid; else hi = mid; } sym = lo; }   // last bin with lower <= x0 (bin 0 below that)
+    for (uint32_t k = 0; k < kDirectHistRange / 256; k++) {
+      const uint64_t x = x0 + k;
+      while (sym + 1 < pv[v].n_bins && lower_of(sym + 1) <= x) sym++;
+      (vt + 2048 + 256)[u0 + k] = (uint8_t)sym;
+    }
   }
   __syncthreads();
   const uint32_t wave = threadIdx.x >> 6;
@@ -121,8 +154,14 @@ __device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncF
       uint32_t search_log = 0; while ((1u << search_log) < pv[v].n_bins) search_log++;
       const uint64_t at = pstart + pv[v].skip + base, fat = fast_at(pg, pv[v].skip) + base;
       uint32_t PCO_GLOBAL* ob_out = (uint32_t PCO_GLOBAL*)fx.bat + (((uint64_t)p * 3 + v) * fx.bat_stride + batch) * 2;
-      if (v == 0) dissect_batch<uint32_t>(smem + v * kDisVarBytes, lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, ob_out, cnt, pv[v].n_bins, search_log);
-      else dissect_batch<L>(smem + v * kDisVarBytes, lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, ob_out, cnt, pv[v].n_bins, search_log);
+      const uint8_t PCO_LDS* vt = smem + v * kDisVarBytes;
+      if (v == 0) {
+        if (use_lut[v]) dissect_batch<uint32_t, true>(vt, lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, ob_out, cnt, pv[v].n_bins, search_log, (uint32_t)minv[v]);
+        else dissect_batch<uint32_t, false>(vt, lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, ob_out, cnt, pv[v].n_bins, search_log, (uint32_t)minv[v]);
+      } else {
+        if (use_lut[v]) dissect_batch<L, true>(vt, lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, ob_out, cnt, pv[v].n_bins, search_log, (L)minv[v]);
+        else dissect_batch<L, false>(vt, lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, ob_out, cnt, pv[v].n_bins, search_log, (L)minv[v]);
+      }
     }
   }
 }
