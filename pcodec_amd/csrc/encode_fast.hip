@@ -20,7 +20,7 @@
 
 namespace pcogfx {
 
-constexpr uint32_t kRunBatches = 16;          // batches per dissect block / pack run
+constexpr uint32_t kRunBatches = 64;          // batches per dissect block / pack run
 
 struct EncFast {
   uint8_t* sym;         // [task][slot][n_stride] bin symbols, quad-transposed per page variable
@@ -44,7 +44,7 @@ __device__ __forceinline__ uint16_t PCO_GLOBAL* fansw_ptr(const EncWorkspace& ws
 }
 
 // The page's view of one variable (as in page_task)
-struct PageVar { uint32_t present, n_bins, asl, max_ob, needs_ans, trivial, skip, n_lat; };
+struct PageVar { uint32_t present, n_bins, asl, max_ob, needs_ans, trivial, skip, n_lat, compact; uint64_t minv; };
 __device__ __forceinline__ PageVar page_var(const EncChunk PCO_GLOBAL* ch, uint32_t v, uint32_t page_n) {
   PageVar r;
   r.present = uni(ch->v[v].present); r.n_bins = uni(ch->v[v].n_bins); r.asl = uni(ch->v[v].ans_size_log); r.max_ob = uni(ch->v[v].max_ob);
@@ -52,6 +52,8 @@ __device__ __forceinline__ PageVar page_var(const EncChunk PCO_GLOBAL* ch, uint3
   r.skip = v == 2 ? 0u : uni(ch->v[v].lat_start);
   if (r.skip > page_n) r.skip = page_n;
   r.n_lat = page_n - r.skip;
+  r.compact = uni(ch->v[v].hist_path) == 0 ? 1u : 0u;   // histogram by LDS counting: compact latents exist (clat_ptr)
+  r.minv = uni((uint64_t)ch->v[v].minv);
   return r;
 }
 
@@ -64,20 +66,21 @@ constexpr uint32_t kDisLdsBytes = 3 * kDisVarBytes;
 // One batch of one variable.  kLut: the variable's value range is below kDirectHistRange, so the bin of a latent is one
 // LDS table lookup away; otherwise the branch-free lower bound over the padded lowers (compression_table.rs:51-74),
 // with the four searches of a lane interleaved so that their LDS round trips overlap.
-template <class LV, bool kLut>
-__device__ __forceinline__ void dissect_batch(const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, uint8_t PCO_GLOBAL* sym_out, uint32_t PCO_GLOBAL* ob_bits_out,
-                                              uint32_t cnt, uint32_t n_bins, uint32_t search_log, LV minv) {
+// LV: element type read (the latent type, or uint16_t for compact latents, whose lowers are stored relative to the minimum)
+template <class LV, bool kLut, bool kFull>
+__device__ __forceinline__ void dissect_batch_t(const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, uint8_t PCO_GLOBAL* sym_out, uint32_t PCO_GLOBAL* ob_bits_out,
+                                                uint32_t cnt, uint32_t n_bins, uint32_t search_log, uint64_t minv) {
   const uint32_t lane = lane_id();
-  const LV PCO_LDS* low = (const LV PCO_LDS*)vt;
+  const uint64_t PCO_LDS* low = (const uint64_t PCO_LDS*)vt;
   const uint8_t PCO_LDS* obs = vt + 2048;
   const uint8_t PCO_LDS* lut = vt + 2048 + 256;
-  LV x[4]; uint32_t sym[4] = {0, 0, 0, 0};
-  if (cnt == kBatchN) {
+  uint64_t x[4]; uint32_t sym[4] = {0, 0, 0, 0};
+  if (kFull) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = lat[4 * lane + k];
+    for (int k = 0; k < 4; k++) x[k] = (uint64_t)lat[4 * lane + k];
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = 4 * lane + k < cnt ? lat[4 * lane + k] : minv;
+    for (int k = 0; k < 4; k++) x[k] = 4 * lane + k < cnt ? (uint64_t)lat[4 * lane + k] : minv;
   }
   if (kLut) {
 #pragma unroll
@@ -86,18 +89,34 @@ __device__ __forceinline__ void dissect_batch(const uint8_t PCO_LDS* vt, const L
     for (uint32_t depth = 0; depth < search_log; depth++) {
       const uint32_t bis = 1u << (search_log - 1 - depth);
 #pragma unroll
-      for (int k = 0; k < 4; k++) if (x[k] >= low[sym[k] + bis]) sym[k] += bis;
+      for (int k = 0; k < 4; k++) { const uint64_t probe = low[sym[k] + bis]; sym[k] += x[k] >= probe ? bis : 0u; }
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) sym[k] = sym[k] < n_bins - 1 ? sym[k] : n_bins - 1;
   }
   uint32_t packed = 0, t = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) { if (4 * lane + k < cnt) t += obs[sym[k]]; else sym[k] = 0; packed |= sym[k] << (8 * k); }
+  for (int k = 0; k < 4; k++) {   // unconditional LDS reads + selects: no divergent control flow in the batch body
+    const uint32_t ob = obs[sym[k]];
+    const bool act = kFull || 4 * lane + k < cnt;
+    t += act ? ob : 0u;
+    packed |= (act ? sym[k] : 0u) << (8 * k);
+  }
   const uint32_t tr = quad_transpose_u8(packed, lane & 3);
-  if (4 * lane < ((cnt + 15u) & ~15u)) *(u32_unaligned PCO_GLOBAL*)(sym_out + 4 * lane) = tr;   // whole 16-latent blocks
+  if (kFull || 4 * lane < ((cnt + 15u) & ~15u)) *(u32_unaligned PCO_GLOBAL*)(sym_out + 4 * lane) = tr;   // whole 16-latent blocks
   const uint32_t total = wave_sum(t);
   if (lane == 0) *ob_bits_out = total;
+}
+template <class LV>
+__device__ __forceinline__ void dissect_batch(const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, uint8_t PCO_GLOBAL* sym_out, uint32_t PCO_GLOBAL* ob_bits_out,
+                                              uint32_t cnt, uint32_t n_bins, uint32_t search_log, uint64_t minv, bool use_lut) {
+  if (cnt == kBatchN) {
+    if (use_lut) dissect_batch_t<LV, true, true>(vt, lat, sym_out, ob_bits_out, cnt, n_bins, search_log, minv);
+    else dissect_batch_t<LV, false, true>(vt, lat, sym_out, ob_bits_out, cnt, n_bins, search_log, minv);
+  } else {
+    if (use_lut) dissect_batch_t<LV, true, false>(vt, lat, sym_out, ob_bits_out, cnt, n_bins, search_log, minv);
+    else dissect_batch_t<LV, false, false>(vt, lat, sym_out, ob_bits_out, cnt, n_bins, search_log, minv);
+  }
 }
 
 template <class L>
@@ -111,19 +130,18 @@ __device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncF
 #pragma unroll
   for (int v = 0; v < 3; v++) { pv[v] = page_var(ch, v, page_n); if (pv[v].present && pv[v].n_bins > 1 && (uint64_t)run * kRunBatches * kBatchN < pv[v].n_lat) any = true; }
   if (!any) return;
-  bool use_lut[3]; uint64_t minv[3];
+  bool use_lut[3]; uint64_t rel0[3];   // rel0: what the element values are relative to (the minimum for compact latents, else 0)
 #pragma unroll
   for (int v = 0; v < 3; v++) {
-    use_lut[v] = false; minv[v] = 0;
+    use_lut[v] = false; rel0[v] = 0;
     if (!pv[v].present || pv[v].n_bins <= 1) continue;
     const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
-    minv[v] = uni((uint64_t)ch->v[v].minv);
-    const uint64_t range = uni((uint64_t)ch->v[v].maxv) - minv[v];
+    const uint64_t range = uni((uint64_t)ch->v[v].maxv) - pv[v].minv;
     use_lut[v] = range < kDirectHistRange;
+    rel0[v] = pv[v].compact ? pv[v].minv : 0ull;
     uint8_t PCO_LDS* vt = smem + v * kDisVarBytes;
-    const uint32_t b = threadIdx.x;  // 256 threads: one padded bin each
-    if (v == 0) ((uint32_t PCO_LDS*)vt)[b] = b < pv[v].n_bins ? (uint32_t)plan->blower[b] : 0xffffffffu;
-    else ((L PCO_LDS*)vt)[b] = b < pv[v].n_bins ? (L)plan->blower[b] : (L)~(L)0;
+    const uint32_t b = threadIdx.x;  // 256 threads: one padded bin each; lowers as u64 relative to rel0, padded with the maximum
+    ((uint64_t PCO_LDS*)vt)[b] = b < pv[v].n_bins ? (uint64_t)plan->blower[b] - rel0[v] : ~0ull;
     (vt + 2048)[b] = b < pv[v].n_bins ? plan->bob[b] : 0;
   }
   __syncthreads();
@@ -131,14 +149,14 @@ __device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncF
   for (int v = 0; v < 3; v++) {   // value -> bin table: each thread fills 16 consecutive values (one search, then a walk over the sorted lowers)
     if (!use_lut[v]) continue;
     uint8_t PCO_LDS* vt = smem + v * kDisVarBytes;
-    auto lower_of = [&](uint32_t b) -> uint64_t { return v == 0 ? (uint64_t)((const uint32_t PCO_LDS*)vt)[b] : (uint64_t)((const L PCO_LDS*)vt)[b]; };
+    const uint64_t PCO_LDS* low = (const uint64_t PCO_LDS*)vt;
     const uint32_t u0 = threadIdx.x * (kDirectHistRange / 256);
-    const uint64_t x0 = minv[v] + u0;
+    const uint64_t x0 = pv[v].minv - rel0[v] + u0;   // value of table slot u0, in the units of `low`
     uint32_t sym = 0;
-    { uint32_t lo = 0, hi = pv[v].n_bins; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lower_of(mid) <= x0) lo = mid; else hi = mid; } sym = lo; }   // last bin with lower <= x0 (bin 0 below that)
+    { uint32_t lo = 0, hi = pv[v].n_bins; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (low[mid] <= x0) lo = mid; else hi = mid; } sym = lo; }   // last bin with lower <= x0 (bin 0 below that)
     for (uint32_t k = 0; k < kDirectHistRange / 256; k++) {
       const uint64_t x = x0 + k;
-      while (sym + 1 < pv[v].n_bins && lower_of(sym + 1) <= x) sym++;
+      while (sym + 1 < pv[v].n_bins && low[sym + 1] <= x) sym++;
       (vt + 2048 + 256)[u0 + k] = (uint8_t)sym;
     }
   }
@@ -155,13 +173,11 @@ __device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncF
       const uint64_t at = pstart + pv[v].skip + base, fat = fast_at(pg, pv[v].skip) + base;
       uint32_t PCO_GLOBAL* ob_out = (uint32_t PCO_GLOBAL*)fx.bat + (((uint64_t)p * 3 + v) * fx.bat_stride + batch) * 2;
       const uint8_t PCO_LDS* vt = smem + v * kDisVarBytes;
-      if (v == 0) {
-        if (use_lut[v]) dissect_batch<uint32_t, true>(vt, lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, ob_out, cnt, pv[v].n_bins, search_log, (uint32_t)minv[v]);
-        else dissect_batch<uint32_t, false>(vt, lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, ob_out, cnt, pv[v].n_bins, search_log, (uint32_t)minv[v]);
-      } else {
-        if (use_lut[v]) dissect_batch<L, true>(vt, lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, ob_out, cnt, pv[v].n_bins, search_log, (L)minv[v]);
-        else dissect_batch<L, false>(vt, lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, ob_out, cnt, pv[v].n_bins, search_log, (L)minv[v]);
-      }
+      uint8_t PCO_GLOBAL* so = fsym_ptr(ws, fx, t, v) + fat;
+      const uint64_t m0 = pv[v].minv - rel0[v];   // the table's slot 0 in element units
+      if (pv[v].compact) dissect_batch<uint16_t>(vt, clat_ptr(ws, t, v) + at, so, ob_out, cnt, pv[v].n_bins, search_log, m0, use_lut[v]);
+      else if (v == 0) dissect_batch<uint32_t>(vt, lat_ptr<uint32_t>(ws, t, 0) + at, so, ob_out, cnt, pv[v].n_bins, search_log, m0, use_lut[v]);
+      else dissect_batch<L>(vt, lat_ptr<L>(ws, t, v) + at, so, ob_out, cnt, pv[v].n_bins, search_log, m0, use_lut[v]);
     }
   }
 }
@@ -432,17 +448,15 @@ struct PackSink {
     for (uint32_t i = lane_id(); i < kStgDwords; i += 64) stg[i] = 0;
     enc_wave_sync();
   }
-  __device__ __forceinline__ void put(uint32_t rel, uint64_t val, uint32_t nbits) {   // nbits <= 64 of val at bit `rel` after the staged bits
-    if (nbits == 0) return;
-    if (nbits < 64) val &= ((uint64_t)1 << nbits) - 1;
+  // nbits <= 64 of val at bit `rel` after the staged bits.  Branch-free: always three ORs (the third is zero for narrow fields).
+  __device__ __forceinline__ void put(uint32_t rel, uint64_t val, uint32_t nbits) {
+    val &= nbits >= 64 ? ~0ull : (((uint64_t)1 << nbits) - 1);
     const uint32_t pos = (uint32_t)(outbit & 31) + pend + rel;
     const uint32_t dw = pos >> 5, sh = pos & 31;
-    atomicOr((uint32_t*)&stg[dw], (uint32_t)(val << sh));
-    if (sh + nbits > 32) {
-      const uint64_t rest = sh ? (val >> (32 - sh)) : (val >> 32);
-      atomicOr((uint32_t*)&stg[dw + 1], (uint32_t)rest);
-      if (sh + nbits > 64) atomicOr((uint32_t*)&stg[dw + 2], (uint32_t)(rest >> 32));
-    }
+    const uint64_t lo = val << sh;
+    atomicOr((uint32_t*)&stg[dw], (uint32_t)lo);
+    atomicOr((uint32_t*)&stg[dw + 1], (uint32_t)(lo >> 32));
+    atomicOr((uint32_t*)&stg[dw + 2], (uint32_t)((val >> 1) >> (63 - sh)));   // val >> (64 - sh), 0 when sh == 0
   }
   __device__ __forceinline__ void commit(uint32_t total) { pend += total; }
   __device__ __forceinline__ void flush() {
@@ -484,23 +498,28 @@ __device__ __forceinline__ void pack_load(PackItem& it, const LV PCO_GLOBAL* lat
                                           uint32_t cnt, bool needs_ans, bool single_bin, bool has_offsets) {
   const uint32_t lane = lane_id();
   typedef uint64_t __attribute__((aligned(2))) u64_align2;
-  const bool blk_on = 4 * lane < ((cnt + 15u) & ~15u);
-  it.syms = (!single_bin && blk_on) ? *(const u32_unaligned PCO_GLOBAL*)(sym + 4 * lane) : 0u;
-  uint64_t w = 0;
-  if (needs_ans && blk_on) w = *(const u64_align2 PCO_GLOBAL*)(answ + 4 * lane);
-  it.a = (uint32_t)w; it.b = (uint32_t)(w >> 32);
-  if (!has_offsets) { it.x[0] = it.x[1] = it.x[2] = it.x[3] = 0; return; }
-  if (cnt == kBatchN) {
+  it.syms = 0; it.a = it.b = 0; it.x[0] = it.x[1] = it.x[2] = it.x[3] = 0;
+  if (cnt == kBatchN) {   // the common case carries no per-lane predicates
+    if (!single_bin) it.syms = *(const u32_unaligned PCO_GLOBAL*)(sym + 4 * lane);
+    if (needs_ans) { const uint64_t w = *(const u64_align2 PCO_GLOBAL*)(answ + 4 * lane); it.a = (uint32_t)w; it.b = (uint32_t)(w >> 32); }
+    if (has_offsets) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) it.x[k] = (uint64_t)lat[4 * lane + k];
-  } else {
+      for (int k = 0; k < 4; k++) it.x[k] = (uint64_t)lat[4 * lane + k];
+    }
+    return;
+  }
+  const bool blk_on = 4 * lane < ((cnt + 15u) & ~15u);
+  if (!single_bin && blk_on) it.syms = *(const u32_unaligned PCO_GLOBAL*)(sym + 4 * lane);
+  if (needs_ans && blk_on) { const uint64_t w = *(const u64_align2 PCO_GLOBAL*)(answ + 4 * lane); it.a = (uint32_t)w; it.b = (uint32_t)(w >> 32); }
+  if (has_offsets) {
 #pragma unroll
     for (int k = 0; k < 4; k++) it.x[k] = 4 * lane + k < cnt ? (uint64_t)lat[4 * lane + k] : 0ull;
   }
 }
 
 // pack one item: its tANS fields, then its offset fields (chunk_latent_compressor.rs:134-169)
-__device__ __forceinline__ void pack_item(PackSink& sink, const uint8_t PCO_LDS* vt, const PackItem& it, uint32_t cnt, uint32_t asl, bool needs_ans, uint32_t max_ob, bool single_bin) {
+template <bool kFull>
+__device__ __forceinline__ void pack_item_t(PackSink& sink, const uint8_t PCO_LDS* vt, const PackItem& it, uint32_t cnt, uint32_t asl, bool needs_ans, uint32_t max_ob, bool single_bin) {
   const uint32_t lane = lane_id();
   const uint64_t PCO_LDS* low = (const uint64_t PCO_LDS*)vt;
   const uint8_t PCO_LDS* obs = vt + 2048;
@@ -512,7 +531,11 @@ __device__ __forceinline__ void pack_item(PackSink& sink, const uint8_t PCO_LDS*
     const uint32_t f[4] = {a & 0xffffu, a >> 16, b & 0xffffu, b >> 16};
     uint64_t acc = 0; uint32_t accbits = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) if (4 * lane + k < cnt) { const uint32_t nb = f[k] >> 12; acc |= (uint64_t)(f[k] & 0xfffu) << accbits; accbits += nb; }
+    for (int k = 0; k < 4; k++) {
+      const bool act = kFull || 4 * lane + k < cnt;
+      const uint32_t nb = act ? f[k] >> 12 : 0u;
+      acc |= (uint64_t)(act ? f[k] & 0xfffu : 0u) << accbits; accbits += nb;
+    }
     const uint32_t incl = wave_incl_scan(accbits);
     sink.put(incl - accbits, acc, accbits);  // <= 48 bits
     sink.commit(wave_last(incl));
@@ -522,7 +545,8 @@ __device__ __forceinline__ void pack_item(PackSink& sink, const uint8_t PCO_LDS*
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint32_t s = (syms >> (8 * k)) & 0xffu;
-      ob[k] = 4 * lane + k < cnt ? (uint32_t)obs[s] : 0u;
+      const uint32_t o = obs[s];
+      ob[k] = (kFull || 4 * lane + k < cnt) ? o : 0u;
       x[k] = it.x[k] - low[s];
       t += ob[k];
     }
@@ -531,7 +555,7 @@ __device__ __forceinline__ void pack_item(PackSink& sink, const uint8_t PCO_LDS*
     if (max_ob <= 16) {  // the lane's four fields fit one 64-bit word: one put
       uint64_t acc = 0; uint32_t sh = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) { acc |= (x[k] & (((uint64_t)1 << ob[k]) - 1)) << sh; sh += ob[k]; }
+      for (int k = 0; k < 4; k++) { acc |= (uint64_t)__builtin_amdgcn_ubfe((uint32_t)x[k], 0u, ob[k]) << sh; sh += ob[k]; }
       sink.put(rel, acc, t);
     } else {
 #pragma unroll
@@ -539,6 +563,10 @@ __device__ __forceinline__ void pack_item(PackSink& sink, const uint8_t PCO_LDS*
     }
     sink.commit(wave_last(incl));
   }
+}
+__device__ __forceinline__ void pack_item(PackSink& sink, const uint8_t PCO_LDS* vt, const PackItem& it, uint32_t cnt, uint32_t asl, bool needs_ans, uint32_t max_ob, bool single_bin) {
+  if (cnt == kBatchN) pack_item_t<true>(sink, vt, it, cnt, asl, needs_ans, max_ob, single_bin);
+  else pack_item_t<false>(sink, vt, it, cnt, asl, needs_ans, max_ob, single_bin);
 }
 
 template <class L>
@@ -612,7 +640,8 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
     if (!on[v]) continue;
     const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
     uint8_t PCO_LDS* vt = smem + kPackLdsVar + ws.slot_of_var[v] * kPackVarBytes;
-    for (uint32_t b = lane; b < pv[v].n_bins; b += 64) { ((uint64_t PCO_LDS*)vt)[b] = plan->blower[b]; (vt + 2048)[b] = plan->bob[b]; }
+    const uint64_t rel0 = pv[v].compact ? pv[v].minv : 0ull;   // compact latents are relative to the minimum
+    for (uint32_t b = lane; b < pv[v].n_bins; b += 64) { ((uint64_t PCO_LDS*)vt)[b] = plan->blower[b] - rel0; (vt + 2048)[b] = plan->bob[b]; }
   }
   enc_wave_sync();
   // batches of the run; the next batch's loads are issued before the current one is packed
@@ -624,7 +653,8 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
       if (!on[v] || base >= pv[v].n_lat) continue;
       const uint32_t cnt = pv[v].n_lat - base < kBatchN ? pv[v].n_lat - base : kBatchN;
       const uint64_t at = pstart + pv[v].skip + base, fat = fast_at(pg, pv[v].skip) + base;
-      if (v == 0) pack_load<uint32_t>(dstv[v], lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, fansw_ptr(ws, fx, t, 0) + fat, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
+      if (pv[v].compact) pack_load<uint16_t>(dstv[v], clat_ptr(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, fansw_ptr(ws, fx, t, v) + fat, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
+      else if (v == 0) pack_load<uint32_t>(dstv[v], lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, fansw_ptr(ws, fx, t, 0) + fat, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
       else pack_load<L>(dstv[v], lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, fansw_ptr(ws, fx, t, v) + fat, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
     }
   };

@@ -103,6 +103,12 @@ template <class L> __device__ __forceinline__ L PCO_GLOBAL* lat_ptr(const EncWor
 __device__ __forceinline__ uint32_t PCO_GLOBAL* dissect_ptr(const EncWorkspace& ws, uint32_t task, uint32_t var) {
   return (uint32_t PCO_GLOBAL*)(ws.dissect + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * ws.n_stride);
 }
+// Compact latents (x - min as u16) of the variables whose histogram was built by LDS counting (value range below
+// kWideHistRange): written by the histogram kernels, read by the dissect / pack kernels instead of the 8-byte latents.
+// They live in the (task, slot) region of the dissect buffer, which only enc_page_kernel uses otherwise.
+__device__ __forceinline__ uint16_t PCO_GLOBAL* clat_ptr(const EncWorkspace& ws, uint32_t task, uint32_t var) {
+  return (uint16_t PCO_GLOBAL*)dissect_ptr(ws, task, var);
+}
 template <class L> __device__ __forceinline__ L PCO_GLOBAL* sort_ptr(const EncWorkspace& ws, uint32_t task, uint32_t which) {
   return (L PCO_GLOBAL*)(ws.sort + ((uint64_t)task * 2 + which) * ws.n_stride * 8);
 }
@@ -598,16 +604,26 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     constexpr uint32_t PER = R / T;   // counters per thread in the prefix pass
     for (uint32_t i = tid; i < R + 8; i += T) counts[i] = 0;
     __syncthreads();
-    {  // counting: 8 loads in flight per thread
+    {  // counting: 8 loads in flight per thread; the compact copy (x - min, u16) is written on the way
+      uint16_t PCO_GLOBAL* clat = clat_ptr(ws, t, var);
       uint32_t base = 0;
       for (; base + 8 * T <= n_all; base += 8 * T) {
         L x[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) x[k] = lat[base + k * T + tid];
 #pragma unroll
-        for (int k = 0; k < 8; k++) if (stored(base + k * T + tid)) atomicAdd((uint32_t*)&counts[(uint32_t)(x[k] - minv)], 1u);
+        for (int k = 0; k < 8; k++) {
+          const uint32_t i = base + k * T + tid;
+          const uint32_t c = (uint32_t)(x[k] - minv);
+          clat[i] = (uint16_t)c;
+          if (stored(i)) atomicAdd((uint32_t*)&counts[c], 1u);
+        }
       }
-      for (uint32_t i = base + tid; i < n_all; i += T) if (stored(i)) atomicAdd((uint32_t*)&counts[(uint32_t)(lat[i] - minv)], 1u);
+      for (uint32_t i = base + tid; i < n_all; i += T) {
+        const uint32_t c = (uint32_t)(lat[i] - minv);
+        clat[i] = (uint16_t)c;
+        if (stored(i)) atomicAdd((uint32_t*)&counts[c], 1u);
+      }
     }
     __syncthreads();
     // exclusive prefix over R counters: PER per thread + block scan
