@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chunks", type=int, default=2048, help="chunks per GPU per step")
+    ap.add_argument("--chunks", type=int, default=8192, help="chunks per GPU per step (8192 x 2 MiB = 16 GiB of numbers per GPU)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--gather", action="store_true", help="also gather the compressed pages to rank 0 over RCCL each step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -214,8 +214,16 @@ def main():
         # algorithmic bytes per launch: encode = n*sizeof(T) read + C written; decode = C read + n*sizeof(T) written
         alg = nch * chunk_bytes + comp_bytes
         dom = max(kavg, key=kavg.get)
+        traffic = None
+        try:  # HBM bytes of the dominant kernel from the committed PMC passes (profiles/), scaled to this run's chunk count
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj.get("workload") == args.workload and dom in tj["kernels"]:
+                kk = tj["kernels"][dom]
+                traffic = int((kk["fetch_bytes_per_launch"] + kk["write_bytes_per_launch"]) * nch / tj["chunks"])
+        except (OSError, ValueError, KeyError):
+            pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(alg / (kavg[dom] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(alg / (kavg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(alg / (kavg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4),
                 "per_kernel_avg_ms": {k: round(v, 4) for k, v in sorted(kavg.items())}}
         line = {
