@@ -38,7 +38,10 @@ WORKLOADS = {
     # name: (torch dtype name, pco dtype byte, config kwargs, description)
     "c2": ("int64", 2, dict(mode=1, delta=2, delta_order=1), "u64 classic delta-1 noisy ramp, 2^18-element chunks (BASELINE configs[1])"),
     "c3": ("float64", 6, dict(mode=2, mode_f64=0.01, delta=1), "f64 float-mult(0.01) decimals, 2^18-element chunks (BASELINE configs[2])"),
+    "c1": ("int32", 1, dict(mode=1, delta=1), "u32 classic no-delta uniform random, 2^18-element chunks (BASELINE configs[0], incompressible)"),
+    "c4": ("int64", 4, dict(mode=1, delta=3), "i64 seasonal (period 365) lookback delta, 2^18-element chunks (BASELINE configs[3])"),
 }
+ELEM_BYTES = {"c1": 4, "c2": 8, "c3": 8, "c4": 8}
 
 
 def make_chunks(torch, kind, n_chunks, rank, device):
@@ -53,6 +56,12 @@ def make_chunks(torch, kind, n_chunks, rank, device):
     if kind == "c3":
         cents = torch.randint(1000, 10000, (n_chunks, N18), generator=g, device=device, dtype=torch.int64)
         return (cents.to(torch.float64) / 100.0).contiguous()
+    if kind == "c1":
+        return torch.randint(-(1 << 31), 1 << 31, (n_chunks, N18), generator=g, device=device, dtype=torch.int64).to(torch.int32).contiguous()
+    if kind == "c4":
+        base = torch.randint(-(1 << 40), 1 << 40, (365,), generator=g, device=device, dtype=torch.int64)
+        idx = torch.arange(N18, device=device) % 365
+        return (base[idx].unsqueeze(0) + torch.randint(-3, 4, (n_chunks, N18), generator=g, device=device, dtype=torch.int64)).contiguous()
     raise KeyError(kind)
 
 
@@ -124,7 +133,7 @@ def main():
     gcfg = G.make_config(**cfg_kw)
     nch = args.chunks
     data = make_chunks(torch, args.workload, nch, rank, device)
-    chunk_bytes = N18 * 8
+    chunk_bytes = N18 * ELEM_BYTES[args.workload]
     cap = (L.pco_gfx_guarantee_chunk_size(N18, dtb) + 64 + 15) // 16 * 16
     comp = torch.zeros(nch * cap, dtype=torch.uint8, device=device)
     out = torch.empty_like(data)
@@ -173,7 +182,7 @@ def main():
     assert torch.equal(out, data), "decode(encode(x)) != x"
     if rank == 0:
         import oracle_lib as O
-        first = data[0].cpu().numpy().view(np.uint64 if tdt == "int64" else np.float64)
+        first = data[0].cpu().numpy().view({"c1": np.uint32, "c2": np.uint64, "c3": np.float64, "c4": np.int64}[args.workload])
         want = O.simple_compress(first, O.make_config(**cfg_kw))
         got = bytes(comp[: int(enc_res["n_out"][0])].cpu().numpy())
         hdr = len(want) - 1 - len(got)
@@ -229,11 +238,11 @@ def main():
         line = {
             "metric": "encode+decode GB/s (uncompressed) per chunk, u64/f64 2^18-elem", "value": round(value, 2), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if args.workload == "c2" else "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"c1": "u32", "c2": "u64", "c3": "f64", "c4": "i64"}[args.workload],
             "data": "synthetic",
             "config": {"workload": desc, "chunks_per_gpu": nch, "chunk_n": N18, "compression_level": 8,
-                       "mode_spec": "Classic" if args.workload == "c2" else "TryFloatMult(0.01)",
-                       "delta_spec": "TryConsecutive(1)" if args.workload == "c2" else "NoOp",
+                       "mode_spec": "TryFloatMult(0.01)" if args.workload == "c3" else "Classic",
+                       "delta_spec": {"c1": "NoOp", "c2": "TryConsecutive(1)", "c3": "NoOp", "c4": "TryLookback"}[args.workload],
                        "parallelism": f"chunk-sharded x{world}" + (" + RCCL gather of pages" if args.gather else ""),
                        "compressed_bytes_per_chunk": comp_bytes // nch,
                        "encode_GBps": round(world * nch * chunk_bytes * args.steps / t_enc / 1e9, 2),

@@ -15,18 +15,22 @@
 
 namespace pcogfx {
 
-constexpr uint32_t kWQ = 8;                      // chunks per wave in dec_walk_kernel: FOUR LANES (one per tANS chain) per chunk
-constexpr uint32_t kGrpWinOff = 0;               // u64[56] ANS window of the chunk's current batch
-constexpr uint32_t kGrpVarOff = 448;             // VarInfo[3]
-constexpr uint32_t kGrpTblOff = 640;             // per variable: entries u32[T] | offset_bits u8[n_bins]
-constexpr uint32_t kGrpTblBytes = 4272;
-constexpr uint32_t kGrpBytes = kGrpTblOff + kGrpTblBytes;   // 4912
-constexpr uint32_t kWalkTmpOff = kWQ * kGrpBytes;            // u32[264] scratch for the table build (one chunk at a time)
-constexpr uint32_t kWalkLdsBytes = kWalkTmpOff + 1056;       // 40352: four waves per CU
+// dec_walk_kernel<L, KQ>: KQ chunks per wave (8, or 4 for chunks whose tANS tables need a bigger LDS slice), FOUR LANES
+// (one per tANS chain) per chunk.  Slice of a chunk: u64[56] ANS window | VarInfo[3] | per variable: entries u32[T], offset_bits u8[n_bins].
+constexpr uint32_t kGrpWinOff = 0;
+constexpr uint32_t kGrpVarOff = 448;
+constexpr uint32_t kGrpTblOff = 640;
+template <uint32_t KQ> struct WalkCfg {
+  static constexpr uint32_t kGrpBytes = KQ == 8 ? 4912u : 9952u;
+  static constexpr uint32_t kGrpTblBytes = kGrpBytes - kGrpTblOff;      // 4272 / 9312
+  static constexpr uint32_t kWalkTmpOff = KQ * kGrpBytes;                // u32[264] scratch for the table build (one chunk at a time)
+  static constexpr uint32_t kWalkLdsBytes = kWalkTmpOff + 1056;          // 40352 / 40864: four waves per CU
+  static_assert(kGrpBytes % 16 == 0, "chunk slices must stay 16-byte aligned");
+  static_assert(kWalkLdsBytes < 65536, "walk entries hold 16-bit LDS addresses");
+};
 constexpr uint32_t kFastMaxBins = 256;
 constexpr uint32_t kStatusRetryLegacy = 100;     // internal: hand the task to the single-kernel decoder
-static_assert(kGrpBytes % 16 == 0, "chunk slices must stay 16-byte aligned");
-static_assert(kWalkLdsBytes < 65536, "walk entries hold 16-bit LDS addresses");
+constexpr uint32_t kStatusRetryK4 = 101;         // internal: tables too big for an 8-chunk wave, try the 4-chunk walker
 
 struct DecPlan {   // written by dec_walk_kernel, read by dec_expand_kernel
   uint32_t status, n;
@@ -47,8 +51,9 @@ __device__ __forceinline__ uint32_t make_wentry(uint32_t addr, uint32_t sym, uin
 
 // Build one variable's walk table for chunk slot `q`: u32 entries and per-bin offset bits in LDS; lowers / offset bits
 // go to the global bins area for dec_expand_kernel.  All 64 lanes cooperate.  (ans/spec.rs:37-59, ans/decoding.rs:27-47)
-template <class LV>
+template <class LV, uint32_t KQ>
 __device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader& mr, uint8_t PCO_GLOBAL* bins_out, uint32_t& status) {
+  constexpr uint32_t kGrpBytes = WalkCfg<KQ>::kGrpBytes, kWalkTmpOff = WalkCfg<KQ>::kWalkTmpOff;
   const uint32_t lane = lane_id();
   uint8_t PCO_LDS* grp = lds_base() + q * kGrpBytes;
   VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(grp + kGrpVarOff) + vi;
@@ -130,8 +135,9 @@ struct FrontOut {
 };
 
 // Everything before the page body for one task, executed by the whole wave on behalf of group q.
-template <class L>
+template <class L, uint32_t KQ>
 __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q, DecPlan PCO_GLOBAL* plan, uint8_t PCO_GLOBAL* bins_out, FrontOut& out) {
+  constexpr uint32_t kGrpBytes = WalkCfg<KQ>::kGrpBytes, kGrpTblBytes = WalkCfg<KQ>::kGrpTblBytes;
   const uint32_t lane = lane_id();
   gcptr_u8 src = (gcptr_u8)task.src;
   const uint64_t src_len = uni((uint64_t)task.src_len);
@@ -221,13 +227,14 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
     }
   }
   wave_sync_lds();
-  if (too_big || total_tbl > kGrpTblBytes) { fail(kStatusRetryLegacy); return; }
+  if (too_big || total_tbl > WalkCfg<4>::kGrpTblBytes) { fail(kStatusRetryLegacy); return; }
+  if (total_tbl > kGrpTblBytes) { fail(kStatusRetryK4); return; }
   if (dkind == kDeltaLookback && (mode_kind != kClassic || sec_uses_delta)) { fail(kStatusRetryLegacy); return; }  // the general path reports it
 #pragma unroll
   for (int vi = 0; vi < 3; vi++) {
     if (!present[vi]) continue;
     mr.bit += kBitsAnsSizeLog + kBitsNBins;
-    const bool ok = vi == 0 ? fast_build_var<uint32_t>(q, vi, mr, bins_out, status) : fast_build_var<L>(q, vi, mr, bins_out, status);
+    const bool ok = vi == 0 ? fast_build_var<uint32_t, KQ>(q, vi, mr, bins_out, status) : fast_build_var<L, KQ>(q, vi, mr, bins_out, status);
     if (!ok) { fail(status); return; }
   }
   if (!mr.drain_empty_byte()) { if (mr.in_bounds()) { fail(PCO_GFX_CORRUPTION); return; } }
@@ -335,9 +342,10 @@ __device__ __forceinline__ void walk_step(WalkRegs& r, uint32_t sel_bb, uint32_t
   r.w4 = (uint32_t)nq; r.w5 = (uint32_t)(nq >> 32);
 }
 
-template <class L>
+template <class L, uint32_t kWQ>
 __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                                       uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride) {
+  constexpr uint32_t kGrpBytes = WalkCfg<kWQ>::kGrpBytes;
   const uint32_t lane = lane_id();
   const uint32_t slot = lane >> 2, j = lane & 3;
   // ---- phase 0: metadata + tables, one task at a time with the whole wave; slot q belongs to lanes 4q..4q+3 ----
@@ -349,9 +357,10 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
     const uint32_t bi = blockIdx.x * kWQ + q;
     if (bi >= n_ids) break;
     const uint32_t ti = task_ids ? task_ids[bi] : bi;
+    if (kWQ != 8 && uni(((const DecPlan PCO_GLOBAL*)plans + ti)->status) != kStatusRetryK4) continue;   // the 8-chunk walker dealt with this task
     const PcoGfxDecodeTask task = tasks[ti];
     FrontOut fo;
-    fast_front<L>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);
+    fast_front<L, kWQ>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);
     if (slot == q) {
       my_ti = ti; my_active = fo.status == PCO_GFX_OK ? 1u : 0u; my_front_ok = my_active; my_n = fo.n; my_bitpos = fo.bitpos;
       my_len = task.src_len; my_flags = task.flags; my_src = (gcptr_u8)task.src;
@@ -707,7 +716,8 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
         if (dk[1] == kDeltaConsecutive) consecutive_decode<L>(prim, dord[1], moments0);
         if (present[2] && dk[2] == kDeltaConsecutive) consecutive_decode<L>(sec, dord[2], moments1);
         if (dk[1] == kDeltaLookback) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+          // history lives in dst: earlier batches' stores were acknowledged by L2 before their wave passed the turn on
+          // (s_waitcnt vmcnt(0) below), and the loads here are agent-scope atomics, i.e. served by L2
           __builtin_amdgcn_wave_barrier();
           const uint32_t window_n = 1u << window_n_log;
           const uint64_t kbase = (uint64_t)j0;
@@ -740,7 +750,7 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
             wave_sync_lds();
           }
           for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; if (i < prim_cnt) dst[state_n + kbase + i] = from_latent_ordered<L>(scratch[i], num_kind); }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

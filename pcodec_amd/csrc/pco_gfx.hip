@@ -130,14 +130,6 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     d_sym = (uint8_t*)ws.dec_sym.ensure(n_tasks * 3 * sym_stride + 64);
     d_offpos = (uint64_t*)ws.dec_offpos.ensure(n_tasks * 3 * offpos_stride * 8);
   }
-  if (fast) {  // the walker keeps kWQ chunks' tables in one wave's LDS: opt in to more than 64 KB of dynamic LDS, once
-    static const bool walk_lds_ok = [] {
-      return hipFuncSetAttribute((const void*)dec_walk_kernel<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsBytes) == hipSuccess &&
-             hipFuncSetAttribute((const void*)dec_walk_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsBytes) == hipSuccess &&
-             hipFuncSetAttribute((const void*)dec_walk_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsBytes) == hipSuccess;
-    }();
-    if (!walk_lds_ok) throw HostError{PCO_GFX_DEVICE_ERROR, "cannot reserve LDS for dec_walk_kernel"};
-  }
   for (int g = 0; g < 3; g++) {
     if (ids[g].empty()) continue;
     const uint32_t cnt = (uint32_t)ids[g].size();
@@ -145,14 +137,16 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     const uint32_t* idp = mixed ? d_ids + id_off[g] : nullptr;
     const uint32_t* filt = fast ? (const uint32_t*)d_plans : nullptr;
     const uint32_t fstride = (uint32_t)(sizeof(DecPlan) / 4);
-    if (fast) {
-      const uint32_t wgrid = (cnt + kWQ - 1) / kWQ;
-      if (g == 0) { PCO_TIMED_LAUNCH("dec_walk_kernel<u64>", stream, dec_walk_kernel<uint64_t>, dim3(wgrid), dim3(64), kWalkLdsBytes, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
-                    PCO_TIMED_LAUNCH("dec_expand_kernel<u64>", stream, dec_expand_kernel<uint64_t>, dim3(grid), dim3(256), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
-      else if (g == 1) { PCO_TIMED_LAUNCH("dec_walk_kernel<u32>", stream, dec_walk_kernel<uint32_t>, dim3(wgrid), dim3(64), kWalkLdsBytes, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
-                         PCO_TIMED_LAUNCH("dec_expand_kernel<u32>", stream, dec_expand_kernel<uint32_t>, dim3(grid), dim3(256), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
-      else { PCO_TIMED_LAUNCH("dec_walk_kernel<u16>", stream, dec_walk_kernel<uint16_t>, dim3(wgrid), dim3(64), kWalkLdsBytes, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
-             PCO_TIMED_LAUNCH("dec_expand_kernel<u16>", stream, dec_expand_kernel<uint16_t>, dim3(grid), dim3(256), kExpLdsBytes, stream, d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride); }
+    if (fast) {  // walk with 8 chunks per wave, then with 4 for the chunks whose tables did not fit, then expand
+#define PCO_FAST_DECODE(L, name)                                                                                                                         \
+      PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8>), dim3((cnt + 7) / 8), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,  \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);                                                 \
+      PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4>), dim3((cnt + 3) / 4), dim3(64), WalkCfg<4>::kWalkLdsBytes, stream, \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);                                                 \
+      PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, dec_expand_kernel<L>, dim3(grid), dim3(256), kExpLdsBytes, stream,                       \
+                       d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
+      if (g == 0) { PCO_FAST_DECODE(uint64_t, "u64") } else if (g == 1) { PCO_FAST_DECODE(uint32_t, "u32") } else { PCO_FAST_DECODE(uint16_t, "u16") }
+#undef PCO_FAST_DECODE
     }
     if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
     else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
