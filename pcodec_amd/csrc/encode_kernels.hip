@@ -565,12 +565,15 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
 constexpr uint32_t kHistLdsRecV = 0;
 constexpr uint32_t kHistLdsCounts = 4 * 2048 + 2 * 1024 + 2048;
 constexpr uint32_t kWideHistRange = 32768;
+constexpr uint32_t kSelBucketsLog = 13, kSelBuckets = 1u << kSelBucketsLog, kSelMaxNeeded = 1600;
 __host__ __device__ constexpr uint32_t hist_lds_bytes(uint32_t range) { return kHistLdsCounts + (range + 8) * 4; }
 constexpr uint32_t kHistLdsBytes = hist_lds_bytes(kDirectHistRange);
+// enc_hist_sort_kernel: radix counters u32[2048] | bucket prefix u32[8200] | marks u32[256] | marked-bucket list u32[2][1600 + 1]
+constexpr uint32_t kHistSortLdsBytes = kHistLdsCounts + (2048 + kSelBuckets + 8 + kSelBuckets / 32 + 2 * (kSelMaxNeeded + 1)) * 4;
 
 // T threads per block; R = value range handled by LDS counting.  kWide: only variables whose range lies in
 // [kDirectHistRange, R) are processed (enc_hist_wide_kernel); otherwise those are left to that kernel.
-template <class L, uint32_t T, uint32_t R, bool kWide>
+template <class L, uint32_t T, uint32_t R, bool kWide, bool kSort>
 __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log) {
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   EncVar PCO_GLOBAL* ev = &ch->v[var];
@@ -580,7 +583,8 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   if (n_lat == 0) { if (tid == 0) ev->n_hist = 0; return; }
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   const L range = (L)(maxv - minv);
-  if (kWide ? ((uint64_t)range < kDirectHistRange || (uint64_t)range >= R) : ((uint64_t)range >= kDirectHistRange && (uint64_t)range < kWideHistRange)) return;
+  // enc_hist_kernel: range < 4096; enc_hist_wide_kernel: [4096, 32768); enc_hist_sort_kernel: the rest
+  if (kSort ? (uint64_t)range < kWideHistRange : (kWide ? ((uint64_t)range < kDirectHistRange || (uint64_t)range >= R) : (uint64_t)range >= kDirectHistRange)) return;
   // Stored latents = every position that is not among the first `skip` of its page (wrapped/chunk_compressor.rs:129-140).
   const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
   const uint32_t n_all = (uint32_t)ch->n, skip = ev->lat_start, plow = ch->page_low, pr = ch->page_r;
@@ -656,29 +660,114 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     __syncthreads();
     return;
   }
-  if constexpr (kWide) return;
-  // ---------------- sorted path: stable LSD radix sort on key = x - min (256 threads) ----------------
-  if constexpr (!kWide) {
+  if constexpr (!kSort) return;
+  // ---------------- sorted path (256 threads) ----------------
+  // The histogram only asks for the values (and their runs) at <= 2^bins_log ranks, so most of a wide-range variable
+  // never needs ordering.  (1) count the latents into 8192 buckets by the top bits of key = x - min; (2) mark the
+  // buckets that hold a queried rank, plus the nearest non-empty bucket on either side (predecessor / successor of
+  // a run); (3) stable LSD radix sort (8-bit digits) of the latents of the marked buckets only -- typically 5-20 %
+  // of the chunk; (4) answer the rank queries in the sorted subset, translating ranks through the bucket prefix.
+  if constexpr (kSort) {
+  constexpr uint32_t NB = kSelBuckets;
   const uint32_t sig_bits = bitlen<L>(range);
+  const uint32_t bshift = sig_bits > kSelBucketsLog ? sig_bits - kSelBucketsLog : 0u;
   const uint32_t npass = (sig_bits + 7) / 8;
   L PCO_GLOBAL* bufA = sort_ptr<L>(ws, t, 0);
   L PCO_GLOBAL* bufB = sort_ptr<L>(ws, t, 1);
   uint32_t PCO_LDS* cnt = counts;            // [4][256]
   uint32_t PCO_LDS* cursor = counts + 1024;  // [4][256]
+  uint32_t PCO_LDS* P = counts + 2048;                 // u32[NB + 8]: bucket counts, then exclusive prefix
+  uint32_t PCO_LDS* need = P + NB + 8;                 // u32[NB / 32] bitmap
+  uint32_t PCO_LDS* nl_k = need + NB / 32;             // u32[kSelMaxNeeded] marked buckets in order
+  uint32_t PCO_LDS* nl_oc = nl_k + kSelMaxNeeded;      // u32[kSelMaxNeeded + 1] sorted-subset offset of each marked bucket
+  auto bucket_of = [&](L x) { return (uint32_t)((L)(x - minv) >> bshift); };
+  // (1) bucket counts + prefix
+  for (uint32_t i = tid; i < NB + 8; i += 256) P[i] = 0;
+  for (uint32_t i = tid; i < NB / 32; i += 256) need[i] = 0;
+  __syncthreads();
+  {
+    uint32_t base = 0;
+    for (; base + 8 * 256 <= n_all; base += 8 * 256) {
+      L x[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) x[k] = lat[base + k * 256 + tid];
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (stored(base + k * 256 + tid)) atomicAdd((uint32_t*)&P[bucket_of(x[k])], 1u);
+    }
+    for (uint32_t i = base + tid; i < n_all; i += 256) if (stored(i)) atomicAdd((uint32_t*)&P[bucket_of(lat[i])], 1u);
+  }
+  __syncthreads();
+  {
+    constexpr uint32_t PER = NB / 256;
+    uint32_t s0 = 0;
+    for (uint32_t k = 0; k < PER; k++) s0 += P[tid * PER + k];
+    const uint32_t incl = wave_incl_scan(s0);
+    if (lane == 63) scan[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0; for (uint32_t w = 0; w < wave; w++) wbase += scan[w];
+    uint32_t run = wbase + incl - s0;
+    for (uint32_t k = 0; k < PER; k++) { const uint32_t c = P[tid * PER + k]; P[tid * PER + k] = run; run += c; }
+    if (tid == 255) P[NB] = run;  // == n_lat
+  }
+  __syncthreads();
+  auto bucket_of_rank = [&](uint32_t r) {   // the (non-empty) bucket holding rank r: last k with P[k] <= r
+    uint32_t lo = 0, hi = NB;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P[mid] <= r) lo = mid; else hi = mid; }
+    return lo;
+  };
+  // (2) mark
+  if (tid < B) {
+    const uint32_t c = c_count(tid);
+    for (uint32_t which = 0; which < 2; which++) {
+      const uint32_t r = c - 1 + which;
+      if (r >= n_lat) continue;
+      const uint32_t k = bucket_of_rank(r);
+      atomicOr((uint32_t*)&need[k >> 5], 1u << (k & 31));
+      if (P[k] > 0) { const uint32_t kp = bucket_of_rank(P[k] - 1); atomicOr((uint32_t*)&need[kp >> 5], 1u << (kp & 31)); }
+      if (P[k + 1] < n_lat) { const uint32_t kn = bucket_of_rank(P[k + 1]); atomicOr((uint32_t*)&need[kn >> 5], 1u << (kn & 31)); }
+    }
+  }
+  __syncthreads();
+  // list of marked buckets (ascending) with the offset of each one's latents in the sorted subset
+  uint32_t n_need = 0, n_sub = 0;
+  {
+    const uint32_t word = need[tid];        // NB / 32 == 256 words: one per thread
+    uint32_t nb_here = __popc(word), el_here = 0;
+    for (uint32_t w = word; w; w &= w - 1) { const uint32_t k = tid * 32 + (uint32_t)__builtin_ctz(w); el_here += P[k + 1] - P[k]; }
+    const uint32_t i_nb = wave_incl_scan(nb_here), i_el = wave_incl_scan(el_here);
+    if (lane == 63) { scan[wave] = i_nb; scan[16 + wave] = i_el; }
+    __syncthreads();
+    uint32_t b_nb = 0, b_el = 0; for (uint32_t w = 0; w < wave; w++) { b_nb += scan[w]; b_el += scan[16 + w]; }
+    uint32_t slot = b_nb + i_nb - nb_here, off = b_el + i_el - el_here;
+    for (uint32_t w = word; w; w &= w - 1) {
+      const uint32_t k = tid * 32 + (uint32_t)__builtin_ctz(w);
+      if (slot < kSelMaxNeeded) { nl_k[slot] = k; nl_oc[slot] = off; }
+      slot++; off += P[k + 1] - P[k];
+    }
+    n_need = scan[0] + scan[1] + scan[2] + scan[3]; n_sub = scan[16] + scan[17] + scan[18] + scan[19];
+  }
+  __syncthreads();
+  if (tid == 0) nl_oc[n_need < kSelMaxNeeded ? n_need : kSelMaxNeeded] = n_sub;
+  const bool subset = n_need <= kSelMaxNeeded;   // always true (<= 6 marks per queried rank); otherwise sort everything
+  auto needed = [&](L x) { const uint32_t k = bucket_of(x); return !subset || ((need[k >> 5] >> (k & 31)) & 1u) != 0; };
+  const uint32_t n_sort = subset ? n_sub : n_lat;
+  __syncthreads();
+  // (3) stable LSD radix sort of the marked buckets' latents
   for (uint32_t p = 0; p < npass; p++) {
     const L PCO_GLOBAL* in = p == 0 ? lat : ((p & 1) ? bufA : bufB);
     L PCO_GLOBAL* out = (p & 1) ? bufB : bufA;
     const uint32_t shift = 8 * p;
-    // pass 0 reads the page-structured latent array (skipping each page's junk prefix); later passes are dense
-    const uint32_t n_in = p == 0 ? n_all : n_lat;
+    // pass 0 reads the page-structured latent array (skipping each page's junk prefix and unmarked buckets); later passes are dense
+    const uint32_t n_in = p == 0 ? n_all : n_sort;
     const uint32_t q = (n_in + 3) / 4;       // per-wave contiguous quarter (keeps the scatter stable)
     const uint32_t w_begin = wave * q < n_in ? wave * q : n_in;
     const uint32_t w_end = (wave + 1) * q < n_in ? (wave + 1) * q : n_in;
     for (uint32_t i = tid; i < 1024; i += 256) cnt[i] = 0;
     __syncthreads();
     for (uint32_t i = w_begin + lane; i < w_end; i += 64) {
-      if (p == 0 && !stored(i)) continue;
-      const uint32_t d = (uint32_t)(((L)(in[i] - minv)) >> shift) & 255u;
+      const L x = in[i];
+      if (p == 0 && (!stored(i) || !needed(x))) continue;
+      const uint32_t d = (uint32_t)(((L)(x - minv)) >> shift) & 255u;
       atomicAdd((uint32_t*)&cnt[wave * 256 + d], 1u);
     }
     __syncthreads();
@@ -696,10 +785,11 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     uint32_t PCO_LDS* mycur = cursor + wave * 256;
     for (uint32_t i0 = w_begin; i0 < w_end; i0 += 64) {
       const uint32_t i = i0 + lane;
-      const bool act = i < w_end && (p != 0 || stored(i));
-      const L x = act ? in[i] : (L)0;
+      const L x = i < w_end ? in[i] : (L)0;
+      const bool act = i < w_end && (p != 0 || (stored(i) && needed(x)));
       const uint32_t d = act ? ((uint32_t)(((L)(x - minv)) >> shift) & 255u) : 0xffffffffu;
       uint64_t m = __ballot(act);
+      if (m == 0) continue;
 #pragma unroll
       for (uint32_t bit = 0; bit < 8; bit++) { const uint64_t bm = __ballot((d >> bit) & 1); m &= ((d >> bit) & 1) ? bm : ~bm; }
       const uint64_t lt = ((uint64_t)1 << lane) - 1;
@@ -714,22 +804,33 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     __syncthreads();
   }
   const L PCO_GLOBAL* S = (npass & 1) ? bufA : bufB;
+  // (4) rank queries.  A rank r lives in bucket k = bucket_of_rank(r), whose latents occupy S[oc .. oc + count) -- runs of
+  // equal values never leave their bucket, so run bounds are found inside that window and translated back.
+  auto window_of = [&](uint32_t k, uint32_t& oc) {   // position of marked bucket k in the list
+    if (!subset) { oc = P[k]; return; }
+    uint32_t lo = 0, hi = n_need;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (nl_k[mid] <= k) lo = mid; else hi = mid; }
+    oc = nl_oc[lo];
+  };
+  auto value_at = [&](uint32_t r) { const uint32_t k = bucket_of_rank(r); uint32_t oc; window_of(k, oc); return S[oc + (r - P[k])]; };
   auto lookup_sorted = [&](uint32_t r, L& value, uint32_t& st, uint32_t& en) {
-    value = S[r];
-    uint32_t lo = 0, hi = r;   // first index with S[idx] >= value (S[r] == value)
+    const uint32_t k = bucket_of_rank(r); uint32_t oc; window_of(k, oc);
+    const uint32_t at = oc + (r - P[k]), wend = oc + (P[k + 1] - P[k]);
+    value = S[at];
+    uint32_t lo = oc, hi = at;   // first index with S[idx] >= value (S[at] == value)
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S[mid] < value) lo = mid + 1; else hi = mid; }
-    st = lo;
-    lo = r + 1; hi = n_lat;    // first index with S[idx] > value
+    st = P[k] + (lo - oc);
+    lo = at + 1; hi = wend;      // first index with S[idx] > value
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S[mid] <= value) lo = mid + 1; else hi = mid; }
-    en = lo;
+    en = P[k] + (lo - oc);
   };
   if (tid < B) {
     const uint32_t c = c_count(tid);
     L v; uint32_t st, en; lookup_sorted(c - 1, v, st, en);
     rv[tid] = v; rst[tid] = st; ren[tid] = en;
-    rnext[tid] = c < n_lat ? S[c] : (L)0;
-    rpred[tid] = st > 0 ? S[st - 1] : (L)0;
-    rsucc[tid] = en < n_lat ? S[en] : (L)0;
+    rnext[tid] = c < n_lat ? value_at(c) : (L)0;
+    rpred[tid] = st > 0 ? value_at(st - 1) : (L)0;
+    rsucc[tid] = en < n_lat ? value_at(en) : (L)0;
   }
   __syncthreads();
   if (tid == 0) { uint32_t nh = 0; hist_state_machine<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, nh); ev->n_hist = nh; ev->hist_path = 1; }
@@ -737,7 +838,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   }
 }
 
-template <uint32_t T, uint32_t R, bool kWide>
+template <uint32_t T, uint32_t R, bool kWide, bool kSort>
 __device__ __forceinline__ void hist_chunk(const EncWorkspace& ws, uint32_t t) {
   const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
   if (uni(ch->status) != PCO_GFX_OK) return;
@@ -747,18 +848,22 @@ __device__ __forceinline__ void hist_chunk(const EncWorkspace& ws, uint32_t t) {
     if (!uni(ch->v[var].present)) continue;
     // secondary latents get fewer bins (wrapped/chunk_compressor.rs:238-248)
     const uint32_t bl = var == 2 ? (ubl < 6 ? ubl : 6) : ubl;
-    if (var == 0) hist_var<uint32_t, T, R, kWide>(ws, t, var, bl);
-    else if (bits == 64) hist_var<uint64_t, T, R, kWide>(ws, t, var, bl);
-    else if (bits == 32) hist_var<uint32_t, T, R, kWide>(ws, t, var, bl);
-    else hist_var<uint16_t, T, R, kWide>(ws, t, var, bl);
+    if (var == 0) hist_var<uint32_t, T, R, kWide, kSort>(ws, t, var, bl);
+    else if (bits == 64) hist_var<uint64_t, T, R, kWide, kSort>(ws, t, var, bl);
+    else if (bits == 32) hist_var<uint32_t, T, R, kWide, kSort>(ws, t, var, bl);
+    else hist_var<uint16_t, T, R, kWide, kSort>(ws, t, var, bl);
   }
 }
 __global__ __launch_bounds__(256) void enc_hist_kernel(EncWorkspace ws, uint32_t n_tasks) {
-  if (blockIdx.x < n_tasks) hist_chunk<256, kDirectHistRange, false>(ws, blockIdx.x);
+  if (blockIdx.x < n_tasks) hist_chunk<256, kDirectHistRange, false, false>(ws, blockIdx.x);
+}
+// value ranges >= 32768: bucket pre-selection + radix sort of the needed part
+__global__ __launch_bounds__(256) void enc_hist_sort_kernel(EncWorkspace ws, uint32_t n_tasks) {
+  if (blockIdx.x < n_tasks) hist_chunk<256, kDirectHistRange, false, true>(ws, blockIdx.x);
 }
 // value ranges in [4096, 32768): LDS counting with one 1024-thread block (131 KB of counters) per chunk
 __global__ __launch_bounds__(1024) void enc_hist_wide_kernel(EncWorkspace ws, uint32_t n_tasks) {
-  if (blockIdx.x < n_tasks) hist_chunk<1024, kWideHistRange, true>(ws, blockIdx.x);
+  if (blockIdx.x < n_tasks) hist_chunk<1024, kWideHistRange, true, false>(ws, blockIdx.x);
 }
 
 // =========================================================================================================
