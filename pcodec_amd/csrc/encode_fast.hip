@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void enc_dissect_kernel(EncWorkspace ws, EncFa
   const int bits = dtype_bits(uni(ch->dtype));
   if (bits == 64) dissect_block<uint64_t>(ws, fx, p, run, pg, ch);
   else if (bits == 32) dissect_block<uint32_t>(ws, fx, p, run, pg, ch);
-  else dissect_block<uint16_t>(ws, fx, p, run, pg, ch);
+  else if (bits == 16) dissect_block<uint16_t>(ws, fx, p, run, pg, ch);
+  else dissect_block<uint8_t>(ws, fx, p, run, pg, ch);
 }
 
 // =========================================================================================================
@@ -686,7 +687,8 @@ __global__ __launch_bounds__(64) void enc_pack_kernel(EncWorkspace ws, EncFast f
   const int bits = dtype_bits(uni(ch->dtype));
   if (bits == 64) pack_run<uint64_t>(ws, fx, p, run, pg, ch);
   else if (bits == 32) pack_run<uint32_t>(ws, fx, p, run, pg, ch);
-  else pack_run<uint16_t>(ws, fx, p, run, pg, ch);
+  else if (bits == 16) pack_run<uint16_t>(ws, fx, p, run, pg, ch);
+  else pack_run<uint8_t>(ws, fx, p, run, pg, ch);
 }
 
 }  // namespace pcogfx

@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const P
   if (bits == 64) enc_split_mode<uint64_t>(ws, task, t, pg, tile, mode_kind);
   else if (bits == 32) enc_split_mode<uint32_t>(ws, task, t, pg, tile, mode_kind);
   else if (bits == 16) enc_split_mode<uint16_t>(ws, task, t, pg, tile, mode_kind);
+  else if (bits == 8) enc_split_mode<uint8_t>(ws, task, t, pg, tile, mode_kind);
 }
 
 // =========================================================================================================
@@ -504,7 +505,8 @@ __global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, uint3
   const int bits = dtype_bits(uni(ch->dtype));
   if (bits == 64) lookback_page<uint64_t>(ws, t, pg, hash_tbl, gcounts);
   else if (bits == 32) lookback_page<uint32_t>(ws, t, pg, hash_tbl, gcounts);
-  else lookback_page<uint16_t>(ws, t, pg, hash_tbl, gcounts);
+  else if (bits == 16) lookback_page<uint16_t>(ws, t, pg, hash_tbl, gcounts);
+  else lookback_page<uint8_t>(ws, t, pg, hash_tbl, gcounts);
 }
 
 // =========================================================================================================
@@ -851,7 +853,8 @@ __device__ __forceinline__ void hist_chunk(const EncWorkspace& ws, uint32_t t) {
     if (var == 0) hist_var<uint32_t, T, R, kWide, kSort>(ws, t, var, bl);
     else if (bits == 64) hist_var<uint64_t, T, R, kWide, kSort>(ws, t, var, bl);
     else if (bits == 32) hist_var<uint32_t, T, R, kWide, kSort>(ws, t, var, bl);
-    else hist_var<uint16_t, T, R, kWide, kSort>(ws, t, var, bl);
+    else if (bits == 16) hist_var<uint16_t, T, R, kWide, kSort>(ws, t, var, bl);
+    else hist_var<uint8_t, T, R, kWide, kSort>(ws, t, var, bl);
   }
 }
 __global__ __launch_bounds__(256) void enc_hist_kernel(EncWorkspace ws, uint32_t n_tasks) {
@@ -1093,7 +1096,8 @@ __global__ __launch_bounds__(64) void enc_train_kernel(EncWorkspace ws, uint32_t
     if (var == 0) train_var<uint32_t>(ws, t, var);
     else if (bits == 64) train_var<uint64_t>(ws, t, var);
     else if (bits == 32) train_var<uint32_t>(ws, t, var);
-    else train_var<uint16_t>(ws, t, var);
+    else if (bits == 16) train_var<uint16_t>(ws, t, var);
+    else train_var<uint8_t>(ws, t, var);
     __threadfence_block();
     enc_wave_sync();
   }
@@ -1488,7 +1492,8 @@ __global__ __launch_bounds__(64, PCO_PAGE_MIN_WAVES) void enc_page_kernel(EncWor
   const int bits = dtype_bits(uni(task.dtype));
   if (bits == 64) page_task<uint64_t>(ws, task, pg, res);
   else if (bits == 32) page_task<uint32_t>(ws, task, pg, res);
-  else page_task<uint16_t>(ws, task, pg, res);
+  else if (bits == 16) page_task<uint16_t>(ws, task, pg, res);
+  else page_task<uint8_t>(ws, task, pg, res);
 }
 
 }  // namespace pcogfx

@@ -44,6 +44,7 @@ __host__ __device__ inline uint32_t offset_bits_bits(int latent_bits) {  // bits
 }
 
 template <class L> struct LBits;
+template <> struct LBits<uint8_t> { static constexpr uint32_t v = 8; };
 template <> struct LBits<uint16_t> { static constexpr uint32_t v = 16; };
 template <> struct LBits<uint32_t> { static constexpr uint32_t v = 32; };
 template <> struct LBits<uint64_t> { static constexpr uint32_t v = 64; };
@@ -52,6 +53,7 @@ template <class L> __host__ __device__ constexpr L lmid() { return (L)((L)1 << (
 // order preserving bijections (data_types/unsigned.rs:155-161, signed.rs:46-52, float.rs:392-411)
 // Branch-free: `kind` is wave-uniform, the masks below stay in SGPRs.
 template <class L> struct SignedOf;
+template <> struct SignedOf<uint8_t> { typedef int8_t T; };
 template <> struct SignedOf<uint16_t> { typedef int16_t T; };
 template <> struct SignedOf<uint32_t> { typedef int32_t T; };
 template <> struct SignedOf<uint64_t> { typedef int64_t T; };

@@ -93,29 +93,29 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
   if (n_tasks == 0) return;
   Workspace& ws = workspace();
   // group task ids by number width: one kernel instantiation per width present in the batch
-  std::vector<uint32_t> ids[3];
+  std::vector<uint32_t> ids[4];
   bool any_bad = false;
   for (size_t i = 0; i < n_tasks; i++) {
     const int b = dtype_bits(tasks[i].dtype);
-    if (b == 64) ids[0].push_back((uint32_t)i); else if (b == 32) ids[1].push_back((uint32_t)i); else if (b == 16) ids[2].push_back((uint32_t)i); else any_bad = true;
+    if (b == 64) ids[0].push_back((uint32_t)i); else if (b == 32) ids[1].push_back((uint32_t)i); else if (b == 16) ids[2].push_back((uint32_t)i); else if (b == 8) ids[3].push_back((uint32_t)i); else any_bad = true;
   }
-  if (any_bad) throw HostError{PCO_GFX_UNSUPPORTED, "decode: only 16/32/64-bit number types are implemented on the device"};
+  if (any_bad) throw HostError{PCO_GFX_INVALID_ARGUMENT, "decode: invalid number type"};
   const size_t task_bytes = n_tasks * sizeof(PcoGfxDecodeTask);
   uint8_t* d_base = (uint8_t*)ws.tasks.ensure(task_bytes + n_tasks * sizeof(uint32_t) + 64);
   PcoGfxDecodeTask* d_tasks = (PcoGfxDecodeTask*)d_base;
   uint32_t* d_ids = (uint32_t*)(d_base + ((task_bytes + 15) & ~(size_t)15));
   PcoGfxTaskResult* d_results = d_results_user ? d_results_user : (PcoGfxTaskResult*)ws.results.ensure(n_tasks * sizeof(PcoGfxTaskResult));
   PCO_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks, task_bytes, hipMemcpyHostToDevice, stream));
-  const bool mixed = (ids[0].size() != n_tasks) && (ids[1].size() != n_tasks) && (ids[2].size() != n_tasks);
+  const bool mixed = (ids[0].size() != n_tasks) && (ids[1].size() != n_tasks) && (ids[2].size() != n_tasks) && (ids[3].size() != n_tasks);
   std::vector<uint32_t> flat;
-  size_t id_off[3] = {0, 0, 0};
+  size_t id_off[4] = {0, 0, 0, 0};
   if (mixed) {
-    for (int g = 0; g < 3; g++) { id_off[g] = flat.size(); flat.insert(flat.end(), ids[g].begin(), ids[g].end()); }
+    for (int g = 0; g < 4; g++) { id_off[g] = flat.size(); flat.insert(flat.end(), ids[g].begin(), ids[g].end()); }
     PCO_HIP_CHECK(hipMemcpyAsync(d_ids, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   }
   const uint32_t budget = g_decode_lds_bytes - kLdsFixed;
   size_t max_grid = 0;
-  for (int g = 0; g < 3; g++) max_grid = std::max(max_grid, std::min<size_t>(ids[g].size(), 16384));
+  for (int g = 0; g < 4; g++) max_grid = std::max(max_grid, std::min<size_t>(ids[g].size(), 16384));
   uint8_t* tbl = (uint8_t*)ws.tbl_ws.ensure(max_grid * kTblWsBytes);
   // Fast path (decode_fast.hip): walk 8 chunks per wave, then expand one chunk per wave; whatever it cannot take
   // (multi-chunk streams, big tANS tables, wrapped pages, ...) is finished by the single-kernel decoder.
@@ -130,7 +130,7 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     d_sym = (uint8_t*)ws.dec_sym.ensure(n_tasks * 3 * sym_stride + 64);
     d_offpos = (uint64_t*)ws.dec_offpos.ensure(n_tasks * 3 * offpos_stride * 8);
   }
-  for (int g = 0; g < 3; g++) {
+  for (int g = 0; g < 4; g++) {
     if (ids[g].empty()) continue;
     const uint32_t cnt = (uint32_t)ids[g].size();
     const uint32_t grid = (uint32_t)std::min<size_t>(cnt, 16384);
@@ -145,24 +145,18 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
                        d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);                                                 \
       PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, dec_expand_kernel<L>, dim3(grid), dim3(256), kExpLdsBytes, stream,                       \
                        d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
-      if (g == 0) { PCO_FAST_DECODE(uint64_t, "u64") } else if (g == 1) { PCO_FAST_DECODE(uint32_t, "u32") } else { PCO_FAST_DECODE(uint16_t, "u16") }
+      if (g == 0) { PCO_FAST_DECODE(uint64_t, "u64") } else if (g == 1) { PCO_FAST_DECODE(uint32_t, "u32") } else if (g == 2) { PCO_FAST_DECODE(uint16_t, "u16") } else { PCO_FAST_DECODE(uint8_t, "u8") }
 #undef PCO_FAST_DECODE
     }
     if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
     else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
-    else PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
+    else if (g == 2) PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
+    else PCO_TIMED_LAUNCH("pco_decode_kernel<u8>", stream, pco_decode_kernel<uint8_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
     PCO_HIP_CHECK(hipGetLastError());
   }
   if (results) {
     PCO_HIP_CHECK(hipMemcpyAsync(results, d_results, n_tasks * sizeof(PcoGfxTaskResult), hipMemcpyDeviceToHost, stream));
     PCO_HIP_CHECK(hipStreamSynchronize(stream));
-  }
-  if (const char* dump = std::getenv("PCO_GFX_DEBUG_DUMP")) if (fast) {  // TEMP debug aid
-    PCO_HIP_CHECK(hipStreamSynchronize(stream));
-    std::vector<uint8_t> syms(3 * sym_stride); std::vector<uint64_t> op(3 * offpos_stride);
-    PCO_HIP_CHECK(hipMemcpy(syms.data(), d_sym, syms.size(), hipMemcpyDeviceToHost));
-    PCO_HIP_CHECK(hipMemcpy(op.data(), d_offpos, op.size() * 8, hipMemcpyDeviceToHost));
-    FILE* f = fopen(dump, "wb"); uint64_t hdr[2] = {sym_stride, offpos_stride}; fwrite(hdr, 8, 2, f); fwrite(syms.data(), 1, syms.size(), f); fwrite(op.data(), 8, op.size(), f); fclose(f);
   }
 }
 

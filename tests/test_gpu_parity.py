@@ -38,11 +38,6 @@ def fix_cfg(name):
 def test_decode_reference_golden_assets(L):
     from test_oracle_golden import EXPECTED, asset
     for name, exp in sorted(EXPECTED.items()):
-        if exp.dtype.itemsize == 1:
-            with pytest.raises(G.PcoGfxError) as ei:
-                U.gpu_simple_decompress(asset(name), exp.dtype, exp.size)
-            assert ei.value.status == G.ST_UNSUPPORTED  # 8-bit types: declared gap, refused loudly
-            continue
         got = U.gpu_simple_decompress(asset(name), exp.dtype, max(exp.size, 1))
         assert U.bits_equal(got, exp), name
     for name, dt in (("v1_0_0_dict.pco", np.uint64), ("v1_0_0_conv1.pco", np.int32)):
@@ -135,7 +130,7 @@ def test_auto_specs(L):
 def test_encode_matrix_small(L):
     rng = np.random.default_rng(99)
     bad = []
-    for dt in (np.uint32, np.int32, np.uint64, np.int64, np.float32, np.float64, np.uint16, np.int16):
+    for dt in (np.uint32, np.int32, np.uint64, np.int64, np.float32, np.float64, np.uint16, np.int16, np.uint8, np.int8):
         for n in (1, 2, 3, 255, 256, 257, 513, 2000):
             for dk, do in ((1, 0), (2, 1), (2, 3), (2, 7)):
                 if np.dtype(dt).kind == "f":
@@ -145,13 +140,34 @@ def test_encode_matrix_small(L):
                     ii = np.iinfo(dt)
                     nums = [rng.integers(max(ii.min, -(1 << 40)), min(ii.max, 1 << 40), n), np.cumsum(rng.integers(-3, 9, n)) % min(ii.max, 1 << 40)][n % 2].astype(dt)
                 kw = dict(mode=1, delta=dk, delta_order=do)
-                want = O.simple_compress(nums, O.make_config(**kw))
+                want = O.simple_compress(nums, O.make_config(enable_8_bit=True, **kw))
                 got = U.gpu_simple_compress(nums, G.make_config(enable_8_bit=True, **kw))
                 if got != want:
                     bad.append((np.dtype(dt).name, n, dk, do))
                 elif not U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, n), nums):
                     bad.append(("decode", np.dtype(dt).name, n, dk, do))
     assert not bad, bad[:10]
+
+
+def test_eight_bit_types(L):
+    """u8 / i8 (chunk_config.rs:306: refused unless enable_8_bit): the reference's v1_0_0_{u8,i8}.pco golden files are
+    reproduced byte for byte by the GPU encoder with Auto mode + Auto delta, and decode to the generator's arrays."""
+    from test_oracle_golden import EXPECTED, asset
+    for name in ("v1_0_0_u8.pco", "v1_0_0_i8.pco"):
+        exp = EXPECTED[name]
+        assert U.bits_equal(U.gpu_simple_decompress(asset(name), exp.dtype, exp.size), exp)
+        assert U.gpu_simple_compress(exp, G.make_config(enable_8_bit=True)) == bytes(asset(name)), name
+    with pytest.raises(G.PcoGfxError) as ei:   # refused without the opt-in, like the reference
+        U.gpu_simple_compress(np.arange(100, dtype=np.uint8), G.make_config(mode=1, delta=1))
+    assert ei.value.status == G.ST_INVALID_ARGUMENT
+    rng = np.random.default_rng(12)
+    for dt in (np.uint8, np.int8):
+        nums = (np.cumsum(rng.integers(-2, 3, 70000)) % 200).astype(dt)
+        for kw in (dict(mode=1, delta=1), dict(mode=1, delta=2, delta_order=1), dict(mode=4, mode_u64=5, delta=1), dict()):
+            want = O.simple_compress(nums, O.make_config(enable_8_bit=True, **kw))
+            got = U.gpu_simple_compress(nums, G.make_config(enable_8_bit=True, **kw))
+            assert got == want, (dt, kw)
+            assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums)
 
 
 def test_levels_and_histogram_paths(L):
