@@ -370,13 +370,18 @@ __global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const P
 // over 16 proposals (6 brute, 4 "repeating", 6 hashed), so one wave owns one page: each 64-element tile first
 // resolves all hash-table proposals in parallel (the table reads of a tile are independent of the choices; the
 // in-tile read-after-write hazards are patched with a 64-step broadcast), then lanes 0..15 score the 16
-// proposals element by element.  State: last-index hash tables in HBM (2 x 2^(w+1) u32), lookback counts in LDS
-// for lookbacks <= 8192 and in HBM beyond.
+// proposals element by element.  The element loop is a serial chain (the counts and the "repeating" proposals depend
+// on the previous choice), so its latency is what matters: the latents of the last kLbRing positions live in an LDS
+// ring and the counts of lookbacks <= kLbCountsLds in LDS (both cover the usual short / seasonal lookbacks; longer
+// ones fall back to HBM), the 16-way arg-max runs on the DPP network, and the chosen lookbacks of a tile are stored
+// once per tile.  Other state: last-index hash tables in HBM (2 x 2^(w+1) u32).
 // =========================================================================================================
-constexpr uint32_t kLbCountsLds = 8192;
-constexpr uint32_t kLbLdsCounts = 0;                       // u32[8192]
+constexpr uint32_t kLbCountsLds = 2048;
+constexpr uint32_t kLbRing = 2048;                         // must be >= 64 + the largest lookback served from LDS
+constexpr uint32_t kLbLdsCounts = 0;                       // u32[2048]
 constexpr uint32_t kLbLdsHp = kLbCountsLds * 4;            // u32[64][6] hash proposals of the tile
-constexpr uint32_t kLbLdsBytes = kLbLdsHp + 64 * 6 * 4;
+constexpr uint32_t kLbLdsRing = kLbLdsHp + 64 * 6 * 4;     // u64[2048] latents of positions i - 2047 .. i (by position mod 2048)
+constexpr uint32_t kLbLdsBytes = kLbLdsRing + kLbRing * 8;
 struct LookbackScratch { uint32_t* hash; uint32_t* counts; };  // per page: hash[2 << (wlog+1)], counts[1 << wlog]
 
 template <class L>
@@ -391,9 +396,11 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
   L PCO_GLOBAL* out = lat_ptr<L>(ws, t, 1) + pstart;
   uint32_t PCO_LDS* lcounts = (uint32_t PCO_LDS*)(enc_lds_base() + kLbLdsCounts);
   uint32_t PCO_LDS* hp = (uint32_t PCO_LDS*)(enc_lds_base() + kLbLdsHp);
+  uint64_t PCO_LDS* ring = (uint64_t PCO_LDS*)(enc_lds_base() + kLbLdsRing);
   // delta state = the first state_n latents, right aligned (lookback.rs:179-181); state_n == 1 from this encoder
   if (lane == 0) for (uint32_t i = 0; i < state_n && i < 8; i++) pg->moments[i] = i < n ? (uint64_t)pre[i] : 0ull;
   if (n <= state_n) return;
+  for (uint32_t i = lane; i < state_n; i += 64) ring[i & (kLbRing - 1)] = (uint64_t)pre[i];   // the positions before the first tile
   const uint32_t n_counts = window_n < n ? window_n : n;
   for (uint32_t i = lane; i < kLbCountsLds; i += 64) lcounts[i] = 1;
   for (uint32_t i = kLbCountsLds + lane; i < n_counts; i += 64) gcounts[i] = 1;
@@ -411,6 +418,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
     const uint32_t ie = i0 + lane;
     const bool act = lane < tile_n;
     const uint64_t lv = act ? (uint64_t)pre[ie] : 0ull;
+    if (act) ring[ie & (kLbRing - 1)] = lv;
     uint32_t slot[6], val[6];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -438,42 +446,44 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
     }
     enc_wave_sync();
     // ---- phase 2: element by element, lanes 0..15 = the 16 proposals ----
+    uint32_t my_lb = 1;   // lane e keeps the lookback chosen for element e of the tile
     for (uint32_t e = 0; e < tile_n; e++) {
       const uint32_t i = i0 + e;
-      const L l = pre[i];   // uniform
+      const L l = (L)ring[i & (kLbRing - 1)];   // uniform
       const uint32_t new_brute = i < 16 ? i : 16;
       if (lane == new_brute - 1) proposed = new_brute;
       if (lane >= 10 && lane < 16) proposed = hp[e * 6 + (lane - 10)];
       uint32_t key = 0;
       if (lane < 16) {
         const uint32_t lb = proposed;
-        const uint32_t cnt = lb - 1 < kLbCountsLds ? lcounts[lb - 1] : __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const L other = pre[i - lb];
+        uint32_t cnt; L other;
+        if (lb < kLbRing - 64) other = (L)ring[(i - lb) & (kLbRing - 1)]; else other = pre[i - lb];
+        if (lb - 1 < kLbCountsLds) cnt = lcounts[lb - 1]; else cnt = __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const L d1 = (L)(l - other), d2 = (L)(other - l);
         const L dlt = d1 < d2 ? d1 : d2;
         const uint32_t lz = LBits<L>::v - bitlen<L>(dlt);
         const uint32_t goodness = (32u - clz_u32(cnt)) + lz;
         key = (goodness << 4) | (15u - lane);  // max key = max goodness, first proposal on ties (lookback.rs:88-96)
       }
-#pragma unroll
-      for (int d = 8; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(key, d, 64); key = o > key ? o : key; }
-      const uint32_t best_p = 15u - (uni(key) & 15u);
+      // arg-max over lanes 0..15 on the DPP network (row 0): after row_shr 1, 2, 4, 8 lane 15 holds the maximum
+      { uint32_t o = dpp0<0x111, 0xf>(key); key = o > key ? o : key; o = dpp0<0x112, 0xf>(key); key = o > key ? o : key;
+        o = dpp0<0x114, 0xf>(key); key = o > key ? o : key; o = dpp0<0x118, 0xf>(key); key = o > key ? o : key; }
+      const uint32_t best_p = 15u - ((uint32_t)__builtin_amdgcn_readlane((int)key, 15) & 15u);
       const uint32_t new_best = (uint32_t)__builtin_amdgcn_readlane((int)proposed, (int)best_p);
       if (new_best != best_lookback) repeating_idx++;
       if (lane == 6 + (repeating_idx & 3u)) proposed = new_best;
       best_lookback = new_best;
+      if (lane == e) my_lb = new_best;
       if (lane == 0) {
-        lbs[i] = new_best;
         if (new_best - 1 < kLbCountsLds) lcounts[new_best - 1] += 1;
         else { const uint32_t c = __hip_atomic_load(&gcounts[new_best - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&gcounts[new_best - 1], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       }
       enc_wave_sync();
     }
-    __threadfence_block();
-    enc_wave_sync();
+    if (act) lbs[ie] = my_lb;
     // ---- apply (lookback.rs:166-185): l[i] -= l[i - lb], + MID; reads the un-delta'd copy so it is parallel ----
     if (act) {
-      const uint32_t lb = lbs[ie];
+      const uint32_t lb = my_lb;
       const L d = (L)((L)lv - pre[ie - lb] + lmid<L>());
       out[ie] = d;
       mn1 = d < mn1 ? d : mn1; mx1 = d > mx1 ? d : mx1; mn0 = lb < mn0 ? lb : mn0; mx0 = lb > mx0 ? lb : mx0;
