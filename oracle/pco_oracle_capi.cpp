@@ -79,6 +79,34 @@ int pco_oracle_simple_compress(const void* nums, size_t n, uint8_t dtype, const 
   });
 }
 
+// wrapped::ChunkCompressor (wrapped/chunk_compressor.rs:442-705): ChunkMeta bytes, then every page's bytes back to back.
+// sizes[0] = meta bytes, sizes[1 + i] = bytes of page i, page_ns[i] = numbers in page i; *n_pages <= cap_pages.
+int pco_oracle_wrapped_compress(const void* nums, size_t n, uint8_t dtype, const PcoOracleConfig* config, uint8_t* dst, size_t dst_cap,
+                                size_t* sizes, size_t* page_ns, size_t cap_pages, size_t* n_pages) {
+  return guard([&] {
+    if (!dtype_valid(dtype)) fail(kInvalidArgument, "invalid dtype");
+    ChunkConfig cfg = to_cfg(config);
+    dispatch_bits(dtype_bits(dtype), [&](auto tag) {
+      typedef decltype(tag) LTYPE;
+      ChunkCompressor<LTYPE>* cc = new ChunkCompressor<LTYPE>();
+      try {
+        chunk_compressor_new<LTYPE>(*cc, (const LTYPE*)nums, n, dtype, cfg);
+        if (cc->n_pages() > cap_pages) fail(kInvalidArgument, "too many pages");
+        size_t pos = 0;
+        auto emit = [&](BitWriter& w, size_t& out_size) {
+          w.buf.resize(w.byte_len());
+          if (pos + w.buf.size() > dst_cap) fail(kInvalidArgument, "destination too small");
+          std::memcpy(dst + pos, w.buf.data(), w.buf.size()); pos += w.buf.size(); out_size = w.buf.size();
+        };
+        { BitWriter w; cc->write_meta(w); emit(w, sizes[0]); }
+        for (size_t i = 0; i < cc->n_pages(); i++) { BitWriter w; cc->write_page(i, w); emit(w, sizes[1 + i]); page_ns[i] = cc->page_infos[i].page_n; }
+        *n_pages = cc->n_pages();
+      } catch (...) { delete cc; throw; }
+      delete cc;
+    });
+  });
+}
+
 int pco_oracle_simple_decompress(const uint8_t* src, size_t len, uint8_t dtype, void* dst, size_t dst_cap_elems, size_t* n_written) {
   return guard([&] {
     if (!dtype_valid(dtype)) fail(kInvalidArgument, "invalid dtype");

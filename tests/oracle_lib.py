@@ -117,6 +117,21 @@ def simple_decompress(data, np_dtype, cap=None):
     return out[: n_written.value].copy()
 
 
+def wrapped_compress(arr, config, max_pages=4096):
+    """wrapped::ChunkCompressor on the oracle: (meta bytes, [page bytes], [page n])."""
+    arr = np.ascontiguousarray(arr)
+    cap = file_size_bound(arr.size, dtype_byte(arr), int(config.max_page_n)) + 65536
+    dst = np.empty(cap, np.uint8)
+    sizes = (C.c_size_t * (max_pages + 1))(); page_ns = (C.c_size_t * max_pages)(); n_pages = C.c_size_t(0)
+    rc = lib().pco_oracle_wrapped_compress(arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.size), C.c_uint8(dtype_byte(arr)), C.byref(config),
+                                           dst.ctypes.data_as(C.c_void_p), C.c_size_t(cap), sizes, page_ns, C.c_size_t(max_pages), C.byref(n_pages))
+    _check(rc)
+    pos = sizes[0]; meta = dst[:pos].tobytes(); pages = []
+    for i in range(n_pages.value):
+        pages.append(dst[pos: pos + sizes[1 + i]].tobytes()); pos += sizes[1 + i]
+    return meta, pages, [int(page_ns[i]) for i in range(n_pages.value)]
+
+
 def inspect_first_chunk(data, max_bins=4096):
     buf = np.frombuffer(bytes(data), dtype=np.uint8)
     info = ChunkInfo()

@@ -194,6 +194,59 @@ def test_levels_and_histogram_paths(L):
                 assert got == want, (level, name)
 
 
+def test_histogram_range_boundaries_and_skew(L):
+    """The three histogram kernels split on the value range (max - min): < 4096 LDS counting, < 32768 wide LDS counting,
+    else bucket pre-selection + radix sort of the needed buckets.  Ranges straddling both boundaries, heavy skew (a dense
+    core plus far outliers: every queried rank in one bucket) and ties must all give the oracle's bytes."""
+    rng = np.random.default_rng(21)
+    n = 70000
+    cases = {}
+    for r in (4094, 4095, 4096, 4097, 32766, 32767, 32768, 32769, 100000):
+        x = rng.integers(0, r + 1, n).astype(np.uint64); x[0] = 0; x[1] = r      # range exactly r
+        cases[f"uniform_range_{r}"] = x + np.uint64(1 << 33)
+    core = rng.integers(1000, 1008, n).astype(np.int64)
+    core[rng.integers(0, n, 20)] = rng.integers(-(1 << 50), 1 << 50, 20)
+    cases["dense_core_with_outliers"] = core
+    cases["two_clusters"] = np.where(rng.random(n) < 0.5, rng.integers(0, 50, n), rng.integers(1 << 40, (1 << 40) + 50, n)).astype(np.uint64)
+    cases["random_u32"] = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    cases["random_f64"] = rng.standard_normal(n) * 1e6
+    cases["wide_with_ties"] = (rng.integers(0, 300, n) * np.uint64(0x10000000001)).astype(np.uint64)
+    for name, nums in cases.items():
+        for kw in (dict(mode=1, delta=1), dict(mode=1, delta=2, delta_order=1)):
+            ocfg = O.make_config(**kw)
+            want = O.simple_compress(nums, ocfg)
+            _, _, fb = O.chunk_plan(nums, ocfg)
+            got = U.gpu_simple_compress(nums, G.make_config(**kw))
+            if fb:  # the reference's order-dependent heapsort fallback ran (DESIGN.md section 2)
+                assert U.bits_equal(O.simple_decompress(got, nums.dtype, cap=n + 8), nums), name
+            else:
+                assert got == want, (name, kw)
+            assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, n), nums), name
+
+
+def test_multi_page_chunks_match_the_oracle_bytes(L):
+    """PagingSpec::EqualPagesUpTo (chunk_config.rs:134-182): a standalone file is always one page per chunk, so the
+    wrapped surface is compared page by page with the oracle's wrapped chunk (meta + pages)."""
+    rng = np.random.default_rng(22)
+    nums = (np.cumsum(rng.integers(-20, 90, 50000)) + (1 << 35)).astype(np.int64)
+    for kw in (dict(mode=1, delta=2, delta_order=1, max_page_n=7000), dict(mode=1, delta=1, max_page_n=4096), dict(mode=4, mode_u64=3, delta=2, delta_order=2, max_page_n=20000)):
+        cfg = G.make_config(**kw)
+        cc = C.c_void_p()
+        G.check(L.pco_chunk_compressor_new(nums.ctypes.data_as(C.c_void_p), C.c_size_t(nums.size), C.c_ubyte(4), C.byref(cfg), C.byref(cc)))
+        L.pco_chunk_compressor_n_pages.restype = C.c_size_t; L.pco_chunk_compressor_page_n.restype = C.c_size_t
+        n_pages = L.pco_chunk_compressor_n_pages(cc)
+        buf = np.zeros(1 << 20, np.uint8); w = C.c_size_t(0)
+        G.check(L.pco_chunk_compressor_write_meta(cc, buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), C.byref(w)))
+        meta = bytes(buf[: w.value]); pages = []; page_ns = []
+        for i in range(n_pages):
+            G.check(L.pco_chunk_compressor_write_page(cc, C.c_size_t(i), buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), C.byref(w)))
+            pages.append(bytes(buf[: w.value])); page_ns.append(L.pco_chunk_compressor_page_n(cc, C.c_size_t(i)))
+        L.pco_chunk_compressor_free(cc)
+        want_meta, want_pages, want_ns = O.wrapped_compress(nums, O.make_config(**kw))
+        assert page_ns == want_ns and meta == want_meta, kw
+        assert pages == want_pages, kw
+
+
 def test_unsupported_requests_fail_loudly(L):
     nums = np.arange(1000, dtype=np.uint32)
     for kw in (dict(level=12, mode=1, delta=1), dict(mode=5, delta=1), dict(mode=1, delta=4, delta_order=2)):
