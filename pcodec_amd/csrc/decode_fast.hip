@@ -15,8 +15,10 @@
 
 namespace pcogfx {
 
-// dec_walk_kernel<L, KQ>: KQ chunks per wave (8, or 4 for chunks whose tANS tables need a bigger LDS slice), FOUR LANES
-// (one per tANS chain) per chunk.  Slice of a chunk: u64[56] ANS window | VarInfo[3] | per variable: entries u32[T], offset_bits u8[n_bins].
+// dec_walk_kernel<L, KQ>: KQ chunks per wave -- 8 (tables up to 4.2 KB: one variable at ans_size_log 10) or 4 (9.1 KB) -- FOUR
+// LANES (one per tANS chain) per chunk.  Tasks whose tables do not fit the 8-chunk slices are handed to the 4-chunk stage
+// through DecPlan::status.  (Packing 16 per wave was tried: level-8 chunks mostly need ans_size_log 9-10, whose tables do not
+// fit a 2.4 KB slice, and a launch that splits its chunks over two stages pays the walk latency twice.)  Slice of a chunk: u64[56] ANS window | VarInfo[3] | per variable: entries u32[T], offset_bits u8[n_bins].
 constexpr uint32_t kGrpWinOff = 0;
 constexpr uint32_t kGrpVarOff = 448;
 constexpr uint32_t kGrpTblOff = 640;
@@ -25,6 +27,7 @@ template <uint32_t KQ> struct WalkCfg {
   static constexpr uint32_t kGrpTblBytes = kGrpBytes - kGrpTblOff;      // 4272 / 9312
   static constexpr uint32_t kWalkTmpOff = KQ * kGrpBytes;                // u32[264] scratch for the table build (one chunk at a time)
   static constexpr uint32_t kWalkLdsBytes = kWalkTmpOff + 1056;          // 40352 / 40864: four waves per CU
+  static constexpr uint32_t kRetryStatus = KQ == 8 ? 101u : 100u;       // where a task goes whose tables do not fit
   static_assert(kGrpBytes % 16 == 0, "chunk slices must stay 16-byte aligned");
   static_assert(kWalkLdsBytes < 65536, "walk entries hold 16-bit LDS addresses");
 };
@@ -228,7 +231,7 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
   }
   wave_sync_lds();
   if (too_big || total_tbl > WalkCfg<4>::kGrpTblBytes) { fail(kStatusRetryLegacy); return; }
-  if (total_tbl > kGrpTblBytes) { fail(kStatusRetryK4); return; }
+  if (total_tbl > kGrpTblBytes) { fail(WalkCfg<KQ>::kRetryStatus); return; }
   if (dkind == kDeltaLookback && (mode_kind != kClassic || sec_uses_delta)) { fail(kStatusRetryLegacy); return; }  // the general path reports it
 #pragma unroll
   for (int vi = 0; vi < 3; vi++) {
@@ -342,9 +345,11 @@ __device__ __forceinline__ void walk_step(WalkRegs& r, uint32_t sel_bb, uint32_t
   r.w4 = (uint32_t)nq; r.w5 = (uint32_t)(nq >> 32);
 }
 
+// accept_status: 0 = the first stage (every task), else only the tasks an earlier stage left with that status
 template <class L, uint32_t kWQ>
 __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
-                                                      uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride) {
+                                                      uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
+                                                      uint32_t accept_status) {
   constexpr uint32_t kGrpBytes = WalkCfg<kWQ>::kGrpBytes;
   const uint32_t lane = lane_id();
   const uint32_t slot = lane >> 2, j = lane & 3;
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
     const uint32_t bi = blockIdx.x * kWQ + q;
     if (bi >= n_ids) break;
     const uint32_t ti = task_ids ? task_ids[bi] : bi;
-    if (kWQ != 8 && uni(((const DecPlan PCO_GLOBAL*)plans + ti)->status) != kStatusRetryK4) continue;   // the 8-chunk walker dealt with this task
+    if (accept_status != 0 && uni(((const DecPlan PCO_GLOBAL*)plans + ti)->status) != accept_status) continue;   // an earlier stage dealt with this task
     const PcoGfxDecodeTask task = tasks[ti];
     FrontOut fo;
     fast_front<L, kWQ>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);

@@ -86,6 +86,7 @@ struct EncWorkspace {
   uint64_t n_stride;
   uint32_t n_slots;         // latent slots allocated per task
   uint32_t slot_of_var[3];  // slot index per var (0xffffffff = not allocated)
+  uint32_t* need_sort;      // device flag: some variable's value range is >= kWideHistRange (enc_hist_sort_kernel and the sort buffers are needed)
 };
 
 __device__ __forceinline__ uint8_t PCO_LDS* enc_lds_base() {
@@ -596,6 +597,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   const L range = (L)(maxv - minv);
   // enc_hist_kernel: range < 4096; enc_hist_wide_kernel: [4096, 32768); enc_hist_sort_kernel: the rest
+  if (!kSort && !kWide && (uint64_t)range >= kWideHistRange && tid == 0) atomicOr(ws.need_sort, 1u);
   if (kSort ? (uint64_t)range < kWideHistRange : (kWide ? ((uint64_t)range < kDirectHistRange || (uint64_t)range >= R) : (uint64_t)range >= kDirectHistRange)) return;
   // Stored latents = every position that is not among the first `skip` of its page (wrapped/chunk_compressor.rs:129-140).
   const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);

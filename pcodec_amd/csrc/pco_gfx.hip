@@ -138,12 +138,12 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     const uint32_t* filt = fast ? (const uint32_t*)d_plans : nullptr;
     const uint32_t fstride = (uint32_t)(sizeof(DecPlan) / 4);
     if (fast) {  // walk with 8 chunks per wave, then with 4 for the chunks whose tables did not fit, then expand
-#define PCO_FAST_DECODE(L, name)                                                                                                                         \
-      PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8>), dim3((cnt + 7) / 8), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,  \
-                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);                                                 \
-      PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4>), dim3((cnt + 3) / 4), dim3(64), WalkCfg<4>::kWalkLdsBytes, stream, \
-                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);                                                 \
-      PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, dec_expand_kernel<L>, dim3(grid), dim3(256), kExpLdsBytes, stream,                       \
+#define PCO_FAST_DECODE(L, name)                                                                                                                          \
+      PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8>), dim3((cnt + 7) / 8), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,   \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u);                                               \
+      PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4>), dim3((cnt + 3) / 4), dim3(64), WalkCfg<4>::kWalkLdsBytes, stream,  \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4);                                  \
+      PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, dec_expand_kernel<L>, dim3(grid), dim3(256), kExpLdsBytes, stream,                        \
                        d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
       if (g == 0) { PCO_FAST_DECODE(uint64_t, "u64") } else if (g == 1) { PCO_FAST_DECODE(uint32_t, "u32") } else if (g == 2) { PCO_FAST_DECODE(uint16_t, "u16") } else { PCO_FAST_DECODE(uint8_t, "u8") }
 #undef PCO_FAST_DECODE
