@@ -382,7 +382,10 @@ constexpr uint32_t kLbRing = 2048;                         // must be >= 64 + th
 constexpr uint32_t kLbLdsCounts = 0;                       // u32[2048]
 constexpr uint32_t kLbLdsHp = kLbCountsLds * 4;            // u32[64][6] hash proposals of the tile
 constexpr uint32_t kLbLdsRing = kLbLdsHp + 64 * 6 * 4;     // u64[2048] latents of positions i - 2047 .. i (by position mod 2048)
-constexpr uint32_t kLbLdsBytes = kLbLdsRing + kLbRing * 8;
+constexpr uint32_t kLbLdsHpOther = kLbLdsRing + kLbRing * 8;   // u64[64][6] latent at the far hashed proposals of the tile (prefetched)
+constexpr uint32_t kLbLdsHpCnt = kLbLdsHpOther + 64 * 6 * 8;   // u32[64][6] their lookback counts as of the tile start
+constexpr uint32_t kLbLdsBig = kLbLdsHpCnt + 64 * 6 * 4;       // u32[64] lookbacks > kLbCountsLds chosen inside the tile (their global counts are bumped at the tile end)
+constexpr uint32_t kLbLdsBytes = kLbLdsBig + 64 * 4;
 struct LookbackScratch { uint32_t* hash; uint32_t* counts; };  // per page: hash[2 << (wlog+1)], counts[1 << wlog]
 
 template <class L>
@@ -398,6 +401,9 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
   uint32_t PCO_LDS* lcounts = (uint32_t PCO_LDS*)(enc_lds_base() + kLbLdsCounts);
   uint32_t PCO_LDS* hp = (uint32_t PCO_LDS*)(enc_lds_base() + kLbLdsHp);
   uint64_t PCO_LDS* ring = (uint64_t PCO_LDS*)(enc_lds_base() + kLbLdsRing);
+  uint64_t PCO_LDS* hp_other = (uint64_t PCO_LDS*)(enc_lds_base() + kLbLdsHpOther);
+  uint32_t PCO_LDS* hp_cnt = (uint32_t PCO_LDS*)(enc_lds_base() + kLbLdsHpCnt);
+  uint32_t PCO_LDS* big = (uint32_t PCO_LDS*)(enc_lds_base() + kLbLdsBig);
   // delta state = the first state_n latents, right aligned (lookback.rs:179-181); state_n == 1 from this encoder
   if (lane == 0) for (uint32_t i = 0; i < state_n && i < 8; i++) pg->moments[i] = i < n ? (uint64_t)pre[i] : 0ull;
   if (n <= state_n) return;
@@ -443,23 +449,34 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
     for (int r = 0; r < 6; r++) {
       const uint32_t lb = ie - val[r];
       const uint32_t pidx = 10 + r;
-      hp[lane * 6 + r] = lb <= window_n ? lb : (pidx < ie ? pidx : ie);
+      const uint32_t plb = lb <= window_n ? lb : (pidx < ie ? pidx : ie);
+      hp[lane * 6 + r] = plb;
+      // far proposals: their latent and their count (as of now) are fetched here, for the whole tile at once
+      if (act && plb >= kLbRing - 64) hp_other[lane * 6 + r] = (uint64_t)pre[ie - plb];
+      if (act && plb - 1 >= kLbCountsLds) hp_cnt[lane * 6 + r] = __hip_atomic_load(&gcounts[plb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    uint32_t n_big = 0;   // uniform
     enc_wave_sync();
     // ---- phase 2: element by element, lanes 0..15 = the 16 proposals ----
     uint32_t my_lb = 1;   // lane e keeps the lookback chosen for element e of the tile
     for (uint32_t e = 0; e < tile_n; e++) {
       const uint32_t i = i0 + e;
       const L l = (L)ring[i & (kLbRing - 1)];   // uniform
-      const uint32_t new_brute = i < 16 ? i : 16;
-      if (lane == new_brute - 1) proposed = new_brute;
+      if (i <= 16) { const uint32_t new_brute = i < 16 ? i : 16; if (lane == new_brute - 1) proposed = new_brute; }   // the brute-force lookbacks 1..16 fill up over the first 16 positions
       if (lane >= 10 && lane < 16) proposed = hp[e * 6 + (lane - 10)];
       uint32_t key = 0;
       if (lane < 16) {
         const uint32_t lb = proposed;
         uint32_t cnt; L other;
-        if (lb < kLbRing - 64) other = (L)ring[(i - lb) & (kLbRing - 1)]; else other = pre[i - lb];
-        if (lb - 1 < kLbCountsLds) cnt = lcounts[lb - 1]; else cnt = __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool hashed = lane >= 10;
+        if (lb < kLbRing - 64) other = (L)ring[(i - lb) & (kLbRing - 1)];
+        else if (hashed) other = (L)hp_other[e * 6 + (lane - 10)];
+        else other = pre[i - lb];
+        if (lb - 1 < kLbCountsLds) cnt = lcounts[lb - 1];
+        else {  // count at the tile start + the times this lookback was chosen earlier in the tile
+          cnt = hashed ? hp_cnt[e * 6 + (lane - 10)] : __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (uint32_t k = 0; k < n_big; k++) cnt += big[k] == lb ? 1u : 0u;
+        }
         const L d1 = (L)(l - other), d2 = (L)(other - l);
         const L dlt = d1 < d2 ? d1 : d2;
         const uint32_t lz = LBits<L>::v - bitlen<L>(dlt);
@@ -475,13 +492,13 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
       if (lane == 6 + (repeating_idx & 3u)) proposed = new_best;
       best_lookback = new_best;
       if (lane == e) my_lb = new_best;
-      if (lane == 0) {
-        if (new_best - 1 < kLbCountsLds) lcounts[new_best - 1] += 1;
-        else { const uint32_t c = __hip_atomic_load(&gcounts[new_best - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&gcounts[new_best - 1], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      }
+      if (new_best - 1 < kLbCountsLds) { if (lane == 0) lcounts[new_best - 1] += 1; }
+      else { if (lane == 0) big[n_big] = new_best; n_big++; }
       enc_wave_sync();
     }
     if (act) lbs[ie] = my_lb;
+    if (lane < n_big) atomicAdd((uint32_t*)&gcounts[big[lane] - 1], 1u);   // publish before the next tile prefetches counts
+    __threadfence_block();   // (the atomics above and the agent-scope loads of the next tile are ordered per address)
     // ---- apply (lookback.rs:166-185): l[i] -= l[i - lb], + MID; reads the un-delta'd copy so it is parallel ----
     if (act) {
       const uint32_t lb = my_lb;
