@@ -199,12 +199,18 @@ __global__ __launch_bounds__(256) void enc_dissect_kernel(EncWorkspace ws, EncFa
 // =========================================================================================================
 // reverse tANS walk
 // =========================================================================================================
-constexpr uint32_t kEwQ = 8;                       // (page, variable) items per wave
-constexpr uint32_t kEwNsOff = 0;                   // u16[1024] next states
-constexpr uint32_t kEwInfoOff = 2048;              // u64[256]: cutoff | min_renorm_bits << 16, LDS address of the symbol's next-state row
-constexpr uint32_t kEwSymOff = 4096;               // u8[2][256] symbols of the current / next batch
-constexpr uint32_t kEwSlotBytes = 4608;
-constexpr uint32_t kEwLdsBytes = kEwQ * kEwSlotBytes;
+// Q (page, variable) items per wave: 8 (slot 4608 B: any table of the fast path) or 16 (slot 2304 B, all 64 lanes busy).
+// The walk is latency-bound, so what matters is that every item is resident at once: with more than 8192 items the launch
+// first walks the items whose tables fit the small slots 16 per wave, then the rest 8 per wave (never worse than two rounds
+// of 8 per wave).  Slot: next states u16[T] | info u64[n_bins] (cutoff | min_renorm_bits << 16, LDS address of the symbol's
+// next-state row) | ... | symbols u8[2][256] of the current / next batch.
+template <uint32_t Q> struct EwCfg {
+  static constexpr uint32_t kSlotBytes = Q == 16 ? 2304u : 4608u;
+  static constexpr uint32_t kSymOff = kSlotBytes - 512;
+  static constexpr uint32_t kLdsBytes = Q * kSlotBytes;   // 36864
+};
+__device__ __forceinline__ uint32_t ew_info_off(uint32_t asl) { return ((2u << asl) + 7u) & ~7u; }
+__device__ __forceinline__ bool ew_fits16(uint32_t asl, uint32_t n_bins) { return ew_info_off(asl) + 8u * n_bins <= EwCfg<16>::kSymOff; }
 
 // one reverse step of one chain: (ans/encoding.rs:65-87)
 __device__ __forceinline__ uint32_t ew_step(uint32_t& state, uint32_t& bits_acc, uint64_t info) {
@@ -217,14 +223,17 @@ __device__ __forceinline__ uint32_t ew_step(uint32_t& state, uint32_t& bits_acc,
   return (bits << 12) | val;
 }
 
-__global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+// stage: 0 = every item; 1 = only the items that fit the 16-per-wave slots; 2 = only those that do not
+template <uint32_t kEwQ>
+__global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages, uint32_t stage) {
+  constexpr uint32_t kEwSlotBytes = EwCfg<kEwQ>::kSlotBytes, kEwSymOff = EwCfg<kEwQ>::kSymOff, kEwNsOff = 0;
   const uint32_t lane = lane_id();
   const uint32_t slot = lane >> 2, j = lane & 3;
   uint8_t PCO_LDS* smem = enc_lds_base();
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t n_items = n_pages * ws.n_slots;
   // ---- phase 0: tables of the wave's items into LDS (all lanes cooperate, one item at a time) ----
-  uint32_t my_n_lat = 0, my_T = 0, my_p = 0, my_v = 0;
+  uint32_t my_n_lat = 0, my_T = 0, my_p = 0, my_v = 0, my_info_off = 0;
   uint64_t my_at = 0; uint32_t my_task = 0;
   for (uint32_t q = 0; q < kEwQ; q++) {
     const uint32_t item = blockIdx.x * kEwQ + q;
@@ -238,9 +247,11 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
     const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
     const PageVar pv = page_var(ch, v, page_n);
     if (!pv.present || pv.n_bins <= 1 || pv.n_lat == 0) {
-      if (pv.present && lane < 4) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
+      if (pv.present && lane < 4 && stage != 2) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
       continue;
     }
+    if (stage != 0 && ew_fits16(pv.asl, pv.n_bins) != (stage == 1)) continue;   // the other stage's item
+    const uint32_t kEwInfoOff = ew_info_off(pv.asl);
     const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
     uint8_t PCO_LDS* sl = smem + q * kEwSlotBytes;
     const uint32_t T = 1u << pv.asl;
@@ -251,13 +262,13 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
       const uint32_t row_addr = lds0 + q * kEwSlotBytes + kEwNsOff + 2u * row;
       ((uint64_t PCO_LDS*)(sl + kEwInfoOff))[b] = (uint64_t)(cutoff | (minb << 16)) | ((uint64_t)row_addr << 32);
     }
-    if (slot == q) { my_n_lat = pv.n_lat; my_T = T; my_p = p; my_v = v; my_task = t; my_at = fast_at(pg, pv.skip); }
+    if (slot == q) { my_n_lat = pv.n_lat; my_T = T; my_p = p; my_v = v; my_task = t; my_at = fast_at(pg, pv.skip); my_info_off = kEwInfoOff; }
   }
   enc_wave_sync();
   if (my_n_lat == 0) { if (__all(my_n_lat == 0)) return; }
   // ---- phase 1: batches in reverse ----
   const uint32_t slice = lds0 + (slot < kEwQ ? slot : 0u) * kEwSlotBytes;
-  const uint32_t info_addr = slice + kEwInfoOff, symbuf = slice + kEwSymOff;
+  const uint32_t info_addr = slice + my_info_off, symbuf = slice + kEwSymOff;
   const uint8_t PCO_GLOBAL* gsym = (const uint8_t PCO_GLOBAL*)fsym_ptr(ws, fx, my_task, my_v) + my_at;
   uint16_t PCO_GLOBAL* gans = fansw_ptr(ws, fx, my_task, my_v) + my_at;
   uint32_t PCO_GLOBAL* gbat = (uint32_t PCO_GLOBAL*)fx.bat + ((uint64_t)my_p * 3 + my_v) * fx.bat_stride * 2;

@@ -601,6 +601,20 @@ constexpr uint32_t kHistLdsBytes = hist_lds_bytes(kDirectHistRange);
 // enc_hist_sort_kernel: radix counters u32[2048] | bucket prefix u32[8200] | marks u32[256] | marked-bucket list u32[2][1600 + 1]
 constexpr uint32_t kHistSortLdsBytes = kHistLdsCounts + (2048 + kSelBuckets + 8 + kSelBuckets / 32 + 2 * (kSelMaxNeeded + 1)) * 4;
 
+// counts[c] += 1 for the lanes with `on`; the lanes that share the first active lane's value are added with one atomic
+// (secondary latents and residuals are often dominated by one value: 64 same-address LDS atomics would serialise)
+__device__ __forceinline__ void hist_count(uint32_t PCO_LDS* counts, uint32_t c, bool on, bool aggregate) {
+  if (!aggregate) { if (on) atomicAdd((uint32_t*)&counts[c], 1u); return; }
+  const uint64_t act = __ballot(on);
+  if (act == 0) return;
+  const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)__builtin_ctzll(act));
+  const uint64_t same = __ballot(on && c == c0);
+  if (on) {
+    if (c != c0) atomicAdd((uint32_t*)&counts[c], 1u);
+    else if ((same & (((uint64_t)1 << lane_id()) - 1)) == 0) atomicAdd((uint32_t*)&counts[c0], (uint32_t)__popcll(same));
+  }
+}
+
 // T threads per block; R = value range handled by LDS counting.  kWide: only variables whose range lies in
 // [kDirectHistRange, R) are processed (enc_hist_wide_kernel); otherwise those are left to that kernel.
 template <class L, uint32_t T, uint32_t R, bool kWide, bool kSort>
@@ -641,6 +655,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     __syncthreads();
     {  // counting: 8 loads in flight per thread; the compact copy (x - min, u16) is written on the way
       uint16_t PCO_GLOBAL* clat = clat_ptr(ws, t, var);
+      const bool agg = uni((uint32_t)((uint64_t)range < 256 ? 1u : 0u)) != 0;   // (wave-uniform) few distinct values: same-address atomics would serialise, aggregate per wave
       uint32_t base = 0;
       for (; base + 8 * T <= n_all; base += 8 * T) {
         L x[8];
@@ -651,13 +666,14 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
           const uint32_t i = base + k * T + tid;
           const uint32_t c = (uint32_t)(x[k] - minv);
           clat[i] = (uint16_t)c;
-          if (stored(i)) atomicAdd((uint32_t*)&counts[c], 1u);
+          hist_count(counts, c, stored(i), agg);
         }
       }
-      for (uint32_t i = base + tid; i < n_all; i += T) {
-        const uint32_t c = (uint32_t)(lat[i] - minv);
-        clat[i] = (uint16_t)c;
-        if (stored(i)) atomicAdd((uint32_t*)&counts[c], 1u);
+      for (uint32_t i0 = base; i0 < n_all; i0 += T) {   // whole waves enter hist_count
+        const uint32_t i = i0 + tid;
+        const uint32_t c = i < n_all ? (uint32_t)(lat[i] - minv) : 0u;
+        if (i < n_all) clat[i] = (uint16_t)c;
+        hist_count(counts, c, i < n_all && stored(i), agg);
       }
     }
     __syncthreads();
