@@ -594,7 +594,7 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
 // the direct path (R = 4096 in enc_hist_kernel, 32768 in enc_hist_wide_kernel) or the radix counters of the sorted path
 constexpr uint32_t kHistLdsRecV = 0;
 constexpr uint32_t kHistLdsCounts = 4 * 2048 + 2 * 1024 + 2048;
-constexpr uint32_t kWideHistRange = 32768;
+constexpr uint32_t kWideHistRange = 32768, kMidHistRange = 16384;   // the two LDS-counting tiers above kDirectHistRange (2 resp. 1 block per CU)
 constexpr uint32_t kSelBucketsLog = 13, kSelBuckets = 1u << kSelBucketsLog, kSelMaxNeeded = 1600;
 __host__ __device__ constexpr uint32_t hist_lds_bytes(uint32_t range) { return kHistLdsCounts + (range + 8) * 4; }
 constexpr uint32_t kHistLdsBytes = hist_lds_bytes(kDirectHistRange);
@@ -627,9 +627,9 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   if (n_lat == 0) { if (tid == 0) ev->n_hist = 0; return; }
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   const L range = (L)(maxv - minv);
-  // enc_hist_kernel: range < 4096; enc_hist_wide_kernel: [4096, 32768); enc_hist_sort_kernel: the rest
+  // enc_hist_kernel: range < 4096; enc_hist_wide_kernel<16384>: [4096, 16384), <32768>: [16384, 32768); enc_hist_sort_kernel: the rest
   if (!kSort && !kWide && (uint64_t)range >= kWideHistRange && tid == 0) atomicOr(ws.need_sort, 1u);
-  if (kSort ? (uint64_t)range < kWideHistRange : (kWide ? ((uint64_t)range < kDirectHistRange || (uint64_t)range >= R) : (uint64_t)range >= kDirectHistRange)) return;
+  if (kSort ? (uint64_t)range < kWideHistRange : (kWide ? ((uint64_t)range < (R == kWideHistRange ? kMidHistRange : kDirectHistRange) || (uint64_t)range >= R) : (uint64_t)range >= kDirectHistRange)) return;
   // Stored latents = every position that is not among the first `skip` of its page (wrapped/chunk_compressor.rs:129-140).
   const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
   const uint32_t n_all = (uint32_t)ch->n, skip = ev->lat_start, plow = ch->page_low, pr = ch->page_r;
@@ -909,9 +909,10 @@ __global__ __launch_bounds__(256) void enc_hist_kernel(EncWorkspace ws, uint32_t
 __global__ __launch_bounds__(256) void enc_hist_sort_kernel(EncWorkspace ws, uint32_t n_tasks) {
   if (blockIdx.x < n_tasks) hist_chunk<256, kDirectHistRange, false, true>(ws, blockIdx.x);
 }
-// value ranges in [4096, 32768): LDS counting with one 1024-thread block (131 KB of counters) per chunk
+// value ranges in [4096, 16384) / [16384, 32768): LDS counting with 1024-thread blocks (66 KB / 131 KB of counters: 2 / 1 per CU)
+template <uint32_t R>
 __global__ __launch_bounds__(1024) void enc_hist_wide_kernel(EncWorkspace ws, uint32_t n_tasks) {
-  if (blockIdx.x < n_tasks) hist_chunk<1024, kWideHistRange, true, false>(ws, blockIdx.x);
+  if (blockIdx.x < n_tasks) hist_chunk<1024, R, true, false>(ws, blockIdx.x);
 }
 
 // =========================================================================================================

@@ -201,7 +201,7 @@ def test_histogram_range_boundaries_and_skew(L):
     rng = np.random.default_rng(21)
     n = 70000
     cases = {}
-    for r in (4094, 4095, 4096, 4097, 32766, 32767, 32768, 32769, 100000):
+    for r in (4094, 4095, 4096, 4097, 16382, 16383, 16384, 16385, 32766, 32767, 32768, 32769, 100000):
         x = rng.integers(0, r + 1, n).astype(np.uint64); x[0] = 0; x[1] = r      # range exactly r
         cases[f"uniform_range_{r}"] = x + np.uint64(1 << 33)
     core = rng.integers(1000, 1008, n).astype(np.int64)
