@@ -40,14 +40,15 @@ WORKLOADS = {
     "c3": ("float64", 6, dict(mode=2, mode_f64=0.01, delta=1), "f64 float-mult(0.01) decimals, 2^18-element chunks (BASELINE configs[2])"),
     "c1": ("int32", 1, dict(mode=1, delta=1), "u32 classic no-delta uniform random, 2^18-element chunks (BASELINE configs[0], incompressible)"),
     "c4": ("int64", 4, dict(mode=1, delta=3), "i64 seasonal (period 365) lookback delta, 2^18-element chunks (BASELINE configs[3])"),
+    "c2auto": ("int64", 2, dict(), "u64 noisy ramp, default ChunkConfig (Auto mode + Auto delta), 2^18-element chunks"),
 }
-ELEM_BYTES = {"c1": 4, "c2": 8, "c3": 8, "c4": 8}
+ELEM_BYTES = {"c1": 4, "c2": 8, "c3": 8, "c4": 8, "c2auto": 8}
 
 
 def make_chunks(torch, kind, n_chunks, rank, device):
     g = torch.Generator(device=device)
     g.manual_seed(1234 + 7919 * rank)
-    if kind == "c2":
+    if kind in ("c2", "c2auto"):
         i = torch.arange(N18, device=device, dtype=torch.int64)
         base = (1 << 40) + 1000 * i
         noise = torch.randint(0, 512, (n_chunks, N18), generator=g, device=device, dtype=torch.int64)
@@ -182,7 +183,7 @@ def main():
     assert torch.equal(out, data), "decode(encode(x)) != x"
     if rank == 0:
         import oracle_lib as O
-        first = data[0].cpu().numpy().view({"c1": np.uint32, "c2": np.uint64, "c3": np.float64, "c4": np.int64}[args.workload])
+        first = data[0].cpu().numpy().view({"c1": np.uint32, "c2": np.uint64, "c3": np.float64, "c4": np.int64, "c2auto": np.uint64}[args.workload])
         want = O.simple_compress(first, O.make_config(**cfg_kw))
         got = bytes(comp[: int(enc_res["n_out"][0])].cpu().numpy())
         hdr = len(want) - 1 - len(got)
@@ -238,11 +239,11 @@ def main():
         line = {
             "metric": "encode+decode GB/s (uncompressed) per chunk, u64/f64 2^18-elem", "value": round(value, 2), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"c1": "u32", "c2": "u64", "c3": "f64", "c4": "i64"}[args.workload],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"c1": "u32", "c2": "u64", "c3": "f64", "c4": "i64", "c2auto": "u64"}[args.workload],
             "data": "synthetic",
             "config": {"workload": desc, "chunks_per_gpu": nch, "chunk_n": N18, "compression_level": 8,
                        "mode_spec": "TryFloatMult(0.01)" if args.workload == "c3" else "Classic",
-                       "delta_spec": {"c1": "NoOp", "c2": "TryConsecutive(1)", "c3": "NoOp", "c4": "TryLookback"}[args.workload],
+                       "delta_spec": {"c1": "NoOp", "c2": "TryConsecutive(1)", "c3": "NoOp", "c4": "TryLookback", "c2auto": "Auto"}[args.workload],
                        "parallelism": f"chunk-sharded x{world}" + (" + RCCL gather of pages" if args.gather else ""),
                        "compressed_bytes_per_chunk": comp_bytes // nch,
                        "encode_GBps": round(world * nch * chunk_bytes * args.steps / t_enc / 1e9, 2),

@@ -4,6 +4,8 @@
 #include "pco_host.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
