@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherTask* tasks) {
   const uint32_t i = g.idx[k];
   if (g.elem_bytes == 8) ((uint64_t*)g.dst)[k] = ((const uint64_t*)g.src)[i];
   else if (g.elem_bytes == 4) ((uint32_t*)g.dst)[k] = ((const uint32_t*)g.src)[i];
-  else ((uint16_t*)g.dst)[k] = ((const uint16_t*)g.src)[i];
+  else if (g.elem_bytes == 2) ((uint16_t*)g.dst)[k] = ((const uint16_t*)g.src)[i];
+  else ((uint8_t*)g.dst)[k] = ((const uint8_t*)g.src)[i];
 }
 
 // compact per-task record of a trained plan, for the host-side size estimate of Auto delta trials

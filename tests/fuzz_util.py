@@ -1,0 +1,93 @@
+"""Randomised parity sweep shared by tests/test_gpu_parity.py and scripts/gpu_fuzz.py: random dtype / size / distribution /
+ChunkConfig; the GPU's bytes must equal the oracle's (unless the reference's order-dependent heapsort fallback ran) and the
+GPU must decode the oracle's bytes to the input."""
+import numpy as np
+
+import oracle_lib as O
+import gpu_util as U
+from pcodec_amd import _lib as G
+
+INT = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.uint64, np.int64]
+FLT = [np.float32, np.float64]
+
+
+def gen(rng, dt, n):
+    kind = rng.integers(0, 9)
+    if np.dtype(dt).kind == "f":
+        if kind == 0: x = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6)
+        elif kind == 1: x = rng.integers(0, 5000, n) / 100.0
+        elif kind == 2: x = np.round(rng.standard_normal(n) * 100) * 0.25
+        elif kind == 3: x = np.cumsum(rng.standard_normal(n))
+        elif kind == 4: x = rng.choice([0.0, -0.0, 1.5, np.inf, -np.inf, np.nan, 1e30, 1e-30], n)
+        elif kind == 5: x = rng.integers(-1000, 1000, n).astype(np.float64)
+        elif kind == 6: x = np.full(n, 3.25)
+        elif kind == 7: x = rng.integers(0, 100, n) * 0.1 + rng.standard_normal(n) * 1e-9
+        else: x = np.frombuffer(rng.bytes(n * 8), np.uint64).astype(np.float64)
+        return x.astype(dt)
+    ii = np.iinfo(dt); lo, hi = int(ii.min), int(ii.max)
+    cap = min(hi, (1 << 62) - 1)   # modulus that fits every intermediate int64
+    if kind == 0: x = rng.integers(lo, hi, n, dtype=np.int64 if hi < 2 ** 63 else np.uint64, endpoint=True) if dt != np.uint64 else rng.integers(0, hi, n, dtype=np.uint64, endpoint=True)
+    elif kind == 1: x = rng.integers(0, min(300, cap), n)
+    elif kind == 2: x = np.cumsum(rng.integers(-3, 9, n)) % (min(hi, 1 << 40) + 1)
+    elif kind == 3: x = (rng.integers(0, 50, n) * int(rng.integers(2, 100))) % (cap + 1)
+    elif kind == 4: x = np.where(rng.random(n) < 0.8, 7, rng.integers(0, min(cap, 1 << 40), n))
+    elif kind == 5: x = np.arange(n) % (cap + 1)
+    elif kind == 6: x = rng.geometric(0.02, n) % (cap + 1)
+    elif kind == 7:
+        base = rng.integers(0, min(cap, 1 << 30), 37); x = base[np.arange(n) % 37] + rng.integers(0, 3, n)
+        x = x % (cap + 1)
+    else: x = np.full(n, int(rng.integers(0, cap)))
+    return np.asarray(x).astype(dt)
+
+
+
+def run(n_cases, seed, only_8bit=False):
+    rng = np.random.default_rng(seed)
+    bad = []; skipped = 0; fails = {}
+    for case in range(n_cases):
+        dt = (INT + FLT)[rng.integers(0, 10)] if not only_8bit else INT[rng.integers(0, 2)]
+        n = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4099, 20000, 70000], p=[.04, .03, .03, .05, .05, .05, .05, .2, .2, .2, .1]))
+        nums = gen(rng, dt, n)
+        isf = np.dtype(dt).kind == "f"
+        kw = dict(level=int(rng.integers(0, 9)))
+        m = rng.integers(0, 5)
+        if m == 0: kw["mode"] = 0
+        elif m == 1: kw["mode"] = 1
+        elif m == 2 and not isf: kw.update(mode=4, mode_u64=int(rng.integers(1, 1000)))
+        elif m == 3 and isf and np.dtype(dt).itemsize >= 4: kw.update(mode=2, mode_f64=float(rng.choice([0.01, 0.1, 0.25, 1.0, 3.0])))
+        elif m == 4 and isf and np.dtype(dt).itemsize >= 4: kw.update(mode=3, mode_u64=int(rng.integers(1, 20)))
+        else: kw["mode"] = 1
+        if kw.get("mode") == 0 and np.dtype(dt) == np.float16: kw["mode"] = 1
+        d = rng.integers(0, 5)
+        if d == 0: kw["delta"] = 0
+        elif d == 1: kw["delta"] = 1
+        elif d in (2, 3): kw.update(delta=2, delta_order=int(rng.integers(1, 8)))
+        else: kw["delta"] = 3
+        if kw.get("delta") == 3 and kw.get("mode", 1) != 1: kw["delta"] = 1   # lookback decode needs classic mode on the device
+        if rng.random() < 0.15: kw["max_page_n"] = int(rng.integers(1, max(n, 2)))
+        try:
+            ocfg = O.make_config(enable_8_bit=True, **kw)
+            want = O.simple_compress(nums, ocfg)
+            _, _, fb = O.chunk_plan(nums, ocfg) if "max_page_n" not in kw else (None, None, False)
+        except O.OracleError as e:
+            try:
+                U.gpu_simple_compress(nums, G.make_config(enable_8_bit=True, **kw)); bad.append(("gpu accepted what the oracle refused", case, np.dtype(dt).name, n, kw))
+            except G.PcoGfxError:
+                pass
+            skipped += 1; continue
+        try:
+            got = U.gpu_simple_compress(nums, G.make_config(enable_8_bit=True, **kw))
+        except G.PcoGfxError as e:
+            if e.status == G.ST_UNSUPPORTED: skipped += 1; continue
+            bad.append(("gpu error", case, np.dtype(dt).name, n, kw, str(e))); continue
+        if got != want and not fb:
+            bad.append(("bytes", case, np.dtype(dt).name, n, kw))
+            fails[f"case{case}_nums"] = nums; fails[f"case{case}_got"] = np.frombuffer(got, np.uint8); fails[f"case{case}_kw"] = np.array(repr(kw))
+            continue
+        try:
+            back = U.gpu_simple_decompress(want, nums.dtype, n)
+            if not U.bits_equal(back, nums): bad.append(("decode", case, np.dtype(dt).name, n, kw))
+        except G.PcoGfxError as e:
+            if e.status != G.ST_UNSUPPORTED: bad.append(("decode error", case, np.dtype(dt).name, n, kw, str(e)))
+
+    return bad, skipped, fails

@@ -247,6 +247,16 @@ def test_multi_page_chunks_match_the_oracle_bytes(L):
         assert pages == want_pages, kw
 
 
+def test_randomised_parity_sweep(L):
+    """Random dtype x size x distribution x ChunkConfig (tests/fuzz_util.py): encode bytes identical to the oracle's, decode of
+    the oracle's bytes bit-exact.  (This sweep found the 1-byte case missing from the Auto-delta sample gather.)"""
+    import fuzz_util
+    bad, _, _ = fuzz_util.run(400, 2024)
+    assert not bad, bad[:10]
+    bad, _, _ = fuzz_util.run(250, 2025, only_8bit=True)
+    assert not bad, bad[:10]
+
+
 def test_unsupported_requests_fail_loudly(L):
     nums = np.arange(1000, dtype=np.uint32)
     for kw in (dict(level=12, mode=1, delta=1), dict(mode=5, delta=1), dict(mode=1, delta=4, delta_order=2)):
