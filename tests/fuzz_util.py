@@ -8,7 +8,7 @@ import gpu_util as U
 from pcodec_amd import _lib as G
 
 INT = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.uint64, np.int64]
-FLT = [np.float32, np.float64]
+FLT = [np.float16, np.float32, np.float64]
 
 
 def gen(rng, dt, n):
@@ -45,7 +45,7 @@ def run(n_cases, seed, only_8bit=False):
     rng = np.random.default_rng(seed)
     bad = []; skipped = 0; fails = {}
     for case in range(n_cases):
-        dt = (INT + FLT)[rng.integers(0, 10)] if not only_8bit else INT[rng.integers(0, 2)]
+        dt = (INT + FLT)[rng.integers(0, 11)] if not only_8bit else INT[rng.integers(0, 2)]
         n = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4099, 20000, 70000], p=[.04, .03, .03, .05, .05, .05, .05, .2, .2, .2, .1]))
         nums = gen(rng, dt, n)
         isf = np.dtype(dt).kind == "f"
@@ -55,7 +55,7 @@ def run(n_cases, seed, only_8bit=False):
         elif m == 1: kw["mode"] = 1
         elif m == 2 and not isf: kw.update(mode=4, mode_u64=int(rng.integers(1, 1000)))
         elif m == 3 and isf and np.dtype(dt).itemsize >= 4: kw.update(mode=2, mode_f64=float(rng.choice([0.01, 0.1, 0.25, 1.0, 3.0])))
-        elif m == 4 and isf and np.dtype(dt).itemsize >= 4: kw.update(mode=3, mode_u64=int(rng.integers(1, 20)))
+        elif m == 4 and isf: kw.update(mode=3, mode_u64=int(rng.integers(1, 20 if np.dtype(dt).itemsize >= 4 else 10)))
         else: kw["mode"] = 1
         if kw.get("mode") == 0 and np.dtype(dt) == np.float16: kw["mode"] = 1
         d = rng.integers(0, 5)
