@@ -50,7 +50,7 @@ constexpr uint64_t kBinsAreaPerTask = 3 * kBinsAreaPerVar;
 
 // walk entry (one u32 per tANS state): bits 0..15 LDS byte address of the entry of next_state_idx_base, 16..23 the bin
 // symbol, 24..31 bits_to_read.  The byte-aligned fields let the walker move them with v_perm_b32.
-__device__ __forceinline__ uint32_t make_wentry(uint32_t addr, uint32_t sym, uint32_t btr) { return addr | (sym << 16) | (btr << 24); }
+__device__ __forceinline__ uint32_t make_wentry(uint32_t addr, uint32_t sym, uint32_t btr) { return btr | (sym << 8) | (addr << 16); }
 
 // Build one variable's walk table for chunk slot `q`: u32 entries and per-bin offset bits in LDS; lowers / offset bits
 // go to the global bins area for dec_expand_kernel.  All 64 lanes cooperate.  (ans/spec.rs:37-59, ans/decoding.rs:27-47)
@@ -300,51 +300,63 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
 // ---------------------------------------------------------------------------------------------------------
 // dec_walk_kernel: kWQ chunks per wave, four lanes per chunk (lane 4c+j walks tANS chain j of chunk slot c).
 //
-// The walk is a serial chain of n/4 steps per chunk, so the kernel is LATENCY-bound by construction; everything in
-// walk_step() is arranged around its critical path
-//   ds_read entry -> v_perm (bits_to_read into byte j) -> 2 quad DPP adds -> and + v_sad_u8 (bit position)
-//   -> v_alignbit / 2 v_cndmask (window extract) -> v_bfe -> v_lshl_add (next entry address).
-// The chunk's bit window lives in registers (w0..w5, refilled from the LDS copy of the batch's ANS section) so no
-// second LDS round trip sits on that path.  Symbols leave in 16-element blocks: dword j of a block holds chain j's
-// symbols of four consecutive steps (dec_expand_kernel undoes this).
+// The walk is a serial chain of n/4 steps per chunk and a wave has no other wave to hide behind (the tables fill
+// the LDS at one wave per SIMD), so a step costs  LDS latency + every instruction between the entry's arrival and
+// the next ds_read.  walk_step() keeps that stretch to
+//   3 x v_and_dpp + v_add3 (row_shr 1,2,3 masked to the quad: bits read by the chains before mine; the entry's low byte is
+//   bits_to_read, so the raw entries are summed and only bits [5:0] of the sum are consumed)
+//   -> 2 x v_alignbit (the 64 window bits at the chunk's bit position; their three dwords were fetched from the
+//   LDS copy of the batch's ANS section in the shadow of the previous step) -> v_lshrrev_b64 -> v_bfe (width =
+//   entry[4:0]) -> v_lshl_add (next entry address)
+// and does everything else -- the step's total bit count, the next window fetch, the symbol and its offset-bit
+// count -- in the shadow of that ds_read.  Symbols leave in 16-element
+// blocks: dword j of a block holds chain j's symbols of four consecutive steps (dec_expand_kernel undoes this).
 // ---------------------------------------------------------------------------------------------------------
 struct WalkRegs {
   uint32_t saddr;                    // LDS byte address of the current state's entry
-  uint32_t w0, w1, w2, w3, w4, w5;   // 192-bit window; bit `rel` of (w1:w0) is the next unread bit
-  uint32_t rel, wq_addr;             // wq_addr: LDS address of the qword currently in (w5:w4)
+  uint32_t e;                        // that entry (its load is issued as soon as the address is known)
+  uint32_t pos;                      // bit position of the next unread bit, relative to the staged window
+  uint32_t a, b, c;                  // the window dwords pos/32, +1, +2
   uint32_t obsum, symacc;
 };
 
-template <int K, bool kTail>
-__device__ __forceinline__ void walk_step(WalkRegs& r, uint32_t sel_bb, uint32_t lowmask, uint32_t obs_addr, bool chain_on) {
-  const uint32_t e = *(const uint32_t PCO_LDS*)(uintptr_t)r.saddr;
-  uint32_t bb = __builtin_amdgcn_perm(e, 0u, sel_bb);
-  if (kTail) bb = chain_on ? bb : 0u;
-  uint32_t P = bb + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bb, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-  P = P + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x4E, 0xf, 0xf, false);               // quad_perm [2,3,0,1]
-  const uint32_t h = __builtin_amdgcn_sad_u8(P & lowmask, 0u, r.rel);
-  const uint32_t rel2 = __builtin_amdgcn_sad_u8(P, 0u, r.rel);
-  const uint32_t c0 = __builtin_amdgcn_alignbit(r.w1, r.w0, h), c1 = __builtin_amdgcn_alignbit(r.w2, r.w1, h);
-  const uint32_t c2 = __builtin_amdgcn_alignbit(r.w3, r.w2, h), c3 = __builtin_amdgcn_alignbit(r.w4, r.w3, h);
-  const uint32_t c01 = h < 32 ? c0 : c1, c23 = h < 96 ? c2 : c3;
-  const uint32_t vraw = h < 64 ? c01 : c23;
-  const uint32_t btr = e >> 24;
-  const uint32_t v = __builtin_amdgcn_ubfe(vraw, 0u, btr);
-  const uint32_t next = ((e & 0xffffu) + (v << 2));
-  if (kTail) r.saddr = chain_on ? next : r.saddr; else r.saddr = next;
-  // off the critical path: symbol, offset bits, window advance
-  constexpr uint32_t sel_sym = K == 0 ? 0x03020106u : (K == 1 ? 0x03020600u : (K == 2 ? 0x03060100u : 0x06020100u));
-  r.symacc = __builtin_amdgcn_perm(e, r.symacc, sel_sym);
-  const uint32_t ob = *(const uint8_t PCO_LDS*)(uintptr_t)(obs_addr + ((e >> 16) & 0xffu));
-  if (kTail) r.obsum += chain_on ? ob : 0u; else r.obsum += ob;
-  const bool adv = rel2 >= 64;
-  r.w0 = adv ? r.w2 : r.w0; r.w1 = adv ? r.w3 : r.w1; r.w2 = adv ? r.w4 : r.w2; r.w3 = adv ? r.w5 : r.w3;
-  r.wq_addr += adv ? 8u : 0u;
-  r.rel = rel2 & 63u;
-  const uint64_t nq = *(const uint64_t PCO_LDS*)(uintptr_t)r.wq_addr;
-  r.w4 = (uint32_t)nq; r.w5 = (uint32_t)(nq >> 32);
+__device__ __forceinline__ void walk_fetch_window(WalkRegs& r, uint32_t win_addr) {
+  const uint32_t PCO_LDS* w = (const uint32_t PCO_LDS*)(uintptr_t)(win_addr + (__builtin_amdgcn_ubfe(r.pos, 5u, 27u) << 2));   // v_bfe + v_lshl_add
+  r.a = w[0]; r.b = w[1]; r.c = w[2];
 }
 
+struct QuadMasks { uint32_t m1, m2, m3; };   // all-ones where chain j >= 1, 2, 3
+
+template <int K, bool kTail>
+__device__ __forceinline__ void walk_step(WalkRegs& r, const QuadMasks& m, uint32_t win_addr, uint32_t obs_addr, bool chain_on) {
+  uint32_t e = r.e;
+  if (kTail) e = chain_on ? e : 0u;   // an exhausted chain reads no bits and keeps its state
+  // ---- critical path ----
+  const uint32_t p = ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0x111, 0xf, 0xf, true) & m.m1) +   // row_shr:1, chains 1..3
+                     ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0x112, 0xf, 0xf, true) & m.m2) +   // row_shr:2, chains 2..3
+                     ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0x113, 0xf, 0xf, true) & m.m3);    // row_shr:3, chain 3
+  const uint32_t x0 = __builtin_amdgcn_alignbit(r.b, r.a, r.pos), x1 = __builtin_amdgcn_alignbit(r.c, r.b, r.pos);   // 64 bits from pos
+  const uint64_t xs = (((uint64_t)x1 << 32) | x0) >> (p & 63u);
+  const uint32_t v = __builtin_amdgcn_ubfe((uint32_t)xs, 0u, e);                                 // width = e[4:0]
+  const uint32_t next = (e >> 16) + (v << 2);
+  if (kTail) r.saddr = chain_on ? next : r.saddr; else r.saddr = next;
+  r.e = *(const uint32_t PCO_LDS*)(uintptr_t)r.saddr;
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- in the shadow of that load ----
+  const uint32_t t = p + e;                                                                       // bits [5:0]: through my chain
+  r.pos += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0xFF, 0xf, 0xf, true) & 63u;          // quad_perm [3,3,3,3]: the step's total
+  walk_fetch_window(r, win_addr);
+  constexpr uint32_t sel_sym = K == 0 ? 0x03020105u : (K == 1 ? 0x03020500u : (K == 2 ? 0x03050100u : 0x05020100u));
+  r.symacc = __builtin_amdgcn_perm(e, r.symacc, sel_sym);
+  const uint32_t ob = *(const uint8_t PCO_LDS*)(uintptr_t)(obs_addr + ((e >> 8) & 0xffu));
+  if (kTail) r.obsum += chain_on ? ob : 0u; else r.obsum += ob;
+  __builtin_amdgcn_sched_barrier(0);   // keep the shadow work ahead of the next step's wait for the entry
+}
+
+#ifdef PCO_WALK_TIMING
+__device__ unsigned long long g_walk_timing[8];
+#define WT_NOW() __builtin_readcyclecounter()
+#endif
 // accept_status: 0 = the first stage (every task), else only the tasks an earlier stage left with that status
 template <class L, uint32_t kWQ>
 __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
@@ -392,8 +404,11 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
     st1 = lds0 + slice + kGrpTblOff + vinfo[1].off_nodes + 4u * st1;
     st2 = lds0 + slice + kGrpTblOff + vinfo[2].off_nodes + 4u * st2;
   }
-  const uint32_t sel_bb = j == 0 ? 0x0c0c0c07u : (j == 1 ? 0x0c0c070cu : (j == 2 ? 0x0c070c0cu : 0x070c0c0cu));
-  const uint32_t lowmask = (1u << (8 * j)) - 1u;
+  QuadMasks qm = {j >= 1 ? ~0u : 0u, j >= 2 ? ~0u : 0u, j >= 3 ? ~0u : 0u};
+  asm volatile("" : "+v"(qm.m1), "+v"(qm.m2), "+v"(qm.m3));   // opaque, so that they stay VGPR operands of v_and_b32_dpp
+#ifdef PCO_WALK_TIMING
+  unsigned long long wt_stage = 0, wt_walk = 0, wt_tail = 0, wt_rounds = 0, wt_t0 = WT_NOW(), wt_start = wt_t0;
+#endif
   while (__any(my_active != 0)) {
     uint32_t cnt = 0, nb = 0, asl = 0, off_ob = 0;
     bool walk = false;
@@ -411,53 +426,67 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
     const uint64_t q0 = my_bitpos >> 6;   // first qword of the window, in qwords from src
     WalkRegs r;
     r.saddr = cur_v == 0 ? st0 : (cur_v == 1 ? st1 : st2);
-    r.rel = (uint32_t)(my_bitpos & 63); r.obsum = 0; r.symacc = 0;
-    r.w0 = r.w1 = r.w2 = r.w3 = r.w4 = r.w5 = 0; r.wq_addr = lds0 + slice + kGrpWinOff + 16;
+    r.pos = (uint32_t)(my_bitpos & 63); r.obsum = 0; r.symacc = 0; r.e = 0; r.a = r.b = r.c = 0;
+    const uint32_t win_addr = lds0 + slice + kGrpWinOff;
     if (walk) {  // stage the batch's ANS section: the chunk's 4 lanes copy qword pairs, all loads in flight at once
-      const uint32_t nq = ((r.rel + cnt * asl + 63u) >> 6) + 3u;   // <= 53
+      const uint32_t nq = ((((r.pos + cnt * asl + 63u) >> 6) + 3u) + 1u) & ~1u;   // even, <= 54 of the window's 56 qwords
       uint64_t lo[7], hi[7];
+      if ((q0 + nq) * 8 <= my_len + 16) {   // the whole section is inside the buffer
 #pragma unroll
-      for (int k = 0; k < 7; k++) {
-        const uint32_t qi = 2 * j + 8 * k;
-        lo[k] = 0; hi[k] = 0;
-        if (qi < nq) { lo[k] = load_u64_le_safe(my_src, (q0 + qi) * 8, my_len + 16); hi[k] = load_u64_le_safe(my_src, (q0 + qi + 1) * 8, my_len + 16); }
+        for (int k = 0; k < 7; k++) {
+          const uint32_t qi = 2 * j + 8 * k, qc = qi < nq ? qi : nq - 2;   // no branch: the loads issue back to back
+          lo[k] = load_u64_le(my_src + (q0 + qc) * 8); hi[k] = load_u64_le(my_src + (q0 + qc) * 8 + 8);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+          const uint32_t qi = 2 * j + 8 * k;
+          lo[k] = 0; hi[k] = 0;
+          if (qi < nq) { lo[k] = load_u64_le_safe(my_src, (q0 + qi) * 8, my_len + 16); hi[k] = load_u64_le_safe(my_src, (q0 + qi + 1) * 8, my_len + 16); }
+        }
       }
 #pragma unroll
       for (int k = 0; k < 7; k++) { const uint32_t qi = 2 * j + 8 * k; if (qi < nq) { win[qi] = lo[k]; win[qi + 1] = hi[k]; } }
     }
     wave_sync_lds();
+#ifdef PCO_WALK_TIMING
+    { const unsigned long long t = WT_NOW(); wt_stage += t - wt_t0; wt_t0 = t; }
+#endif
     const uint32_t obs_addr = lds0 + slice + kGrpTblOff + off_ob;
     uint8_t PCO_GLOBAL* sym_out = (uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)(my_ti == 0xffffffffu ? 0u : my_ti) * 3 + cur_v) * sym_stride + (uint64_t)batch * kBatchN + 4 * j;
     if (walk) {
-      const uint64_t a = win[0], b = win[1], c = win[2];
-      r.w0 = (uint32_t)a; r.w1 = (uint32_t)(a >> 32); r.w2 = (uint32_t)b; r.w3 = (uint32_t)(b >> 32); r.w4 = (uint32_t)c; r.w5 = (uint32_t)(c >> 32);
+      r.e = *(const uint32_t PCO_LDS*)(uintptr_t)r.saddr;
+      walk_fetch_window(r, win_addr);
       if (__all(!walk || cnt == kBatchN)) {   // (lanes outside `walk` are masked off here anyway)
         for (uint32_t blk = 0; blk < 16; blk++) {
-          walk_step<0, false>(r, sel_bb, lowmask, obs_addr, true);
-          walk_step<1, false>(r, sel_bb, lowmask, obs_addr, true);
-          walk_step<2, false>(r, sel_bb, lowmask, obs_addr, true);
-          walk_step<3, false>(r, sel_bb, lowmask, obs_addr, true);
+          walk_step<0, false>(r, qm, win_addr, obs_addr, true);
+          walk_step<1, false>(r, qm, win_addr, obs_addr, true);
+          walk_step<2, false>(r, qm, win_addr, obs_addr, true);
+          walk_step<3, false>(r, qm, win_addr, obs_addr, true);
           *(uint32_t PCO_GLOBAL*)(sym_out + 16 * blk) = r.symacc;
         }
       } else {
         const uint32_t steps = (cnt + 3) >> 2;
         for (uint32_t blk = 0; blk * 4 < steps; blk++) {
           const uint32_t g = blk * 4;
-          if (g + 0 < steps) walk_step<0, true>(r, sel_bb, lowmask, obs_addr, 4 * (g + 0) + j < cnt);
-          if (g + 1 < steps) walk_step<1, true>(r, sel_bb, lowmask, obs_addr, 4 * (g + 1) + j < cnt);
-          if (g + 2 < steps) walk_step<2, true>(r, sel_bb, lowmask, obs_addr, 4 * (g + 2) + j < cnt);
-          if (g + 3 < steps) walk_step<3, true>(r, sel_bb, lowmask, obs_addr, 4 * (g + 3) + j < cnt);
+          if (g + 0 < steps) walk_step<0, true>(r, qm, win_addr, obs_addr, 4 * (g + 0) + j < cnt);
+          if (g + 1 < steps) walk_step<1, true>(r, qm, win_addr, obs_addr, 4 * (g + 1) + j < cnt);
+          if (g + 2 < steps) walk_step<2, true>(r, qm, win_addr, obs_addr, 4 * (g + 2) + j < cnt);
+          if (g + 3 < steps) walk_step<3, true>(r, qm, win_addr, obs_addr, 4 * (g + 3) + j < cnt);
           *(uint32_t PCO_GLOBAL*)(sym_out + 16 * blk) = r.symacc;
         }
       }
       if (cur_v == 0) st0 = r.saddr; else if (cur_v == 1) st1 = r.saddr; else st2 = r.saddr;
     }
+#ifdef PCO_WALK_TIMING
+    { const unsigned long long t = WT_NOW(); wt_walk += t - wt_t0; wt_t0 = t; }
+#endif
     if (my_active) {
       // the four chains' offset-bit sums -> the chunk total (quad butterfly)
       uint32_t obq = r.obsum;
       obq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)obq, 0xB1, 0xf, 0xf, false);
       obq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)obq, 0x4E, 0xf, 0xf, false);
-      const uint64_t ans_end = walk ? ((q0 << 6) + (uint64_t)((r.wq_addr - (lds0 + slice + kGrpWinOff + 16)) >> 3) * 64 + r.rel) : my_bitpos;
+      const uint64_t ans_end = walk ? (q0 << 6) + r.pos : my_bitpos;
       uint64_t ob_total = 0;
       if (cnt > 0) ob_total = walk ? (uint64_t)obq : (nb == 1 ? (uint64_t)cnt * *(const uint8_t PCO_LDS*)(uintptr_t)obs_addr : 0ull);
       if (cnt > 0 && j == 0) offpos_area[((uint64_t)my_ti * 3 + cur_v) * offpos_stride + batch] = ans_end;
@@ -474,7 +503,13 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
       cur_v = nv;
     }
     wave_sync_lds();
+#ifdef PCO_WALK_TIMING
+    { const unsigned long long t = WT_NOW(); wt_tail += t - wt_t0; wt_t0 = t; wt_rounds++; }
+#endif
   }
+#ifdef PCO_WALK_TIMING
+  if (blockIdx.x == 0 && lane == 0 && wt_rounds > 0) { g_walk_timing[0] = wt_stage; g_walk_timing[1] = wt_walk; g_walk_timing[2] = wt_tail; g_walk_timing[3] = wt_rounds; g_walk_timing[4] = wt_start; g_walk_timing[5] = WT_NOW(); }
+#endif
   // ---- page end (page_decompressor.rs:184-188) and stream end ----
   if (my_ti != 0xffffffffu && j == 0 && slot < kWQ) {
     DecPlan PCO_GLOBAL* plan = (DecPlan PCO_GLOBAL*)plans + my_ti;

@@ -193,6 +193,7 @@ template <class T> __device__ __forceinline__ T PCO_GLOBAL* as_global(T* p) { re
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ __forceinline__ uint64_t load_u64_le(gcptr_u8 p) { return *(const u64_unaligned PCO_GLOBAL*)p; }
+struct __attribute__((packed, aligned(1))) u128_unaligned { uint64_t lo, hi; };
 __device__ __forceinline__ uint32_t load_u32_le(gcptr_u8 p) { return *(const u32_unaligned PCO_GLOBAL*)p; }
 // bounds-safe: bytes at or beyond `len` read as zero
 __device__ __forceinline__ uint64_t load_u64_le_safe(gcptr_u8 base, uint64_t byte, uint64_t len) {

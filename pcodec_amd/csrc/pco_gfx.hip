@@ -289,3 +289,9 @@ enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size
 }  // extern "C"
 
 #include "pco_gfx_encode_api.inc"
+
+#ifdef PCO_WALK_TIMING
+extern "C" int pco_gfx_debug_walk_timing(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_walk_timing), 64);
+}
+#endif
