@@ -48,9 +48,11 @@ struct DecPlan {   // written by dec_walk_kernel, read by dec_expand_kernel
 constexpr uint64_t kBinsAreaPerVar = kFastMaxBins * 8 + kFastMaxBins;   // lowers (8 B stride) then offset bits
 constexpr uint64_t kBinsAreaPerTask = 3 * kBinsAreaPerVar;
 
-// walk entry (one u32 per tANS state): bits 0..15 LDS byte address of the entry of next_state_idx_base, 16..23 the bin
-// symbol, 24..31 bits_to_read.  The byte-aligned fields let the walker move them with v_perm_b32.
-__device__ __forceinline__ uint32_t make_wentry(uint32_t addr, uint32_t sym, uint32_t btr) { return btr | (sym << 8) | (addr << 16); }
+// walk entry (one u32 per tANS state): bits 0..5 bits_to_read (<= 11; the two spare bits keep the sum of three of them
+// inside the field), 6..12 the bin's offset bits, 13..20 the bin symbol, 21..31 next_state_idx_base - T (the walker adds
+// the bits it read and turns the sum into an LDS address with the table's base).
+__device__ __forceinline__ uint32_t make_wentry(uint32_t next_base, uint32_t sym, uint32_t btr, uint32_t ob) { return btr | (ob << 6) | (sym << 13) | (next_base << 21); }
+// (a table with ans_size_log 12 does not fit a slice, so 11 bits of state index are enough)
 
 // Build one variable's walk table for chunk slot `q`: u32 entries and per-bin offset bits in LDS; lowers / offset bits
 // go to the global bins area for dec_expand_kernel.  All 64 lanes cooperate.  (ans/spec.rs:37-59, ans/decoding.rs:27-47)
@@ -94,7 +96,7 @@ __device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader&
   if (lane == 0) vinfo->max_ob = max_ob;
   if (!mr.in_bounds()) { status = PCO_GFX_INSUFFICIENT_DATA; return false; }
   if (uni(wave_or_u32(bad))) { status = PCO_GFX_CORRUPTION; return false; }
-  if (n_bins == 0) { if (lane == 0) entries[0] = make_wentry(tbl_addr, 0, 0); wave_sync_lds(); return true; }
+  if (n_bins == 0) { if (lane == 0) entries[0] = make_wentry(0, 0, 0, 0); wave_sync_lds(); return true; }
   if (carry != T) { status = PCO_GFX_CORRUPTION; return false; }
   wave_sync_lds();
   uint32_t stride = (3 * T) / 5; if ((stride & 1) == 0) stride += 1;
@@ -125,7 +127,7 @@ __device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader&
     wave_sync_lds();
     if (act && rank == 0) cum[s] = basec + gcount;
     wave_sync_lds();
-    if (act) { const uint32_t x_s = basec + rank; const uint32_t btr = clz_u32(x_s) - clz_u32(T); entries[i] = make_wentry(tbl_addr + 4u * ((x_s << btr) - T), s, btr); }
+    if (act) { const uint32_t x_s = basec + rank; const uint32_t btr = clz_u32(x_s) - clz_u32(T); entries[i] = make_wentry((x_s << btr) - T, s, btr, obs[s]); }
   }
   wave_sync_lds();
   return true;
@@ -301,55 +303,59 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
 // dec_walk_kernel: kWQ chunks per wave, four lanes per chunk (lane 4c+j walks tANS chain j of chunk slot c).
 //
 // The walk is a serial chain of n/4 steps per chunk and a wave has no other wave to hide behind (the tables fill
-// the LDS at one wave per SIMD), so a step costs  LDS latency + every instruction between the entry's arrival and
-// the next ds_read.  walk_step() keeps that stretch to
-//   3 x v_and_dpp + v_add3 (row_shr 1,2,3 masked to the quad: bits read by the chains before mine; the entry's low byte is
-//   bits_to_read, so the raw entries are summed and only bits [5:0] of the sum are consumed)
-//   -> 2 x v_alignbit (the 64 window bits at the chunk's bit position; their three dwords were fetched from the
-//   LDS copy of the batch's ANS section in the shadow of the previous step) -> v_lshrrev_b64 -> v_bfe (width =
-//   entry[4:0]) -> v_lshl_add (next entry address)
-// and does everything else -- the step's total bit count, the next window fetch, the symbol and its offset-bit
-// count -- in the shadow of that ds_read.  Symbols leave in 16-element
+// the LDS at one wave per SIMD), so a step costs the entry's LDS latency plus every instruction between its arrival
+// and the next ds_read, plus the DS instructions themselves: a lone wave pays 15-30 issue cycles per DS instruction
+// that nothing hides (scripts/micro/lds_micro.hip), and the CU's four walker waves share one LDS.  walk_step()
+// therefore keeps the dependent stretch to
+//   3 x v_and_dpp + v_add3 (row_shr 1,2,3 masked to the quad: bits read by the chains before mine; an entry's low
+//   six bits are bits_to_read, so the raw entries are summed and only bits [5:0] of the sum are consumed)
+//   -> 2 x v_alignbit (the 64 window bits at the chunk's bit position, from three dwords fetched in the shadow of
+//   the previous step) -> v_lshrrev_b64 -> v_bfe (width = entry[4:0]) -> v_lshrrev, v_add_lshl, v_add (next address)
+// does everything else (the step's total bit count, the next window fetch, the symbol, the offset-bit count) after
+// that ds_read has been issued, and issues three DS instructions per step (entry, ds_read2_b32 + ds_read_b32 for
+// the window): the bin's offset-bit count rides in the entry instead of being looked up.  Measured alternatives at
+// four waves per CU: a look-ahead window fetch that takes the cut off the dependent stretch needs a byte-granular
+// 16-byte read (unaligned ds_read_b128) or four dwords and a three-way cut, and both lose (7.96 / 9.56 vs 6.89 ms);
+// a register-resident window advanced by v_cndmask costs 34 VALU per step (11.3 ms).  Symbols leave in 16-element
 // blocks: dword j of a block holds chain j's symbols of four consecutive steps (dec_expand_kernel undoes this).
 // ---------------------------------------------------------------------------------------------------------
 struct WalkRegs {
   uint32_t saddr;                    // LDS byte address of the current state's entry
   uint32_t e;                        // that entry (its load is issued as soon as the address is known)
-  uint32_t pos;                      // bit position of the next unread bit, relative to the staged window
-  uint32_t a, b, c;                  // the window dwords pos/32, +1, +2
+  uint32_t bitaddr;                  // LDS BIT address (8 x byte address + bit) of the next unread bit
+  uint32_t d0, d1, d2;               // the window dwords holding bits [bitaddr, bitaddr + 64)
   uint32_t obsum, symacc;
 };
 
-__device__ __forceinline__ void walk_fetch_window(WalkRegs& r, uint32_t win_addr) {
-  const uint32_t PCO_LDS* w = (const uint32_t PCO_LDS*)(uintptr_t)(win_addr + (__builtin_amdgcn_ubfe(r.pos, 5u, 27u) << 2));   // v_bfe + v_lshl_add
-  r.a = w[0]; r.b = w[1]; r.c = w[2];
+// Advance the bit position by `tot` and fetch the three window dwords at the new position.
+__device__ __forceinline__ void walk_window(WalkRegs& r, uint32_t tot) {
+  r.bitaddr += tot;
+  const uint32_t PCO_LDS* w = (const uint32_t PCO_LDS*)(uintptr_t)((r.bitaddr >> 3) & ~3u);
+  r.d0 = w[0]; r.d1 = w[1]; r.d2 = w[2];
 }
 
-struct QuadMasks { uint32_t m1, m2, m3; };   // all-ones where chain j >= 1, 2, 3
+struct QuadMasks { uint32_t m1, m2, m3, c63; };   // all-ones where chain j >= 1, 2, 3; 63
 
 template <int K, bool kTail>
-__device__ __forceinline__ void walk_step(WalkRegs& r, const QuadMasks& m, uint32_t win_addr, uint32_t obs_addr, bool chain_on) {
+__device__ __forceinline__ void walk_step(WalkRegs& r, const QuadMasks& m, uint32_t tbl_addr, bool chain_on) {
   uint32_t e = r.e;
   if (kTail) e = chain_on ? e : 0u;   // an exhausted chain reads no bits and keeps its state
   // ---- critical path ----
   const uint32_t p = ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0x111, 0xf, 0xf, true) & m.m1) +   // row_shr:1, chains 1..3
                      ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0x112, 0xf, 0xf, true) & m.m2) +   // row_shr:2, chains 2..3
                      ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0x113, 0xf, 0xf, true) & m.m3);    // row_shr:3, chain 3
-  const uint32_t x0 = __builtin_amdgcn_alignbit(r.b, r.a, r.pos), x1 = __builtin_amdgcn_alignbit(r.c, r.b, r.pos);   // 64 bits from pos
+  const uint32_t x0 = __builtin_amdgcn_alignbit(r.d1, r.d0, r.bitaddr), x1 = __builtin_amdgcn_alignbit(r.d2, r.d1, r.bitaddr);   // 64 bits from the position
   const uint64_t xs = (((uint64_t)x1 << 32) | x0) >> (p & 63u);
   const uint32_t v = __builtin_amdgcn_ubfe((uint32_t)xs, 0u, e);                                 // width = e[4:0]
-  const uint32_t next = (e >> 16) + (v << 2);
+  const uint32_t next = tbl_addr + (((e >> 21) + v) << 2);
   if (kTail) r.saddr = chain_on ? next : r.saddr; else r.saddr = next;
   r.e = *(const uint32_t PCO_LDS*)(uintptr_t)r.saddr;
   __builtin_amdgcn_sched_barrier(0);
   // ---- in the shadow of that load ----
   const uint32_t t = p + e;                                                                       // bits [5:0]: through my chain
-  r.pos += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0xFF, 0xf, 0xf, true) & 63u;          // quad_perm [3,3,3,3]: the step's total
-  walk_fetch_window(r, win_addr);
-  constexpr uint32_t sel_sym = K == 0 ? 0x03020105u : (K == 1 ? 0x03020500u : (K == 2 ? 0x03050100u : 0x05020100u));
-  r.symacc = __builtin_amdgcn_perm(e, r.symacc, sel_sym);
-  const uint32_t ob = *(const uint8_t PCO_LDS*)(uintptr_t)(obs_addr + ((e >> 8) & 0xffu));
-  if (kTail) r.obsum += chain_on ? ob : 0u; else r.obsum += ob;
+  walk_window(r, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0xFF, 0xf, 0xf, true) & m.c63);  // quad_perm [3,3,3,3]: the step's total
+  if (K == 0) r.symacc = __builtin_amdgcn_ubfe(e, 13u, 8u); else r.symacc |= __builtin_amdgcn_ubfe(e, 13u, 8u) << (8 * K);
+  r.obsum += __builtin_amdgcn_ubfe(e, 6u, 7u);   // (an exhausted chain's e is 0)
   __builtin_amdgcn_sched_barrier(0);   // keep the shadow work ahead of the next step's wait for the entry
 }
 
@@ -404,17 +410,17 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
     st1 = lds0 + slice + kGrpTblOff + vinfo[1].off_nodes + 4u * st1;
     st2 = lds0 + slice + kGrpTblOff + vinfo[2].off_nodes + 4u * st2;
   }
-  QuadMasks qm = {j >= 1 ? ~0u : 0u, j >= 2 ? ~0u : 0u, j >= 3 ? ~0u : 0u};
-  asm volatile("" : "+v"(qm.m1), "+v"(qm.m2), "+v"(qm.m3));   // opaque, so that they stay VGPR operands of v_and_b32_dpp
+  QuadMasks qm = {j >= 1 ? ~0u : 0u, j >= 2 ? ~0u : 0u, j >= 3 ? ~0u : 0u, 63u};
+  asm volatile("" : "+v"(qm.m1), "+v"(qm.m2), "+v"(qm.m3), "+v"(qm.c63));   // opaque, so that they stay VGPR operands of v_and_b32_dpp
 #ifdef PCO_WALK_TIMING
   unsigned long long wt_stage = 0, wt_walk = 0, wt_tail = 0, wt_rounds = 0, wt_t0 = WT_NOW(), wt_start = wt_t0;
 #endif
   while (__any(my_active != 0)) {
-    uint32_t cnt = 0, nb = 0, asl = 0, off_ob = 0;
+    uint32_t cnt = 0, nb = 0, asl = 0, off_ob = 0, off_nodes = 0;
     bool walk = false;
     if (my_active) {
       const VarInfo PCO_LDS* vi = vinfo + cur_v;
-      nb = vi->n_bins; asl = vi->ans_size_log; off_ob = vi->off_ob;
+      nb = vi->n_bins; asl = vi->ans_size_log; off_ob = vi->off_ob; off_nodes = vi->off_nodes;
       const uint32_t batch_n = n_rem < kBatchN ? n_rem : kBatchN;
       if (cur_v == 0) { const uint32_t lim = n_rem > nlps1 ? n_rem - nlps1 : 0; cnt = lim < batch_n ? lim : batch_n; }
       else {
@@ -426,10 +432,10 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
     const uint64_t q0 = my_bitpos >> 6;   // first qword of the window, in qwords from src
     WalkRegs r;
     r.saddr = cur_v == 0 ? st0 : (cur_v == 1 ? st1 : st2);
-    r.pos = (uint32_t)(my_bitpos & 63); r.obsum = 0; r.symacc = 0; r.e = 0; r.a = r.b = r.c = 0;
-    const uint32_t win_addr = lds0 + slice + kGrpWinOff;
+    const uint32_t win_addr = lds0 + slice + kGrpWinOff, rel0 = (uint32_t)(my_bitpos & 63);
+    r.bitaddr = 8u * win_addr + rel0; r.obsum = 0; r.symacc = 0; r.e = 0; r.d0 = r.d1 = r.d2 = 0;
     if (walk) {  // stage the batch's ANS section: the chunk's 4 lanes copy qword pairs, all loads in flight at once
-      const uint32_t nq = ((((r.pos + cnt * asl + 63u) >> 6) + 3u) + 1u) & ~1u;   // even, <= 54 of the window's 56 qwords
+      const uint32_t nq = ((((rel0 + cnt * asl + 63u) >> 6) + 3u) + 1u) & ~1u;   // even, <= 54 of the window's 56 qwords
       uint64_t lo[7], hi[7];
       if ((q0 + nq) * 8 <= my_len + 16) {   // the whole section is inside the buffer
 #pragma unroll
@@ -452,27 +458,27 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
 #ifdef PCO_WALK_TIMING
     { const unsigned long long t = WT_NOW(); wt_stage += t - wt_t0; wt_t0 = t; }
 #endif
-    const uint32_t obs_addr = lds0 + slice + kGrpTblOff + off_ob;
+    const uint32_t obs_addr = lds0 + slice + kGrpTblOff + off_ob, tbl_addr = lds0 + slice + kGrpTblOff + off_nodes;
     uint8_t PCO_GLOBAL* sym_out = (uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)(my_ti == 0xffffffffu ? 0u : my_ti) * 3 + cur_v) * sym_stride + (uint64_t)batch * kBatchN + 4 * j;
     if (walk) {
       r.e = *(const uint32_t PCO_LDS*)(uintptr_t)r.saddr;
-      walk_fetch_window(r, win_addr);
+      walk_window(r, 0u);
       if (__all(!walk || cnt == kBatchN)) {   // (lanes outside `walk` are masked off here anyway)
         for (uint32_t blk = 0; blk < 16; blk++) {
-          walk_step<0, false>(r, qm, win_addr, obs_addr, true);
-          walk_step<1, false>(r, qm, win_addr, obs_addr, true);
-          walk_step<2, false>(r, qm, win_addr, obs_addr, true);
-          walk_step<3, false>(r, qm, win_addr, obs_addr, true);
+          walk_step<0, false>(r, qm, tbl_addr, true);
+          walk_step<1, false>(r, qm, tbl_addr, true);
+          walk_step<2, false>(r, qm, tbl_addr, true);
+          walk_step<3, false>(r, qm, tbl_addr, true);
           *(uint32_t PCO_GLOBAL*)(sym_out + 16 * blk) = r.symacc;
         }
       } else {
         const uint32_t steps = (cnt + 3) >> 2;
         for (uint32_t blk = 0; blk * 4 < steps; blk++) {
           const uint32_t g = blk * 4;
-          if (g + 0 < steps) walk_step<0, true>(r, qm, win_addr, obs_addr, 4 * (g + 0) + j < cnt);
-          if (g + 1 < steps) walk_step<1, true>(r, qm, win_addr, obs_addr, 4 * (g + 1) + j < cnt);
-          if (g + 2 < steps) walk_step<2, true>(r, qm, win_addr, obs_addr, 4 * (g + 2) + j < cnt);
-          if (g + 3 < steps) walk_step<3, true>(r, qm, win_addr, obs_addr, 4 * (g + 3) + j < cnt);
+          if (g + 0 < steps) walk_step<0, true>(r, qm, tbl_addr, 4 * (g + 0) + j < cnt);
+          if (g + 1 < steps) walk_step<1, true>(r, qm, tbl_addr, 4 * (g + 1) + j < cnt);
+          if (g + 2 < steps) walk_step<2, true>(r, qm, tbl_addr, 4 * (g + 2) + j < cnt);
+          if (g + 3 < steps) walk_step<3, true>(r, qm, tbl_addr, 4 * (g + 3) + j < cnt);
           *(uint32_t PCO_GLOBAL*)(sym_out + 16 * blk) = r.symacc;
         }
       }
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
       uint32_t obq = r.obsum;
       obq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)obq, 0xB1, 0xf, 0xf, false);
       obq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)obq, 0x4E, 0xf, 0xf, false);
-      const uint64_t ans_end = walk ? (q0 << 6) + r.pos : my_bitpos;
+      const uint64_t ans_end = walk ? (q0 << 6) + (r.bitaddr - 8u * win_addr) : my_bitpos;
       uint64_t ob_total = 0;
       if (cnt > 0) ob_total = walk ? (uint64_t)obq : (nb == 1 ? (uint64_t)cnt * *(const uint8_t PCO_LDS*)(uintptr_t)obs_addr : 0ull);
       if (cnt > 0 && j == 0) offpos_area[((uint64_t)my_ti * 3 + cur_v) * offpos_stride + batch] = ans_end;

@@ -202,8 +202,7 @@ __global__ __launch_bounds__(256) void enc_dissect_kernel(EncWorkspace ws, EncFa
 // Q (page, variable) items per wave: 8 (slot 4608 B: any table of the fast path) or 16 (slot 2304 B, all 64 lanes busy).
 // The walk is latency-bound, so what matters is that every item is resident at once: with more than 8192 items the launch
 // first walks the items whose tables fit the small slots 16 per wave, then the rest 8 per wave (never worse than two rounds
-// of 8 per wave).  Slot: next states u16[T] | info u64[n_bins] (cutoff | min_renorm_bits << 16, LDS address of the symbol's
-// next-state row) | ... | symbols u8[2][256] of the current / next batch.
+// of 8 per wave).  Slot: next states u16[T] | info u64[n_bins] (see ew_step) | ... | symbols u8[2][256] of the current / next batch.
 template <uint32_t Q> struct EwCfg {
   static constexpr uint32_t kSlotBytes = Q == 16 ? 2304u : 4608u;
   static constexpr uint32_t kSymOff = kSlotBytes - 512;
@@ -212,15 +211,18 @@ template <uint32_t Q> struct EwCfg {
 __device__ __forceinline__ uint32_t ew_info_off(uint32_t asl) { return ((2u << asl) + 7u) & ~7u; }
 __device__ __forceinline__ bool ew_fits16(uint32_t asl, uint32_t n_bins) { return ew_info_off(asl) + 8u * n_bins <= EwCfg<16>::kSymOff; }
 
-// one reverse step of one chain: (ans/encoding.rs:65-87)
+// one reverse step of one chain (ans/encoding.rs:65-87).  info = D | row << 32 with D = ((min_renorm_bits + 1) << 16) - cutoff,
+// so that bits = min_renorm_bits + (state >= cutoff) = (state + D) >> 16 (states are below 2^13), and row = the LDS address
+// of the symbol's next-state row.  The dependent stretch is v_add, v_lshrrev, v_lshrrev, v_lshl_add -> ds_read_u16; the value
+// and the bit count are taken care of after that read has been issued (the wave has nothing else to hide its latency behind).
 __device__ __forceinline__ uint32_t ew_step(uint32_t& state, uint32_t& bits_acc, uint64_t info) {
-  const uint32_t lo = (uint32_t)info, row = (uint32_t)(info >> 32);
-  const uint32_t cutoff = lo & 0xffffu, minb = lo >> 16;
-  const uint32_t bits = minb + (state >= cutoff ? 1u : 0u);
-  const uint32_t val = __builtin_amdgcn_ubfe(state, 0u, bits);
-  state = *(const uint16_t PCO_LDS*)(uintptr_t)(row + ((state >> bits) << 1));
+  const uint32_t d = (uint32_t)info, row = (uint32_t)(info >> 32);
+  const uint32_t old = state;
+  const uint32_t bits = (old + d) >> 16;
+  state = *(const uint16_t PCO_LDS*)(uintptr_t)(row + ((old >> bits) << 1));
+  __builtin_amdgcn_sched_barrier(0);
   bits_acc += bits;
-  return (bits << 12) | val;
+  return (bits << 12) | __builtin_amdgcn_ubfe(old, 0u, bits);
 }
 
 // stage: 0 = every item; 1 = only the items that fit the 16-per-wave slots; 2 = only those that do not
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
       const uint32_t si = plan->syminfo[b];   // cutoff(14) | min_renorm_bits(4) << 14 | (row + 8192)(14) << 18
       const uint32_t cutoff = si & 0x3fffu, minb = (si >> 14) & 15u, row = (si >> 18) - 8192u;   // row may be "negative": wraps mod 2^32 below
       const uint32_t row_addr = lds0 + q * kEwSlotBytes + kEwNsOff + 2u * row;
-      ((uint64_t PCO_LDS*)(sl + kEwInfoOff))[b] = (uint64_t)(cutoff | (minb << 16)) | ((uint64_t)row_addr << 32);
+      ((uint64_t PCO_LDS*)(sl + kEwInfoOff))[b] = (uint64_t)(((minb + 1u) << 16) - cutoff) | ((uint64_t)row_addr << 32);
     }
     if (slot == q) { my_n_lat = pv.n_lat; my_T = T; my_p = p; my_v = v; my_task = t; my_at = fast_at(pg, pv.skip); my_info_off = kEwInfoOff; }
   }
@@ -335,24 +337,31 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
     if (act) {
       uint32_t bits_acc = 0;
       uint16_t PCO_GLOBAL* ga = gans + (uint64_t)b * kBatchN + 4 * j;
-      // software pipeline: the symbol dword and its four info words of block blk-1 are fetched while block blk is walked
+      // software pipeline: block blk-1's four info words are fetched one per step, each in the shadow of a state read of
+      // block blk, and block blk-2's symbol dword with the last of them
       uint32_t sd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * 15 + 4 * j);
+      uint32_t nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * 14 + 4 * j);
       uint64_t i0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (sd & 0xffu));
       uint64_t i1 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> 8) & 0xffu));
       uint64_t i2 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> 16) & 0xffu));
       uint64_t i3 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (sd >> 24));
       for (uint32_t blk = 16; blk-- > 0;) {
-        const uint32_t nblk = blk > 0 ? blk - 1 : 0;
-        const uint32_t nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * nblk + 4 * j);
-        const uint64_t n0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd & 0xffu));
-        const uint64_t n1 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((nsd >> 8) & 0xffu));
-        const uint64_t n2 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((nsd >> 16) & 0xffu));
-        const uint64_t n3 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd >> 24));
+        const uint32_t nnblk = blk > 1 ? blk - 2 : 0;
         const uint32_t o3 = ew_step(state, bits_acc, i3);
+        const uint64_t n3 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd >> 24));
+        __builtin_amdgcn_sched_barrier(0);
         const uint32_t o2 = ew_step(state, bits_acc, i2);
+        const uint64_t n2 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((nsd >> 16) & 0xffu));
+        const uint32_t o23 = o2 | (o3 << 16);
+        __builtin_amdgcn_sched_barrier(0);
         const uint32_t o1 = ew_step(state, bits_acc, i1);
+        const uint64_t n1 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((nsd >> 8) & 0xffu));
+        __builtin_amdgcn_sched_barrier(0);
         const uint32_t o0 = ew_step(state, bits_acc, i0);
-        *(u64_align2 PCO_GLOBAL*)(ga + 16 * blk) = (uint64_t)(o0 | (o1 << 16)) | ((uint64_t)(o2 | (o3 << 16)) << 32);
+        const uint64_t n0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd & 0xffu));
+        nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * nnblk + 4 * j);
+        *(u64_align2 PCO_GLOBAL*)(ga + 16 * blk) = (uint64_t)(o0 | (o1 << 16)) | ((uint64_t)o23 << 32);
+        __builtin_amdgcn_sched_barrier(0);
         i0 = n0; i1 = n1; i2 = n2; i3 = n3;
       }
       bits_acc += quad_dpp<0xB1>(bits_acc); bits_acc += quad_dpp<0x4E>(bits_acc);
