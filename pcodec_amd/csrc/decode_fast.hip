@@ -316,8 +316,9 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
 // the window): the bin's offset-bit count rides in the entry instead of being looked up.  Measured alternatives at
 // four waves per CU: a look-ahead window fetch that takes the cut off the dependent stretch needs a byte-granular
 // 16-byte read (unaligned ds_read_b128) or four dwords and a three-way cut, and both lose (7.96 / 9.56 vs 6.89 ms);
-// a register-resident window advanced by v_cndmask costs 34 VALU per step (11.3 ms).  Symbols leave in 16-element
-// blocks: dword j of a block holds chain j's symbols of four consecutive steps (dec_expand_kernel undoes this).
+// a register-resident window advanced by v_cndmask costs 34 VALU per step (11.3 ms).  Symbols leave in groups of 64:
+// bytes [16 j + 4 b, +4) of a group hold chain j's symbols of the four steps of the group's block b (one 16-byte store per
+// lane and group -- sixteen 4-byte stores per batch backed up the VMEM queue; dec_expand_kernel undoes the layout).
 // ---------------------------------------------------------------------------------------------------------
 struct WalkRegs {
   uint32_t saddr;                    // LDS byte address of the current state's entry
@@ -410,10 +411,14 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
     st1 = lds0 + slice + kGrpTblOff + vinfo[1].off_nodes + 4u * st1;
     st2 = lds0 + slice + kGrpTblOff + vinfo[2].off_nodes + 4u * st2;
   }
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   QuadMasks qm = {j >= 1 ? ~0u : 0u, j >= 2 ? ~0u : 0u, j >= 3 ? ~0u : 0u, 63u};
   asm volatile("" : "+v"(qm.m1), "+v"(qm.m2), "+v"(qm.m3), "+v"(qm.c63));   // opaque, so that they stay VGPR operands of v_and_b32_dpp
 #ifdef PCO_WALK_TIMING
-  unsigned long long wt_stage = 0, wt_walk = 0, wt_tail = 0, wt_rounds = 0, wt_t0 = WT_NOW(), wt_start = wt_t0;
+  unsigned long long wt_stage = 0, wt_walk = 0, wt_tail = 0, wt_rounds = 0, wt_t0 = WT_NOW(), wt_start = wt_t0, wt_s1 = 0, wt_s2 = 0, wt_s3 = 0, wt_t1 = wt_t0;
+#endif
+#ifndef PCO_WALK_NO_TOUCH
+  uint64_t touch_prev = my_bitpos >> 3; uint32_t touch_r0 = 0, touch_r1 = 0;
 #endif
   while (__any(my_active != 0)) {
     uint32_t cnt = 0, nb = 0, asl = 0, off_ob = 0, off_nodes = 0;
@@ -430,6 +435,9 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
       walk = cnt > 0 && nb > 1;
     }
     const uint64_t q0 = my_bitpos >> 6;   // first qword of the window, in qwords from src
+#ifdef PCO_WALK_TIMING
+    { const unsigned long long t = WT_NOW(); wt_s1 += t - wt_t0; wt_t1 = t; }
+#endif
     WalkRegs r;
     r.saddr = cur_v == 0 ? st0 : (cur_v == 1 ? st1 : st2);
     const uint32_t win_addr = lds0 + slice + kGrpWinOff, rel0 = (uint32_t)(my_bitpos & 63);
@@ -451,35 +459,70 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
           if (qi < nq) { lo[k] = load_u64_le_safe(my_src, (q0 + qi) * 8, my_len + 16); hi[k] = load_u64_le_safe(my_src, (q0 + qi + 1) * 8, my_len + 16); }
         }
       }
+#ifdef PCO_WALK_TIMING
+      { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = WT_NOW(); wt_s2 += t - wt_t1; wt_t1 = t; }
+#endif
 #pragma unroll
       for (int k = 0; k < 7; k++) { const uint32_t qi = 2 * j + 8 * k; if (qi < nq) { win[qi] = lo[k]; win[qi + 1] = hi[k]; } }
     }
     wave_sync_lds();
 #ifdef PCO_WALK_TIMING
+    { const unsigned long long t = WT_NOW(); wt_s3 += t - wt_t1; }
+#endif
+#ifndef PCO_WALK_NO_TOUCH
+    // Warm the L2 with the lines this chunk's NEXT round will stage (its position is only known after this walk; the staging
+    // loads otherwise wait ~1600 cycles on HBM every round): predicted start = this start + the previous stride, and the
+    // chunk's four lanes touch eight 128-byte lines around it.  The loads are fire-and-forget inline asm (the compiler would
+    // wait for a C++ load's value here); their target registers are kept reserved until the next round's staging loads
+    // have been waited for, which -- VMEM returning in order -- is after they landed.
+    asm volatile("" :: "v"(touch_r0), "v"(touch_r1));
+    if (walk) {
+      const uint64_t cur = q0 * 8, pred = cur + (cur - touch_prev);
+      touch_prev = cur;
+      const uint64_t line0 = (pred & ~(uint64_t)127) - (pred >= 128 ? 128u : 0u);
+      const uint64_t a0 = line0 + 128u * j, a1 = a0 + 512u;
+      const uint8_t PCO_GLOBAL* p0 = my_src + (a0 + 4 <= my_len ? a0 : 0), * p1 = my_src + (a1 + 4 <= my_len ? a1 : 0);
+      asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(touch_r0), "=&v"(touch_r1) : "v"(p0), "v"(p1));
+    }
+#endif
+#ifdef PCO_WALK_TIMING
     { const unsigned long long t = WT_NOW(); wt_stage += t - wt_t0; wt_t0 = t; }
 #endif
     const uint32_t obs_addr = lds0 + slice + kGrpTblOff + off_ob, tbl_addr = lds0 + slice + kGrpTblOff + off_nodes;
-    uint8_t PCO_GLOBAL* sym_out = (uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)(my_ti == 0xffffffffu ? 0u : my_ti) * 3 + cur_v) * sym_stride + (uint64_t)batch * kBatchN + 4 * j;
+    uint8_t PCO_GLOBAL* sym_out = (uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)(my_ti == 0xffffffffu ? 0u : my_ti) * 3 + cur_v) * sym_stride + (uint64_t)batch * kBatchN + 16 * j;
     if (walk) {
       r.e = *(const uint32_t PCO_LDS*)(uintptr_t)r.saddr;
       walk_window(r, 0u);
       if (__all(!walk || cnt == kBatchN)) {   // (lanes outside `walk` are masked off here anyway)
-        for (uint32_t blk = 0; blk < 16; blk++) {
-          walk_step<0, false>(r, qm, tbl_addr, true);
-          walk_step<1, false>(r, qm, tbl_addr, true);
-          walk_step<2, false>(r, qm, tbl_addr, true);
-          walk_step<3, false>(r, qm, tbl_addr, true);
-          *(uint32_t PCO_GLOBAL*)(sym_out + 16 * blk) = r.symacc;
+        for (uint32_t grp = 0; grp < 4; grp++) {
+          u32x4 acc;
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            walk_step<0, false>(r, qm, tbl_addr, true);
+            walk_step<1, false>(r, qm, tbl_addr, true);
+            walk_step<2, false>(r, qm, tbl_addr, true);
+            walk_step<3, false>(r, qm, tbl_addr, true);
+            acc[b] = r.symacc;
+          }
+          *(u32x4 PCO_GLOBAL*)(sym_out + 64 * grp) = acc;
         }
       } else {
         const uint32_t steps = (cnt + 3) >> 2;
-        for (uint32_t blk = 0; blk * 4 < steps; blk++) {
-          const uint32_t g = blk * 4;
-          if (g + 0 < steps) walk_step<0, true>(r, qm, tbl_addr, 4 * (g + 0) + j < cnt);
-          if (g + 1 < steps) walk_step<1, true>(r, qm, tbl_addr, 4 * (g + 1) + j < cnt);
-          if (g + 2 < steps) walk_step<2, true>(r, qm, tbl_addr, 4 * (g + 2) + j < cnt);
-          if (g + 3 < steps) walk_step<3, true>(r, qm, tbl_addr, 4 * (g + 3) + j < cnt);
-          *(uint32_t PCO_GLOBAL*)(sym_out + 16 * blk) = r.symacc;
+        for (uint32_t grp = 0; grp * 16 < steps; grp++) {
+          u32x4 acc = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const uint32_t g = grp * 16 + b * 4;
+            if (g < steps) {
+              r.symacc = 0;
+              if (g + 0 < steps) walk_step<0, true>(r, qm, tbl_addr, 4 * (g + 0) + j < cnt);
+              if (g + 1 < steps) walk_step<1, true>(r, qm, tbl_addr, 4 * (g + 1) + j < cnt);
+              if (g + 2 < steps) walk_step<2, true>(r, qm, tbl_addr, 4 * (g + 2) + j < cnt);
+              if (g + 3 < steps) walk_step<3, true>(r, qm, tbl_addr, 4 * (g + 3) + j < cnt);
+              acc[b] = r.symacc;
+            }
+          }
+          *(u32x4 PCO_GLOBAL*)(sym_out + 64 * grp) = acc;
         }
       }
       if (cur_v == 0) st0 = r.saddr; else if (cur_v == 1) st1 = r.saddr; else st2 = r.saddr;
@@ -514,7 +557,7 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
 #endif
   }
 #ifdef PCO_WALK_TIMING
-  if (blockIdx.x == 0 && lane == 0 && wt_rounds > 0) { g_walk_timing[0] = wt_stage; g_walk_timing[1] = wt_walk; g_walk_timing[2] = wt_tail; g_walk_timing[3] = wt_rounds; g_walk_timing[4] = wt_start; g_walk_timing[5] = WT_NOW(); }
+  if (blockIdx.x == 0 && lane == 0 && wt_rounds > 0) { g_walk_timing[0] = wt_stage; g_walk_timing[1] = wt_walk; g_walk_timing[2] = wt_tail; g_walk_timing[3] = wt_rounds; g_walk_timing[4] = wt_start; g_walk_timing[5] = WT_NOW(); g_walk_timing[6] = wt_s1; g_walk_timing[7] = wt_s2 | (wt_s3 << 32); }
 #endif
   // ---- page end (page_decompressor.rs:184-188) and stream end ----
   if (my_ti != 0xffffffffu && j == 0 && slot < kWQ) {
@@ -562,7 +605,7 @@ __device__ __forceinline__ void expand_prefetch(ExpPre& pre, gcptr_u8 src, uint6
   const uint32_t lane = lane_id();
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
-  pre.syms = (!single_bin && 4 * lane < ((cnt + 15u) & ~15u)) ? *(const uint32_t PCO_GLOBAL*)(syms + 4 * lane) : 0u;
+  pre.syms = (!single_bin && 64 * (lane >> 4) < cnt) ? *(const uint32_t PCO_GLOBAL*)(syms + 4 * lane) : 0u;   // chain (lane / 4) % 4, block 4 (lane / 16) + lane % 4 (see dec_walk_kernel)
   const uint64_t byte0 = (start_bit >> 5) * 4;
   const uint32_t need_bytes = need_bits == 0 ? 0u : (((uint32_t)(start_bit & 31) + need_bits + 31u) / 32u) * 4u + 8u;
   const uint32_t off = 32 * lane;
@@ -597,7 +640,9 @@ __device__ __forceinline__ void expand_item(const ExpPre& pre, uint32_t PCO_LDS*
     }
   }
   wave_sync_lds();
-  const uint32_t syms = single_bin ? 0u : quad_transpose_u8(pre.syms, lane & 3);
+  // the walker's layout has chain c, block b of a 64-symbol group at dword 4 c + b; this lane wants chain lane % 4 of block lane / 4
+  const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ((lane & 48u) + 4u * (lane & 3u) + ((lane >> 2) & 3u))), (int)pre.syms);
+  const uint32_t syms = single_bin ? 0u : quad_transpose_u8(mine, lane & 3);
   uint32_t ob[4]; LV low[4]; uint32_t t = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {

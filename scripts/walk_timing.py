@@ -51,4 +51,5 @@ ok = bool(torch.equal(out, data))
 buf = (C.c_ulonglong * 8)()
 L.pco_gfx_debug_walk_timing(buf)
 stage, walk, tail, rounds, t0, t1 = list(buf)[:6]
-print(f"rounds {rounds} stage {stage / max(rounds, 1):.0f} walk {walk / max(rounds, 1):.0f} tail {tail / max(rounds, 1):.0f} total {t1 - t0} roundtrip_ok {ok}")
+s1 = buf[6]; s2 = buf[7] & 0xffffffff; s3 = buf[7] >> 32
+print(f"rounds {rounds} [pre-load {s1 / max(rounds, 1):.0f} loads {s2 / max(rounds, 1):.0f} lds-write+sync {s3 / max(rounds, 1):.0f}] stage {stage / max(rounds, 1):.0f} walk {walk / max(rounds, 1):.0f} tail {tail / max(rounds, 1):.0f} total {t1 - t0} roundtrip_ok {ok}")
