@@ -48,7 +48,9 @@ struct EncChunk {
   uint32_t delta_kind, delta_order, window_n_log, state_n_log;
   uint32_t fallback, unopt_bins_log;
   uint32_t n_pages, page_low, page_r, page_first;  // PagingSpec::EqualPagesUpTo layout: the first page_r pages hold page_low+1
-  uint32_t fast_ok, pad2;   // 1: the chunk's pages go through the dissect / walk / scan / pack kernels (encode_fast.hip)
+  uint32_t fast_ok;         // 1: the chunk's pages go through the dissect / walk / scan / pack kernels (encode_fast.hip)
+  uint32_t c16_ok;          // speculative 16-bit latents (enc_split_kernel): 0 = off (full-width latents), 1 = on and holding, 2 = a tile did not fit
+  uint64_t c16_ref[2];      // what the 16-bit latents of variables 1 / 2 are relative to
   EncVar v[3];
 };
 static_assert(sizeof(EncChunk) % 8 == 0, "EncChunk");
@@ -132,7 +134,7 @@ struct EncModePlan {  // host-resolved mode / delta (explicit specs; Auto is res
   uint32_t ubl_override, pad;   // 0xffffffff = derive from (level, n); trials use the full chunk's value
 };
 
-__global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, const EncModePlan* plans, uint32_t n_tasks, uint32_t level) {
+__global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, const EncModePlan* plans, uint32_t n_tasks, uint32_t level, uint32_t c16_enable) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_tasks) return;
   const PcoGfxEncodeTask task = tasks[t];
@@ -156,6 +158,7 @@ __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, 
   c.v[2].present = mp.mode_kind == kIntMult || mp.mode_kind == kFloatMult || mp.mode_kind == kFloatQuant;
   c.v[2].latent_bits = lbits; c.v[2].lat_start = 0; c.v[2].n_lat = (uint32_t)n;
   if (c.unopt_bins_log > kMaxUnoptBinsLog) c.status = PCO_GFX_UNSUPPORTED;
+  c.c16_ok = c16_enable && mp.delta_kind != kDeltaLookback ? 1u : 0u;   // (lookback reads the full-width primary back)
   ws.chunks[t] = c;
 }
 
@@ -227,7 +230,7 @@ constexpr uint32_t kSplitLdsPrev = 0;                       // L[257][7]: slot 0
 constexpr uint32_t kSplitLdsRed = 257 * 7 * 8;              // u64[4 waves][4]
 constexpr uint32_t kSplitLdsBytes = kSplitLdsRed + 128;
 
-template <class L, int MODE>
+template <class L, int MODE, bool kSpec>
 __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const PcoGfxEncodeTask& task, uint32_t t, EncPage PCO_GLOBAL* pg, uint32_t tile) {
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   const uint64_t n = uni((uint64_t)pg->n), pstart = uni((uint64_t)pg->start);
@@ -240,8 +243,8 @@ __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const Pco
   const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)task.src + pstart;
   const bool lookback = delta_kind == kDeltaLookback;
   // lookback: stage the un-delta'd primary in sort buffer A; enc_lookback_kernel turns it into lat[0] / lat[1]
-  L PCO_GLOBAL* lat1 = (lookback ? sort_ptr<L>(ws, t, 0) : lat_ptr<L>(ws, t, 1)) + pstart;
-  L PCO_GLOBAL* lat2 = has_sec ? lat_ptr<L>(ws, t, 2) + pstart : nullptr;
+  L PCO_GLOBAL* lat1 = kSpec ? nullptr : (lookback ? sort_ptr<L>(ws, t, 0) : lat_ptr<L>(ws, t, 1)) + pstart;
+  L PCO_GLOBAL* lat2 = has_sec && !kSpec ? lat_ptr<L>(ws, t, 2) + pstart : nullptr;
   uint8_t PCO_LDS* smem = enc_lds_base();
   const uint32_t tid = threadIdx.x;
   const uint64_t tile0 = (uint64_t)tile * kSplitTile;
@@ -278,17 +281,18 @@ __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const Pco
   L mn1 = (L)~(L)0, mx1 = 0, mn2 = (L)~(L)0, mx2 = 0;
   L d[kSplitE];
   const L toggle = order > 0 ? lmid<L>() : (L)0;
-  if (full && e0 >= order) {
+#pragma unroll
+  for (uint32_t k = 0; k < kSplitE; k++) d[k] = (L)(a[7 + k] + toggle);
+  if (kSpec) {
+  } else if (full && e0 >= order) {
 #pragma unroll
     for (uint32_t k = 0; k < kSplitE; k++) {
-      d[k] = (L)(a[7 + k] + toggle);
       mn1 = d[k] < mn1 ? d[k] : mn1; mx1 = d[k] > mx1 ? d[k] : mx1;
       if (has_sec) { mn2 = sec[k] < mn2 ? sec[k] : mn2; mx2 = sec[k] > mx2 ? sec[k] : mx2; }
     }
   } else {
 #pragma unroll
     for (uint32_t k = 0; k < kSplitE; k++) {
-      d[k] = (L)(a[7 + k] + toggle);
       const uint64_t i = e0 + k;
       if (i < n) {
         if (i >= order) { mn1 = d[k] < mn1 ? d[k] : mn1; mx1 = d[k] > mx1 ? d[k] : mx1; }   // positions < order are junk (not stored)
@@ -297,7 +301,76 @@ __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const Pco
     }
   }
   if (lookback) { mn1 = (L)~(L)0; mx1 = 0; }   // enc_lookback_kernel owns the primary's range
-  if (full) {
+  if (kSpec) {
+    // Speculative 16-bit latents: most chunks' latents sit within 2^14 of a value known up front (the centre of a delta'd
+    // variable, else the chunk's first latent), and then 2 bytes per latent instead of 8 leave this kernel and enter the
+    // histogram.  A tile that does not fit flags the chunk; enc_split_kernel<false> then rewrites the chunk at full width.
+    // The reference is kept 2^14 away from both ends of the latent type, so that "d - (ref - 2^14) < 2^15" in the type's
+    // modular arithmetic is a statement about numeric distance (the histogram path is chosen from the numeric range);
+    // 8-bit latents always fit and are stored as they are.
+    constexpr L kBias = sizeof(L) == 1 ? (L)0 : (L)16384, kLmax = (L)~(L)0;
+    auto clamp_ref = [&](L x) { return sizeof(L) == 1 ? (L)0 : (x < kBias ? kBias : (x > (L)(kLmax - kBias) ? (L)(kLmax - kBias) : x)); };
+    L ref1 = sizeof(L) == 1 ? (L)0 : toggle, ref2 = 0;
+    if (order == 0 || has_sec) { L p0, s0; split_one<L, MODE>(num_kind, mode_base, mode_k, aux_inv, aux_base, ((const L PCO_GLOBAL*)task.src)[0], p0, s0); if (order == 0) ref1 = clamp_ref(p0); ref2 = clamp_ref(s0); }
+    if (pstart == 0 && e0 == 0) { ch->c16_ref[0] = (uint64_t)ref1; ch->c16_ref[1] = (uint64_t)ref2; }
+    const L lo1 = (L)(ref1 - kBias), lo2 = (L)(ref2 - kBias);
+    uint16_t PCO_GLOBAL* c1 = clat_ptr(ws, t, 1) + pstart;
+    uint16_t PCO_GLOBAL* c2 = has_sec ? clat_ptr(ws, t, 2) + pstart : nullptr;
+    uint32_t bad = 0, rmin1 = 0xffffffffu, rmax1 = 0, rmin2 = 0xffffffffu, rmax2 = 0;
+    uint16_t w1[kSplitE], w2[kSplitE];
+#pragma unroll
+    for (uint32_t k = 0; k < kSplitE; k++) {
+      const uint64_t i = e0 + k;
+      const L t1 = (L)(d[k] - lo1);
+      const uint32_t u1 = (uint32_t)t1;
+      w1[k] = (uint16_t)(u1 - (uint32_t)kBias);
+      if (i < n && i >= order) { if ((uint64_t)t1 >= 32768u) bad = 1; rmin1 = u1 < rmin1 ? u1 : rmin1; rmax1 = u1 > rmax1 ? u1 : rmax1; }
+      if (has_sec) {
+        const L t2 = (L)(sec[k] - lo2);
+        const uint32_t u2 = (uint32_t)t2;
+        w2[k] = (uint16_t)(u2 - (uint32_t)kBias);
+        if (i < n) { if ((uint64_t)t2 >= 32768u) bad = 1; rmin2 = u2 < rmin2 ? u2 : rmin2; rmax2 = u2 > rmax2 ? u2 : rmax2; }
+      }
+    }
+    if (full) {   // one 16-byte store per variable (2-byte aligned: a page may start at an odd index)
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      typedef u32x4 __attribute__((aligned(2))) u32x4_a2;
+      static_assert(kSplitE == 8, "eight 16-bit latents per thread");
+      u32x4 q1; q1.x = w1[0] | ((uint32_t)w1[1] << 16); q1.y = w1[2] | ((uint32_t)w1[3] << 16); q1.z = w1[4] | ((uint32_t)w1[5] << 16); q1.w = w1[6] | ((uint32_t)w1[7] << 16);
+      *(u32x4_a2 PCO_GLOBAL*)(c1 + e0) = q1;
+      if (has_sec) {
+        u32x4 q2; q2.x = w2[0] | ((uint32_t)w2[1] << 16); q2.y = w2[2] | ((uint32_t)w2[3] << 16); q2.z = w2[4] | ((uint32_t)w2[5] << 16); q2.w = w2[6] | ((uint32_t)w2[7] << 16);
+        *(u32x4_a2 PCO_GLOBAL*)(c2 + e0) = q2;
+      }
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < kSplitE; k++) if (e0 + k < n) { c1[e0 + k] = w1[k]; if (has_sec) c2[e0 + k] = w2[k]; }
+    }
+    // range of the tile, on the 32-bit relative values (a tile that does not fit contributes nothing: its chunk is redone)
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+      const uint32_t o1 = __shfl_xor(rmin1, dlt, 64), o2 = __shfl_xor(rmax1, dlt, 64);
+      rmin1 = o1 < rmin1 ? o1 : rmin1; rmax1 = o2 > rmax1 ? o2 : rmax1;
+      if (has_sec) { const uint32_t o3 = __shfl_xor(rmin2, dlt, 64), o4 = __shfl_xor(rmax2, dlt, 64); rmin2 = o3 < rmin2 ? o3 : rmin2; rmax2 = o4 > rmax2 ? o4 : rmax2; }
+    }
+    const uint32_t wbad = __any(bad != 0) ? 1u : 0u;
+    uint32_t PCO_LDS* red32 = (uint32_t PCO_LDS*)(smem + kSplitLdsRed);
+    if (lane_id() == 0) { const uint32_t w = tid >> 6; red32[w * 5 + 0] = rmin1; red32[w * 5 + 1] = rmax1; red32[w * 5 + 2] = rmin2; red32[w * 5 + 3] = rmax2; red32[w * 5 + 4] = wbad; }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t m1 = 0xffffffffu, x1 = 0, m2 = 0xffffffffu, x2 = 0, anybad = 0;
+      for (uint32_t w = 0; w < 4; w++) {
+        m1 = red32[w * 5] < m1 ? red32[w * 5] : m1; x1 = red32[w * 5 + 1] > x1 ? red32[w * 5 + 1] : x1;
+        m2 = red32[w * 5 + 2] < m2 ? red32[w * 5 + 2] : m2; x2 = red32[w * 5 + 3] > x2 ? red32[w * 5 + 3] : x2;
+        anybad |= red32[w * 5 + 4];
+      }
+      if (anybad) atomicCAS(&ws.chunks[t].c16_ok, 1u, 2u);
+      else {
+        if (m1 <= x1) { atomicMin((unsigned long long*)&ws.chunks[t].v[1].minv, (unsigned long long)(L)(lo1 + (L)m1)); atomicMax((unsigned long long*)&ws.chunks[t].v[1].maxv, (unsigned long long)(L)(lo1 + (L)x1)); }
+        if (has_sec && m2 <= x2) { atomicMin((unsigned long long*)&ws.chunks[t].v[2].minv, (unsigned long long)(L)(lo2 + (L)m2)); atomicMax((unsigned long long*)&ws.chunks[t].v[2].maxv, (unsigned long long)(L)(lo2 + (L)x2)); }
+      }
+    }
+  } else if (full) {
 #pragma unroll
     for (uint32_t k = 0; k < kSplitE; k++) lat1[e0 + k] = d[k];
     if (has_sec) {
@@ -319,6 +392,7 @@ __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const Pco
       for (uint32_t jj = 0; jj + 1 < 8; jj++) q[jj] = (L)(q[jj + 1] - q[jj]);
     }
   }
+  if (kSpec) return;
   // min / max: wave reduce, block reduce through LDS, one atomic pair per block
   for (int dlt = 32; dlt >= 1; dlt >>= 1) {
     L o1 = shfl_idx(mn1, (int)(lane_id() ^ dlt)); mn1 = o1 < mn1 ? o1 : mn1;
@@ -342,29 +416,45 @@ __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const Pco
   }
 }
 
-template <class L>
+template <class L, bool kSpec>
 __device__ __forceinline__ void enc_split_mode(const EncWorkspace& ws, const PcoGfxEncodeTask& task, uint32_t t, EncPage PCO_GLOBAL* pg, uint32_t tile, uint32_t mode_kind) {
-  if (mode_kind == kClassic) enc_split_body<L, kClassic>(ws, task, t, pg, tile);
-  else if (mode_kind == kIntMult) enc_split_body<L, kIntMult>(ws, task, t, pg, tile);
-  else if (mode_kind == kFloatQuant) enc_split_body<L, kFloatQuant>(ws, task, t, pg, tile);
-  else enc_split_body<L, kFloatMult>(ws, task, t, pg, tile);
+  if (mode_kind == kClassic) enc_split_body<L, kClassic, kSpec>(ws, task, t, pg, tile);
+  else if (mode_kind == kIntMult) enc_split_body<L, kIntMult, kSpec>(ws, task, t, pg, tile);
+  else if (mode_kind == kFloatQuant) enc_split_body<L, kFloatQuant, kSpec>(ws, task, t, pg, tile);
+  else enc_split_body<L, kFloatMult, kSpec>(ws, task, t, pg, tile);
 }
 
-// grid pages * tiles_per_page, 256 threads
-__global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, uint32_t tiles_per_page) {
-  const uint32_t page = blockIdx.x / tiles_per_page, tile = blockIdx.x % tiles_per_page;
+// grid pages * ceil(tiles_per_page / tiles_per_block), 256 threads.  enc_split_kernel<true>: the chunks that speculate on
+// 16-bit latents (EncChunk::c16_ok == 1).  enc_split_kernel<false>: full-width latents for the chunks whose c16_ok == want --
+// 0: never speculated (launched when the call has such chunks), 2: the speculation failed (launched after the <true> kernel;
+// the blocks of all other chunks leave at once, which several tiles per block keep cheap).
+template <bool kSpec, bool kLoop>
+__global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, uint32_t tiles_per_page, uint32_t tiles_per_block, uint32_t want) {
+  const uint32_t blocks_per_page = kLoop ? (tiles_per_page + tiles_per_block - 1) / tiles_per_block : tiles_per_page;
+  const uint32_t page = blockIdx.x / blocks_per_page, tile0 = (blockIdx.x % blocks_per_page) * (kLoop ? tiles_per_block : 1u);
   EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + page;
   if (uni(pg->flags) & kPageFlagMetaOnly) return;
   const uint32_t t = uni(pg->chunk);
-  const PcoGfxEncodeTask task = tasks[t];
-  if ((uint64_t)tile * kSplitTile >= uni((uint64_t)pg->n)) return;
   if (uni(ws.chunks[t].status) != PCO_GFX_OK) return;
+  if (uni(__hip_atomic_load(&ws.chunks[t].c16_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != want) return;   // (a failed chunk's remaining <true> tiles stop here too)
+  const PcoGfxEncodeTask task = tasks[t];
   const int bits = dtype_bits(uni(task.dtype));
   const uint32_t mode_kind = uni(ws.chunks[t].mode_kind);
-  if (bits == 64) enc_split_mode<uint64_t>(ws, task, t, pg, tile, mode_kind);
-  else if (bits == 32) enc_split_mode<uint32_t>(ws, task, t, pg, tile, mode_kind);
-  else if (bits == 16) enc_split_mode<uint16_t>(ws, task, t, pg, tile, mode_kind);
-  else if (bits == 8) enc_split_mode<uint8_t>(ws, task, t, pg, tile, mode_kind);
+  if (!kLoop) {
+    if ((uint64_t)tile0 * kSplitTile >= uni((uint64_t)pg->n)) return;
+    if (bits == 64) enc_split_mode<uint64_t, kSpec>(ws, task, t, pg, tile0, mode_kind);
+    else if (bits == 32) enc_split_mode<uint32_t, kSpec>(ws, task, t, pg, tile0, mode_kind);
+    else if (bits == 16) enc_split_mode<uint16_t, kSpec>(ws, task, t, pg, tile0, mode_kind);
+    else if (bits == 8) enc_split_mode<uint8_t, kSpec>(ws, task, t, pg, tile0, mode_kind);
+    return;
+  }
+  for (uint32_t tile = tile0; tile < tile0 + tiles_per_block && (uint64_t)tile * kSplitTile < uni((uint64_t)pg->n); tile++) {
+    if (tile != tile0) __syncthreads();   // the tile body reuses its LDS
+    if (bits == 64) enc_split_mode<uint64_t, kSpec>(ws, task, t, pg, tile, mode_kind);
+    else if (bits == 32) enc_split_mode<uint32_t, kSpec>(ws, task, t, pg, tile, mode_kind);
+    else if (bits == 16) enc_split_mode<uint16_t, kSpec>(ws, task, t, pg, tile, mode_kind);
+    else if (bits == 8) enc_split_mode<uint8_t, kSpec>(ws, task, t, pg, tile, mode_kind);
+  }
 }
 
 // =========================================================================================================
@@ -657,22 +747,39 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     {  // counting: 8 loads in flight per thread; the compact copy (x - min, u16) is written on the way
       uint16_t PCO_GLOBAL* clat = clat_ptr(ws, t, var);
       const bool agg = uni((uint32_t)((uint64_t)range < 256 ? 1u : 0u)) != 0;   // (wave-uniform) few distinct values: same-address atomics would serialise, aggregate per wave
+      const bool c16 = uni(ch->c16_ok) == 1;   // the split left 16-bit latents relative to c16_ref (in the compact copy's place)
+      const uint16_t c16_off = (uint16_t)((uint64_t)minv - (uint64_t)ch->c16_ref[var == 2 ? 1 : 0]);
       uint32_t base = 0;
-      for (; base + 8 * T <= n_all; base += 8 * T) {
-        L x[8];
+      if (c16) {
+        for (; base + 8 * T <= n_all; base += 8 * T) {
+          uint16_t x[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = lat[base + k * T + tid];
+          for (int k = 0; k < 8; k++) x[k] = clat[base + k * T + tid];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const uint32_t i = base + k * T + tid;
-          const uint32_t c = (uint32_t)(x[k] - minv);
-          clat[i] = (uint16_t)c;
-          hist_count(counts, c, stored(i), agg);
+          for (int k = 0; k < 8; k++) {
+            const uint32_t i = base + k * T + tid;
+            const uint32_t c = (uint16_t)(x[k] - c16_off);
+            clat[i] = (uint16_t)c;
+            hist_count(counts, c, stored(i), agg);
+          }
+        }
+      } else {
+        for (; base + 8 * T <= n_all; base += 8 * T) {
+          L x[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) x[k] = lat[base + k * T + tid];
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const uint32_t i = base + k * T + tid;
+            const uint32_t c = (uint32_t)(x[k] - minv);
+            clat[i] = (uint16_t)c;
+            hist_count(counts, c, stored(i), agg);
+          }
         }
       }
       for (uint32_t i0 = base; i0 < n_all; i0 += T) {   // whole waves enter hist_count
         const uint32_t i = i0 + tid;
-        const uint32_t c = i < n_all ? (uint32_t)(lat[i] - minv) : 0u;
+        const uint32_t c = i < n_all ? (c16 ? (uint32_t)(uint16_t)(clat[i] - c16_off) : (uint32_t)(lat[i] - minv)) : 0u;
         if (i < n_all) clat[i] = (uint16_t)c;
         hist_count(counts, c, i < n_all && stored(i), agg);
       }
