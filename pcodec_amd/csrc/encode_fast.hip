@@ -508,7 +508,7 @@ struct PackSink {
 };
 
 constexpr uint32_t kPackLdsVar = kPageLdsStg + kStgDwords * 4;   // 2816: per latent slot (lowers u64[256] | offset bits u8[256])
-constexpr uint32_t kPackVarBytes = 2048 + 256;
+constexpr uint32_t kPackVarBytes = 2048 + 256 + 1024;   // lowers u64[256] | offset bits u8[256] | compact latents: lower | offset bits << 16, u32[256]
 __host__ __device__ constexpr uint32_t pack_lds_bytes(uint32_t n_slots) { return kPackLdsVar + n_slots * kPackVarBytes; }
 
 // what one lane holds of one (batch, variable) item: 4 symbols, 4 tANS fields, 4 latents
@@ -540,7 +540,7 @@ __device__ __forceinline__ void pack_load(PackItem& it, const LV PCO_GLOBAL* lat
 
 // pack one item: its tANS fields, then its offset fields (chunk_latent_compressor.rs:134-169)
 template <bool kFull>
-__device__ __forceinline__ void pack_item_t(PackSink& sink, const uint8_t PCO_LDS* vt, const PackItem& it, uint32_t cnt, uint32_t asl, bool needs_ans, uint32_t max_ob, bool single_bin) {
+__device__ __forceinline__ void pack_item_t(PackSink& sink, const uint8_t PCO_LDS* vt, const PackItem& it, uint32_t cnt, uint32_t asl, bool needs_ans, uint32_t max_ob, bool single_bin, bool compact) {
   const uint32_t lane = lane_id();
   const uint64_t PCO_LDS* low = (const uint64_t PCO_LDS*)vt;
   const uint8_t PCO_LDS* obs = vt + 2048;
@@ -561,7 +561,20 @@ __device__ __forceinline__ void pack_item_t(PackSink& sink, const uint8_t PCO_LD
     sink.put(incl - accbits, acc, accbits);  // <= 48 bits
     sink.commit(wave_last(incl));
   }
-  if (max_ob != 0) {
+  if (max_ob != 0 && compact) {   // 16-bit latents relative to the minimum: one packed table word per symbol, 32-bit arithmetic, one put
+    const uint32_t PCO_LDS* cpk = (const uint32_t PCO_LDS*)(vt + 2304);
+    uint64_t acc = 0; uint32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t e = cpk[(syms >> (8 * k)) & 0xffu];
+      const uint32_t o = (kFull || 4 * lane + k < cnt) ? e >> 16 : 0u;
+      acc |= (uint64_t)__builtin_amdgcn_ubfe((uint32_t)it.x[k] - (e & 0xffffu), 0u, o) << t;
+      t += o;
+    }
+    const uint32_t incl = wave_incl_scan(t);
+    sink.put(incl - t, acc, t);
+    sink.commit(wave_last(incl));
+  } else if (max_ob != 0) {
     uint32_t ob[4]; uint64_t x[4]; uint32_t t = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -585,9 +598,9 @@ __device__ __forceinline__ void pack_item_t(PackSink& sink, const uint8_t PCO_LD
     sink.commit(wave_last(incl));
   }
 }
-__device__ __forceinline__ void pack_item(PackSink& sink, const uint8_t PCO_LDS* vt, const PackItem& it, uint32_t cnt, uint32_t asl, bool needs_ans, uint32_t max_ob, bool single_bin) {
-  if (cnt == kBatchN) pack_item_t<true>(sink, vt, it, cnt, asl, needs_ans, max_ob, single_bin);
-  else pack_item_t<false>(sink, vt, it, cnt, asl, needs_ans, max_ob, single_bin);
+__device__ __forceinline__ void pack_item(PackSink& sink, const uint8_t PCO_LDS* vt, const PackItem& it, uint32_t cnt, uint32_t asl, bool needs_ans, uint32_t max_ob, bool single_bin, bool compact) {
+  if (cnt == kBatchN) pack_item_t<true>(sink, vt, it, cnt, asl, needs_ans, max_ob, single_bin, compact);
+  else pack_item_t<false>(sink, vt, it, cnt, asl, needs_ans, max_ob, single_bin, compact);
 }
 
 template <class L>
@@ -662,7 +675,11 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
     const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
     uint8_t PCO_LDS* vt = smem + kPackLdsVar + ws.slot_of_var[v] * kPackVarBytes;
     const uint64_t rel0 = pv[v].compact ? pv[v].minv : 0ull;   // compact latents are relative to the minimum
-    for (uint32_t b = lane; b < pv[v].n_bins; b += 64) { ((uint64_t PCO_LDS*)vt)[b] = plan->blower[b] - rel0; (vt + 2048)[b] = plan->bob[b]; }
+    for (uint32_t b = lane; b < pv[v].n_bins; b += 64) {
+      const uint64_t lw = plan->blower[b] - rel0; const uint32_t ob = plan->bob[b];
+      ((uint64_t PCO_LDS*)vt)[b] = lw; (vt + 2048)[b] = (uint8_t)ob;
+      if (pv[v].compact) ((uint32_t PCO_LDS*)(vt + 2304))[b] = ((uint32_t)lw & 0xffffu) | (ob << 16);
+    }
   }
   enc_wave_sync();
   // batches of the run; the next batch's loads are issued before the current one is packed
@@ -688,7 +705,7 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
     for (int v = 0; v < 3; v++) {
       if (!on[v] || base >= pv[v].n_lat) continue;
       const uint32_t cnt = pv[v].n_lat - base < kBatchN ? pv[v].n_lat - base : kBatchN;
-      pack_item(sink, smem + kPackLdsVar + ws.slot_of_var[v] * kPackVarBytes, cur[v], cnt, pv[v].asl, pv[v].needs_ans != 0, pv[v].max_ob, pv[v].n_bins <= 1);
+      pack_item(sink, smem + kPackLdsVar + ws.slot_of_var[v] * kPackVarBytes, cur[v], cnt, pv[v].asl, pv[v].needs_ans != 0, pv[v].max_ob, pv[v].n_bins <= 1, pv[v].compact != 0);
     }
 #pragma unroll
     for (int v = 0; v < 3; v++) cur[v] = nxt[v];
