@@ -625,7 +625,7 @@ __device__ __forceinline__ void expand_prefetch(ExpPre& pre, gcptr_u8 src, uint6
 // Turn a prefetched item into latents: bins from the symbols, offsets from the staged section (page_latent_decompressor.rs:15-44,179-213).
 template <class LV>
 __device__ __forceinline__ void expand_item(const ExpPre& pre, uint32_t PCO_LDS* stg, gcptr_u8 src, uint64_t src_len, uint64_t start_bit, uint32_t need_bits, uint32_t cnt,
-                                            const uint64_t PCO_LDS* lowers, const uint8_t PCO_LDS* obs, bool single_bin, LV out[4]) {
+                                            const uint64_t PCO_LDS* lowers, const uint8_t PCO_LDS* obs, bool single_bin, uint32_t max_ob, LV out[4]) {
   const uint32_t lane = lane_id();
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   if (need_bits != 0) {
@@ -654,6 +654,18 @@ __device__ __forceinline__ void expand_item(const ExpPre& pre, uint32_t PCO_LDS*
   }
   const uint32_t incl = wave_incl_scan(t);
   uint32_t r = (uint32_t)(start_bit & 31) + incl - t;
+  if (need_bits != 0 && max_ob <= 16) {   // the lane's four fields span at most 64 bits: one window fetch (three dwords), fields cut from registers
+    const uint32_t d = r >> 5;
+    const uint32_t w0 = stg[d], w1 = stg[d + 1], w2 = stg[d + 2];
+    uint64_t v64 = (uint64_t)__builtin_amdgcn_alignbit(w1, w0, r) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, r) << 32);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      out[k] = (LV)(low[k] + (LV)__builtin_amdgcn_ubfe((uint32_t)v64, 0u, ob[k]));
+      v64 >>= ob[k];
+    }
+    wave_sync_lds();   // the staging area is reused by the next item
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     LV val = 0;
@@ -788,12 +800,12 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
         const bool single_bin = n_bins[v] <= 1;
         if (v == 0) {
           uint32_t tmp[4];
-          if (max_ob[0] != 0 || !single_bin) expand_item<uint32_t>(pre[0], stg, src, src_len, st_cur[0], cnt * max_ob[0], cnt, lowers, obs, single_bin, tmp);
+          if (max_ob[0] != 0 || !single_bin) expand_item<uint32_t>(pre[0], stg, src, src_len, st_cur[0], cnt * max_ob[0], cnt, lowers, obs, single_bin, max_ob[0], tmp);
           else { const uint32_t l0 = (uint32_t)lowers[0]; for (int k = 0; k < 4; k++) tmp[k] = l0; }
           for (int k = 0; k < 4; k++) dlat[4 * lane + k] = 4 * lane + k < cnt ? tmp[k] : 0u;
         } else {
           L tmp[4];
-          if (max_ob[v] != 0 || !single_bin) expand_item<L>(pre[sl], stg, src, src_len, st_cur[sl], cnt * max_ob[v], cnt, lowers + v * 256, obs + v * 256, single_bin, tmp);
+          if (max_ob[v] != 0 || !single_bin) expand_item<L>(pre[sl], stg, src, src_len, st_cur[sl], cnt * max_ob[v], cnt, lowers + v * 256, obs + v * 256, single_bin, max_ob[v], tmp);
           else { const L l0 = (L)lowers[v * 256]; for (int k = 0; k < 4; k++) tmp[k] = 4 * lane + k < cnt ? l0 : (L)0; }
           if (v == 1) { for (int k = 0; k < 4; k++) prim[k] = tmp[k]; prim_cnt = cnt; } else { for (int k = 0; k < 4; k++) sec[k] = tmp[k]; }
         }
