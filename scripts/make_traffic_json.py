@@ -1,0 +1,52 @@
+"""profiles/<tag>_traffic.json from the two PMC passes of scripts/profile_round.sh (pmc_FETCH_SIZE.txt, pmc_WRITE_SIZE.txt).
+
+usage: make_traffic_json.py <dir with the pmc_*.txt> <chunks> <workload> <out.json> <out.txt>
+Counters are kilobytes per dispatch; FETCH_SIZE is doubled (gfx950 note, MI355X_MICROARCH.md HBM section).  Kernel names are
+mapped to the names bench.py reports (the library's launch-timer labels)."""
+import json
+import re
+import sys
+
+d, chunks, workload, out_json, out_txt = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+TY = {"unsigned long": "u64", "unsigned int": "u32", "unsigned short": "u16", "unsigned char": "u8"}
+
+
+def label(name):
+    name = name.strip()
+    m = re.match(r"dec_walk_kernel<(.*), (\d)u>", name)
+    if m:
+        return ("dec_walk_kernel" if m.group(2) == "8" else "dec_walk4_kernel") + f"<{TY.get(m.group(1), m.group(1))}>"
+    m = re.match(r"(dec_expand_kernel|pco_decode_kernel)<(.*)>", name)
+    if m:
+        return f"{m.group(1)}<{TY.get(m.group(2), m.group(2))}>"
+    if name.startswith("enc_walk_kernel"):
+        return "enc_walk_kernel"
+    if name.startswith("enc_split_kernel"):
+        return {"<true, false>": "enc_split_kernel<c16>", "<false, true>": "enc_split_kernel(redo)"}.get(name[len("enc_split_kernel"):], "enc_split_kernel")
+    m = re.match(r"enc_hist_wide_kernel<(\d+)u>", name)
+    if m:
+        return f"enc_hist_wide_kernel<{m.group(1)}>"
+    return name
+
+
+def parse(path):
+    rows = {}
+    for line in open(path):
+        m = re.match(r"^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.e+]+)\s+\(", line)
+        if m and not line.startswith("kernel"):
+            rows[label(m.group(1))] = (float(m.group(4)), float(m.group(3)))
+    return rows
+
+
+f, w = parse(f"{d}/pmc_FETCH_SIZE.txt"), parse(f"{d}/pmc_WRITE_SIZE.txt")
+kern = {}
+for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, (0, 0))[1])):
+    kern[k] = {"fetch_bytes_per_launch": int(2 * f.get(k, (0, 0))[0] * 1000), "write_bytes_per_launch": int(w.get(k, (0, 0))[0] * 1000)}
+json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --chunks {chunks} "
+                     "--no-cpu-baseline; counters are kilobytes per dispatch; FETCH_SIZE doubled (gfx950 note, MI355X_MICROARCH.md HBM section)",
+           "chunks": chunks, "workload": workload, "kernels": kern}, open(out_json, "w"), indent=1)
+with open(out_txt, "w") as o:
+    o.write(open(f"{d}/pmc_FETCH_SIZE.txt").read()); o.write(open(f"{d}/pmc_WRITE_SIZE.txt").read())
+    o.write("\nper launch, bytes (FETCH_SIZE x 2 x 1000, WRITE_SIZE x 1000):\n")
+    for k, v in kern.items():
+        o.write(f"{k.ljust(34)} fetch {v['fetch_bytes_per_launch'] / 1e9:8.3f} GB  write {v['write_bytes_per_launch'] / 1e9:8.3f} GB\n")

@@ -17,3 +17,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
   python3 $ROOT/scripts/pmc_summary.py "$DB" > $OUT/pmc_$C.txt
   cat $OUT/pmc_$C.txt
 done
+python3 $ROOT/scripts/make_traffic_json.py $OUT $CH c2 $OUT/traffic.json $OUT/pmc_hbm_traffic.txt
