@@ -1,0 +1,129 @@
+"""The pcodec-style Python surface (pcodec_amd.{standalone,wrapped}) exercised the way the reference's own Python tests do it
+(pco_python/test/test_standalone.py, test_wrapped.py), on the GPU, with the oracle as the byte-level checker."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, ".."))
+
+pytestmark = pytest.mark.gpu
+
+ALL_DTYPES = ("f2", "f4", "f8", "i2", "i4", "i8", "u2", "u4", "u8")
+
+
+def cfg_for(P, dtype, **kw):
+    """The default ChunkConfig, except that ModeSpec::Auto on f16 is an open gap (refused loudly): f16 is compressed Classic."""
+    if dtype == "f2":
+        kw["mode_spec"] = P.ModeSpec.classic()
+    return P.ChunkConfig(**kw)
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pcodec_amd as P
+    from pcodec_amd import _lib as G
+    assert G.lib().pco_gfx_device_count() >= 1, "these tests need an MI355X; the product has no CPU path"
+    return P
+
+
+@pytest.mark.parametrize("length", (0, 900))
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_round_trip_decompress_into(P, length, dtype):   # test_standalone.py:24-36
+    rng = np.random.default_rng(12345)
+    data = rng.uniform(0, 1000, size=length).astype(dtype)
+    compressed = P.standalone.simple_compress(data, cfg_for(P, dtype))
+    out = np.empty_like(data)
+    progress = P.standalone.simple_decompress_into(compressed, out)
+    np.testing.assert_array_equal(data, out)
+    assert progress.n_processed == data.size and progress.finished
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_round_trip_simple_decompress_paged(P, dtype):   # test_standalone.py:39-47
+    rng = np.random.default_rng(7)
+    data = rng.uniform(0, 1000, size=900).astype(dtype)
+    compressed = P.standalone.simple_compress(data, cfg_for(P, dtype, paging_spec=P.PagingSpec.equal_pages_up_to(300)))
+    np.testing.assert_array_equal(data, P.standalone.simple_decompress(compressed))
+
+
+def test_inexact_decompression_and_type_mismatch(P):   # test_standalone.py:50-78
+    rng = np.random.default_rng(3)
+    data = rng.uniform(size=300)
+    compressed = P.standalone.simple_compress(data, P.ChunkConfig())
+    out = np.zeros(3)
+    progress = P.standalone.simple_decompress_into(compressed, out)
+    np.testing.assert_array_equal(out, data[:3])
+    assert progress.n_processed == 3 and not progress.finished
+    out = np.zeros(600)
+    progress = P.standalone.simple_decompress_into(compressed, out)
+    np.testing.assert_array_equal(out[:300], data)
+    np.testing.assert_array_equal(out[300:], np.zeros(300))
+    assert progress.n_processed == 300 and progress.finished
+    with pytest.raises(RuntimeError, match="does not match chunk's number type"):
+        P.standalone.simple_decompress_into(P.standalone.simple_compress(data.astype(np.float32), P.ChunkConfig()), np.zeros(100))
+
+
+def test_compression_options(P):   # test_standalone.py:117-172 (Dict and Conv1 are outside the hot-path scope: refused loudly)
+    from pcodec_amd import _lib as G
+    rng = np.random.default_rng(5)
+    data = rng.normal(size=100).astype(np.float32)
+    default_size = len(P.standalone.simple_compress(data, P.ChunkConfig()))
+    for delta_spec in (P.DeltaSpec.no_op(), P.DeltaSpec.try_consecutive(1), P.DeltaSpec.try_lookback()):
+        compressed = P.standalone.simple_compress(data, P.ChunkConfig(compression_level=0, delta_spec=delta_spec, mode_spec=P.ModeSpec.classic(),
+                                                                      paging_spec=P.PagingSpec.equal_pages_up_to(77)))
+        np.testing.assert_array_equal(data, P.standalone.simple_decompress(compressed))
+        assert len(compressed) >= default_size
+    ints = (rng.normal(size=100) * 1000).astype(np.int32)
+    for mode_spec in (P.ModeSpec.auto(), P.ModeSpec.classic(), P.ModeSpec.try_int_mult(10)):
+        np.testing.assert_array_equal(ints, P.standalone.simple_decompress(P.standalone.simple_compress(ints, P.ChunkConfig(mode_spec=mode_spec))))
+    floats = (rng.normal(size=100) * 1000).astype(np.int32) * np.pi
+    for mode_spec in (P.ModeSpec.auto(), P.ModeSpec.classic(), P.ModeSpec.try_float_mult(10.0), P.ModeSpec.try_float_quant(4)):
+        np.testing.assert_array_equal(floats, P.standalone.simple_decompress(P.standalone.simple_compress(floats, P.ChunkConfig(mode_spec=mode_spec))))
+    for cfg in (P.ChunkConfig(mode_spec=P.ModeSpec.try_dict()), P.ChunkConfig(delta_spec=P.DeltaSpec.try_conv1(1))):
+        with pytest.raises(G.PcoGfxError) as ei:
+            P.standalone.simple_compress(ints, cfg)
+        assert ei.value.status == G.ST_UNSUPPORTED
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_wrapped_compress(P, dtype):   # test_wrapped.py:11-52, with EqualPagesUpTo paging (6 + 4 numbers -> 2 pages of 5)
+    import oracle_lib as O
+    from pcodec_amd.wrapped import FileCompressor, FileDecompressor
+    rng = np.random.default_rng(12345)
+    data = rng.uniform(0, 1000, size=[10]).astype(dtype)
+    pco_number_type = dtype[0].upper() + str(int(dtype[1]) * 8)
+    fc = FileCompressor()
+    header = fc.write_header()
+    cc = fc.chunk_compressor(data, cfg_for(P, dtype, paging_spec=P.PagingSpec.equal_pages_up_to(6)))
+    assert cc.n_per_page() == [5, 5]
+    chunk_meta = cc.write_meta()
+    page0, page1 = cc.write_page(0), cc.write_page(1)
+    with pytest.raises(RuntimeError, match="page idx exceeds num pages"):
+        cc.write_page(2)
+    want_meta, want_pages, want_ns = O.wrapped_compress(data, O.make_config(max_page_n=6, **({"mode": 1} if dtype == "f2" else {})))
+    assert (chunk_meta, [page0, page1], [5, 5]) == (want_meta, want_pages, want_ns)
+    fd, n_bytes_read = FileDecompressor.new(header)
+    assert n_bytes_read == len(header)
+    _, n_bytes_read = FileDecompressor.new(header + b"foo")   # undershooting is fine
+    assert n_bytes_read == len(header)
+    cd, n_bytes_read = fd.chunk_decompressor(chunk_meta, pco_number_type)
+    assert n_bytes_read == len(chunk_meta)
+    dst1 = np.zeros(100).astype(dtype)
+    _progress, n_bytes_read = cd.read_page_into(page1, 5, dst1)
+    np.testing.assert_array_equal(dst1[5:], np.zeros(95))
+    np.testing.assert_array_equal(dst1[:5], data[5:])
+    assert n_bytes_read == len(page1)
+    dst0 = np.zeros(5).astype(dtype)
+    _progress, n_bytes_read = cd.read_page_into(page0, 5, dst0)
+    np.testing.assert_array_equal(dst0, data[:5])
+    assert n_bytes_read == len(page0)
+
+
+def test_argument_errors(P):   # test_standalone.py:185-199
+    rng = np.random.default_rng(1)
+    with pytest.raises(TypeError, match="1D"):
+        P.standalone.simple_compress(rng.normal(size=[10, 11]), P.ChunkConfig())
