@@ -472,17 +472,17 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
 #ifndef PCO_WALK_NO_TOUCH
     // Warm the L2 with the lines this chunk's NEXT round will stage (its position is only known after this walk; the staging
     // loads otherwise wait ~1600 cycles on HBM every round): predicted start = this start + the previous stride, and the
-    // chunk's four lanes touch eight 128-byte lines around it.  The loads are fire-and-forget inline asm (the compiler would
-    // wait for a C++ load's value here); their target registers are kept reserved until the next round's staging loads
-    // have been waited for, which -- VMEM returning in order -- is after they landed.
-    asm volatile("" :: "v"(touch_r0), "v"(touch_r1));
+    // chunk's four lanes touch eight 128-byte lines around it.  The loaded values get their (dummy) use one round later,
+    // right here, where this round's staging loads have already been waited for -- VMEM returns in order, so that use
+    // never waits.
+    ((uint32_t PCO_LDS*)(lds_base() + WalkCfg<kWQ>::kWalkTmpOff))[lane] = touch_r0 ^ touch_r1;   // (the table-build scratch is idle during the walk)
     if (walk) {
       const uint64_t cur = q0 * 8, pred = cur + (cur - touch_prev);
       touch_prev = cur;
       const uint64_t line0 = (pred & ~(uint64_t)127) - (pred >= 128 ? 128u : 0u);
       const uint64_t a0 = line0 + 128u * j, a1 = a0 + 512u;
-      const uint8_t PCO_GLOBAL* p0 = my_src + (a0 + 4 <= my_len ? a0 : 0), * p1 = my_src + (a1 + 4 <= my_len ? a1 : 0);
-      asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(touch_r0), "=&v"(touch_r1) : "v"(p0), "v"(p1));
+      touch_r0 = load_u32_le(my_src + (a0 + 4 <= my_len ? a0 : 0));
+      touch_r1 = load_u32_le(my_src + (a1 + 4 <= my_len ? a1 : 0));
     }
 #endif
 #ifdef PCO_WALK_TIMING

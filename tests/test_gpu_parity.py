@@ -305,27 +305,29 @@ def test_batched_device_api_mixed_dtypes(L):
         elif k == 1: a = rng.standard_normal(n).astype(np.float32)
         else: a = (rng.pareto(0.5, n) * 10).clip(0, 2e9).astype(np.int32)
         arrays.append(a)
-    kw = dict(mode=1, delta=2, delta_order=1)
-    gcfg = G.make_config(**kw)
     srcs = [torch.from_numpy(a.view(np.uint8)).cuda() for a in arrays]
     caps = [(L.pco_gfx_guarantee_chunk_size(a.size, G.DTYPE_BYTE[a.dtype.name]) + 64 + 15) // 16 * 16 for a in arrays]
-    dsts = [torch.zeros(c, dtype=torch.uint8, device="cuda") for c in caps]
-    tasks = (G.EncodeTask * len(arrays))(*[G.EncodeTask(s.data_ptr(), a.size, d.data_ptr(), c, G.DTYPE_BYTE[a.dtype.name], 0)
-                                           for a, s, d, c in zip(arrays, srcs, dsts, caps)])
-    res = (G.TaskResult * len(arrays))()
-    G.check(L.pco_gfx_compress_chunks(len(arrays), tasks, C.byref(gcfg), res, None, None))
-    outs = [torch.empty(a.nbytes, dtype=torch.uint8, device="cuda") for a in arrays]
-    dtasks = (G.DecodeTask * len(arrays))(*[G.DecodeTask(d.data_ptr(), res[i].n_out, o.data_ptr(), a.size, G.DTYPE_BYTE[a.dtype.name], 0)
-                                            for i, (a, d, o) in enumerate(zip(arrays, dsts, outs))])
-    dres = (G.TaskResult * len(arrays))()
-    G.check(L.pco_gfx_decompress_chunks(len(arrays), dtasks, dres, None, None))
-    for i, a in enumerate(arrays):
-        want = O.simple_compress(a, O.make_config(**kw))
-        got = bytes(dsts[i][: res[i].n_out].cpu().numpy())
-        hdr = len(want) - 1 - len(got)
-        assert got == want[hdr:-1], i
-        assert dres[i].n_out == a.size and dres[i].consumed == res[i].n_out
-        assert U.bits_equal(outs[i].cpu().numpy().view(a.dtype), a), i
+    # explicit consecutive delta (16-bit latents hold for the ramps and fail for the rest: both split passes in one call), the
+    # Auto specs (per-chunk deltas, lookback among them: chunks that never speculate next to chunks that do), lookback for all
+    for kw in (dict(mode=1, delta=2, delta_order=1), dict(), dict(mode=1, delta=3)):
+        gcfg = G.make_config(**kw)
+        dsts = [torch.zeros(c, dtype=torch.uint8, device="cuda") for c in caps]
+        tasks = (G.EncodeTask * len(arrays))(*[G.EncodeTask(s.data_ptr(), a.size, d.data_ptr(), c, G.DTYPE_BYTE[a.dtype.name], 0)
+                                               for a, s, d, c in zip(arrays, srcs, dsts, caps)])
+        res = (G.TaskResult * len(arrays))()
+        G.check(L.pco_gfx_compress_chunks(len(arrays), tasks, C.byref(gcfg), res, None, None))
+        outs = [torch.empty(a.nbytes, dtype=torch.uint8, device="cuda") for a in arrays]
+        dtasks = (G.DecodeTask * len(arrays))(*[G.DecodeTask(d.data_ptr(), res[i].n_out, o.data_ptr(), a.size, G.DTYPE_BYTE[a.dtype.name], 0)
+                                                for i, (a, d, o) in enumerate(zip(arrays, dsts, outs))])
+        dres = (G.TaskResult * len(arrays))()
+        G.check(L.pco_gfx_decompress_chunks(len(arrays), dtasks, dres, None, None))
+        for i, a in enumerate(arrays):
+            want = O.simple_compress(a, O.make_config(**kw))
+            got = bytes(dsts[i][: res[i].n_out].cpu().numpy())
+            hdr = len(want) - 1 - len(got)
+            assert got == want[hdr:-1], (kw, i)
+            assert dres[i].n_out == a.size and dres[i].consumed == res[i].n_out
+            assert U.bits_equal(outs[i].cpu().numpy().view(a.dtype), a), (kw, i)
     # a .pco file assembled from device-produced chunks with the library's framing == the oracle's file
     a = arrays[0]
     hdr = np.zeros(32, np.uint8); k = L.pco_gfx_write_standalone_header(hdr.ctypes.data_as(C.c_void_p), 32, a.size, 0)
