@@ -919,11 +919,21 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     const uint32_t w_end = (wave + 1) * q < n_in ? (wave + 1) * q : n_in;
     for (uint32_t i = tid; i < 1024; i += 256) cnt[i] = 0;
     __syncthreads();
-    for (uint32_t i = w_begin + lane; i < w_end; i += 64) {
-      const L x = in[i];
-      if (p == 0 && (!stored(i) || !needed(x))) continue;
+    auto count_one = [&](uint32_t i, L x) {
+      if (p == 0 && (!stored(i) || !needed(x))) return;
       const uint32_t d = (uint32_t)(((L)(x - minv)) >> shift) & 255u;
       atomicAdd((uint32_t*)&cnt[wave * 256 + d], 1u);
+    };
+    {
+      uint32_t i0 = w_begin;
+      for (; i0 + 8 * 64 <= w_end; i0 += 8 * 64) {   // 8 loads in flight per lane (a wave has only three others to hide behind)
+        L x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = in[i0 + 64 * k + lane];
+#pragma unroll
+        for (int k = 0; k < 8; k++) count_one(i0 + 64 * k + lane, x[k]);
+      }
+      for (uint32_t i = i0 + lane; i < w_end; i += 64) count_one(i, in[i]);
     }
     __syncthreads();
     {  // thread = digit: exclusive scan over digits of the per-digit totals, then per-wave bases
@@ -938,13 +948,12 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     }
     __syncthreads();
     uint32_t PCO_LDS* mycur = cursor + wave * 256;
-    for (uint32_t i0 = w_begin; i0 < w_end; i0 += 64) {
+    auto scatter_group = [&](uint32_t i0, L x) {   // 64 consecutive elements, in order: match-any ranking within the wave
       const uint32_t i = i0 + lane;
-      const L x = i < w_end ? in[i] : (L)0;
       const bool act = i < w_end && (p != 0 || (stored(i) && needed(x)));
       const uint32_t d = act ? ((uint32_t)(((L)(x - minv)) >> shift) & 255u) : 0xffffffffu;
       uint64_t m = __ballot(act);
-      if (m == 0) continue;
+      if (m == 0) return;
 #pragma unroll
       for (uint32_t bit = 0; bit < 8; bit++) { const uint64_t bm = __ballot((d >> bit) & 1); m &= ((d >> bit) & 1) ? bm : ~bm; }
       const uint64_t lt = ((uint64_t)1 << lane) - 1;
@@ -954,6 +963,17 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
       if (act && rank == 0) mycur[d] = basec + gcount;
       enc_wave_sync();
       if (act) out[basec + rank] = x;
+    };
+    {
+      uint32_t i0 = w_begin;
+      for (; i0 + 8 * 64 <= w_end; i0 += 8 * 64) {   // the loads of eight groups are issued together, the groups still scatter in order
+        L x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = in[i0 + 64 * k + lane];
+#pragma unroll
+        for (int k = 0; k < 8; k++) scatter_group(i0 + 64 * k, x[k]);
+      }
+      for (; i0 < w_end; i0 += 64) scatter_group(i0, i0 + lane < w_end ? in[i0 + lane] : (L)0);
     }
     __threadfence_block();
     __syncthreads();
