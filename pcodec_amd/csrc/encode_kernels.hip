@@ -907,20 +907,48 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   auto needed = [&](L x) { const uint32_t k = bucket_of(x); return !subset || ((need[k >> 5] >> (k & 31)) & 1u) != 0; };
   const uint32_t n_sort = subset ? n_sub : n_lat;
   __syncthreads();
-  // (3) stable LSD radix sort of the marked buckets' latents
+  // (3a) gather the marked buckets' latents into sort buffer B, in any order (the keys carry no payload, so only the
+  //      radix passes themselves have to be stable): one more read of the variable instead of two by the first pass
+  if (subset) {
+    uint32_t PCO_LDS* fill = scan + 32;
+    if (tid == 0) *fill = 0;
+    __syncthreads();
+    auto gather_group = [&](uint32_t i, L x, bool in_range) {
+      const bool act = in_range && stored(i) && needed(x);
+      const uint64_t m = __ballot(act);
+      if (m == 0) return;
+      uint32_t base0 = 0;
+      if (lane == 0) base0 = atomicAdd((uint32_t*)fill, (uint32_t)__popcll(m));
+      base0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)base0);
+      if (act) bufB[base0 + __popcll(m & (((uint64_t)1 << lane) - 1))] = x;
+    };
+    uint32_t i0 = 0;
+    for (; i0 + 8 * 256 <= n_all; i0 += 8 * 256) {
+      L x[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) x[k] = lat[i0 + 256 * k + tid];
+#pragma unroll
+      for (int k = 0; k < 8; k++) gather_group(i0 + 256 * k + tid, x[k], true);
+    }
+    for (; i0 < n_all; i0 += 256) { const uint32_t i = i0 + tid; gather_group(i, i < n_all ? lat[i] : (L)0, i < n_all); }
+    __threadfence_block();
+    __syncthreads();
+  }
+  // (3) stable LSD radix sort of those latents
   for (uint32_t p = 0; p < npass; p++) {
-    const L PCO_GLOBAL* in = p == 0 ? lat : ((p & 1) ? bufA : bufB);
+    const L PCO_GLOBAL* in = p == 0 ? (subset ? bufB : lat) : ((p & 1) ? bufA : bufB);
     L PCO_GLOBAL* out = (p & 1) ? bufB : bufA;
     const uint32_t shift = 8 * p;
-    // pass 0 reads the page-structured latent array (skipping each page's junk prefix and unmarked buckets); later passes are dense
-    const uint32_t n_in = p == 0 ? n_all : n_sort;
+    // without the gather (never in practice) pass 0 reads the page-structured latent array, skipping each page's junk prefix
+    const bool raw0 = p == 0 && !subset;
+    const uint32_t n_in = raw0 ? n_all : n_sort;
     const uint32_t q = (n_in + 3) / 4;       // per-wave contiguous quarter (keeps the scatter stable)
     const uint32_t w_begin = wave * q < n_in ? wave * q : n_in;
     const uint32_t w_end = (wave + 1) * q < n_in ? (wave + 1) * q : n_in;
     for (uint32_t i = tid; i < 1024; i += 256) cnt[i] = 0;
     __syncthreads();
     auto count_one = [&](uint32_t i, L x) {
-      if (p == 0 && (!stored(i) || !needed(x))) return;
+      if (raw0 && !stored(i)) return;
       const uint32_t d = (uint32_t)(((L)(x - minv)) >> shift) & 255u;
       atomicAdd((uint32_t*)&cnt[wave * 256 + d], 1u);
     };
@@ -950,7 +978,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     uint32_t PCO_LDS* mycur = cursor + wave * 256;
     auto scatter_group = [&](uint32_t i0, L x) {   // 64 consecutive elements, in order: match-any ranking within the wave
       const uint32_t i = i0 + lane;
-      const bool act = i < w_end && (p != 0 || (stored(i) && needed(x)));
+      const bool act = i < w_end && (!raw0 || stored(i));
       const uint32_t d = act ? ((uint32_t)(((L)(x - minv)) >> shift) & 255u) : 0xffffffffu;
       uint64_t m = __ballot(act);
       if (m == 0) return;
