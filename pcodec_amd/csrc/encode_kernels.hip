@@ -89,6 +89,7 @@ struct EncWorkspace {
   uint32_t n_slots;         // latent slots allocated per task
   uint32_t slot_of_var[3];  // slot index per var (0xffffffff = not allocated)
   uint32_t* need_sort;      // device flag: some variable's value range is >= kWideHistRange (enc_hist_sort_kernel and the sort buffers are needed)
+  uint32_t* need_full0;     // device counter: chunks that enc_presample_kernel took out of the 16-bit speculation
 };
 
 __device__ __forceinline__ uint8_t PCO_LDS* enc_lds_base() {
@@ -455,6 +456,64 @@ __global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const P
     else if (bits == 16) enc_split_mode<uint16_t, kSpec>(ws, task, t, pg, tile, mode_kind);
     else if (bits == 8) enc_split_mode<uint8_t, kSpec>(ws, task, t, pg, tile, mode_kind);
   }
+}
+
+// One wave per chunk: would the chunk's latents fit 16 bits?  64 sampled positions are split and differenced the way the
+// tiles do it; if one of them is out of range the chunk is taken out of the speculation up front (c16_ok = 0: it goes
+// through the full-width kernel once) instead of being split twice.  A sample that fits proves nothing -- the tiles check
+// every latent.  Single-page chunks of at least 4096 numbers only (pages break the difference at their starts).
+template <class L, int MODE>
+__device__ __forceinline__ bool presample_bad(const PcoGfxEncodeTask& task, const EncChunk PCO_GLOBAL* ch) {
+  const uint32_t lane = lane_id();
+  const uint32_t num_kind = dtype_kind(uni(task.dtype));
+  const uint32_t mode_k = uni(ch->mode_k);
+  const L mode_base = (L)uni((uint64_t)ch->mode_base); const uint64_t aux_inv = uni((uint64_t)ch->mode_aux), aux_base = uni((uint64_t)ch->mode_aux2);
+  const uint32_t order = uni(ch->delta_kind) == kDeltaConsecutive ? uni(ch->delta_order) : 0;
+  constexpr bool has_sec = MODE != kClassic;
+  const uint64_t n = uni((uint64_t)ch->n);
+  const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)task.src;
+  constexpr L kBias = sizeof(L) == 1 ? (L)0 : (L)16384, kLmax = (L)~(L)0;
+  if (sizeof(L) == 1) return false;
+  auto clamp_ref = [&](L x) { return x < kBias ? kBias : (x > (L)(kLmax - kBias) ? (L)(kLmax - kBias) : x); };
+  L ref1 = order > 0 ? lmid<L>() : (L)0, ref2 = 0;
+  if (order == 0 || has_sec) { L p0, s0; split_one<L, MODE>(num_kind, mode_base, mode_k, aux_inv, aux_base, src[0], p0, s0); if (order == 0) ref1 = clamp_ref(p0); ref2 = clamp_ref(s0); }
+  const uint64_t pos = (uint64_t)lane * ((n - 8) / 64);   // order <= 7: positions pos .. pos + order are inside the chunk
+  L a[8];
+  L sec_last = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 8; k++) { L pp = 0, ss = 0; if (k <= order) split_one<L, MODE>(num_kind, mode_base, mode_k, aux_inv, aux_base, src[pos + k], pp, ss); a[k] = pp; if (k == order) sec_last = ss; }
+  for (uint32_t r = 0; r < order; r++) {
+#pragma unroll
+    for (uint32_t idx = 7; idx >= 1; idx--) a[idx] = (L)(a[idx] - a[idx - 1]);
+  }
+  L d = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 8; k++) if (k == order) d = a[k];
+  d = (L)(d + (order > 0 ? lmid<L>() : (L)0));
+  bool bad = (uint64_t)(L)(d - (L)(ref1 - kBias)) >= 32768u;
+  if (has_sec) bad = bad || (uint64_t)(L)(sec_last - (L)(ref2 - kBias)) >= 32768u;
+  return __any(bad) != 0;
+}
+template <class L>
+__device__ __forceinline__ bool presample_mode(const PcoGfxEncodeTask& task, const EncChunk PCO_GLOBAL* ch, uint32_t mode_kind) {
+  if (mode_kind == kClassic) return presample_bad<L, kClassic>(task, ch);
+  if (mode_kind == kIntMult) return presample_bad<L, kIntMult>(task, ch);
+  if (mode_kind == kFloatQuant) return presample_bad<L, kFloatQuant>(task, ch);
+  return presample_bad<L, kFloatMult>(task, ch);
+}
+__global__ __launch_bounds__(64) void enc_presample_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, uint32_t n_tasks) {
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tasks) return;
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (uni(ch->status) != PCO_GFX_OK || uni(ch->c16_ok) != 1 || uni(ch->n_pages) != 1 || uni((uint64_t)ch->n) < 4096) return;
+  const PcoGfxEncodeTask task = tasks[t];
+  const int bits = dtype_bits(uni(task.dtype));
+  const uint32_t mode_kind = uni(ch->mode_kind);
+  bool bad = false;
+  if (bits == 64) bad = presample_mode<uint64_t>(task, ch, mode_kind);
+  else if (bits == 32) bad = presample_mode<uint32_t>(task, ch, mode_kind);
+  else if (bits == 16) bad = presample_mode<uint16_t>(task, ch, mode_kind);
+  if (bad && lane_id() == 0) { ch->c16_ok = 0; atomicAdd(ws.need_full0, 1u); }
 }
 
 // =========================================================================================================
