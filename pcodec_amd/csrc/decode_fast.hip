@@ -18,15 +18,16 @@ namespace pcogfx {
 // dec_walk_kernel<L, KQ>: KQ chunks per wave -- 8 (tables up to 4.2 KB: one variable at ans_size_log 10) or 4 (9.1 KB) -- FOUR
 // LANES (one per tANS chain) per chunk.  Tasks whose tables do not fit the 8-chunk slices are handed to the 4-chunk stage
 // through DecPlan::status.  (Packing 16 per wave was tried: level-8 chunks mostly need ans_size_log 9-10, whose tables do not
-// fit a 2.4 KB slice, and a launch that splits its chunks over two stages pays the walk latency twice.)  Slice of a chunk: u64[56] ANS window | VarInfo[3] | per variable: entries u32[T], offset_bits u8[n_bins].
+// fit a 2.4 KB slice, and a launch that splits its chunks over two stages pays the walk latency twice.)  Slice of a chunk: u64[56] ANS window | VarInfo[3] | per variable: entries u32[T], offset bits of bin 0 (8 B).
 constexpr uint32_t kGrpWinOff = 0;
 constexpr uint32_t kGrpVarOff = 448;
 constexpr uint32_t kGrpTblOff = 640;
 template <uint32_t KQ> struct WalkCfg {
   static constexpr uint32_t kGrpBytes = KQ == 8 ? 4912u : 9952u;
   static constexpr uint32_t kGrpTblBytes = kGrpBytes - kGrpTblOff;      // 4272 / 9312
-  static constexpr uint32_t kWalkTmpOff = KQ * kGrpBytes;                // u32[264] scratch for the table build (one chunk at a time)
-  static constexpr uint32_t kWalkLdsBytes = kWalkTmpOff + 1056;          // 40352 / 40864: four waves per CU
+  static constexpr uint32_t kWalkTmpOff = KQ * kGrpBytes;                // scratch for the table build (one chunk at a time): u32[264] cumulative weights | u8[256] offset bits
+  static constexpr uint32_t kWalkTmpObOff = kWalkTmpOff + 1056;
+  static constexpr uint32_t kWalkLdsBytes = kWalkTmpObOff + 256;         // 40608 / 41120: four waves per CU
   static constexpr uint32_t kRetryStatus = KQ == 8 ? 101u : 100u;       // where a task goes whose tables do not fit
   static_assert(kGrpBytes % 16 == 0, "chunk slices must stay 16-byte aligned");
   static_assert(kWalkLdsBytes < 65536, "walk entries hold 16-bit LDS addresses");
@@ -66,7 +67,8 @@ __device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader&
   const uint32_t T = 1u << asl;
   const uint32_t tbl_addr = (uint32_t)(uintptr_t)lds_base() + q * kGrpBytes + kGrpTblOff + uni(vinfo->off_nodes);   // absolute LDS byte address
   uint32_t PCO_LDS* entries = (uint32_t PCO_LDS*)(grp + kGrpTblOff + uni(vinfo->off_nodes));
-  uint8_t PCO_LDS* obs = grp + kGrpTblOff + uni(vinfo->off_ob);
+  uint8_t PCO_LDS* obs = lds_base() + WalkCfg<KQ>::kWalkTmpObOff;   // every bin's offset bits, for the entries being built
+  uint8_t PCO_LDS* ob0 = grp + kGrpTblOff + uni(vinfo->off_ob);      // the slice keeps bin 0's only (what a single-bin variable needs)
   uint32_t PCO_LDS* cum = (uint32_t PCO_LDS*)(lds_base() + kWalkTmpOff);
   uint64_t PCO_GLOBAL* g_low = (uint64_t PCO_GLOBAL*)(bins_out + (uint64_t)vi * kBinsAreaPerVar);
   uint8_t PCO_GLOBAL* g_ob = bins_out + (uint64_t)vi * kBinsAreaPerVar + kFastMaxBins * 8;
@@ -84,6 +86,7 @@ __device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader&
       const uint32_t ob = (uint32_t)mr.peek(at + asl + latent_bits, obb);
       if (ob > latent_bits) bad = 1;
       g_low[b] = lower; g_ob[b] = (uint8_t)ob; obs[b] = (uint8_t)ob;
+      if (b == 0) ob0[0] = (uint8_t)ob;
       max_ob = max_ob > ob ? max_ob : ob;
     }
     const uint32_t incl = wave_incl_scan(w);
@@ -223,8 +226,7 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
         if ((1u << a) < nb || (nb == 1 && a > 0) || a > kMaxAnsBits) { fail(PCO_GFX_CORRUPTION); return; }
         v.ans_size_log = a; v.n_bins = nb;
         v.off_nodes = total_tbl; v.off_lower = 0; v.off_ob = total_tbl + (4u << a);
-        total_tbl += (4u << a) + ((nb + 7u) & ~7u);
-        total_tbl = (total_tbl + 7u) & ~7u;
+        total_tbl += (4u << a) + 8u;   // entries + bin 0's offset bits (the other bins' ride in the entries)
         if (nb > kFastMaxBins || a > 12) too_big = true;
         peek.bit += (uint64_t)nb * (a + v.latent_bits + offset_bits_bits(v.latent_bits));
       }

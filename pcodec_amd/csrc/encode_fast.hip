@@ -591,6 +591,13 @@ __device__ __forceinline__ void pack_item_t(PackSink& sink, const uint8_t PCO_LD
 #pragma unroll
       for (int k = 0; k < 4; k++) { acc |= (uint64_t)__builtin_amdgcn_ubfe((uint32_t)x[k], 0u, ob[k]) << sh; sh += ob[k]; }
       sink.put(rel, acc, t);
+    } else if (max_ob <= 32) {  // two fields per 64-bit word: two puts
+#pragma unroll
+      for (int k = 0; k < 4; k += 2) {
+        const uint64_t lo = x[k] & (((uint64_t)1 << ob[k]) - 1), hi = x[k + 1] & (((uint64_t)1 << ob[k + 1]) - 1);
+        sink.put(rel, lo | (hi << ob[k]), ob[k] + ob[k + 1]);
+        rel += ob[k] + ob[k + 1];
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 4; k++) { sink.put(rel, x[k], ob[k]); rel += ob[k]; }
