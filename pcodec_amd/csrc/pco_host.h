@@ -42,6 +42,23 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// A growable pinned host buffer for read-backs (a fresh std::vector of 100 MB costs more in page faults than the copy).
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void* ensure(size_t bytes) {
+    if (bytes > cap) {
+      if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+      size_t want = bytes + bytes / 8 + 256;
+      hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+      if (e != hipSuccess) { p = nullptr; throw HostError{PCO_GFX_DEVICE_ERROR, std::string("hipHostMalloc failed: ") + hipGetErrorString(e)}; }
+      cap = want;
+    }
+    return p;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct Workspace {
   int device = -1;
   DevBuf tasks, results, tbl_ws;          // decode
@@ -51,9 +68,10 @@ struct Workspace {
   DevBuf enc_lat, enc_sort, enc_ans, enc_small, enc_lb;
   DevBuf enc_sym, enc_answ, enc_bat, enc_run, enc_fstate;   // encode fast path (encode_fast.hip)
   DevBuf auto_idx, auto_samp, auto_tasks, auto_sum;  // Auto spec resolution
+  HostBuf h_samp, h_sum;                             // ... and its read-backs
   void release_all() {
     tasks.release(); results.release(); tbl_ws.release(); dec_plans.release(); dec_bins.release(); dec_sym.release(); dec_offpos.release(); io_in.release(); io_out.release();
-    enc_state.release(); enc_lat.release(); enc_sort.release(); enc_ans.release(); enc_small.release(); enc_lb.release(); enc_sym.release(); enc_answ.release(); enc_bat.release(); enc_run.release(); enc_fstate.release(); auto_idx.release(); auto_samp.release(); auto_tasks.release(); auto_sum.release();
+    enc_state.release(); enc_lat.release(); enc_sort.release(); enc_ans.release(); enc_small.release(); enc_lb.release(); enc_sym.release(); enc_answ.release(); enc_bat.release(); enc_run.release(); enc_fstate.release(); auto_idx.release(); auto_samp.release(); auto_tasks.release(); auto_sum.release(); h_samp.release(); h_sum.release();
   }
 };
 Workspace& workspace();
