@@ -107,6 +107,10 @@ def test_auto_specs(L):
         "intmult_i64": (rng.integers(-1000, 1000, n) * 8 - 1).astype(np.int64),
         "walk_i32": np.cumsum(rng.integers(-50, 60, n)).astype(np.int32),
         "smooth_i64": (np.cumsum(np.cumsum(rng.integers(-3, 4, n))) + (1 << 30)).astype(np.int64),
+        # high consecutive orders: the second wave of delta trials (orders 4..7) decides these
+        "quintic_i64": (np.arange(n, dtype=np.int64) ** 5 % (1 << 62) + rng.integers(0, 2, n)).astype(np.int64),
+        "order6_i64": np.cumsum(np.cumsum(np.cumsum(np.cumsum(np.cumsum(np.cumsum(rng.integers(-1, 2, n))))))).astype(np.int64),
+        "order4_u32": (np.cumsum(np.cumsum(np.cumsum(np.cumsum(rng.integers(0, 3, n))))) % (1 << 32)).astype(np.uint32),
         "seasonal_i64": U.synth("c4", n),
         "uniform_u32": rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32),
         "normal_f32": rng.standard_normal(n).astype(np.float32),
