@@ -338,6 +338,49 @@ def test_batched_device_api_mixed_dtypes(L):
     assert bytes(hdr[:k]) + bytes(dsts[0][: res[0].n_out].cpu().numpy()) + b"\x00" == O.simple_compress(a, O.make_config(**kw))
 
 
+def test_batched_api_asynchronous_form(L):
+    """results == NULL + a device results array: nothing is read back mid-pipeline, so every kernel of
+    the encode pipeline is launched (both split passes, the sort histogram with buffers allocated up front)."""
+    import torch
+    rng = np.random.default_rng(5)
+    arrays = []
+    for i in range(24):
+        n = int(rng.integers(1, 50000))
+        k = i % 4
+        if k == 0: a = (np.uint64(1 << 40) + np.uint64(1000) * np.arange(n, dtype=np.uint64) + rng.integers(0, 512, n).astype(np.uint64))
+        elif k == 1: a = rng.standard_normal(n).astype(np.float32)
+        elif k == 2: a = (rng.integers(1000, 10000, n) / 100.0)
+        else: a = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        arrays.append(a)
+    res_dt = np.dtype([("n_out", "<u8"), ("consumed", "<u8"), ("status", "<u4"), ("aux", "<u4")])
+    srcs = [torch.from_numpy(a.view(np.uint8)).cuda() for a in arrays]
+    caps = [(L.pco_gfx_guarantee_chunk_size(a.size, G.DTYPE_BYTE[a.dtype.name]) + 64 + 15) // 16 * 16 for a in arrays]
+    for kw in (dict(mode=1, delta=2, delta_order=1), dict(mode=1, delta=1)):
+        gcfg = G.make_config(**kw)
+        dsts = [torch.zeros(c, dtype=torch.uint8, device="cuda") for c in caps]
+        tasks = (G.EncodeTask * len(arrays))(*[G.EncodeTask(s.data_ptr(), a.size, d.data_ptr(), c, G.DTYPE_BYTE[a.dtype.name], 0)
+                                               for a, s, d, c in zip(arrays, srcs, dsts, caps)])
+        d_res = torch.zeros(len(arrays) * res_dt.itemsize, dtype=torch.uint8, device="cuda")
+        G.check(L.pco_gfx_compress_chunks(len(arrays), tasks, C.byref(gcfg), None, C.c_void_p(d_res.data_ptr()), None))
+        torch.cuda.synchronize()
+        res = d_res.cpu().numpy().view(res_dt)
+        assert (res["status"] == 0).all()
+        outs = [torch.empty(a.nbytes, dtype=torch.uint8, device="cuda") for a in arrays]
+        dtasks = (G.DecodeTask * len(arrays))(*[G.DecodeTask(d.data_ptr(), int(res["n_out"][i]), o.data_ptr(), a.size, G.DTYPE_BYTE[a.dtype.name], 0)
+                                                for i, (a, d, o) in enumerate(zip(arrays, dsts, outs))])
+        d_dres = torch.zeros(len(arrays) * res_dt.itemsize, dtype=torch.uint8, device="cuda")
+        G.check(L.pco_gfx_decompress_chunks(len(arrays), dtasks, None, C.c_void_p(d_dres.data_ptr()), None))
+        torch.cuda.synchronize()
+        dres = d_dres.cpu().numpy().view(res_dt)
+        for i, a in enumerate(arrays):
+            want = O.simple_compress(a, O.make_config(**kw))
+            got = bytes(dsts[i][: int(res["n_out"][i])].cpu().numpy())
+            hdr = len(want) - 1 - len(got)
+            assert got == want[hdr:-1], (kw, i)
+            assert dres["status"][i] == 0 and dres["n_out"][i] == a.size
+            assert U.bits_equal(outs[i].cpu().numpy().view(a.dtype), a), (kw, i)
+
+
 def test_wrapped_surface_round_trip(L):
     """wrapped::ChunkCompressor / ChunkDecompressor (tests/low_level.rs:39-129): multi-page chunk, page by page."""
     rng = np.random.default_rng(8)
