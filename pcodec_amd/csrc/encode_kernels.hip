@@ -527,19 +527,29 @@ __global__ __launch_bounds__(64) void enc_presample_kernel(EncWorkspace ws, cons
 // ones fall back to HBM), the 16-way arg-max runs on the DPP network, and the chosen lookbacks of a tile are stored
 // once per tile.  Other state: last-index hash tables in HBM (2 x 2^(w+1) u32).
 // =========================================================================================================
-constexpr uint32_t kLbCountsLds = 2048;
-constexpr uint32_t kLbRing = 2048;                         // must be >= 64 + the largest lookback served from LDS
-constexpr uint32_t kLbLdsCounts = 0;                       // u32[2048]
-constexpr uint32_t kLbLdsHp = kLbCountsLds * 4;            // u32[64][6] hash proposals of the tile
-constexpr uint32_t kLbLdsRing = kLbLdsHp + 64 * 6 * 4;     // u64[2048] latents of positions i - 2047 .. i (by position mod 2048)
-constexpr uint32_t kLbLdsHpOther = kLbLdsRing + kLbRing * 8;   // u64[64][6] latent at the far hashed proposals of the tile (prefetched)
-constexpr uint32_t kLbLdsHpCnt = kLbLdsHpOther + 64 * 6 * 8;   // u32[64][6] their lookback counts as of the tile start
-constexpr uint32_t kLbLdsBig = kLbLdsHpCnt + 64 * 6 * 4;       // u32[64] lookbacks > kLbCountsLds chosen inside the tile (their global counts are bumped at the tile end)
-constexpr uint32_t kLbLdsBytes = kLbLdsBig + 64 * 4;
+// LDS layout, in two sizes: the full one for real pages, and a small one for the 6.6 k-number sample pages of the Auto-delta
+// trials (thousands of them per call: at 12 KB instead of 31 KB per wave, 13 instead of 5 of them share a CU)
+template <uint32_t kCounts, uint32_t kRingN> struct LbCfg {
+  static constexpr uint32_t kLbCountsLds = kCounts;
+  static constexpr uint32_t kLbRing = kRingN;                        // must be >= 64 + the largest lookback served from LDS
+  static constexpr uint32_t kLbLdsCounts = 0;                        // u32[kCounts]
+  static constexpr uint32_t kLbLdsHp = kCounts * 4;                  // u32[64][6] hash proposals of the tile
+  static constexpr uint32_t kLbLdsRing = kLbLdsHp + 64 * 6 * 4;      // u64[kRingN] latents of the last kRingN positions (by position mod kRingN)
+  static constexpr uint32_t kLbLdsHpOther = kLbLdsRing + kRingN * 8; // u64[64][6] latent at the far hashed proposals of the tile (prefetched)
+  static constexpr uint32_t kLbLdsHpCnt = kLbLdsHpOther + 64 * 6 * 8;   // u32[64][6] their lookback counts as of the tile start
+  static constexpr uint32_t kLbLdsBig = kLbLdsHpCnt + 64 * 6 * 4;       // u32[64] lookbacks > kCounts chosen inside the tile (their global counts are bumped at the tile end)
+  static constexpr uint32_t kLbLdsBytes = kLbLdsBig + 64 * 4;
+};
+typedef LbCfg<2048, 2048> LbFull;
+typedef LbCfg<512, 512> LbSmall;
+constexpr uint32_t kLbSmallMaxPage = 8192;   // pages up to this size take the small layout
+
 struct LookbackScratch { uint32_t* hash; uint32_t* counts; };  // per page: hash[2 << (wlog+1)], counts[1 << wlog]
 
-template <class L>
+template <class L, class Cfg>
 __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, uint32_t PCO_GLOBAL* hash_tbl, uint32_t PCO_GLOBAL* gcounts) {
+  constexpr uint32_t kLbCountsLds = Cfg::kLbCountsLds, kLbRing = Cfg::kLbRing, kLbLdsCounts = Cfg::kLbLdsCounts, kLbLdsHp = Cfg::kLbLdsHp, kLbLdsRing = Cfg::kLbLdsRing;
+  constexpr uint32_t kLbLdsHpOther = Cfg::kLbLdsHpOther, kLbLdsHpCnt = Cfg::kLbLdsHpCnt, kLbLdsBig = Cfg::kLbLdsBig;
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   const uint32_t lane = lane_id();
   const uint32_t wlog = uni(ch->window_n_log), state_n = 1u << uni(ch->state_n_log);
@@ -669,6 +679,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
   }
 }
 
+template <class Cfg>
 __global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, uint32_t n_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32) {
   const uint32_t p = blockIdx.x;
   if (p >= n_pages) return;
@@ -681,10 +692,10 @@ __global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, uint3
   const uint32_t wlog = uni(ch->window_n_log);
   uint32_t PCO_GLOBAL* hash_tbl = base; uint32_t PCO_GLOBAL* gcounts = base + (4ull << wlog);
   const int bits = dtype_bits(uni(ch->dtype));
-  if (bits == 64) lookback_page<uint64_t>(ws, t, pg, hash_tbl, gcounts);
-  else if (bits == 32) lookback_page<uint32_t>(ws, t, pg, hash_tbl, gcounts);
-  else if (bits == 16) lookback_page<uint16_t>(ws, t, pg, hash_tbl, gcounts);
-  else lookback_page<uint8_t>(ws, t, pg, hash_tbl, gcounts);
+  if (bits == 64) lookback_page<uint64_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
+  else if (bits == 32) lookback_page<uint32_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
+  else if (bits == 16) lookback_page<uint16_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
+  else lookback_page<uint8_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
 }
 
 // =========================================================================================================
