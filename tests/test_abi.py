@@ -104,3 +104,28 @@ def test_python_mirror_surface():
         assert callable(getattr(P.standalone, name))
     with pytest.raises(RuntimeError):
         P.standalone.simple_decompress(b"nope!....")
+
+
+def test_python_surface_host_side(lib):
+    """What of pcodec_amd.{standalone,wrapped} is host-only framing works without a GPU; what computes fails loudly."""
+    import pcodec_amd as P
+    from pcodec_amd.wrapped import FileCompressor, FileDecompressor
+    header = FileCompressor().write_header()
+    assert header == b"\x04\x01"                       # wrapped header = format version (file_compressor.rs:54)
+    fd, used = FileDecompressor.new(header + b"tail")
+    assert used == 2 and fd.format_version == (4, 1)
+    with pytest.raises(G.PcoGfxError):
+        FileDecompressor.new(b"\x09")                  # a major version from the future (format_version.rs)
+    with pytest.raises(TypeError):
+        FileCompressor().chunk_compressor(np.zeros((2, 2)), P.ChunkConfig())
+    with pytest.raises(RuntimeError, match="unknown number type"):
+        fd.chunk_decompressor(b"", "U128")
+    with pytest.raises(ValueError):
+        P.ChunkConfig(paging_spec=P.PagingSpec.exact_page_sizes([6, 4])).to_c()
+    if lib.pco_gfx_device_count() == 0:
+        with pytest.raises(G.PcoGfxError) as ei:
+            P.standalone.simple_compress(np.arange(10, dtype=np.uint32), P.ChunkConfig())
+        assert ei.value.status == G.ST_DEVICE_ERROR
+        with pytest.raises(G.PcoGfxError) as ei:
+            FileCompressor().chunk_compressor(np.arange(10, dtype=np.uint32), P.ChunkConfig())
+        assert ei.value.status == G.ST_DEVICE_ERROR
