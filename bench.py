@@ -242,7 +242,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"c1": "u32", "c2": "u64", "c3": "f64", "c4": "i64", "c2auto": "u64"}[args.workload],
             "data": "synthetic",
             "config": {"workload": desc, "chunks_per_gpu": nch, "chunk_n": N18, "compression_level": 8,
-                       "mode_spec": "TryFloatMult(0.01)" if args.workload == "c3" else "Classic",
+                       "mode_spec": {"c3": "TryFloatMult(0.01)", "c2auto": "Auto"}.get(args.workload, "Classic"),
                        "delta_spec": {"c1": "NoOp", "c2": "TryConsecutive(1)", "c3": "NoOp", "c4": "TryLookback", "c2auto": "Auto"}[args.workload],
                        "parallelism": f"chunk-sharded x{world}" + (" + RCCL gather of pages" if args.gather else ""),
                        "compressed_bytes_per_chunk": comp_bytes // nch,
