@@ -531,8 +531,6 @@ inline void validate_chunk_meta(const ChunkMeta& m) {
     uint64_t window_n = (uint64_t)1 << m.delta.window_n_log;
     for (const DynBin& b : m.vars[kVarDelta].bins)
       if (b.lower < 1 || b.lower > window_n) fail(kCorruption, "delta lookback bin had invalid lower bound");
-  } else if (m.delta.kind == kDeltaConv1) {
-    fail(kUnsupported, "conv1 delta decoding is outside the hot-path scope (SURVEY.md section 2 row 9)");
   }
 }
 inline ChunkMeta read_chunk_meta(BitReader& r, uint8_t format_major, int latent_bits) {

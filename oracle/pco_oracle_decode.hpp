@@ -138,7 +138,29 @@ template <class L> struct LatentDecoder {
         if (oob) fail(kCorruption, "delta lookback exceeded window n");
         break;
       }
-      default: fail(kUnsupported, "conv1 decode out of scope");
+      case kDeltaConv1: {  // delta/conv1.rs:463-484 (decode_in_place), :148-161 (predict_one), :231-251 (decode_residuals)
+        // Conv = i16 / i32 / i64 for 8- / 16- / 32-bit latents (data_types/unsigned.rs:132-134); the sums are formed in 64 bits
+        // and wrapped to the Conv width, which is what wrapping arithmetic in the narrower type yields
+        if (LT<L>::BITS > 32) fail(kCorruption, "Conv1 delta encoding cannot be used with 64-bit latents");
+        const int conv_bits = LT<L>::BITS == 32 ? 64 : 2 * LT<L>::BITS;
+        auto wrap = [&](uint64_t x) -> int64_t { return conv_bits == 64 ? (int64_t)x : (int64_t)(x << (64 - conv_bits)) >> (64 - conv_bits); };
+        const size_t order = delta.weights.size();
+        for (size_t i = 0; i < dst_n; i++) latents[i] = (L)(latents[i] + MID<L>());
+        std::vector<L> residuals(dst_n + order);
+        for (size_t i = 0; i < order; i++) residuals[i] = delta_state[i];
+        for (size_t i = 0; i < dst_n; i++) residuals[order + i] = latents[i];
+        for (size_t i = order; i < residuals.size(); i++) {
+          uint64_t sum = (uint64_t)wrap((uint64_t)delta.bias);
+          for (size_t k = 0; k < order; k++) sum += (uint64_t)wrap((uint64_t)delta.weights[k]) * (uint64_t)(int64_t)(uint64_t)residuals[i - order + k];
+          int64_t sconv = wrap(sum);
+          if (sconv < 0) sconv = 0;
+          residuals[i] = (L)(residuals[i] + (L)(uint64_t)(sconv >> delta.quantization));
+        }
+        for (size_t i = 0; i < dst_n; i++) latents[i] = residuals[i];
+        for (size_t i = 0; i < order; i++) delta_state[i] = residuals[dst_n + i];
+        break;
+      }
+      default: fail(kCorruption, "unknown delta encoding");
     }
   }
 };
@@ -177,7 +199,7 @@ template <class L> void join_latents(const Mode& mode, NumKind kind, const L* pr
       } else fail(kUnsupported, "f16 float-mult arithmetic is not restated in the oracle");
       break;
     }
-    default: fail(kUnsupported, "dict mode is outside the hot-path scope (SURVEY.md section 2 row 8)");
+    default: fail(kCorruption, "dict mode is joined by the chunk decoder");
   }
 }
 
@@ -186,14 +208,17 @@ template <class L> void join_latents(const Mode& mode, NumKind kind, const L* pr
 template <class L> struct ChunkDecoder {
   ChunkMeta meta; NumKind kind;
   LatentDecoder<uint32_t> dvar; LatentDecoder<L> pvar, svar;
+  LatentDecoder<uint32_t> pdict;   // Dict mode: the primary variable holds u32 dictionary indices (mode.rs:197-202)
+  bool dict = false;
   size_t n_remaining = 0;
 
   void init(const ChunkMeta& m, uint8_t dtype) {
     meta = m; kind = dtype_kind(dtype);
     if (!mode_is_valid(m.mode, dtype)) fail(kCorruption, "invalid mode for number type");
-    if (m.mode.kind == kDict) fail(kUnsupported, "dict mode is outside the hot-path scope");
+    dict = m.mode.kind == kDict;
     if (m.vars[kVarDelta].present) dvar.init_chunk(m.vars[kVarDelta], delta_for_latent_var(m.delta, kVarDelta));
-    pvar.init_chunk(m.vars[kVarPrimary], delta_for_latent_var(m.delta, kVarPrimary));
+    if (dict) pdict.init_chunk(m.vars[kVarPrimary], delta_for_latent_var(m.delta, kVarPrimary));
+    else pvar.init_chunk(m.vars[kVarPrimary], delta_for_latent_var(m.delta, kVarPrimary));
     if (m.vars[kVarSecondary].present) svar.init_chunk(m.vars[kVarSecondary], delta_for_latent_var(m.delta, kVarSecondary));
   }
   size_t n_latents_per_delta_state() const { return delta_for_latent_var(meta.delta, kVarPrimary).n_latents_per_state(); }
@@ -210,14 +235,15 @@ template <class L> struct ChunkDecoder {
   // wrapped/page_decompressor.rs:72-90 (+ make_latent_decompressors :36-70)
   void start_page(BitReader& r, size_t n) {
     if (dvar.present) read_page_var_meta(r, dvar, meta.vars[kVarDelta].ans_size_log);
-    read_page_var_meta(r, pvar, meta.vars[kVarPrimary].ans_size_log);
+    if (dict) read_page_var_meta(r, pdict, meta.vars[kVarPrimary].ans_size_log);
+    else read_page_var_meta(r, pvar, meta.vars[kVarPrimary].ans_size_log);
     if (svar.present) read_page_var_meta(r, svar, meta.vars[kVarSecondary].ans_size_log);
     r.drain_empty_byte("non-zero bits at end of data page metadata");
     r.check_in_bounds();
     size_t nlps = n_latents_per_delta_state();
     size_t n_in_body = n > nlps ? n - nlps : 0;
     if (n_in_body > 0) {
-      if ((dvar.present && dvar.n_bins == 0) || pvar.n_bins == 0 || (svar.present && svar.n_bins == 0))
+      if ((dvar.present && dvar.n_bins == 0) || (dict ? pdict.n_bins : pvar.n_bins) == 0 || (svar.present && svar.n_bins == 0))
         fail(kCorruption, "unable to decompress chunk with no bins");
     }
     n_remaining = n;
@@ -229,6 +255,15 @@ template <class L> struct ChunkDecoder {
       size_t limit = std::min(n_remaining > nlps ? n_remaining - nlps : 0, batch_n);
       dvar.read_batch_pre_delta(r, limit);
       r.check_in_bounds();
+    }
+    if (dict) {  // mode/dict.rs:70-90 (join_latents)
+      pdict.read_batch(r, dvar.present ? dvar.latents : nullptr, n_remaining);
+      r.check_in_bounds();
+      for (size_t i = 0; i < batch_n; i++) if (pdict.latents[i] >= meta.mode.dict.size()) fail(kCorruption, "dict index exceeded dict length");
+      for (size_t i = 0; i < batch_n; i++) dst_bits[i] = from_latent_ordered<L>((L)meta.mode.dict[pdict.latents[i]], kind);
+      n_remaining -= batch_n;
+      if (n_remaining == 0) { r.drain_empty_byte("expected trailing bits at end of page to be empty"); r.check_in_bounds(); }
+      return;
     }
     pvar.read_batch(r, dvar.present ? dvar.latents : nullptr, n_remaining);
     r.check_in_bounds();

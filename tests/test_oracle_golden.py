@@ -67,11 +67,42 @@ def test_oracle_decodes_reference_asset(name):
     assert bits_equal(got, exp), name
 
 
-@pytest.mark.parametrize("name", ["v1_0_0_dict.pco", "v1_0_0_conv1.pco"])
-def test_out_of_scope_assets_are_reported_unsupported(name):
-    with pytest.raises(O.OracleError) as ei:
-        O.simple_decompress(asset(name), np.uint64 if "dict" in name else np.int32)
-    assert ei.value.kind == O.ERR_UNSUPPORTED
+def expected_oracle_only():
+    """Dict mode and Conv1 delta are outside the hot-path scope: the GPU product refuses them, but
+    the oracle decodes them, so that every one of the reference's 13 golden assets pins it."""
+    e = {}
+    e["v1_0_0_dict.pco"] = np.array([8924659283, 234897984367, 9827358920] * 1000, dtype=np.uint64)   # compatibility.rs:248-259
+    xm1 = 0.0; xm2 = 0.0; nums = []                                                                     # compatibility.rs:262-278 (f32 arithmetic)
+    for i in range(2000):
+        x = np.float32(np.float32(np.float32(np.float32(xm1) * np.float32(1.99)) - np.float32(xm2)) + np.float32((i * 47) % 77 - 38))
+        nums.append(int(np.int32(np.float32(x + np.float32(10000.0)))))
+        xm2 = xm1; xm1 = float(x)
+    e["v1_0_0_conv1.pco"] = np.array(nums, dtype=np.int32)
+    return e
+
+
+EXPECTED_ORACLE_ONLY = expected_oracle_only()
+
+
+@pytest.mark.parametrize("name", sorted(EXPECTED_ORACLE_ONLY))
+def test_oracle_decodes_out_of_scope_assets(name):
+    exp = EXPECTED_ORACLE_ONLY[name]
+    assert bits_equal(O.simple_decompress(asset(name), exp.dtype), exp), name
+
+
+def test_every_reference_asset_is_pinned():
+    assert sorted(os.listdir(ASSETS)) == sorted(list(EXPECTED) + list(EXPECTED_ORACLE_ONLY))
+
+
+def test_oracle_reports_corrupt_dict_and_conv1_streams():
+    blob = bytearray(asset("v1_0_0_dict.pco"))
+    for cut in (10, 20, 30, len(blob) - 3):
+        with pytest.raises(O.OracleError):
+            O.simple_decompress(bytes(blob[:cut]), np.uint64)
+    blob = bytearray(asset("v1_0_0_conv1.pco"))
+    for cut in (12, 40, len(blob) // 2):
+        with pytest.raises(O.OracleError):
+            O.simple_decompress(bytes(blob[:cut]), np.int32)
 
 
 @pytest.mark.parametrize("name", ["v1_0_0_u8.pco", "v1_0_0_i8.pco"])
