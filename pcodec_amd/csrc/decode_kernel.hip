@@ -321,6 +321,11 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
   }
   const uint32_t window_n_log = uni(vinfo[1].window_n_log);
   const uint32_t state_n = dk[1] == kDeltaLookback ? nlps[1] : 0u;
+  // Lookback keeps its history in dst.  In classic mode dst holds the numbers, whose ordered latents ARE the primary latents; in the
+  // other modes a first pass leaves the primary latents themselves in dst, and a second pass over the page decodes the secondary
+  // variable again and joins in place (this combination only comes from explicit specs or Auto on unusual data; it is not fast).
+  const bool raw_hist = dk[1] == kDeltaLookback && mode_kind != kClassic;
+  const uint32_t n_pass = raw_hist ? 2u : 1u;
 
   // ---- page meta (metadata/page.rs:36-57, page_latent_var.rs:28-49) ----
   uint32_t st[3] = {0, 0, 0};
@@ -332,7 +337,7 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
       const L x = (L)mr.read(lbits);
       if (dk[vi] == kDeltaConsecutive) { if (lane == 0) { if (vi == 2) moments1[i] = x; else moments0[i] = x; } }
       else if (vi == 1 && i < n && mr.in_bounds()) {  // lookback state = the first state_n latents (classic mode only)
-        if (lane == 0) dst[i] = from_latent_ordered<L>(x, num_kind);
+        if (lane == 0) dst[i] = raw_hist ? x : from_latent_ordered<L>(x, num_kind);
       }
     }
     uint32_t mine = 0;
@@ -350,8 +355,16 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
   wave_sync_lds();
 
   uint64_t bitpos = mr.bit;
+  const uint64_t body_start = mr.bit;
+  const uint32_t st_init[3] = {st[0], st[1], st[2]};
   uint32_t n_remaining = n;
   uint32_t lb_oob = 0;
+  for (uint32_t pass = 0; pass < n_pass; pass++) {
+  if (pass == 1) {
+    if (uni(wave_or_u32(lb_oob))) { status = PCO_GFX_CORRUPTION; return; }
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bitpos = body_start; n_remaining = n; st[0] = st_init[0]; st[1] = st_init[1]; st[2] = st_init[2];
+  }
   for (uint32_t j0 = 0; j0 < n; j0 += kBatchN) {
     const uint32_t batch_n = n_remaining < kBatchN ? n_remaining : kBatchN;
     L prim[4] = {0, 0, 0, 0}, sec[4] = {0, 0, 0, 0};
@@ -385,8 +398,8 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
         if (vi == 1) consecutive_decode<L>(prim, dord[1], moments0); else consecutive_decode<L>(sec, dord[2], moments1);
       }
     }
-    if (dk[1] == kDeltaLookback) {
-      // F[state_n + k] = delta_k + MID + F[state_n + k - lb_k]; history lives in dst (classic mode).
+    if (dk[1] == kDeltaLookback && pass == 0) {
+      // F[state_n + k] = delta_k + MID + F[state_n + k - lb_k]; history lives in dst (numbers in classic mode, else primary latents).
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
       const uint32_t window_n = 1u << window_n_log;
@@ -403,7 +416,7 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
           } else if (lb <= i) par = i - lb;
           else {
             const int64_t jsrc = (int64_t)(state_n + kbase + i) - (int64_t)lb;
-            if (jsrc >= 0) val = (L)(val + to_latent_ordered<L>(__hip_atomic_load(&dst[jsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), num_kind));
+            if (jsrc >= 0) { const L h = __hip_atomic_load(&dst[jsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); val = (L)(val + (raw_hist ? h : to_latent_ordered<L>(h, num_kind))); }
           }
         }
         scratch[i] = val; parent[i] = par;
@@ -422,12 +435,15 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
       }
       for (int k = 0; k < 4; k++) {  // store F at its true index (the reference's output lags by state_n)
         const uint32_t i = 4 * lane + k;
-        if (i < prim_cnt) dst[state_n + kbase + i] = from_latent_ordered<L>(scratch[i], num_kind);
+        if (i < prim_cnt) dst[state_n + kbase + i] = raw_hist ? scratch[i] : from_latent_ordered<L>(scratch[i], num_kind);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
     } else {
       // join + coalesced store: 4 contiguous numbers per lane
+      if (raw_hist) {  // second pass: the primary latents are what the first pass left in dst
+        for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; prim[k] = i < batch_n ? __hip_atomic_load(&dst[j0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (L)0; }
+      }
       L outv[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) outv[k] = join_one<L>(mode_kind, num_kind, mode_base, mode_k, prim[k], sec[k]);
@@ -449,6 +465,7 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
       }
     }
     n_remaining -= batch_n;
+  }
   }
   if (uni(wave_or_u32(lb_oob))) { status = PCO_GFX_CORRUPTION; return; }
   // trailing bits of the page must be zero (page_decompressor.rs:184-188)
@@ -551,7 +568,7 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
       if (lw < 1 || lw > (1u << wlog)) bad = 1;
     }
     if (uni(wave_or_u32(bad))) { status = PCO_GFX_CORRUPTION; return; }
-    if (mode_kind != kClassic || sec_uses_delta) { status = PCO_GFX_UNSUPPORTED; return; }  // history lives in dst
+    if (sec_uses_delta) { status = PCO_GFX_UNSUPPORTED; return; }  // (no encoder writes it; the history of a second variable would need its own buffer)
   }
   // mode validity for the number type (data_types/unsigned.rs:65-71, float.rs:377-390)
   {

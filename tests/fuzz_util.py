@@ -63,7 +63,6 @@ def run(n_cases, seed, only_8bit=False):
         elif d == 1: kw["delta"] = 1
         elif d in (2, 3): kw.update(delta=2, delta_order=int(rng.integers(1, 8)))
         else: kw["delta"] = 3
-        if kw.get("delta") == 3 and kw.get("mode", 1) != 1: kw["delta"] = 1   # lookback decode needs classic mode on the device
         if rng.random() < 0.15: kw["max_page_n"] = int(rng.integers(1, max(n, 2)))
         try:
             ocfg = O.make_config(enable_8_bit=True, **kw)

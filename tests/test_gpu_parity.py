@@ -95,6 +95,25 @@ def test_lookback_matrix(L):
         assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums)
 
 
+def test_lookback_with_two_variable_modes(L):
+    """Lookback delta on the primary of int-mult / float-mult / float-quant chunks (delta_encoding.rs:303-304): the decoder keeps
+    the primary latents in dst on a first pass and joins on a second."""
+    rng = np.random.default_rng(23)
+    for n in (5, 300, 4000, 70000):
+        per = rng.integers(0, 1 << 20, 365)
+        ints = ((per[np.arange(n) % 365] + rng.integers(-2, 3, n)) * 8 + rng.integers(0, 2, n)).astype(np.int64)
+        u32s = ((per[np.arange(n) % 365] % 10000 + rng.integers(0, 3, n)) * 12).astype(np.uint32)
+        cents = ((per[np.arange(n) % 365] % 9000 + 1000 + rng.integers(0, 3, n)) / 100.0)
+        f32q = (per[np.arange(n) % 365] + rng.standard_normal(n)).astype(np.float32).astype(np.float64)
+        for nums, kw in ((ints, dict(mode=4, mode_u64=8, delta=3)), (u32s, dict(mode=4, mode_u64=12, delta=3)),
+                         (cents, dict(mode=2, mode_f64=0.01, delta=3)), (cents.astype(np.float32), dict(mode=2, mode_f64=0.01, delta=3)),
+                         (f32q, dict(mode=3, mode_u64=29, delta=3))):
+            want = O.simple_compress(nums, O.make_config(**kw))
+            got = U.gpu_simple_compress(nums, G.make_config(**kw))
+            assert got == want, (nums.dtype, n, kw)
+            assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums), (nums.dtype, n, kw)
+
+
 def test_auto_specs(L):
     """ModeSpec::Auto / DeltaSpec::Auto (the reference's default ChunkConfig, and the NULL config of its C ABI)."""
     rng = np.random.default_rng(31)
