@@ -177,6 +177,15 @@ enum PcoError pco_gfx_decompress_chunks(size_t n_tasks, const PcoGfxDecodeTask* 
                                         PcoGfxTaskResult* results, PcoGfxTaskResult* d_results,
                                         void* stream);
 
+/* Device-side assembly of the chunk stream standalone::simple_compress writes (standalone/simple.rs:62-91: chunks back to back).
+ * `tasks` (HOST array) and `d_results` (DEVICE array) are those of a pco_gfx_compress_chunks call on the same stream (pass a
+ * d_results array to that call; it is filled in synchronous calls too).  Chunk i's bytes are copied to
+ * d_dst[d_offsets[i] .. d_offsets[i+1]) with d_offsets[0] = dst_offset; d_offsets is a DEVICE array of n_tasks + 1 entries.
+ * If `total` is non-NULL the call synchronises `stream` and stores d_offsets[n_tasks] (the end of the stream) there, failing
+ * with PCO_GFX_INVALID_ARGUMENT when it exceeds dst_cap (nothing is copied in that case); with total == NULL it is asynchronous. */
+enum PcoError pco_gfx_compact_chunks(size_t n_tasks, const PcoGfxEncodeTask* tasks, const PcoGfxTaskResult* d_results, void* d_dst,
+                                     uint64_t dst_cap, uint64_t dst_offset, uint64_t* d_offsets, uint64_t* total, void* stream);
+
 /* standalone/compressor.rs:85-105 and :157-162 (host-side framing, tiny) */
 size_t pco_gfx_write_standalone_header(void* dst, size_t dst_cap, uint64_t n_hint, unsigned char uniform_dtype);
 size_t pco_gfx_write_standalone_footer(void* dst, size_t dst_cap);

@@ -308,3 +308,61 @@ int pco_oracle_lookback_encode_u32(uint32_t* latents, size_t n, uint32_t state_n
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// cpu_baseline leg of bench.py: the restated reference algorithm timed on the host cores without Python in the loop.
+// Each thread owns a private copy of the chunk and loops compress -> decompress (what pco_cli's bench does per
+// iteration, pco_cli/src/bench/codecs/mod.rs:150-231) until the deadline.  out[0] = chunks done (all threads),
+// out[1] = wall seconds, out[2] / out[3] = summed per-thread seconds inside compress / decompress.
+// ---------------------------------------------------------------------------
+#include <atomic>
+#include <chrono>
+#include <thread>
+extern "C" int pco_oracle_bench(const void* nums, size_t n, uint8_t dtype, const PcoOracleConfig* config, uint32_t n_threads,
+                                double seconds, double* out) {
+  return guard([&] {
+    if (!dtype_valid(dtype)) fail(kInvalidArgument, "invalid dtype");
+    if (n_threads == 0) n_threads = 1;
+    const ChunkConfig cfg = to_cfg(config);
+    const int bits = dtype_bits(dtype);
+    const size_t bytes = n * (size_t)(bits / 8);
+    std::atomic<uint64_t> done{0}; std::atomic<int> failed{0};
+    std::vector<double> t_enc(n_threads, 0.0), t_dec(n_threads, 0.0);
+    std::atomic<uint32_t> ready{0}; std::atomic<bool> go{false};
+    typedef std::chrono::steady_clock Clock;
+    Clock::time_point deadline;
+    auto worker = [&](uint32_t k) {
+      std::vector<uint8_t> local((const uint8_t*)nums, (const uint8_t*)nums + bytes);
+      ready.fetch_add(1);
+      while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+      try {
+        dispatch_bits(bits, [&](auto tag) {
+          typedef decltype(tag) LTYPE;
+          uint64_t mine = 0;
+          while (Clock::now() < deadline || mine == 0) {
+            const auto a = Clock::now();
+            std::vector<uint8_t> enc = simple_compress_t<LTYPE>((const LTYPE*)local.data(), n, dtype, cfg, false);
+            const auto b = Clock::now();
+            std::vector<LTYPE> back = simple_decompress_t<LTYPE>(enc.data(), enc.size(), dtype);
+            const auto c = Clock::now();
+            if (back.size() != n || std::memcmp(back.data(), local.data(), bytes) != 0) { failed.store(1); return; }
+            t_enc[k] += std::chrono::duration<double>(b - a).count(); t_dec[k] += std::chrono::duration<double>(c - b).count();
+            mine++;
+          }
+          done.fetch_add(mine);
+        });
+      } catch (...) { failed.store(1); }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < n_threads; k++) th.emplace_back(worker, k);
+    while (ready.load() < n_threads) std::this_thread::yield();
+    const auto t0 = Clock::now();
+    deadline = t0 + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(seconds));
+    go.store(true, std::memory_order_release);
+    for (auto& t : th) t.join();
+    const double wall = std::chrono::duration<double>(Clock::now() - t0).count();
+    if (failed.load()) fail(kCorruption, "oracle bench: round trip failed");
+    double se = 0, sd = 0; for (uint32_t k = 0; k < n_threads; k++) { se += t_enc[k]; sd += t_dec[k]; }
+    out[0] = (double)done.load(); out[1] = wall; out[2] = se; out[3] = sd;
+  });
+}

@@ -267,7 +267,11 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
     if (slot == q) { my_n_lat = pv.n_lat; my_T = T; my_p = p; my_v = v; my_task = t; my_at = fast_at(pg, pv.skip); my_info_off = kEwInfoOff; }
   }
   enc_wave_sync();
-  if (my_n_lat == 0) { if (__all(my_n_lat == 0)) return; }
+  // (wave-level vote at a converged point: idle quads -- trivial variables, the other stage's items, slots beyond the
+  // launch -- must stay in the wave, the butterfly maximum over n_full below reads every lane.  Round 1 voted inside
+  // `if (my_n_lat == 0)`, where __all only sees the idle lanes: they left, and a wave whose FIRST live quad had fewer
+  // full batches than a later one stopped walking early -- the wrong secondary stream of sweep seed 2025 case 188.)
+  if (__all(my_n_lat == 0)) return;
   // ---- phase 1: batches in reverse ----
   const uint32_t slice = lds0 + (slot < kEwQ ? slot : 0u) * kEwSlotBytes;
   const uint32_t info_addr = slice + my_info_off, symbuf = slice + kEwSymOff;

@@ -1403,12 +1403,6 @@ __global__ __launch_bounds__(64) void enc_train_kernel(EncWorkspace ws, uint32_t
     ch->fallback = fallback;
     uint32_t fast_ok = fallback ? 0u : 1u;
     for (uint32_t var = 0; var < 3; var++) if (ch->v[var].present && ch->v[var].ans_size_log > kFastEncMaxAsl) fast_ok = 0;
-#ifndef PCO_LOOKBACK_SEC_FAST
-    // lookback on a chunk with a secondary variable: the multi-kernel path produced a wrong secondary tANS stream when the lookback
-    // variable is trivial and the page's last batch holds one number (randomised sweep, seed 2025 case 188; root cause open) --
-    // such chunks (explicit specs, or Auto on unusual data) take the single-kernel page encoder, which is right and slower
-    if (ch->delta_kind == kDeltaLookback && ch->v[2].present) fast_ok = 0;
-#endif
     ch->fast_ok = fast_ok;
   }
 }

@@ -16,6 +16,7 @@
 #include "decode_fast.hip"
 #include "encode_kernels.hip"
 #include "encode_fast.hip"
+#include "stream_kernels.hip"
 
 namespace pcogfx {
 
@@ -258,6 +259,38 @@ enum PcoError pco_gfx_decompress_chunks(size_t n_tasks, const PcoGfxDecodeTask* 
     }
     return PcoSuccess;
   } catch (const HostError& e) { return fail_with(e, PcoDecompressionError); }
+}
+
+enum PcoError pco_gfx_compact_chunks(size_t n_tasks, const PcoGfxEncodeTask* tasks, const PcoGfxTaskResult* d_results, void* d_dst,
+                                     uint64_t dst_cap, uint64_t dst_offset, uint64_t* d_offsets, uint64_t* total, void* stream_) {
+  clear_error();
+  try {
+    require_device();
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_results || !d_offsets || (!d_dst && dst_cap)) throw HostError{PCO_GFX_INVALID_ARGUMENT, "compact: null device array"};
+    if (n_tasks >= (1ull << 31)) throw HostError{PCO_GFX_INVALID_ARGUMENT, "compact: too many chunks"};
+    Workspace& ws = workspace();
+    uint8_t* d_base = (uint8_t*)ws.compact_tasks.ensure(n_tasks * sizeof(PcoGfxEncodeTask) + 64);
+    uint32_t* d_over = (uint32_t*)d_base; PcoGfxEncodeTask* d_tasks = (PcoGfxEncodeTask*)(d_base + 64);
+    uint64_t max_cap = 0;
+    for (size_t i = 0; i < n_tasks; i++) max_cap = std::max<uint64_t>(max_cap, tasks[i].dst_cap);
+    if (n_tasks) PCO_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks, n_tasks * sizeof(PcoGfxEncodeTask), hipMemcpyHostToDevice, stream));
+    PCO_TIMED_LAUNCH("compact_scan_kernel", stream, compact_scan_kernel, dim3(1), dim3(1024), 0, stream, d_results, (uint32_t)n_tasks, dst_offset, dst_cap, d_offsets, d_over);
+    if (n_tasks) {
+      const uint64_t slice = 64 * 1024;   // one block per 64 KiB of a chunk: >> 256 blocks in flight for any many-chunk call
+      const uint32_t slices = (uint32_t)std::max<uint64_t>(1, (max_cap + slice - 1) / slice);
+      PCO_TIMED_LAUNCH("compact_copy_kernel", stream, compact_copy_kernel, dim3(slices, (uint32_t)n_tasks), dim3(256), 0, stream, d_tasks, d_results, d_offsets, (uint8_t*)d_dst, d_over, (uint32_t)n_tasks, slice);
+    }
+    PCO_HIP_CHECK(hipGetLastError());
+    if (total) {
+      uint32_t over = 0;
+      PCO_HIP_CHECK(hipMemcpyAsync(total, d_offsets + n_tasks, 8, hipMemcpyDeviceToHost, stream));
+      PCO_HIP_CHECK(hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, stream));
+      PCO_HIP_CHECK(hipStreamSynchronize(stream));
+      if (over) throw HostError{PCO_GFX_INVALID_ARGUMENT, "compact: destination too small"};
+    }
+    return PcoSuccess;
+  } catch (const HostError& e) { return fail_with(e, PcoCompressionError); }
 }
 
 enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size_t compressed_len, unsigned char dtype,

@@ -12,7 +12,7 @@ import fuzz_util
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad, skipped, fails = fuzz_util.run(n_cases, seed, only_8bit=os.environ.get("FUZZ_8BIT") is not None)
-print(f"cases {n_cases} skipped {skipped} bad {len(bad)}")
+print(f"cases {n_cases} skipped {sum(skipped.values())} {skipped} bad {len(bad)}")
 if fails:
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
     os.makedirs(out, exist_ok=True)

@@ -41,52 +41,121 @@ def gen(rng, dt, n):
 
 
 
-def run(n_cases, seed, only_8bit=False):
+def draw_config(rng, dt, n, max_level=8):
+    isf = np.dtype(dt).kind == "f"
+    kw = dict(level=int(rng.integers(0, max_level + 1)))
+    m = rng.integers(0, 5)
+    if m == 0: kw["mode"] = 0
+    elif m == 1: kw["mode"] = 1
+    elif m == 2 and not isf: kw.update(mode=4, mode_u64=int(rng.integers(1, 1000)))
+    elif m == 3 and isf and np.dtype(dt).itemsize >= 4: kw.update(mode=2, mode_f64=float(rng.choice([0.01, 0.1, 0.25, 1.0, 3.0])))
+    elif m == 4 and isf: kw.update(mode=3, mode_u64=int(rng.integers(1, 20 if np.dtype(dt).itemsize >= 4 else 10)))
+    else: kw["mode"] = 1
+    if kw.get("mode") == 0 and np.dtype(dt) == np.float16: kw["mode"] = 1
+    d = rng.integers(0, 5)
+    if d == 0: kw["delta"] = 0
+    elif d == 1: kw["delta"] = 1
+    elif d in (2, 3): kw.update(delta=2, delta_order=int(rng.integers(1, 8)))
+    else: kw["delta"] = 3
+    return kw
+
+
+def page_sizes(n, max_page_n):
+    """PagingSpec::EqualPagesUpTo (chunk_config.rs:134-182): what standalone::simple_compress cuts the input into."""
+    if n == 0: return []
+    k = -(-n // max_page_n); low, r = divmod(n, k)
+    return [low + 1] * r + [low] * (k - r)
+
+
+def hist_fallback_ran(nums, kw):
+    """Did the reference's order-dependent heapsort fallback (histograms.rs:248-258) run for any chunk of this input?"""
+    sizes = page_sizes(nums.size, kw["max_page_n"]) if kw.get("max_page_n") else [nums.size]
+    pos = 0
+    for sz in sizes:
+        sub_kw = {k: v for k, v in kw.items() if k != "max_page_n"}
+        _, _, fb = O.chunk_plan(nums[pos: pos + sz], O.make_config(enable_8_bit=True, **sub_kw))
+        if fb: return True
+        pos += sz
+    return False
+
+
+SIZES = [1, 2, 3, 17, 255, 256, 257, 513, 1025, 1000, 4099, 20000, 70000, 1 << 18, (1 << 18) + 1]
+SIZE_P = [.04, .03, .03, .04, .04, .04, .05, .04, .04, .18, .18, .17, .08, .02, .02]
+
+
+def run(n_cases, seed, only_8bit=False, max_level=8):
+    """Returns (bad, skipped, fails): `skipped` maps a reason to the number of cases that were not compared -- callers assert a
+    budget on it (a regression that refuses more inputs must not pass as green)."""
     rng = np.random.default_rng(seed)
-    bad = []; skipped = 0; fails = {}
+    bad = []; skipped = {}; fails = {}
+
+    def skip(why): skipped[why] = skipped.get(why, 0) + 1
+
     for case in range(n_cases):
         dt = (INT + FLT)[rng.integers(0, 11)] if not only_8bit else INT[rng.integers(0, 2)]
-        n = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4099, 20000, 70000], p=[.04, .03, .03, .05, .05, .05, .05, .2, .2, .2, .1]))
+        n = int(rng.choice(SIZES, p=SIZE_P))
         nums = gen(rng, dt, n)
-        isf = np.dtype(dt).kind == "f"
-        kw = dict(level=int(rng.integers(0, 9)))
-        m = rng.integers(0, 5)
-        if m == 0: kw["mode"] = 0
-        elif m == 1: kw["mode"] = 1
-        elif m == 2 and not isf: kw.update(mode=4, mode_u64=int(rng.integers(1, 1000)))
-        elif m == 3 and isf and np.dtype(dt).itemsize >= 4: kw.update(mode=2, mode_f64=float(rng.choice([0.01, 0.1, 0.25, 1.0, 3.0])))
-        elif m == 4 and isf: kw.update(mode=3, mode_u64=int(rng.integers(1, 20 if np.dtype(dt).itemsize >= 4 else 10)))
-        else: kw["mode"] = 1
-        if kw.get("mode") == 0 and np.dtype(dt) == np.float16: kw["mode"] = 1
-        d = rng.integers(0, 5)
-        if d == 0: kw["delta"] = 0
-        elif d == 1: kw["delta"] = 1
-        elif d in (2, 3): kw.update(delta=2, delta_order=int(rng.integers(1, 8)))
-        else: kw["delta"] = 3
-        if rng.random() < 0.15: kw["max_page_n"] = int(rng.integers(1, max(n, 2)))
+        kw = draw_config(rng, dt, n, max_level)
+        if rng.random() < 0.15: kw["max_page_n"] = int(rng.integers(1, max(n, 2))) if n < 100000 else int(rng.integers(1 << 16, n))
         try:
             ocfg = O.make_config(enable_8_bit=True, **kw)
             want = O.simple_compress(nums, ocfg)
-            _, _, fb = O.chunk_plan(nums, ocfg) if "max_page_n" not in kw else (None, None, False)
+            fb = hist_fallback_ran(nums, kw)
         except O.OracleError as e:
             try:
                 U.gpu_simple_compress(nums, G.make_config(enable_8_bit=True, **kw)); bad.append(("gpu accepted what the oracle refused", case, np.dtype(dt).name, n, kw))
             except G.PcoGfxError:
                 pass
-            skipped += 1; continue
+            skip("oracle refused: " + str(e)[:60]); continue
         try:
             got = U.gpu_simple_compress(nums, G.make_config(enable_8_bit=True, **kw))
         except G.PcoGfxError as e:
-            if e.status == G.ST_UNSUPPORTED: skipped += 1; continue
+            if e.status == G.ST_UNSUPPORTED: skip("gpu unsupported: " + str(e)[-60:]); continue
             bad.append(("gpu error", case, np.dtype(dt).name, n, kw, str(e))); continue
-        if got != want and not fb:
-            bad.append(("bytes", case, np.dtype(dt).name, n, kw))
-            fails[f"case{case}_nums"] = nums; fails[f"case{case}_got"] = np.frombuffer(got, np.uint8); fails[f"case{case}_kw"] = np.array(repr(kw))
-            continue
+        if got != want:
+            if not fb:
+                bad.append(("bytes", case, np.dtype(dt).name, n, kw))
+                fails[f"case{case}_nums"] = nums; fails[f"case{case}_got"] = np.frombuffer(got, np.uint8); fails[f"case{case}_kw"] = np.array(repr(kw))
+                continue
+            # the reference's order-dependent histogram branch ran (DESIGN.md section 2): the bytes may differ, but they must
+            # still be a valid encoding of the input for both decoders
+            skip("bytes not compared: reference heapsort-fallback histogram")
+            try:
+                if not U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, n), nums) or not U.bits_equal(O.simple_decompress(got, nums.dtype, cap=n + 8), nums):
+                    bad.append(("divergent bytes do not decode to the input", case, np.dtype(dt).name, n, kw))
+            except (G.PcoGfxError, O.OracleError) as e:
+                bad.append(("divergent bytes fail to decode", case, np.dtype(dt).name, n, kw, str(e)))
         try:
             back = U.gpu_simple_decompress(want, nums.dtype, n)
             if not U.bits_equal(back, nums): bad.append(("decode", case, np.dtype(dt).name, n, kw))
         except G.PcoGfxError as e:
             if e.status != G.ST_UNSUPPORTED: bad.append(("decode error", case, np.dtype(dt).name, n, kw, str(e)))
+            else: skip("gpu decode unsupported: " + str(e)[-60:])
 
     return bad, skipped, fails
+
+
+def run_batched(n_calls, seed, max_level=8):
+    """Many chunks of mixed dtype / size / distribution in ONE pco_gfx_compress_chunks call (the path the benchmark and a
+    row-group writer use): every chunk's bytes against the oracle, every chunk decoded back by the batched decoder."""
+    rng = np.random.default_rng(seed)
+    bad = []; skipped = {}
+    for call in range(n_calls):
+        k = int(rng.integers(2, 40))
+        dts = [(INT[2:] + FLT[1:])[rng.integers(0, 8)] for _ in range(k)]
+        ns = [int(rng.choice(SIZES, p=SIZE_P)) for _ in range(k)]
+        arrays = [gen(rng, dt, n) for dt, n in zip(dts, ns)]
+        kw = draw_config(rng, np.uint32, 0, max_level)
+        if kw.get("mode") not in (0, 1): kw["mode"] = int(rng.integers(0, 2))   # a mode every dtype accepts
+        try:
+            chunks, back = U.gpu_batched(arrays, G.make_config(**kw))
+        except G.PcoGfxError as e:
+            if e.status == G.ST_UNSUPPORTED: skipped["gpu unsupported: " + str(e)[-60:]] = skipped.get("gpu unsupported: " + str(e)[-60:], 0) + 1; continue
+            bad.append(("gpu error", call, kw, str(e))); continue
+        for i, a in enumerate(arrays):
+            # (a batched task is ONE chunk whatever its size; the oracle's file writer needs max_page_n >= n to keep it in one)
+            want = O.simple_compress(a, O.make_config(max_page_n=max(a.size, 1 << 18), **kw))
+            if chunks[i] != U.chunk_of_file(want, len(chunks[i])) and not hist_fallback_ran(a, kw):
+                bad.append(("bytes", call, i, a.dtype.name, a.size, kw))
+            if not U.bits_equal(back[i], a): bad.append(("decode", call, i, a.dtype.name, a.size, kw))
+    return bad, skipped

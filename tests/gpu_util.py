@@ -65,3 +65,35 @@ def gpu_simple_compress(arr, cfg, uniform_type=False):
                                              1 if uniform_type else 0, dst.ctypes.data_as(C.c_void_p), cap, C.byref(n))
     G.check(code)
     return dst[: n.value].tobytes()
+
+
+def gpu_batched(arrays, cfg):
+    """One pco_gfx_compress_chunks call over `arrays` (any mix of dtypes / sizes; device buffers through torch), then one
+    pco_gfx_decompress_chunks call over what it produced.  Returns ([standalone chunk bytes], [decoded arrays])."""
+    import torch
+    L = G.lib()
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    srcs = [torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda() for a in arrays]
+    caps = [(L.pco_gfx_guarantee_chunk_size(a.size, G.DTYPE_BYTE[a.dtype.name]) + 64 + 15) // 16 * 16 for a in arrays]
+    dsts = [torch.zeros(c, dtype=torch.uint8, device="cuda") for c in caps]
+    k = len(arrays)
+    tasks = (G.EncodeTask * k)(*[G.EncodeTask(s.data_ptr(), a.size, d.data_ptr(), c, G.DTYPE_BYTE[a.dtype.name], 0)
+                                 for a, s, d, c in zip(arrays, srcs, dsts, caps)])
+    res = (G.TaskResult * k)()
+    G.check(L.pco_gfx_compress_chunks(k, tasks, C.byref(cfg), res, None, None))
+    outs = [torch.empty(max(a.nbytes, 1), dtype=torch.uint8, device="cuda") for a in arrays]
+    dtasks = (G.DecodeTask * k)(*[G.DecodeTask(d.data_ptr(), res[i].n_out, o.data_ptr(), a.size, G.DTYPE_BYTE[a.dtype.name], 0)
+                                  for i, (a, d, o) in enumerate(zip(arrays, dsts, outs))])
+    dres = (G.TaskResult * k)()
+    G.check(L.pco_gfx_decompress_chunks(k, dtasks, dres, None, None))
+    chunks = [bytes(dsts[i][: res[i].n_out].cpu().numpy()) for i in range(k)]
+    back = []
+    for i, a in enumerate(arrays):
+        assert dres[i].n_out == a.size and dres[i].consumed == res[i].n_out, (i, dres[i].n_out, a.size)
+        back.append(outs[i][: a.nbytes].cpu().numpy().view(a.dtype))
+    return chunks, back
+
+
+def chunk_of_file(file_bytes, chunk_len):
+    """The single chunk inside an oracle-written one-chunk standalone file (header | chunk | 0x00)."""
+    return file_bytes[len(file_bytes) - 1 - chunk_len:-1]
