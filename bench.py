@@ -3,22 +3,25 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic chunks that are already resident
-in HBM: pco_gfx_compress_chunks over every chunk, then pco_gfx_decompress_chunks over the chunks
-just produced.  Workload = BASELINE.json configs[1]: u64, classic mode, delta order 1, 2^18-element
-chunks of a noisy linear ramp.  value = uncompressed GB/s over encode+decode, 2*bytes/(t_enc+t_dec),
-aggregated over all ranks (chunks are independent: each rank owns its own chunks, weak scaling, no
-collective on the data path; `--gather` adds the optional RCCL gather of the compressed pages).
+A "step" is one pass of the hot path over one batch of synthetic chunks that are already resident in HBM:
+pco_gfx_compress_chunks over every chunk of the rank (ONE call), then pco_gfx_decompress_chunks over the chunks just
+produced (ONE call).  Default workload = BASELINE.json configs[1]: u64, classic mode, delta order 1, 2^18-element
+chunks of a noisy linear ramp.  value = uncompressed GB/s over encode+decode, 2*bytes/(t_enc+t_dec), aggregated over all
+ranks (chunks are independent: each rank owns a contiguous block of chunks, weak scaling, no collective on the data
+path).  `--gather` adds the file-assembly path of BASELINE configs[4]: device-side compaction of the rank's chunks,
+gather-v of the exact byte ranges to rank 0 over RCCL, and for the decode direction the scatter of the byte ranges back.
 
-For N>1 the driver launches one rank per GPU through torch.distributed.run (RCCL).  PyTorch is only
-plumbing here (device buffers, streams, process group); the codec is libpco_gfx.so.
+With --gpus N > 1 and no torch.distributed environment the script launches the N ranks itself
+(torch.distributed.run, one rank per GPU, RCCL); under an external launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
+PyTorch is only plumbing here (device buffers, streams, process group); the codec is libpco_gfx.so.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -34,73 +37,149 @@ ENC_TASK = np.dtype([("src", "<u8"), ("n", "<u8"), ("dst", "<u8"), ("dst_cap", "
 DEC_TASK = np.dtype([("src", "<u8"), ("src_len", "<u8"), ("dst", "<u8"), ("dst_cap", "<u8"), ("dtype", "<u4"), ("flags", "<u4")])
 RESULT = np.dtype([("n_out", "<u8"), ("consumed", "<u8"), ("status", "<u4"), ("aux", "<u4")])
 
-WORKLOADS = {
-    # name: (torch dtype name, pco dtype byte, config kwargs, description)
-    "c2": ("int64", 2, dict(mode=1, delta=2, delta_order=1), "u64 classic delta-1 noisy ramp, 2^18-element chunks (BASELINE configs[1])"),
-    "c3": ("float64", 6, dict(mode=2, mode_f64=0.01, delta=1), "f64 float-mult(0.01) decimals, 2^18-element chunks (BASELINE configs[2])"),
-    "c1": ("int32", 1, dict(mode=1, delta=1), "u32 classic no-delta uniform random, 2^18-element chunks (BASELINE configs[0], incompressible)"),
-    "c4": ("int64", 4, dict(mode=1, delta=3), "i64 seasonal (period 365) lookback delta, 2^18-element chunks (BASELINE configs[3])"),
-    "c2auto": ("int64", 2, dict(), "u64 noisy ramp, default ChunkConfig (Auto mode + Auto delta), 2^18-element chunks"),
+# chunk kinds: (numpy dtype, pco dtype byte)  -- SURVEY.md section 8(d) synthetic inputs
+KINDS = {
+    "u64ramp": (np.uint64, 2),      # C2: x[i] = 2^40 + 1000 i + U[0, 512)
+    "f64cents": (np.float64, 6),    # C3: U{1000..9999} / 100 (pco_cli/generate_randoms.py:283-286)
+    "u32rand": (np.uint32, 1),      # C1: uniform random 32-bit
+    "i64season": (np.int64, 4),     # C4: period-365 seasonal + U{-3..3}
+    "f32normal": (np.float32, 5),   # C5: standard normal (generate_randoms.py:242-244)
+    "i32lomax": (np.int32, 3),      # C5: lomax(0.5) * 10 (generate_randoms.py:167-169)
 }
-ELEM_BYTES = {"c1": 4, "c2": 8, "c3": 8, "c4": 8, "c2auto": 8}
+WORKLOADS = {
+    # name: (chunk kinds cycled over the chunk index, config kwargs, dtype label, description)
+    "c2": (["u64ramp"], dict(mode=1, delta=2, delta_order=1), "u64", "u64 classic delta-1 noisy ramp, 2^18-element chunks (BASELINE configs[1])"),
+    "c3": (["f64cents"], dict(mode=2, mode_f64=0.01, delta=1), "f64", "f64 float-mult(0.01) decimals, 2^18-element chunks (BASELINE configs[2])"),
+    "c1": (["u32rand"], dict(mode=1, delta=1), "u32", "u32 classic no-delta uniform random, 2^18-element chunks (BASELINE configs[0], incompressible)"),
+    "c4": (["i64season"], dict(mode=1, delta=3), "i64", "i64 seasonal (period 365) lookback delta, 2^18-element chunks (BASELINE configs[3])"),
+    "c2auto": (["u64ramp"], dict(), "u64", "u64 noisy ramp, default ChunkConfig (Auto mode + Auto delta), 2^18-element chunks"),
+    "c5": (["u64ramp", "f32normal", "i32lomax"], dict(mode=1, delta=2, delta_order=1), "u64/f32/i32",
+           "mixed u64 ramp / f32 normal / i32 lomax chunks of 2^18, one call per rank, Classic + TryConsecutive(1) (BASELINE configs[4], explicit specs)"),
+    "c5auto": (["u64ramp", "f32normal", "i32lomax"], dict(), "u64/f32/i32",
+               "mixed u64 ramp / f32 normal / i32 lomax chunks of 2^18, one call per rank, default ChunkConfig (BASELINE configs[4], Auto/Auto)"),
+}
+MODE_NAMES = {0: "Auto", 1: "Classic", 2: "TryFloatMult", 3: "TryFloatQuant", 4: "TryIntMult"}
+DELTA_NAMES = {0: "Auto", 1: "NoOp", 2: "TryConsecutive", 3: "TryLookback"}
 
 
-def make_chunks(torch, kind, n_chunks, rank, device):
-    g = torch.Generator(device=device)
-    g.manual_seed(1234 + 7919 * rank)
-    if kind in ("c2", "c2auto"):
+def make_kind(torch, kind, n_chunks, g, device):
+    """[n_chunks, 2^18] device tensor of one chunk kind (torch dtype with the same bits as the pco dtype)."""
+    if kind == "u64ramp":
         i = torch.arange(N18, device=device, dtype=torch.int64)
-        base = (1 << 40) + 1000 * i
         noise = torch.randint(0, 512, (n_chunks, N18), generator=g, device=device, dtype=torch.int64)
         start = torch.randint(0, 1 << 20, (n_chunks, 1), generator=g, device=device, dtype=torch.int64)
-        return (base.unsqueeze(0) + noise + start).contiguous()  # non-negative: same bits as u64
-    if kind == "c3":
-        cents = torch.randint(1000, 10000, (n_chunks, N18), generator=g, device=device, dtype=torch.int64)
-        return (cents.to(torch.float64) / 100.0).contiguous()
-    if kind == "c1":
-        return torch.randint(-(1 << 31), 1 << 31, (n_chunks, N18), generator=g, device=device, dtype=torch.int64).to(torch.int32).contiguous()
-    if kind == "c4":
+        return ((1 << 40) + 1000 * i).unsqueeze(0) + noise + start   # non-negative: same bits as u64
+    if kind == "f64cents":
+        return torch.randint(1000, 10000, (n_chunks, N18), generator=g, device=device, dtype=torch.int64).to(torch.float64) / 100.0
+    if kind == "u32rand":
+        return torch.randint(-(1 << 31), 1 << 31, (n_chunks, N18), generator=g, device=device, dtype=torch.int64).to(torch.int32)
+    if kind == "i64season":
         base = torch.randint(-(1 << 40), 1 << 40, (365,), generator=g, device=device, dtype=torch.int64)
         idx = torch.arange(N18, device=device) % 365
-        return (base[idx].unsqueeze(0) + torch.randint(-3, 4, (n_chunks, N18), generator=g, device=device, dtype=torch.int64)).contiguous()
+        return base[idx].unsqueeze(0) + torch.randint(-3, 4, (n_chunks, N18), generator=g, device=device, dtype=torch.int64)
+    if kind == "f32normal":
+        return torch.randn((n_chunks, N18), generator=g, device=device, dtype=torch.float32)
+    if kind == "i32lomax":   # numpy's pareto(a) is Lomax: (1 - U)^(-1/a) - 1, a = 0.5
+        u = torch.rand((n_chunks, N18), generator=g, device=device, dtype=torch.float64)
+        return (((1.0 - u) ** -2.0 - 1.0) * 10.0).clamp(0, 2e9).to(torch.int32)
     raise KeyError(kind)
 
 
-def cpu_baseline(kind, cfg_kw, seconds=12.0):
-    """The oracle (a port of the reference's algorithm, NOT the Rust binary) on the host cores."""
-    import oracle_lib as O
+def host_sample(kind, seed=0):
+    """One chunk of a kind on the host (numpy) for the CPU baseline."""
     import gpu_util as U
+    rng = np.random.default_rng(1000 + seed)
+    if kind == "u64ramp": return U.synth("c2")
+    if kind == "f64cents": return U.synth("c3")
+    if kind == "u32rand": return U.synth("c1")
+    if kind == "i64season": return U.synth("c4")
+    if kind == "f32normal": return rng.standard_normal(N18).astype(np.float32)
+    if kind == "i32lomax": return (rng.pareto(0.5, N18) * 10).clip(0, 2e9).astype(np.int32)
+    raise KeyError(kind)
 
-    nums = U.synth(kind)
+
+def cpu_info():
+    info = {"logical_cpus": os.cpu_count() or 1}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            k, _, v = line.partition(":"); k = k.strip(); v = v.strip()
+            if k == "Model name": info["model"] = v
+            elif k == "Socket(s)": info["sockets"] = int(v)
+            elif k == "Core(s) per socket": info["cores_per_socket"] = int(v)
+            elif k == "Thread(s) per core": info["threads_per_core"] = int(v)
+    except Exception:
+        pass
+    if "sockets" in info and "cores_per_socket" in info:
+        info["physical_cores"] = info["sockets"] * info["cores_per_socket"]
+    # a container may own fewer CPUs than it sees: cgroup v2 cpu.max = "<quota> <period>" (v1: cpu.cfs_quota_us / cpu.cfs_period_us)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max": info["cgroup_cpu_quota"] = round(int(q) / int(p), 2)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0: info["cgroup_cpu_quota"] = round(q / p, 2)
+        except Exception:
+            pass
+    try:
+        info["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return info
+
+
+def cpu_baseline(kinds, cfg_kw, seconds=14.0):
+    """The oracle (a C++ restatement of the reference's algorithm, NOT the Rust binary) on the host cores: a native
+    std::thread driver inside oracle/ (pco_oracle_bench) -- every thread loops compress -> decompress over a private copy
+    of one chunk, no Python in the loop.  One thread first (per-direction rates), then one thread per logical CPU."""
+    import oracle_lib as O
+
+    L = O.lib()
     ocfg = O.make_config(**cfg_kw)
-    enc = O.simple_compress(nums, ocfg)
-    cores = os.cpu_count() or 1
-    # single thread, a few chunks
-    t0 = time.perf_counter(); k1 = 0
-    te = td = 0.0
-    while time.perf_counter() - t0 < seconds / 3 or k1 < 2:
-        a = time.perf_counter(); O.simple_compress(nums, ocfg); b = time.perf_counter(); O.simple_decompress(enc, nums.dtype, cap=nums.size + 8); c = time.perf_counter()
-        te += b - a; td += c - b; k1 += 1
-    one = dict(enc_gbs=k1 * nums.nbytes / te / 1e9, dec_gbs=k1 * nums.nbytes / td / 1e9, both_gbs=2 * k1 * nums.nbytes / (te + td) / 1e9)
-    # all cores, one chunk stream per thread (ctypes releases the GIL)
-    counts = [0] * cores
-    stop = time.perf_counter() + 2 * seconds / 3
+    info = cpu_info()
+    # one thread per CPU this process may actually use: more threads than the cgroup quota only get throttled (measured on the
+    # round-2 GPU box: cpu.max = 16 CPUs of a 2 x 64-core EPYC 9575F; linear to 16 threads, 13.7 GB/s, then falling)
+    threads = int(min(info["logical_cpus"], info.get("affinity_cpus", 1 << 30), max(1, int(info.get("cgroup_cpu_quota", 1 << 30)))))
+    per_kind = seconds / len(kinds)
+    one = {"chunks": 0, "bytes": 0.0, "enc_s": 0.0, "dec_s": 0.0}
+    many = {"chunks": 0, "bytes": 0.0, "wall": 0.0}
+    for k, kind in enumerate(kinds):
+        x = host_sample(kind, k)
+        out = (C.c_double * 4)()
 
-    def work(i):
-        local = nums.copy()
-        while time.perf_counter() < stop:
-            e = O.simple_compress(local, ocfg); O.simple_decompress(e, local.dtype, cap=local.size + 8); counts[i] += 1
+        def run(nt, secs):
+            rc = L.pco_oracle_bench(x.ctypes.data_as(C.c_void_p), C.c_size_t(x.size), C.c_uint8(O.dtype_byte(x)), C.byref(ocfg), C.c_uint32(nt), C.c_double(secs), out)
+            if rc != 0:
+                raise RuntimeError("oracle bench failed: " + L.pco_oracle_last_error().decode())
+            return list(out)
 
-    ts = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    t1 = time.perf_counter()
-    for t in ts: t.start()
-    for t in ts: t.join()
-    el = time.perf_counter() - t1
-    total = sum(counts)
-    return {"value": round(2 * total * nums.nbytes / el / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": f"{total} chunks of 2^18 {nums.dtype.name} ({kind}) encode+decode over {cores} threads in {el:.1f}s "
-                      f"(C++ restatement of the reference, g++ -O3 -mavx2; the Rust reference cannot be built here)",
-            "single_thread": {k: round(v, 3) for k, v in one.items()}}
+        done, wall, se, sd = run(1, per_kind * 0.25)
+        one["chunks"] += done; one["bytes"] += done * x.nbytes; one["enc_s"] += se; one["dec_s"] += sd
+        done, wall, se, sd = run(threads, per_kind * 0.75)
+        many["chunks"] += done; many["bytes"] += done * x.nbytes; many["wall"] += wall
+    single = {"enc_gbs": one["bytes"] / one["enc_s"] / 1e9, "dec_gbs": one["bytes"] / one["dec_s"] / 1e9, "both_gbs": 2 * one["bytes"] / (one["enc_s"] + one["dec_s"]) / 1e9}
+    value = 2 * many["bytes"] / many["wall"] / 1e9
+    return {"value": round(value, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"{int(many['chunks'])} chunks of 2^18 ({'/'.join(kinds)}) encode+decode over {threads} native threads in {many['wall']:.1f}s, after "
+                      f"{int(one['chunks'])} chunks on one thread (C++ restatement of the reference, g++ -O3 -mavx2, std::thread driver in oracle/; "
+                      "the Rust reference cannot be built here)",
+            "single_thread": {k: round(v, 3) for k, v in single.items()},
+            "scaling_vs_single_thread": round(value / single["both_gbs"], 1),
+            # what the same code would reach on all physical cores of ONE socket if it kept scaling linearly (it does up to the quota);
+            # an upper bound for the "single-socket CPU" the north star compares with, not a measurement
+            "linear_extrapolation_one_socket": round(single["both_gbs"] * info["cores_per_socket"], 1) if "cores_per_socket" in info else None,
+            "cpu": info}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run (RCCL) and mirror rank 0's line."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -108,68 +187,106 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chunks", type=int, default=8192, help="chunks per GPU per step (8192 x 2 MiB = 16 GiB of numbers per GPU)")
+    ap.add_argument("--chunks", type=int, default=None, help="chunks per GPU per step (default: 16 GiB of numbers per GPU)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--gather", action="store_true", help="also gather the compressed pages to rank 0 over RCCL each step")
+    ap.add_argument("--gather", action="store_true", help="file assembly: compact on device, gather-v the chunk bytes to rank 0 over RCCL, scatter them back for the decode")
+    ap.add_argument("--verify-chunks", type=int, default=64, help="chunks (drawn at random) whose bytes rank 0 compares with the oracle during warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
     from pcodec_amd import _lib as G
+    from pcodec_amd import sharding as S
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: pcodec_amd has no CPU fallback")
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     L = G.lib()
+    L.pco_gfx_compact_chunks.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
 
-    tdt, dtb, cfg_kw, desc = WORKLOADS[args.workload]
+    kinds, cfg_kw, dtype_label, desc = WORKLOADS[args.workload]
     gcfg = G.make_config(**cfg_kw)
-    nch = args.chunks
-    data = make_chunks(torch, args.workload, nch, rank, device)
-    chunk_bytes = N18 * ELEM_BYTES[args.workload]
-    cap = (L.pco_gfx_guarantee_chunk_size(N18, dtb) + 64 + 15) // 16 * 16
-    comp = torch.zeros(nch * cap, dtype=torch.uint8, device=device)
-    out = torch.empty_like(data)
+    elem = [np.dtype(KINDS[k][0]).itemsize for k in kinds]
+    if args.chunks is None:   # 16 GiB of numbers per GPU
+        per_cycle = sum(N18 * e for e in elem)
+        args.chunks = max(len(kinds), int((16 << 30) // per_cycle) * len(kinds))
+    nch = args.chunks = -(-args.chunks // len(kinds)) * len(kinds)   # whole cycles of the kinds: every rank owns the same mix
+    # this rank's block of the global chunk sequence (contiguous blocks, sharding.shard_range); kinds cycle over the GLOBAL index
+    c0, c1 = S.shard_range(nch * world, rank, world)
+    assert c1 - c0 == nch
+    g = torch.Generator(device=device); g.manual_seed(1234 + 7919 * rank)
+    kind_of = np.array([(c0 + i) % len(kinds) for i in range(nch)])
+    data = {}; row_of = np.zeros(nch, np.int64)
+    for k, kind in enumerate(kinds):
+        idx = np.nonzero(kind_of == k)[0]
+        row_of[idx] = np.arange(len(idx))
+        if len(idx): data[k] = make_kind(torch, kind, len(idx), g, device).contiguous()
+    out = {k: torch.empty_like(v) for k, v in data.items()}
+    chunk_bytes = np.array([N18 * elem[k] for k in kind_of], dtype=np.uint64)
+    dtb = np.array([KINDS[kinds[k]][1] for k in kind_of], dtype=np.uint32)
+    caps = np.array([(L.pco_gfx_guarantee_chunk_size(N18, int(b)) + 64 + 15) // 16 * 16 for b in dtb], dtype=np.uint64)
+    cap_off = np.concatenate([[0], np.cumsum(caps)]).astype(np.uint64)
+    comp = torch.zeros(int(cap_off[-1]), dtype=torch.uint8, device=device)
+    src_ptr = np.array([data[k].data_ptr() + int(r) * N18 * elem[k] for k, r in zip(kind_of, row_of)], dtype=np.uint64)
+    out_ptr = np.array([out[k].data_ptr() + int(r) * N18 * elem[k] for k, r in zip(kind_of, row_of)], dtype=np.uint64)
 
     enc_tasks = np.zeros(nch, ENC_TASK)
-    enc_tasks["src"] = data.data_ptr() + np.arange(nch, dtype=np.uint64) * chunk_bytes
-    enc_tasks["n"] = N18; enc_tasks["dtype"] = dtb; enc_tasks["dst_cap"] = cap
-    enc_tasks["dst"] = comp.data_ptr() + np.arange(nch, dtype=np.uint64) * cap
+    enc_tasks["src"] = src_ptr; enc_tasks["n"] = N18; enc_tasks["dtype"] = dtb; enc_tasks["dst_cap"] = caps
+    enc_tasks["dst"] = np.uint64(comp.data_ptr()) + cap_off[:-1]
     dec_tasks = np.zeros(nch, DEC_TASK)
-    dec_tasks["src"] = enc_tasks["dst"]; dec_tasks["dst"] = out.data_ptr() + np.arange(nch, dtype=np.uint64) * chunk_bytes
-    dec_tasks["dst_cap"] = N18; dec_tasks["dtype"] = dtb
+    dec_tasks["src"] = enc_tasks["dst"]; dec_tasks["dst"] = out_ptr; dec_tasks["dst_cap"] = N18; dec_tasks["dtype"] = dtb
     enc_res = np.zeros(nch, RESULT); dec_res = np.zeros(nch, RESULT)
+    d_res = torch.zeros(nch * RESULT.itemsize, dtype=torch.uint8, device=device)
+    # --gather buffers: this rank's compacted stream, its offsets, the scattered copy the decoders read, and (rank 0) the file body
+    if args.gather:
+        stream_cap = int(cap_off[-1]) + 64
+        payload = torch.zeros(stream_cap, dtype=torch.uint8, device=device)
+        d_offs = torch.zeros(nch + 1, dtype=torch.int64, device=device)
+        recv = torch.zeros(stream_cap, dtype=torch.uint8, device=device)
+        file_body = torch.zeros(stream_cap * world, dtype=torch.uint8, device=device) if rank == 0 and world > 1 else None
+    gather_ms = []
 
     def encode():
-        G.check(L.pco_gfx_compress_chunks(nch, enc_tasks.ctypes.data, C.byref(gcfg), enc_res.ctypes.data, None, None))
+        G.check(L.pco_gfx_compress_chunks(nch, enc_tasks.ctypes.data, C.byref(gcfg), enc_res.ctypes.data, d_res.data_ptr() if args.gather else None, None))
+        if args.gather:   # device-side compaction (no Python loop), then the exact-size gather-v to rank 0
+            t = time.perf_counter()
+            total = C.c_uint64(0)
+            G.check(L.pco_gfx_compact_chunks(nch, enc_tasks.ctypes.data, d_res.data_ptr(), payload.data_ptr(), stream_cap - 64, 0, d_offs.data_ptr(), C.byref(total), None))
+            state["n_bytes"] = int(total.value)
+            if world > 1:
+                totals = S.exchange_totals(state["n_bytes"], device)
+                _, state["offs"] = S.gather_stream(payload, state["n_bytes"], dst=0, out=file_body, totals=totals)
+                torch.cuda.synchronize()
+            gather_ms.append((time.perf_counter() - t) * 1e3)
 
     def decode():
-        dec_tasks["src_len"] = enc_res["n_out"]
+        if args.gather:   # decoders read the byte ranges the root hands out
+            if world > 1:
+                S.scatter_stream(file_body, state["offs"], recv, src=0)
+                base = recv.data_ptr()
+            else:
+                base = payload.data_ptr()
+            sizes = enc_res["n_out"]
+            dec_tasks["src"] = np.uint64(base) + np.concatenate([[0], np.cumsum(sizes[:-1])]).astype(np.uint64)
+            dec_tasks["src_len"] = sizes
+        else:
+            dec_tasks["src_len"] = enc_res["n_out"]
         G.check(L.pco_gfx_decompress_chunks(nch, dec_tasks.ctypes.data, dec_res.ctypes.data, None, None))
 
-    def gather_pages():
-        # optional: rank 0 collects every rank's compressed chunks, in chunk order, over RCCL (pcodec_amd/sharding.py)
-        if world == 1:
-            return
-        from pcodec_amd import sharding as S
-        sizes = torch.from_numpy(enc_res["n_out"].astype(np.int64)).to(device)
-        n_out = enc_res["n_out"]
-        payload = torch.cat([comp[i * cap: i * cap + int(n_out[i])] for i in range(nch)])   # chunks back to back
-        S.gather_pages(payload, sizes, dst=0)
-
-    def step():
-        encode()
-        if args.gather:
-            gather_pages()
-        decode()
+    state = {"n_bytes": 0, "offs": None}
 
     def sync_all():
         torch.cuda.synchronize()
@@ -178,38 +295,42 @@ def main():
 
     # warm-up, with the reference bench's bitwise round-trip assertion (pco_cli/src/bench/codecs/mod.rs:176-189)
     for w in range(max(args.warmup, 1)):
-        step()
+        encode(); decode()
     torch.cuda.synchronize()
-    assert torch.equal(out, data), "decode(encode(x)) != x"
-    if rank == 0:
+    for k in data:
+        assert torch.equal(out[k].view(torch.uint8), data[k].view(torch.uint8)), "decode(encode(x)) != x"
+    if rank == 0 and args.verify_chunks > 0:   # parity spot check: randomly drawn chunks against the oracle's bytes
         import oracle_lib as O
-        first = data[0].cpu().numpy().view({"c1": np.uint32, "c2": np.uint64, "c3": np.float64, "c4": np.int64, "c2auto": np.uint64}[args.workload])
-        want = O.simple_compress(first, O.make_config(**cfg_kw))
-        got = bytes(comp[: int(enc_res["n_out"][0])].cpu().numpy())
-        hdr = len(want) - 1 - len(got)
-        assert got == want[hdr:-1], "GPU chunk bytes differ from the oracle"
+        pick = np.random.default_rng(99).choice(nch, size=min(args.verify_chunks, nch), replace=False)
+        for i in pick:
+            k = int(kind_of[i]); r = int(row_of[i])
+            host = data[k][r].cpu().numpy().view(KINDS[kinds[k]][0])
+            want = O.simple_compress(host, O.make_config(**cfg_kw))
+            n_out = int(enc_res["n_out"][i]); o = int(cap_off[i])
+            got = bytes(comp[o: o + n_out].cpu().numpy())
+            assert got == want[len(want) - 1 - n_out:-1], f"GPU chunk {i} ({kinds[k]}) differs from the oracle's bytes"
 
     # timed region: exactly K steps, bracketed by barrier + synchronize
     sync_all()
+    gather_ms.clear()
     L.pco_gfx_profile_begin()
     t_enc = t_dec = 0.0
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        a = time.perf_counter(); encode()
-        if args.gather:
-            gather_pages()
-        b = time.perf_counter(); decode(); c = time.perf_counter()
-        t_enc += b - a; t_dec += c - b
+        a = time.perf_counter(); encode(); b = time.perf_counter(); decode(); c = time.perf_counter()
+        t_enc += b - a; t_dec += c - b; step_ms.append((c - a) * 1e3)
     sync_all()
     elapsed = time.perf_counter() - t0
-    names = C.create_string_buffer(1 << 16); ms = (C.c_float * 4096)()
-    nk = L.pco_gfx_profile_end(names, len(names), ms, 4096)
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    names = C.create_string_buffer(1 << 18); ms = (C.c_float * 65536)()
+    nk = L.pco_gfx_profile_end(names, len(names), ms, 65536)
+    el = torch.tensor([elapsed, t_enc, t_dec], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed, t_enc, t_dec = (float(x) for x in el.tolist())
     ms_per_step = elapsed * 1e3 / args.steps
-    total_bytes = world * nch * chunk_bytes
+    rank_bytes = int(chunk_bytes.sum())
+    total_bytes = world * rank_bytes   # (every rank owns the same mix: kinds cycle with a period that divides nch)
     value = 2 * total_bytes / (ms_per_step * 1e-3) / 1e9
 
     if rank == 0:
@@ -219,39 +340,60 @@ def main():
         per = {}
         for nm, t in zip(kn, ms[:nk]):
             per.setdefault(nm, []).append(float(t))
-        kavg = {k: sum(v) / len(v) for k, v in per.items()}
+        kavg = {k: sum(v) / len(v) for k, v in per.items()}                 # per launch
+        kstep = {k: sum(v) / args.steps for k, v in per.items()}            # per step (a kernel may launch several times per step)
         comp_bytes = int(enc_res["n_out"].sum())
         # algorithmic bytes per launch: encode = n*sizeof(T) read + C written; decode = C read + n*sizeof(T) written
-        alg = nch * chunk_bytes + comp_bytes
+        alg = rank_bytes + comp_bytes
         dom = max(kavg, key=kavg.get)
-        traffic = None
-        try:  # HBM bytes of the dominant kernel from the committed PMC passes (profiles/), scaled to this run's chunk count
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("workload") == args.workload and dom in tj["kernels"]:
-                kk = tj["kernels"][dom]
-                traffic = int((kk["fetch_bytes_per_launch"] + kk["write_bytes_per_launch"]) * nch / tj["chunks"])
-        except (OSError, ValueError, KeyError):
-            pass
+        traffic_tab = {}
+        for tag in ("r02", "r01"):   # HBM bytes per kernel from the committed PMC passes (profiles/), scaled to this run's chunk count
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_traffic_{args.workload}.json" if tag != "r01" else "r01_traffic.json")))
+                if tj.get("workload") == args.workload:
+                    traffic_tab = {k: int((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * nch / tj["chunks"]) for k, v in tj["kernels"].items()}
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
+
+        def direction(prefixes):
+            ks = [k for k in kstep if k.startswith(prefixes)]
+            t = sum(kstep[k] for k in ks)
+            tr = sum(traffic_tab.get(k, 0) for k in ks) if traffic_tab else None
+            return {"kernel_ms": round(t, 4), "achieved": round(alg / (t * 1e-3) / 1e9, 1) if t > 0 else None,
+                    "frac": round(alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None, "traffic": tr,
+                    "traffic_over_algorithmic": round(tr / alg, 2) if tr else None}
+
+        enc_d = direction(("enc_", "gather_", "compact_")); dec_d = direction(("dec_", "pco_decode"))
+        both_t = enc_d["kernel_ms"] + dec_d["kernel_ms"]
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(alg / (kavg[dom] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(alg / (kavg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(alg / (kavg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_tab.get(dom),
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4),
-                "per_kernel_avg_ms": {k: round(v, 4) for k, v in sorted(kavg.items())}}
+                # the honest numbers: a direction's algorithmic bytes over the SUM of its kernels' time (the dominant-kernel
+                # figure above credits one kernel with the whole direction's bytes)
+                "direction": {"encode": enc_d, "decode": dec_d,
+                              "step": {"kernel_ms": round(both_t, 4), "achieved": round(2 * alg / (both_t * 1e-3) / 1e9, 1), "frac": round(2 * alg / (both_t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+                "per_kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kstep.items())}}
         line = {
             "metric": "encode+decode GB/s (uncompressed) per chunk, u64/f64 2^18-elem", "value": round(value, 2), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"c1": "u32", "c2": "u64", "c3": "f64", "c4": "i64", "c2auto": "u64"}[args.workload],
-            "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": desc, "chunks_per_gpu": nch, "chunk_n": N18, "compression_level": 8,
-                       "mode_spec": {"c3": "TryFloatMult(0.01)", "c2auto": "Auto"}.get(args.workload, "Classic"),
-                       "delta_spec": {"c1": "NoOp", "c2": "TryConsecutive(1)", "c3": "NoOp", "c4": "TryLookback", "c2auto": "Auto"}[args.workload],
-                       "parallelism": f"chunk-sharded x{world}" + (" + RCCL gather of pages" if args.gather else ""),
+                       "mode_spec": MODE_NAMES[cfg_kw.get("mode", 0)] + (f"({cfg_kw['mode_f64']})" if "mode_f64" in cfg_kw else ""),
+                       "delta_spec": DELTA_NAMES[cfg_kw.get("delta", 0)] + (f"({cfg_kw['delta_order']})" if "delta_order" in cfg_kw else ""),
+                       "parallelism": f"chunk-sharded x{world}, contiguous chunk blocks" + (", device compaction + RCCL gather-v / scatter of the chunk bytes" if args.gather else ", no data-path collective"),
                        "compressed_bytes_per_chunk": comp_bytes // nch,
-                       "encode_GBps": round(world * nch * chunk_bytes * args.steps / t_enc / 1e9, 2),
-                       "decode_GBps": round(world * nch * chunk_bytes * args.steps / t_dec / 1e9, 2)},
+                       "encode_GBps": round(total_bytes * args.steps / t_enc / 1e9, 2),
+                       "decode_GBps": round(total_bytes * args.steps / t_dec / 1e9, 2),
+                       "median_step_ms_rank0": round(float(np.median(step_ms)), 3),
+                       "oracle_verified_chunks": min(args.verify_chunks, nch)},
             "roofline": roof,
         }
+        if args.gather:
+            line["config"]["gather_ms_per_step_rank0"] = round(float(np.mean(gather_ms)), 3) if gather_ms else None
+            line["config"]["stream_bytes_per_rank"] = state["n_bytes"]
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.workload, cfg_kw)
+            line["cpu_baseline"] = cpu_baseline(kinds, cfg_kw)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -212,7 +212,13 @@ enum PcoError pco_wrapped_read_header(const void* src, size_t len, size_t* consu
 enum PcoError pco_chunk_compressor_new(const void* nums, size_t n, unsigned char dtype,
                                        const PcoChunkConfigEx* config,
                                        PcoGfxChunkCompressor** out);            /* chunk_compressor.rs:442 */
+/* PagingSpec::Exact (chunk_config.rs:124,162-180): the sizes must be non-zero and sum to n */
+enum PcoError pco_chunk_compressor_new_exact(const void* nums, size_t n, unsigned char dtype, const PcoChunkConfigEx* config,
+                                             const size_t* page_sizes, size_t n_pages, PcoGfxChunkCompressor** out);
 size_t pco_chunk_compressor_n_pages(const PcoGfxChunkCompressor*);
+/* exact byte lengths of what write_meta / write_page will write (the *_size_hint functions mirror the reference's estimates) */
+size_t pco_chunk_compressor_meta_size(const PcoGfxChunkCompressor*);
+size_t pco_chunk_compressor_page_size(const PcoGfxChunkCompressor*, size_t page_idx);
 size_t pco_chunk_compressor_page_n(const PcoGfxChunkCompressor*, size_t page_idx); /* n_per_page :544 */
 size_t pco_chunk_compressor_meta_size_hint(const PcoGfxChunkCompressor*);       /* :556 */
 size_t pco_chunk_compressor_page_size_hint(const PcoGfxChunkCompressor*, size_t page_idx); /* :599 */
@@ -228,6 +234,15 @@ enum PcoError pco_chunk_decompressor_read_page(PcoGfxChunkDecompressor*, const v
                                                size_t page_n, void* dst, size_t dst_cap,
                                                size_t* n_processed, size_t* consumed);
 void pco_chunk_decompressor_free(PcoGfxChunkDecompressor*);
+
+/* ChunkDecompressor::page_decompressor + PageDecompressor::read / into_src (wrapped/chunk_decompressor.rs:74-80,
+ * page_decompressor.rs:193-246): `read` fills up to dst_len numbers; dst_len must be a multiple of 256 or at least the count of
+ * numbers remaining in the page (InvalidArgument otherwise); *n_processed / *finished are the reference's Progress. */
+typedef struct PcoGfxPageDecompressor PcoGfxPageDecompressor;
+enum PcoError pco_page_decompressor_new(PcoGfxChunkDecompressor*, const void* src, size_t len, size_t page_n, PcoGfxPageDecompressor** out);
+enum PcoError pco_page_decompressor_read(PcoGfxPageDecompressor*, void* dst, size_t dst_len, size_t* n_processed, int* finished);
+size_t pco_page_decompressor_consumed(const PcoGfxPageDecompressor*);
+void pco_page_decompressor_free(PcoGfxPageDecompressor*);
 
 #if defined(__cplusplus)
 }

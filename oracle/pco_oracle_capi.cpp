@@ -81,11 +81,24 @@ int pco_oracle_simple_compress(const void* nums, size_t n, uint8_t dtype, const 
 
 // wrapped::ChunkCompressor (wrapped/chunk_compressor.rs:442-705): ChunkMeta bytes, then every page's bytes back to back.
 // sizes[0] = meta bytes, sizes[1 + i] = bytes of page i, page_ns[i] = numbers in page i; *n_pages <= cap_pages.
+static int wrapped_compress_impl(const void* nums, size_t n, uint8_t dtype, const PcoOracleConfig* config, const size_t* exact_pages, size_t n_exact,
+                                 uint8_t* dst, size_t dst_cap, size_t* sizes, size_t* page_ns, size_t cap_pages, size_t* n_pages);
 int pco_oracle_wrapped_compress(const void* nums, size_t n, uint8_t dtype, const PcoOracleConfig* config, uint8_t* dst, size_t dst_cap,
                                 size_t* sizes, size_t* page_ns, size_t cap_pages, size_t* n_pages) {
+  return wrapped_compress_impl(nums, n, dtype, config, nullptr, 0, dst, dst_cap, sizes, page_ns, cap_pages, n_pages);
+}
+// the same with PagingSpec::Exact (chunk_config.rs:124,162-180)
+int pco_oracle_wrapped_compress_exact(const void* nums, size_t n, uint8_t dtype, const PcoOracleConfig* config, const size_t* exact_pages, size_t n_exact,
+                                      uint8_t* dst, size_t dst_cap, size_t* sizes, size_t* page_ns, size_t cap_pages, size_t* n_pages) {
+  static const size_t none = 0;
+  return wrapped_compress_impl(nums, n, dtype, config, exact_pages ? exact_pages : &none, n_exact, dst, dst_cap, sizes, page_ns, cap_pages, n_pages);
+}
+static int wrapped_compress_impl(const void* nums, size_t n, uint8_t dtype, const PcoOracleConfig* config, const size_t* exact_pages, size_t n_exact,
+                                 uint8_t* dst, size_t dst_cap, size_t* sizes, size_t* page_ns, size_t cap_pages, size_t* n_pages) {
   return guard([&] {
     if (!dtype_valid(dtype)) fail(kInvalidArgument, "invalid dtype");
     ChunkConfig cfg = to_cfg(config);
+    if (exact_pages) { cfg.paging_exact = true; cfg.exact_pages.assign(exact_pages, exact_pages + n_exact); }
     dispatch_bits(dtype_bits(dtype), [&](auto tag) {
       typedef decltype(tag) LTYPE;
       ChunkCompressor<LTYPE>* cc = new ChunkCompressor<LTYPE>();
@@ -318,11 +331,16 @@ int pco_oracle_lookback_encode_u32(uint32_t* latents, size_t n, uint32_t state_n
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <malloc.h>
 extern "C" int pco_oracle_bench(const void* nums, size_t n, uint8_t dtype, const PcoOracleConfig* config, uint32_t n_threads,
                                 double seconds, double* out) {
   return guard([&] {
     if (!dtype_valid(dtype)) fail(kInvalidArgument, "invalid dtype");
     if (n_threads == 0) n_threads = 1;
+    // The restated algorithm allocates its working vectors per call, like the reference (Vec per chunk).  With glibc's defaults a 2 MiB
+    // vector is an mmap + page faults + munmap every time, and hundreds of threads then serialise on the process's mmap lock; serve
+    // them from the per-thread arenas instead (the equivalent of the reference running under a pooling allocator).
+    mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_ARENA_MAX, (int)n_threads + 8);
     const ChunkConfig cfg = to_cfg(config);
     const int bits = dtype_bits(dtype);
     const size_t bytes = n * (size_t)(bits / 8);

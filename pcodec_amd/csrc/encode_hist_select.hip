@@ -1,0 +1,550 @@
+// encode_hist_select.hip -- the exact quantile histogram (histograms.rs) for variables whose value range is too wide to count
+// in LDS (max - min >= kWideHistRange), without sorting the variable.
+//
+// The histogram only asks for the values (and their runs of equal values) at <= 2 * 2^bins_log ranks, so all it needs is a
+// MONOTONE map of the latents onto a few thousand buckets whose populations are small wherever a queried rank falls: count
+// the buckets, find the buckets that hold queried ranks, gather only those buckets' latents (each bucket into its own
+// window, in any order) and order each window by itself -- windows hold some 32 latents and are sorted by one wave in
+// registers.  Round 1 bucketed by the top bits of x - min; that map collapses on the distributions delta'd and lookback'd data
+// actually have (a dense core plus far outliers, power-law tails, heavy ties): every queried rank then sits in one or two
+// buckets and the "subset" is the whole variable (74 ms per launch on the mixed workload, 13 ms on lookback residuals).
+// Here the map is built from the data: a 2048-latent sample is sorted in LDS, its 64 quantiles cut the value range into
+// segments of (roughly) equal population, and every segment is cut linearly into 128 buckets:
+//     bucket(x) = 128 j + ((x - lo_j) >> sh_j),   j = the segment holding x (6-step search over the 64 lower bounds in LDS)
+// A value that makes up more than 1/64 of the sample gets a segment of its own, [v, v + 1); segments narrower than 128 values
+// have sh_j = 0, i.e. one bucket per value: such "exact" buckets answer rank queries from the bucket counts alone and are
+// never gathered.  What is left are buckets of a few dozen latents; a power-law tail puts at most 1/64 of the variable into
+// the first bucket of the last segment, which the block orders in LDS (up to 8192 latents).  Anything beyond that (never
+// seen in practice) is handed to round 1's radix-sort kernel, which stays as the fallback (EncVar::hist_path == 2).
+//
+// Per chunk and variable: two streaming passes over the latents (count, gather), both bound by LDS traffic (7 reads + 1
+// atomic per latent) at about the rate HBM delivers them; one block of 1024 threads per chunk, one block per CU.
+#pragma once
+
+namespace pcogfx {
+
+constexpr uint32_t kSelT = 1024;
+constexpr uint32_t kSelSegs = 128, kSelSubLog = 6, kSelSample = 2048, kSelSortCap = 8192, kSelBigCap = 256, kSelWaveSortCap = 512;
+static_assert(kSelSegs << kSelSubLog == kSelBuckets, "segments x sub-buckets");
+static_assert(kSelWaveSortCap * (kSelT / 64) == kSelSortCap, "the block sort area is also the waves' private sort areas");
+constexpr uint32_t kSelLdsP = kHistLdsCounts;                                   // u32[8192 + 8] bucket counts, then exclusive prefix
+constexpr uint32_t kSelLdsNeed = kSelLdsP + (kSelBuckets + 8) * 4;              // u32[256] bitmap of the buckets to gather
+constexpr uint32_t kSelLdsSlot = kSelLdsNeed + kSelBuckets / 8;                 // u16[8192] bucket -> position in the list
+constexpr uint32_t kSelLdsNlK = kSelLdsSlot + kSelBuckets * 2;                  // u32[1600] marked buckets, ascending
+constexpr uint32_t kSelLdsNlOc = kSelLdsNlK + kSelMaxNeeded * 4;                // u32[1601 + 1] first subset index of each one's window
+constexpr uint32_t kSelLdsCur = kSelLdsNlOc + (kSelMaxNeeded + 2) * 4;          // u32[1600] fill cursors of the windows
+constexpr uint32_t kSelLdsSegLo = kSelLdsCur + kSelMaxNeeded * 4;               // u64[128] segment lower bounds
+constexpr uint32_t kSelLdsSegPar = kSelLdsSegLo + kSelSegs * 8;                 // u32[128] segment scaling: multiplier | pre-shift << 24
+constexpr uint32_t kSelLdsLut = kSelLdsSegPar + kSelSegs * 4;                   // u16[256 + 8] value cell -> first | last << 8 segment it meets
+constexpr uint32_t kSelLdsBig = kSelLdsLut + (256 + 8) * 2;                     // u32[256 + 4] windows the block orders in LDS; counters
+constexpr uint32_t kSelLdsSort = (kSelLdsBig + (kSelBigCap + 4) * 4 + 15) & ~15u;   // u64[8192] sample / block sort area / 16 x u64[512] wave sort areas
+constexpr uint32_t kSelLdsBytes = kSelLdsSort + kSelSortCap * 8;
+static_assert(kSelLdsBytes <= 160 * 1024, "one block per CU");
+
+// ascending bitonic sort of one latent per lane
+template <class L> __device__ __forceinline__ L wave_sort64(L x) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const L o = shfl_idx(x, (int)(lane ^ j));
+      const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+      const L mn = x < o ? x : o, mx = x < o ? o : x;
+      x = keep_min ? mn : mx;
+    }
+  }
+  return x;
+}
+// the same for kN independent sets at once: the kN exchanges of a stage are issued together (a lone sort is a chain of 21
+// dependent cross-lane reads, some 100 cycles each)
+template <class L, uint32_t kN> __device__ __forceinline__ void wave_sort64_multi(L (&x)[kN]) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      L o[kN];
+#pragma unroll
+      for (uint32_t g = 0; g < kN; g++) o[g] = shfl_idx(x[g], (int)(lane ^ j));
+      const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+#pragma unroll
+      for (uint32_t g = 0; g < kN; g++) { const L mn = x[g] < o[g] ? x[g] : o[g], mx = x[g] < o[g] ? o[g] : x[g]; x[g] = keep_min ? mn : mx; }
+    }
+  }
+}
+// ascending bitonic sort of a[0 .. n) in LDS by the whole block, n a power of two (every thread of the block calls this)
+template <class L> __device__ __forceinline__ void block_sort_lds(L PCO_LDS* a, uint32_t n) {
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t k = 2; k <= n; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < (n >> 1); i += kSelT) {
+        const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l | j;
+        const L x = a[l], y = a[r];
+        const bool asc = (l & k) == 0;
+        if ((x > y) == asc) { a[l] = y; a[r] = x; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+#ifdef PCO_SEL_TIMING
+__device__ unsigned long long g_sel_timing[16];
+#define SEL_STAMP(idx) do { if (threadIdx.x == 0) { const unsigned long long _n = __builtin_readcyclecounter(); atomicAdd(&g_sel_timing[idx], _n - sel_t0); sel_t0 = _n; } } while (0)
+#else
+#define SEL_STAMP(idx) do { } while (0)
+#endif
+
+// ascending bitonic sort of a[0 .. n) in LDS by ONE wave, n a power of two <= kSelWaveSortCap
+template <class L> __device__ __forceinline__ void wave_sort_lds(L PCO_LDS* a, uint32_t n) {
+  const uint32_t lane = lane_id();
+  for (uint32_t k = 2; k <= n; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = lane; i < (n >> 1); i += 64) {
+        const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l | j;
+        const L x = a[l], y = a[r];
+        const bool asc = (l & k) == 0;
+        if ((x > y) == asc) { a[l] = y; a[r] = x; }
+      }
+      enc_wave_sync();
+    }
+  }
+}
+
+template <class L>
+__device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log) {
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  EncVar PCO_GLOBAL* ev = &ch->v[var];
+  EncPlanVar PCO_GLOBAL* plan = (EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + var;
+  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+  const uint32_t n_lat = ev->n_lat;
+  if (n_lat == 0) return;
+  const L minv = (L)ev->minv, maxv = (L)ev->maxv;
+  if ((uint64_t)(L)(maxv - minv) < kWideHistRange) return;   // the LDS-counting kernels own it
+  const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
+  const uint32_t n_all = (uint32_t)ch->n, skip = ev->lat_start, plow = ch->page_low, pr = ch->page_r;
+  const bool single_page = ch->n_pages == 1;
+  const bool exact_paging = ch->exact_paging != 0; const uint32_t n_pg = ch->n_pages;
+  const EncPage PCO_GLOBAL* pgl = (const EncPage PCO_GLOBAL*)ws.pages + ch->page_first;
+  auto exact_start = [&](uint32_t i) {
+    uint32_t lo = 0, hi = n_pg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)pgl[mid].start <= i) lo = mid; else hi = mid; }
+    return (uint64_t)pgl[lo].start;
+  };
+  auto stored = [&](uint32_t i) { return skip == 0 || (single_page ? i >= skip : (uint64_t)i - (exact_paging ? exact_start(i) : page_start_of(i, plow, pr)) >= skip); };
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  L PCO_LDS* rv = (L PCO_LDS*)(smem + kHistLdsRecV);
+  L PCO_LDS* rnext = (L PCO_LDS*)(smem + kHistLdsRecV + 2048);
+  L PCO_LDS* rpred = (L PCO_LDS*)(smem + kHistLdsRecV + 4096);
+  L PCO_LDS* rsucc = (L PCO_LDS*)(smem + kHistLdsRecV + 6144);
+  uint32_t PCO_LDS* rst = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 8192);
+  uint32_t PCO_LDS* ren = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 9216);
+  uint32_t PCO_LDS* scan = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 10240);   // u32[512]
+  uint32_t PCO_LDS* P = (uint32_t PCO_LDS*)(smem + kSelLdsP);
+  uint32_t PCO_LDS* need = (uint32_t PCO_LDS*)(smem + kSelLdsNeed);
+  uint16_t PCO_LDS* slot_of = (uint16_t PCO_LDS*)(smem + kSelLdsSlot);
+  uint32_t PCO_LDS* nl_k = (uint32_t PCO_LDS*)(smem + kSelLdsNlK);
+  uint32_t PCO_LDS* nl_oc = (uint32_t PCO_LDS*)(smem + kSelLdsNlOc);
+  uint32_t PCO_LDS* cur = (uint32_t PCO_LDS*)(smem + kSelLdsCur);
+  L PCO_LDS* seg_lo = (L PCO_LDS*)(smem + kSelLdsSegLo);
+  uint32_t PCO_LDS* seg_par = (uint32_t PCO_LDS*)(smem + kSelLdsSegPar);
+  uint16_t PCO_LDS* lut = (uint16_t PCO_LDS*)(smem + kSelLdsLut);
+  uint16_t PCO_GLOBAL* ids = clat_ptr(ws, t, var);   // bucket of every latent, written by the count pass for the gather pass (the compact-latent area is idle for wide ranges)
+  uint32_t PCO_LDS* big = (uint32_t PCO_LDS*)(smem + kSelLdsBig);   // [0, kSelBigCap): slots; [kSelBigCap]: count; [+1]: fail flag; [+2]: n_seg
+  L PCO_LDS* srt = (L PCO_LDS*)(smem + kSelLdsSort);
+  constexpr uint32_t NB = kSelBuckets;
+  const uint32_t B = 1u << bins_log;
+  const uint64_t n64 = n_lat;
+  auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
+#ifdef PCO_SEL_TIMING
+  unsigned long long sel_t0 = __builtin_readcyclecounter();
+#endif
+  __syncthreads();
+  // ---- (A) sample: 2048 evenly spaced positions (positions that are not stored hold defined junk or, for lookback, possibly
+  //      nothing at all: clamping into [min, max] makes any value a harmless boundary candidate), sorted by the block ----
+  for (uint32_t k = tid; k < kSelSample; k += kSelT) {
+    const uint32_t i = (uint32_t)(((uint64_t)k * n_all) / kSelSample);
+    L x = lat[i];
+    x = x < minv ? minv : (x > maxv ? maxv : x);
+    srt[k] = x;
+  }
+  for (uint32_t i = tid; i < NB + 8; i += kSelT) P[i] = 0;
+  for (uint32_t i = tid; i < NB / 32; i += kSelT) need[i] = 0;
+  for (uint32_t i = tid; i < NB / 2; i += kSelT) ((uint32_t PCO_LDS*)slot_of)[i] = 0xffffffffu;   // bucket -> window: 0xffff = not gathered
+  if (tid < 4) big[kSelBigCap + tid] = 0;
+  __syncthreads();
+  block_sort_lds<L>(srt, kSelSample);
+  SEL_STAMP(0);
+  // ---- (B) segments: lower bounds at sample quantiles -- every 19th sample in the interior, and geometrically closer (8, 4, 2, 1
+  //      samples from either end) in the tails, where a power law would otherwise pile a whole segment's population into its
+  //      first bucket.  Two equal neighbouring quantiles are a heavy value, which gets a segment of its own, [v, v + 1) ----
+  if (tid == 0) {
+    uint32_t ns = 0; L last_q = minv;
+    seg_lo[ns++] = minv;
+    auto cand = [&](uint32_t idx) {
+      const L q = srt[idx];
+      if (q == last_q) { if (seg_lo[ns - 1] == q && q < maxv && ns < kSelSegs) seg_lo[ns++] = (L)(q + 1); }
+      else if (q > seg_lo[ns - 1] && ns < kSelSegs) seg_lo[ns++] = q;
+      last_q = q;
+    };
+    cand(1); cand(2); cand(4); cand(8);
+    for (uint32_t idx = 19; idx + 8 < kSelSample; idx += 19) cand(idx);
+    cand(kSelSample - 8); cand(kSelSample - 4); cand(kSelSample - 2); cand(kSelSample - 1);
+    for (uint32_t j = 0; j < ns; j++) {
+      const L last = j + 1 < ns ? (L)(seg_lo[j + 1] - 1) : maxv;     // last value of the segment
+      const L w1 = (L)(last - seg_lo[j]);                              // width - 1
+      // sub-bucket = ((x - lo) >> pre) * m >> 16, monotone and < 64: segments of at most 64 values get one bucket per value
+      // (pre 0, m 65536: "exact"), the others spread their (pre-shifted, < 2^16) width over all 64 sub-buckets
+      uint32_t pre = 0, m = 65536;
+      if ((uint64_t)w1 >= (1u << kSelSubLog)) {
+        const uint32_t bl = bitlen<L>(w1);
+        pre = bl > 16 ? bl - 16 : 0u;
+        const uint32_t vmax = (uint32_t)(w1 >> pre);
+        m = (uint32_t)(((uint64_t)1 << (16 + kSelSubLog)) / ((uint64_t)vmax + 1));
+      }
+      seg_par[j] = m | (pre << 24);
+    }
+    big[kSelBigCap + 2] = ns;
+  }
+  __syncthreads();
+  const uint32_t n_seg = uni(big[kSelBigCap + 2]);
+  // value cells (the top 8 bits of x - min) -> the segments a cell meets: most cells meet one or two, and the search below
+  // only walks the segments of the latent's cell
+  const uint32_t range_bl = bitlen<L>((L)(maxv - minv));
+  const uint32_t cell_sh = range_bl > 8 ? range_bl - 8 : 0u;
+  if (tid < 256) {
+    auto seg_of = [&](L x) { uint32_t lo = 0, hi = n_seg; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_lo[mid] <= x) lo = mid; else hi = mid; } return lo; };
+    const L c0 = (L)(minv + ((L)tid << cell_sh));
+    L c1 = (L)(c0 + (L)(((L)1 << cell_sh) - 1));
+    const bool in = (uint64_t)tid <= ((uint64_t)(L)(maxv - minv) >> cell_sh);
+    if (c1 > maxv || c1 < c0) c1 = maxv;
+    lut[tid] = in ? (uint16_t)(seg_of(c0) | (seg_of(c1) << 8)) : (uint16_t)0;
+  }
+  __syncthreads();
+  auto bucket_of = [&](L x) {   // monotone in x
+    const uint32_t e = lut[(uint32_t)((L)(x - minv) >> cell_sh)];
+    uint32_t j = e & 0xffu, jn = e >> 8;
+    while (__any(j < jn)) {   // last segment of [j, jn] whose lower bound is <= x
+      const uint32_t mid = (j + jn + 1) >> 1;
+      const bool ge = seg_lo[mid] <= x;
+      j = ge ? mid : j; jn = ge ? jn : mid - 1;
+    }
+    const uint32_t par = seg_par[j];
+    const uint32_t v = (uint32_t)((L)(x - seg_lo[j]) >> (par >> 24));
+    return (j << kSelSubLog) + ((v * (par & 0x1ffffu)) >> 16);
+  };
+  auto bucket_exact = [&](uint32_t k) { return seg_par[k >> kSelSubLog] == 65536u; };
+  auto bucket_value = [&](uint32_t k) { return (L)(seg_lo[k >> kSelSubLog] + (L)(k & ((1u << kSelSubLog) - 1))); };   // of an exact bucket
+  // ---- (C) count; the bucket of every latent is kept (u16) for the gather pass.  A thread owns kE consecutive latents per
+  //      round, fetched with 16-byte loads (64 bytes in flight per thread: dword loads left the block at a third of what HBM gives
+  //      one CU); every stage of the kE searches is issued together ----
+  constexpr uint32_t kE = sizeof(L) == 8 ? 8u : 16u, kV = kE * sizeof(L) / 16;   // latents / 16-byte vectors per thread and round
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  union VecL { u32x4 v[kV]; L x[kE]; };
+  {
+    uint32_t base = 0;
+    VecL nxt;   // the next round's latents are fetched before this round's are worked on (the block's waves run in step: without it
+                // they all wait for HBM together, then all compute together)
+    if (kE * kSelT <= n_all) {
+#pragma unroll
+      for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + tid * kE))[q];
+    }
+    for (; base + kE * kSelT <= n_all; base += kE * kSelT) {
+      VecL d = nxt; uint32_t j[kE], jn[kE];
+      const uint32_t i0 = base + tid * kE;
+      if (base + 2 * kE * kSelT <= n_all) {
+#pragma unroll
+        for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + i0 + kE * kSelT))[q];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kE; k++) {
+        d.x[k] = d.x[k] < minv ? minv : (d.x[k] > maxv ? maxv : d.x[k]);   // (positions that are not stored may hold anything)
+        const uint32_t e = lut[(uint32_t)((L)(d.x[k] - minv) >> cell_sh)];
+        j[k] = e & 0xffu; jn[k] = e >> 8;
+      }
+      for (;;) {
+        bool more = false;
+#pragma unroll
+        for (uint32_t k = 0; k < kE; k++) more = more || j[k] < jn[k];
+        if (!__any(more)) break;
+#pragma unroll
+        for (uint32_t k = 0; k < kE; k++) {
+          const uint32_t mid = (j[k] + jn[k] + 1) >> 1;
+          const bool ge = seg_lo[mid] <= d.x[k];
+          j[k] = ge ? mid : j[k]; jn[k] = ge ? jn[k] : mid - 1;
+        }
+      }
+      uint32_t bb[kE];
+#pragma unroll
+      for (uint32_t k = 0; k < kE; k++) {
+        const uint32_t par = seg_par[j[k]];
+        const uint32_t v = (uint32_t)((L)(d.x[k] - seg_lo[j[k]]) >> (par >> 24));
+        const uint32_t b = (j[k] << kSelSubLog) + ((v * (par & 0x1ffffu)) >> 16);
+        const bool on = stored(i0 + k);
+        bb[k] = on ? b : 0xffffu;
+        if (on) atomicAdd((uint32_t*)&P[b], 1u);
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < kE / 8; q++) {   // eight u16 ids per 16-byte store
+        u32x4 w; w.x = bb[8 * q] | (bb[8 * q + 1] << 16); w.y = bb[8 * q + 2] | (bb[8 * q + 3] << 16); w.z = bb[8 * q + 4] | (bb[8 * q + 5] << 16); w.w = bb[8 * q + 6] | (bb[8 * q + 7] << 16);
+        ((u32x4 PCO_GLOBAL*)(ids + i0))[q] = w;
+      }
+    }
+    for (uint32_t i0 = base; i0 < n_all; i0 += kSelT) {   // (whole waves run bucket_of: its search loop votes)
+      const uint32_t i = i0 + tid;
+      const bool on = i < n_all && stored(i);
+      L xv = i < n_all ? lat[i] : minv; xv = xv < minv ? minv : (xv > maxv ? maxv : xv);
+      const uint32_t b = bucket_of(xv);
+      if (i < n_all) ids[i] = on ? (uint16_t)b : (uint16_t)0xffffu;
+      if (on) atomicAdd((uint32_t*)&P[b], 1u);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  SEL_STAMP(1);
+  // ---- (D) exclusive prefix over the buckets ----
+  {
+    constexpr uint32_t PER = NB / kSelT;
+    uint32_t s0 = 0;
+    for (uint32_t k = 0; k < PER; k++) s0 += P[tid * PER + k];
+    const uint32_t incl = wave_incl_scan(s0);
+    if (lane == 63) scan[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0; for (uint32_t w = 0; w < wave; w++) wbase += scan[w];
+    uint32_t run = wbase + incl - s0;
+    for (uint32_t k = 0; k < PER; k++) { const uint32_t c = P[tid * PER + k]; P[tid * PER + k] = run; run += c; }
+    if (tid == kSelT - 1) P[NB] = run;   // == n_lat
+  }
+  __syncthreads();
+  auto bucket_of_rank = [&](uint32_t r) {   // the (non-empty) bucket holding rank r: last k with P[k] <= r
+    uint32_t lo = 0, hi = NB;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P[mid] <= r) lo = mid; else hi = mid; }
+    return lo;
+  };
+  // ---- (E) mark the buckets that hold a queried rank, and the nearest non-empty bucket on either side; exact buckets answer
+  //      from their counts and are not gathered ----
+  auto mark = [&](uint32_t k) { if (!bucket_exact(k)) atomicOr((uint32_t*)&need[k >> 5], 1u << (k & 31)); };
+  if (tid < B) {
+    const uint32_t c = c_count(tid);
+    for (uint32_t which = 0; which < 2; which++) {
+      const uint32_t r = c - 1 + which;
+      if (r >= n_lat) continue;
+      const uint32_t k = bucket_of_rank(r);
+      mark(k);
+      if (P[k] > 0) mark(bucket_of_rank(P[k] - 1));
+      if (P[k + 1] < n_lat) mark(bucket_of_rank(P[k + 1]));
+    }
+  }
+  __syncthreads();
+  // ---- (F) list of marked buckets (ascending) with the first subset index of each one's window ----
+  uint32_t n_need = 0, n_sub = 0;
+  {
+    uint32_t word = 0, nb_here = 0, el_here = 0;
+    if (tid < NB / 32) {
+      word = need[tid]; nb_here = __popc(word);
+      for (uint32_t w = word; w; w &= w - 1) { const uint32_t k = tid * 32 + (uint32_t)__builtin_ctz(w); el_here += P[k + 1] - P[k]; }
+    }
+    const uint32_t i_nb = wave_incl_scan(nb_here), i_el = wave_incl_scan(el_here);
+    if (lane == 63) { scan[wave] = i_nb; scan[16 + wave] = i_el; }
+    __syncthreads();
+    uint32_t b_nb = 0, b_el = 0; for (uint32_t w = 0; w < wave; w++) { b_nb += scan[w]; b_el += scan[16 + w]; }
+    uint32_t slot = b_nb + i_nb - nb_here, off = b_el + i_el - el_here;
+    for (uint32_t w = word; w; w &= w - 1) {
+      const uint32_t k = tid * 32 + (uint32_t)__builtin_ctz(w);
+      if (slot < kSelMaxNeeded) { nl_k[slot] = k; nl_oc[slot] = off; cur[slot] = 0; slot_of[k] = (uint16_t)slot; }
+      slot++; off += P[k + 1] - P[k];
+    }
+    n_need = scan[0] + scan[1] + scan[2] + scan[3]; n_sub = scan[16] + scan[17] + scan[18] + scan[19];   // (the bitmap's 256 words live in waves 0..3)
+  }
+  __syncthreads();
+  if (n_need > kSelMaxNeeded) {   // cannot happen (<= 6 marks per histogram bin); the radix-sort kernel would deal with it
+    if (tid == 0) ev->hist_path = 2;
+    __syncthreads();
+    return;
+  }
+  if (tid == 0) nl_oc[n_need] = n_sub;
+  L PCO_GLOBAL* S = sort_ptr<L>(ws, t, 1);
+  SEL_STAMP(2);
+  // ---- (G) gather: every latent of a marked bucket goes into its bucket's window, in any order.  Same thread-to-latent mapping
+  //      and load width as the count pass; staged (window lookups, then cursor atomics, then stores) so that the LDS round trips
+  //      of a thread's latents overlap ----
+  {
+    uint32_t base = 0;
+    union IdV { u32x4 v[kE / 8]; uint16_t k[kE]; };
+    VecL nxt; IdV nid;
+    if (kE * kSelT <= n_all) {
+#pragma unroll
+      for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + tid * kE))[q];
+#pragma unroll
+      for (uint32_t q = 0; q < kE / 8; q++) nid.v[q] = ((const u32x4 PCO_GLOBAL*)(ids + tid * kE))[q];
+    }
+    for (; base + kE * kSelT <= n_all; base += kE * kSelT) {
+      VecL d = nxt; IdV id = nid; uint32_t sl[kE], at[kE];
+      const uint32_t i0 = base + tid * kE;
+      if (base + 2 * kE * kSelT <= n_all) {
+#pragma unroll
+        for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + i0 + kE * kSelT))[q];
+#pragma unroll
+        for (uint32_t q = 0; q < kE / 8; q++) nid.v[q] = ((const u32x4 PCO_GLOBAL*)(ids + i0 + kE * kSelT))[q];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kE; k++) sl[k] = id.k[k] == 0xffffu ? 0xffffu : (uint32_t)slot_of[id.k[k]];
+#pragma unroll
+      for (uint32_t k = 0; k < kE; k++) at[k] = sl[k] != 0xffffu ? nl_oc[sl[k]] + atomicAdd((uint32_t*)&cur[sl[k]], 1u) : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < kE; k++) if (sl[k] != 0xffffu) S[at[k]] = d.x[k];
+    }
+    for (uint32_t i = base + tid; i < n_all; i += kSelT) {
+      const uint32_t k = ids[i];
+      const uint32_t sl = k == 0xffffu ? 0xffffu : (uint32_t)slot_of[k];
+      if (sl != 0xffffu) S[nl_oc[sl] + atomicAdd((uint32_t*)&cur[sl], 1u)] = lat[i];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  SEL_STAMP(3);
+  // ---- (H) order every window: one value -> nothing to do; up to 64 latents -> one wave, in registers; up to 8192 -> the
+  //      block, in LDS; more -> the fallback kernel ----
+  {
+    L PCO_LDS* wsrt = srt + wave * kSelWaveSortCap;   // this wave's private sort area
+    constexpr uint32_t kWaves = kSelT / 64, kGrp = 4;
+    uint32_t noc[kGrp], nlen[kGrp]; L nfirst[kGrp];
+    auto fetch = [&](uint32_t s0) {   // the first 64 latents of four windows
+#pragma unroll
+      for (uint32_t g = 0; g < kGrp; g++) {
+        const uint32_t s = s0 + g;
+        noc[g] = s < n_need ? nl_oc[s] : 0u; nlen[g] = s < n_need ? nl_oc[s + 1] - noc[g] : 0u;
+        nfirst[g] = lane < nlen[g] ? S[noc[g] + lane] : (L)0;
+      }
+    };
+    fetch(wave * kGrp);
+    for (uint32_t s0 = wave * kGrp; s0 < n_need; s0 += kWaves * kGrp) {   // four windows per round, the next round's already in flight
+      uint32_t oc[kGrp], len[kGrp]; L first[kGrp];
+#pragma unroll
+      for (uint32_t g = 0; g < kGrp; g++) { oc[g] = noc[g]; len[g] = nlen[g]; first[g] = nfirst[g]; }
+      fetch(s0 + kWaves * kGrp);
+      // windows of up to 64 latents (nearly all of them): padded with the window's maximum, the four sorted in lockstep
+      L key[kGrp]; bool small_multi[kGrp];
+#pragma unroll
+      for (uint32_t g = 0; g < kGrp; g++) {
+        L mx = lane < len[g] ? first[g] : (L)0, mn = lane < len[g] ? first[g] : (L)~(L)0;
+        for (int d = 32; d >= 1; d >>= 1) { const L o1 = shfl_idx(mn, (int)(lane ^ d)), o2 = shfl_idx(mx, (int)(lane ^ d)); mn = o1 < mn ? o1 : mn; mx = o2 > mx ? o2 : mx; }
+        small_multi[g] = len[g] > 1 && len[g] <= 64 && mn != mx;   // (wave-uniform)
+        key[g] = lane < len[g] ? first[g] : mx;
+      }
+      if (small_multi[0] || small_multi[1] || small_multi[2] || small_multi[3]) {
+        wave_sort64_multi<L, kGrp>(key);
+#pragma unroll
+        for (uint32_t g = 0; g < kGrp; g++) if (small_multi[g] && lane < len[g]) S[oc[g] + lane] = key[g];
+      }
+#pragma unroll
+      for (uint32_t g = 0; g < kGrp; g++) {
+        const uint32_t n_w = len[g];
+        if (n_w <= 64) continue;
+        L mn = first[g], mx = first[g];
+        if (n_w <= kSelWaveSortCap) wsrt[lane] = first[g];
+        for (uint32_t i = 64 + lane; i < n_w; i += 64) { const L x = S[oc[g] + i]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; if (n_w <= kSelWaveSortCap) wsrt[i] = x; }
+        for (int d = 32; d >= 1; d >>= 1) { const L o1 = shfl_idx(mn, (int)(lane ^ d)), o2 = shfl_idx(mx, (int)(lane ^ d)); mn = o1 < mn ? o1 : mn; mx = o2 > mx ? o2 : mx; }
+        if (mn == mx) continue;   // one value: in order as it is
+        if (n_w <= kSelWaveSortCap) {
+          uint32_t p2 = 128; while (p2 < n_w) p2 <<= 1;
+          for (uint32_t i = n_w + lane; i < p2; i += 64) wsrt[i] = mx;
+          enc_wave_sync();
+          wave_sort_lds<L>(wsrt, p2);
+          for (uint32_t i = lane; i < n_w; i += 64) S[oc[g] + i] = wsrt[i];
+          enc_wave_sync();
+        } else if (lane == 0) {
+          if (n_w > kSelSortCap) big[kSelBigCap + 1] = 1;
+          else { const uint32_t at = atomicAdd((uint32_t*)&big[kSelBigCap], 1u); if (at < kSelBigCap) big[at] = s0 + g; else big[kSelBigCap + 1] = 1; }
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (big[kSelBigCap + 1] != 0) {
+    if (tid == 0) ev->hist_path = 2;
+    __syncthreads();
+    return;
+  }
+  SEL_STAMP(4);
+  const uint32_t n_big = big[kSelBigCap];
+  for (uint32_t bi = 0; bi < n_big; bi++) {
+    const uint32_t s = big[bi], oc = nl_oc[s], len = nl_oc[s + 1] - oc;
+    uint32_t p2 = 128; while (p2 < len) p2 <<= 1;
+    for (uint32_t i = tid; i < p2; i += kSelT) srt[i] = i < len ? S[oc + i] : maxv;
+    __syncthreads();
+    block_sort_lds<L>(srt, p2);
+    for (uint32_t i = tid; i < len; i += kSelT) S[oc + i] = srt[i];
+    __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+  SEL_STAMP(5);
+  // ---- (I) rank queries (as in the radix-sort path: runs of equal values never leave their bucket) ----
+  auto value_at = [&](uint32_t r) {
+    const uint32_t k = bucket_of_rank(r);
+    if (bucket_exact(k)) return bucket_value(k);
+    return S[nl_oc[slot_of[k]] + (r - P[k])];
+  };
+  auto lookup = [&](uint32_t r, L& value, uint32_t& st, uint32_t& en) {
+    const uint32_t k = bucket_of_rank(r);
+    if (bucket_exact(k)) { value = bucket_value(k); st = P[k]; en = P[k + 1]; return; }
+    const uint32_t oc = nl_oc[slot_of[k]];
+    const uint32_t at = oc + (r - P[k]), wend = oc + (P[k + 1] - P[k]);
+    value = S[at];
+    uint32_t lo = oc, hi = at;   // first index with S[idx] >= value
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S[mid] < value) lo = mid + 1; else hi = mid; }
+    st = P[k] + (lo - oc);
+    lo = at + 1; hi = wend;      // first index with S[idx] > value
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S[mid] <= value) lo = mid + 1; else hi = mid; }
+    en = P[k] + (lo - oc);
+  };
+  if (tid < B) {
+    const uint32_t c = c_count(tid);
+    L v; uint32_t st, en; lookup(c - 1, v, st, en);
+    rv[tid] = v; rst[tid] = st; ren[tid] = en;
+    rnext[tid] = c < n_lat ? value_at(c) : (L)0;
+    rpred[tid] = st > 0 ? value_at(st - 1) : (L)0;
+    rsucc[tid] = en < n_lat ? value_at(en) : (L)0;
+  }
+  __syncthreads();
+  SEL_STAMP(6);
+  if (tid == 0) { uint32_t nh = 0; hist_state_machine<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, nh); ev->n_hist = nh; ev->hist_path = 1; }
+  __syncthreads();
+  SEL_STAMP(7);
+#ifdef PCO_SEL_TIMING
+  if (tid == 0) { atomicAdd(&g_sel_timing[8], 1ull); atomicAdd(&g_sel_timing[9], (unsigned long long)n_need); atomicAdd(&g_sel_timing[10], (unsigned long long)n_sub); atomicAdd(&g_sel_timing[11], (unsigned long long)n_big); atomicAdd(&g_sel_timing[12], (unsigned long long)n_seg); }
+#endif
+}
+
+// grid = chunks, 1024 threads: every wide-range variable of the chunk
+__global__ __launch_bounds__(kSelT) void enc_hist_select_kernel(EncWorkspace ws, uint32_t n_tasks) {
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tasks) return;
+  const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (uni(ch->status) != PCO_GFX_OK) return;
+  const int bits = dtype_bits(uni(ch->dtype));
+  const uint32_t ubl = uni(ch->unopt_bins_log);
+  for (uint32_t var = 0; var < 3; var++) {
+    if (!uni(ch->v[var].present)) continue;
+    const uint32_t bl = var == 2 ? (ubl < 6 ? ubl : 6) : ubl;
+    if (var == 0) select_var<uint32_t>(ws, t, var, bl);
+    else if (bits == 64) select_var<uint64_t>(ws, t, var, bl);
+    else if (bits == 32) select_var<uint32_t>(ws, t, var, bl);
+    else if (bits == 16) select_var<uint16_t>(ws, t, var, bl);
+    else select_var<uint8_t>(ws, t, var, bl);
+  }
+}
+
+// A/B switch (PCO_GFX_NO_HIST_SELECT): hand every wide-range variable to the radix-sort kernel
+__global__ void enc_hist_flag_kernel(EncWorkspace ws, uint32_t n_tasks) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tasks) return;
+  EncChunk* ch = ws.chunks + t;
+  if (ch->status != PCO_GFX_OK) return;
+  for (uint32_t var = 0; var < 3; var++) if (ch->v[var].present && ch->v[var].n_lat != 0 && ch->v[var].maxv - ch->v[var].minv >= kWideHistRange) ch->v[var].hist_path = 2;
+}
+
+}  // namespace pcogfx

@@ -50,6 +50,8 @@ struct EncChunk {
   uint32_t n_pages, page_low, page_r, page_first;  // PagingSpec::EqualPagesUpTo layout: the first page_r pages hold page_low+1
   uint32_t fast_ok;         // 1: the chunk's pages go through the dissect / walk / scan / pack kernels (encode_fast.hip)
   uint32_t c16_ok;          // speculative 16-bit latents (enc_split_kernel): 0 = off (full-width latents), 1 = on and holding, 2 = a tile did not fit
+  uint32_t exact_paging;    // PagingSpec::Exact: page sizes are arbitrary, positions map to pages through the page list (ws.pages[page_first ...])
+  uint32_t pad0;
   uint64_t c16_ref[2];      // what the 16-bit latents of variables 1 / 2 are relative to
   EncVar v[3];
 };
@@ -132,7 +134,7 @@ struct EncModePlan {  // host-resolved mode / delta (explicit specs; Auto is res
   uint32_t mode_kind, mode_k; uint64_t mode_base, mode_aux, mode_aux2;
   uint32_t delta_kind, delta_order, window_n_log, state_n_log;
   uint32_t n_pages, page_low, page_r, page_first;
-  uint32_t ubl_override, pad;   // 0xffffffff = derive from (level, n); trials use the full chunk's value
+  uint32_t ubl_override, exact_paging;   // ubl_override: 0xffffffff = derive from (level, n), trials use the full chunk's value; exact_paging: PagingSpec::Exact
 };
 
 __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, const EncModePlan* plans, uint32_t n_tasks, uint32_t level, uint32_t c16_enable) {
@@ -151,7 +153,8 @@ __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, 
   c.n_pages = mp.n_pages; c.page_low = mp.page_low; c.page_r = mp.page_r; c.page_first = mp.page_first;
   // stored latents of a delta'd variable: every page drops its first nlps (wrapped/chunk_compressor.rs:185-191)
   uint64_t stored = 0;
-  for (uint32_t p = 0; p < mp.n_pages; p++) { const uint64_t pn = mp.page_low + (p < mp.page_r ? 1u : 0u); stored += pn > nlps ? pn - nlps : 0; }
+  for (uint32_t p = 0; p < mp.n_pages; p++) { const uint64_t pn = mp.exact_paging ? ws.pages[mp.page_first + p].n : (uint64_t)(mp.page_low + (p < mp.page_r ? 1u : 0u)); stored += pn > nlps ? pn - nlps : 0; }
+  c.exact_paging = mp.exact_paging;
   for (int v = 0; v < 3; v++) { c.v[v].minv = ~0ull; c.v[v].maxv = 0; }
   c.v[0].present = mp.delta_kind == kDeltaLookback; c.v[0].latent_bits = 32;
   c.v[0].lat_start = nlps; c.v[0].n_lat = (uint32_t)stored;  // lookbacks live at the primary's index (page prefix unused)
@@ -716,7 +719,10 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
                                                    EncPlanVar PCO_GLOBAL* plan, uint32_t& n_hist_out) {
   // sequential (one lane); at most 2 * 2^bins_log iterations
   const uint64_t n = n_lat, B = (uint64_t)1 << bins_log;
-  auto bin_idx = [&](uint64_t pos) { return (uint32_t)((pos << bins_log) / n); };
+  // floor((pos << bins_log) / n) by one multiplication: M = ceil(2^64 / n) is exact for dividends below 2^64 / n, and ours stay below
+  // 2^36 with n <= 2^24 (the 64-bit divisions were most of this serial loop)
+  const uint64_t magic = n > 1 ? (~0ull / n) + 1 : 0ull;
+  auto bin_idx = [&](uint64_t pos) { return n > 1 ? (uint32_t)__umul64hi(pos << bins_log, magic) : (uint32_t)(pos << bins_log); };
   auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n + B - 1) >> bins_log); };
   uint32_t pos = 0; L pos_value = first_value;
   bool pending = false; uint32_t pending_start = 0; L pending_lower = 0;
@@ -791,11 +797,19 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   // enc_hist_kernel: range < 4096; enc_hist_wide_kernel<16384>: [4096, 16384), <32768>: [16384, 32768); enc_hist_sort_kernel: the rest
   if (!kSort && !kWide && (uint64_t)range >= kWideHistRange && tid == 0) atomicOr(ws.need_sort, 1u);
   if (kSort ? (uint64_t)range < kWideHistRange : (kWide ? ((uint64_t)range < (R == kWideHistRange ? kMidHistRange : kDirectHistRange) || (uint64_t)range >= R) : (uint64_t)range >= kDirectHistRange)) return;
+  if (kSort && ev->hist_path != 2) return;   // the radix-sort path is the fallback of enc_hist_select_kernel (encode_hist_select.hip), which flags what it gave up on
   // Stored latents = every position that is not among the first `skip` of its page (wrapped/chunk_compressor.rs:129-140).
   const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
   const uint32_t n_all = (uint32_t)ch->n, skip = ev->lat_start, plow = ch->page_low, pr = ch->page_r;
   const bool single_page = ch->n_pages == 1;
-  auto stored = [&](uint32_t i) { return skip == 0 || (single_page ? i >= skip : (uint64_t)i - page_start_of(i, plow, pr) >= skip); };
+  const bool exact_paging = ch->exact_paging != 0; const uint32_t n_pg = ch->n_pages;
+  const EncPage PCO_GLOBAL* pgl = (const EncPage PCO_GLOBAL*)ws.pages + ch->page_first;
+  auto exact_start = [&](uint32_t i) {   // PagingSpec::Exact: start of the page holding position i (last page whose start <= i)
+    uint32_t lo = 0, hi = n_pg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)pgl[mid].start <= i) lo = mid; else hi = mid; }
+    return (uint64_t)pgl[lo].start;
+  };
+  auto stored = [&](uint32_t i) { return skip == 0 || (single_page ? i >= skip : (uint64_t)i - (exact_paging ? exact_start(i) : page_start_of(i, plow, pr)) >= skip); };
   uint8_t PCO_LDS* smem = enc_lds_base();
   uint32_t PCO_LDS* counts = (uint32_t PCO_LDS*)(smem + kHistLdsCounts);
   L PCO_LDS* rv = (L PCO_LDS*)(smem + kHistLdsRecV);

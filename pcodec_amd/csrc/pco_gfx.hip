@@ -15,6 +15,7 @@
 #include "decode_kernel.hip"
 #include "decode_fast.hip"
 #include "encode_kernels.hip"
+#include "encode_hist_select.hip"
 #include "encode_fast.hip"
 #include "stream_kernels.hip"
 
@@ -327,5 +328,12 @@ enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size
 #ifdef PCO_WALK_TIMING
 extern "C" int pco_gfx_debug_walk_timing(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_walk_timing), 64);
+}
+#endif
+
+#ifdef PCO_SEL_TIMING
+extern "C" int pco_gfx_debug_sel_timing(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(pcogfx::g_sel_timing), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_sel_timing), 128);
 }
 #endif

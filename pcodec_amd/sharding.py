@@ -3,10 +3,16 @@
 Chunks are independent (each carries its own ChunkMeta and page, standalone/simple.rs:62-91), so a many-chunk
 input is partitioned into contiguous blocks of chunk indices, one block per GPU / rank; every rank encodes or
 decodes its block with no collective on the data path.  Only when one rank needs the whole `.pco` file are the
-compressed chunks gathered: an all-gather of the per-chunk byte counts (8 B per chunk) followed by a gather of
-the compressed bytes themselves.  With the `nccl` backend both run over RCCL / xGMI; the `gloo` backend is what
-the CPU tests use.
+compressed chunks gathered:
 
+  1. every rank compacts its chunks into one contiguous byte range on the device (pco_gfx_compact_chunks);
+  2. an all-gather of (chunk count, byte count) per rank -- 16 bytes each -- and of the per-chunk sizes;
+  3. a gather-v of the byte ranges: the root posts one receive per peer straight into its file buffer at that peer's
+     byte offset, every peer sends exactly its bytes (one grouped batch of point-to-point operations: over RCCL that is
+     one ncclGroup of ncclSend / ncclRecv, each pair on its own xGMI link; nothing is padded to the largest rank).
+
+The decode direction is the mirror image: the root scatters byte ranges, every rank decodes its block.
+With the `nccl` backend this runs over RCCL / xGMI; the `gloo` backend is what the CPU tests use.
 torch.distributed is plumbing here; nothing in this module touches the codec.
 """
 from typing import List, Optional, Sequence, Tuple
@@ -34,7 +40,8 @@ def shard_of_chunk(c: int, n_chunks: int, world: int) -> int:
 
 
 def pack_chunks(chunks: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
-    """Concatenate a rank's compressed chunks: (uint8 payload, int64 sizes)."""
+    """Concatenate a rank's compressed chunks on the host: (uint8 payload, int64 sizes).  (Device-resident chunks are
+    compacted by pco_gfx_compact_chunks instead.)"""
     sizes = np.array([len(c) for c in chunks], dtype=np.int64)
     payload = np.frombuffer(b"".join(chunks), dtype=np.uint8).copy() if len(chunks) else np.zeros(0, np.uint8)
     return payload, sizes
@@ -58,29 +65,86 @@ def gather_sizes(sizes, group=None):
     return [o[: int(c.item())] for o, c in zip(out, counts)]
 
 
-def gather_pages(payload, sizes, dst: int = 0, group=None):
-    """Gather every rank's compressed chunks on rank `dst`, in chunk order.
+def exchange_totals(n_bytes: int, device, group=None) -> List[int]:
+    """All-gather of every rank's compacted byte count (8 bytes per rank)."""
+    import torch
+    import torch.distributed as dist
 
-    payload: 1-D uint8 torch tensor holding this rank's compressed chunks back to back; sizes: their lengths.
-    Returns on `dst`: (list of per-rank uint8 tensors trimmed to their true length, list of per-rank size tensors);
-    on the other ranks: (None, all sizes).  The payload gather is padded to the largest per-rank total (the
-    collective needs equal shapes); that is at most the compressed size of one rank's block.
-    """
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(n_bytes)], dtype=torch.int64, device=device)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine, group=group)
+    return [int(g.item()) for g in got]
+
+
+def _p2p(ops):
+    import torch.distributed as dist
+    if not ops:
+        return
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+
+
+def gather_stream(payload, n_bytes: int, dst: int = 0, group=None, out=None, out_offset: int = 0, totals: Optional[List[int]] = None):
+    """Gather every rank's compacted chunk bytes on rank `dst`, in rank (= chunk) order, at exact sizes.
+
+    payload: 1-D uint8 torch tensor whose first n_bytes bytes are this rank's chunks back to back.
+    out (on dst): 1-D uint8 tensor receiving the stream from byte out_offset on (allocated if None).
+    Returns (out or None, per-rank byte offsets relative to out_offset with the total appended)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if totals is None:
+        totals = exchange_totals(n_bytes, payload.device, group)
+    offs = [0]
+    for t in totals:
+        offs.append(offs[-1] + t)
+    if rank == dst:
+        if out is None:
+            out = torch.empty(out_offset + offs[-1] + 64, dtype=torch.uint8, device=payload.device)
+        if out.numel() < out_offset + offs[-1]:
+            raise ValueError("gather_stream: destination too small")
+        ops = [dist.P2POp(dist.irecv, out[out_offset + offs[r]: out_offset + offs[r + 1]], r, group)
+               for r in range(world) if r != dst and totals[r] > 0]
+        out[out_offset + offs[dst]: out_offset + offs[dst + 1]].copy_(payload[:n_bytes])
+        _p2p(ops)
+        return out, offs
+    if n_bytes > 0:
+        _p2p([dist.P2POp(dist.isend, payload[:n_bytes], dst, group)])
+    return None, offs
+
+
+def scatter_stream(stream, offs: Sequence[int], recv, src: int = 0, group=None, stream_offset: int = 0):
+    """The decode direction: rank `src` holds the chunk stream; rank r receives bytes [offs[r], offs[r+1]) into `recv`
+    (1-D uint8 tensor of at least that size + the decoder's 16 bytes of slack).  Returns the number of bytes received."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = offs[rank + 1] - offs[rank]
+    if recv.numel() < mine:
+        raise ValueError("scatter_stream: receive buffer too small")
+    if rank == src:
+        ops = [dist.P2POp(dist.isend, stream[stream_offset + offs[r]: stream_offset + offs[r + 1]], r, group)
+               for r in range(world) if r != src and offs[r + 1] > offs[r]]
+        recv[:mine].copy_(stream[stream_offset + offs[src]: stream_offset + offs[src + 1]])
+        _p2p(ops)
+    elif mine > 0:
+        _p2p([dist.P2POp(dist.irecv, recv[:mine], src, group)])
+    return mine
+
+
+def gather_pages(payload, sizes, dst: int = 0, group=None):
+    """Convenience form used by the tests: gather sizes and bytes; returns on `dst` (list of per-rank uint8 tensors,
+    list of per-rank size tensors), elsewhere (None, sizes)."""
     all_sizes = gather_sizes(sizes, group)
     totals = [int(s.sum().item()) for s in all_sizes]
-    longest = max(totals) if totals else 0
-    padded = torch.zeros(max(longest, 1), dtype=torch.uint8, device=payload.device)
-    padded[: payload.numel()] = payload
-    if rank == dst:
-        bufs = [torch.empty_like(padded) for _ in range(world)]
-        dist.gather(padded, bufs, dst=dst, group=group)
-        return [b[:t] for b, t in zip(bufs, totals)], all_sizes
-    dist.gather(padded, None, dst=dst, group=group)
+    import torch.distributed as dist
+    out, offs = gather_stream(payload, int(sizes.sum().item()), dst, group, totals=totals)
+    if dist.get_rank(group) == dst:
+        return [out[offs[r]: offs[r + 1]] for r in range(len(totals))], all_sizes
     return None, all_sizes
 
 

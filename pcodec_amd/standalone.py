@@ -67,7 +67,12 @@ def simple_decompress(data):
     if dt not in _FILE_DTYPES:
         raise RuntimeError(f"unknown number type byte: {dt}")
     np_dtype = _FILE_DTYPES[dt]
-    cap = max(int(n_hint), 1)
+    # n_hint is untrusted (standalone/decompressor.rs:265-277 caps its preallocation at DEFAULT_MAX_PREALLOC_BYTES): never size
+    # the first attempt beyond 2^27 bytes or beyond what the file could plausibly hold (an all-constant chunk of 2^24 numbers is
+    # ~40 bytes, so "plausible" is per chunk preamble, not per byte); the retry loop below grows on demand
+    itemsize = np.dtype(np_dtype).itemsize
+    plausible = max(1, len(data) // 8) * (1 << 24)
+    cap = max(1, min(int(n_hint), (1 << 27) // itemsize, plausible))
     L = G.lib()
     buf = np.frombuffer(data, np.uint8)
     while True:

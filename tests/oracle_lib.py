@@ -117,14 +117,20 @@ def simple_decompress(data, np_dtype, cap=None):
     return out[: n_written.value].copy()
 
 
-def wrapped_compress(arr, config, max_pages=4096):
-    """wrapped::ChunkCompressor on the oracle: (meta bytes, [page bytes], [page n])."""
+def wrapped_compress(arr, config, max_pages=4096, exact_pages=None):
+    """wrapped::ChunkCompressor on the oracle: (meta bytes, [page bytes], [page n]).  exact_pages: PagingSpec::Exact."""
     arr = np.ascontiguousarray(arr)
-    cap = file_size_bound(arr.size, dtype_byte(arr), int(config.max_page_n)) + 65536
+    n_pg = len(exact_pages) if exact_pages is not None else 0
+    cap = file_size_bound(arr.size, dtype_byte(arr), int(config.max_page_n)) + 65536 + 64 * n_pg
     dst = np.empty(cap, np.uint8)
     sizes = (C.c_size_t * (max_pages + 1))(); page_ns = (C.c_size_t * max_pages)(); n_pages = C.c_size_t(0)
-    rc = lib().pco_oracle_wrapped_compress(arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.size), C.c_uint8(dtype_byte(arr)), C.byref(config),
-                                           dst.ctypes.data_as(C.c_void_p), C.c_size_t(cap), sizes, page_ns, C.c_size_t(max_pages), C.byref(n_pages))
+    if exact_pages is not None:
+        ex = (C.c_size_t * max(n_pg, 1))(*[int(x) for x in exact_pages])
+        rc = lib().pco_oracle_wrapped_compress_exact(arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.size), C.c_uint8(dtype_byte(arr)), C.byref(config), ex, C.c_size_t(n_pg),
+                                                     dst.ctypes.data_as(C.c_void_p), C.c_size_t(cap), sizes, page_ns, C.c_size_t(max_pages), C.byref(n_pages))
+    else:
+        rc = lib().pco_oracle_wrapped_compress(arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.size), C.c_uint8(dtype_byte(arr)), C.byref(config),
+                                               dst.ctypes.data_as(C.c_void_p), C.c_size_t(cap), sizes, page_ns, C.c_size_t(max_pages), C.byref(n_pages))
     _check(rc)
     pos = sizes[0]; meta = dst[:pos].tobytes(); pages = []
     for i in range(n_pages.value):

@@ -344,7 +344,7 @@ def test_two_variable_chunks_with_unequal_batch_counts(L):
     arrays = [c[1] for c in cases if c[2].get("mode") == 4 and c[2].get("delta") == 3 and c[1].dtype == np.uint32][:40]
     chunks, back = U.gpu_batched(arrays, G.make_config(mode=4, mode_u64=8, delta=3))
     for a, ch, b in zip(arrays, chunks, back):
-        want = O.simple_compress(a, O.make_config(mode=4, mode_u64=8, delta=3))
+        want = O.simple_compress(a, O.make_config(mode=4, mode_u64=8, delta=3, max_page_n=max(a.size, 1 << 18)))   # a batched task is ONE chunk
         assert ch == U.chunk_of_file(want, len(ch)) and U.bits_equal(a, b), a.size
 
 

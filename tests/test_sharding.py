@@ -63,14 +63,28 @@ def _worker(rank, world, port, n_chunks, chunk_n, q):
         assert [int(s.numel()) for s in all_sizes] == [S.shard_range(n_chunks, r, world)[1] - S.shard_range(n_chunks, r, world)[0] for r in range(world)]
         if rank == 0:
             q.put([bytes(x.numpy()) for x in bufs])
+        # decode direction: the root scatters the byte ranges of the assembled stream, every rank decodes its own block
+        totals = [int(s.sum().item()) for s in all_sizes]
+        offs = [0]
+        for t in totals: offs.append(offs[-1] + t)
+        stream = torch.cat(bufs) if rank == 0 else None
+        recv = torch.zeros(totals[rank] + 16, dtype=torch.uint8)
+        got = S.scatter_stream(stream, offs, recv, src=0)
+        assert got == totals[rank] and bytes(recv[:got].numpy()) == b"".join(mine)
+        hdr = O.simple_compress(data[0], cfg)[: _header_len(O.simple_compress(data[0], cfg))]
+        pos = 0
+        for k, c in enumerate(range(a, b)):
+            sz = int(all_sizes[rank][k]); blob = hdr + bytes(recv[pos: pos + sz].numpy()) + b"\x00"; pos += sz
+            assert np.array_equal(O.simple_decompress(blob, np.uint64, cap=chunk_n + 8), data[c])
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_gather_reassembles_the_file():
+@pytest.mark.parametrize("n_chunks,world", [(5, 2), (7, 3)])
+def test_gather_reassembles_the_file_and_scatter_feeds_the_decoders(n_chunks, world):
     import torch.multiprocessing as mp
-    n_chunks, chunk_n, world = 5, 3000, 2
+    chunk_n = 3000
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
