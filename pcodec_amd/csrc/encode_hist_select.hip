@@ -161,6 +161,53 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   unsigned long long sel_t0 = __builtin_readcyclecounter();
 #endif
   __syncthreads();
+  if (n_lat <= kSelSortCap) {
+    // ---- small variables (the 6.6 k-latent samples of the Auto-delta trials, short chunks): the whole variable is ordered in LDS ----
+    if (tid == 0) big[kSelBigCap] = 0;
+    __syncthreads();
+    if (single_page) {   // stored latents = positions skip ..
+      for (uint32_t i = skip + tid; i < n_all; i += kSelT) srt[i - skip] = lat[i];
+    } else {             // any order will do: one cursor bump per wave and round
+      for (uint32_t i0 = 0; i0 < n_all; i0 += kSelT) {
+        const uint32_t i = i0 + tid;
+        const bool on = i < n_all && stored(i);
+        const uint64_t m = __ballot(on);
+        uint32_t at = 0;
+        if (lane == 0 && m) at = atomicAdd((uint32_t*)&big[kSelBigCap], (uint32_t)__popcll(m));
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (on) srt[at + __popcll(m & (((uint64_t)1 << lane) - 1))] = lat[i];
+      }
+    }
+    uint32_t p2 = 128; while (p2 < n_lat) p2 <<= 1;
+    for (uint32_t i = n_lat + tid; i < p2; i += kSelT) srt[i] = maxv;
+    __syncthreads();
+    SEL_STAMP(0);
+    block_sort_lds<L>(srt, p2);
+    SEL_STAMP(1);
+    if (tid < B) {
+      const uint32_t c = c_count(tid);
+      const L v = srt[c - 1];
+      uint32_t lo = 0, hi = c - 1;   // first index with srt[idx] >= v
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (srt[mid] < v) lo = mid + 1; else hi = mid; }
+      const uint32_t st = lo;
+      lo = c; hi = n_lat;            // first index with srt[idx] > v
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (srt[mid] <= v) lo = mid + 1; else hi = mid; }
+      const uint32_t en = lo;
+      rv[tid] = v; rst[tid] = st; ren[tid] = en;
+      rnext[tid] = c < n_lat ? srt[c] : (L)0;
+      rpred[tid] = st > 0 ? srt[st - 1] : (L)0;
+      rsucc[tid] = en < n_lat ? srt[en] : (L)0;
+    }
+    __syncthreads();
+    SEL_STAMP(6);
+    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u);
+    __syncthreads();
+    SEL_STAMP(7);
+#ifdef PCO_SEL_TIMING
+    if (tid == 0) atomicAdd(&g_sel_timing[8], 1ull);
+#endif
+    return;
+  }
   // ---- (A) sample: 2048 evenly spaced positions (positions that are not stored hold defined junk or, for lookback, possibly
   //      nothing at all: clamping into [min, max] makes any value a harmless boundary candidate), sorted by the block ----
   for (uint32_t k = tid; k < kSelSample; k += kSelT) {
@@ -511,7 +558,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   }
   __syncthreads();
   SEL_STAMP(6);
-  if (tid == 0) { uint32_t nh = 0; hist_state_machine<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, nh); ev->n_hist = nh; ev->hist_path = 1; }
+  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u);
   __syncthreads();
   SEL_STAMP(7);
 #ifdef PCO_SEL_TIMING

@@ -543,12 +543,18 @@ template <uint32_t kCounts, uint32_t kRingN> struct LbCfg {
   static constexpr uint32_t kLbLdsBig = kLbLdsHpCnt + 64 * 6 * 4;       // u32[64] lookbacks > kCounts chosen inside the tile (their global counts are bumped at the tile end)
   static constexpr uint32_t kLbLdsBytes = kLbLdsBig + 64 * 4;
 };
-typedef LbCfg<2048, 2048> LbFull;
+typedef LbCfg<1024, 1024> LbFull;   // 18 KB of LDS per page: eight pages per CU (lookbacks beyond ~960 read their latent and count from HBM)
 typedef LbCfg<512, 512> LbSmall;
 constexpr uint32_t kLbSmallMaxPage = 8192;   // pages up to this size take the small layout
 
 struct LookbackScratch { uint32_t* hash; uint32_t* counts; };  // per page: hash[2 << (wlog+1)], counts[1 << wlog]
 
+#ifdef PCO_LB_TIMING
+__device__ unsigned long long g_lb_timing[16];
+#define LB_STAMP(idx) do { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long _n = __builtin_readcyclecounter(); lb_acc[idx] += _n - lb_t0; lb_t0 = _n; } while (0)
+#else
+#define LB_STAMP(idx) do { } while (0)
+#endif
 template <class L, class Cfg>
 __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, uint32_t PCO_GLOBAL* hash_tbl, uint32_t PCO_GLOBAL* gcounts) {
   constexpr uint32_t kLbCountsLds = Cfg::kLbCountsLds, kLbRing = Cfg::kLbRing, kLbLdsCounts = Cfg::kLbLdsCounts, kLbLdsHp = Cfg::kLbLdsHp, kLbLdsRing = Cfg::kLbLdsRing;
@@ -578,18 +584,27 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
   __threadfence_block();
   enc_wave_sync();
   auto hash_fn = [&](uint64_t x) { x = (x ^ (x >> 32)) * 11400714819323197441ull; x = x ^ (x >> 32); return (uint32_t)x & hash_mask; };
-  uint32_t proposed = 1;            // lanes 0..15: proposed_lookbacks[lane] = min(lane+1, state_n) with state_n == 1
+  uint32_t proposed = 1;            // (first tile) lanes 0..15: proposed_lookbacks[lane] = min(lane+1, state_n) with state_n == 1
   if (lane < 16) proposed = (lane + 1) < state_n ? (lane + 1) : state_n;
   uint32_t best_lookback = 1, repeating_idx = 0;
+  // (later tiles) the "repeating" proposals (slots 6..9) and their counts, and the count of the current best lookback: wave-uniform
+  uint32_t ring_lb0 = 1, ring_lb1 = 1, ring_lb2 = 1, ring_lb3 = 1, ring_c0 = 1, ring_c1 = 1, ring_c2 = 1, ring_c3 = 1, cnt_best = 1;
   L mn1 = (L)~(L)0, mx1 = 0; uint32_t mn0 = 0xffffffffu, mx0 = 0;
+  // the latent `lb` positions before position i: the LDS ring serves the recent ones
+  auto latent_back = [&](uint32_t i, uint32_t lb) { return lb < kLbRing - 64 ? (L)ring[(i - lb) & (kLbRing - 1)] : pre[i - lb]; };
+  auto lz_of = [&](L l, L other) { const L d1 = (L)(l - other), d2 = (L)(other - l); const L dlt = d1 < d2 ? d1 : d2; return LBits<L>::v - bitlen<L>(dlt); };
+#ifdef PCO_LB_TIMING
+  unsigned long long lb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lb_t0 = __builtin_readcyclecounter(), lb_rounds = 0;
+#endif
   for (uint32_t i0 = state_n; i0 < n; i0 += 64) {
     const uint32_t tile_n = n - i0 < 64 ? n - i0 : 64;
+    const bool first_tile = i0 == state_n;
     // ---- phase 1: hash proposals of the whole tile ----
     const uint32_t ie = i0 + lane;
     const bool act = lane < tile_n;
     const uint64_t lv = act ? (uint64_t)pre[ie] : 0ull;
     if (act) ring[ie & (kLbRing - 1)] = lv;
-    uint32_t slot[6], val[6];
+    uint32_t slot[6], val[6], plb[6];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       const uint64_t bucket = lv >> (c == 0 ? 0 : 8);
@@ -599,69 +614,186 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
     }
 #pragma unroll
     for (int r = 0; r < 6; r++) val[r] = act ? __hip_atomic_load(&hash_tbl[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // L2-served: earlier tiles updated it with atomics
-    // in-tile hazards: an earlier element of the tile wrote its centre bucket (slot[1] / slot[4]) before we read
-    for (uint32_t j = 0; j < tile_n; j++) {
-      const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)slot[1], (int)j), c1 = (uint32_t)__builtin_amdgcn_readlane((int)slot[4], (int)j);
-      if (j < lane) {
+    LB_STAMP(0);
+    // in-tile hazards: an earlier element of the tile wrote its centre bucket (slot[1] / slot[4]) before we read: each of my six
+    // slots needs the LAST earlier lane whose centre slot (same table) equals it.  Eight wave votes per table give every lane the set
+    // of lanes whose centre slot agrees with a given slot in its low 8 bits (usually nobody); the few candidates are checked newest
+    // first.  (Round 1 broadcast every lane's two centre slots in a 64-step loop: 14 k cycles per tile, most of the kernel once
+    // the element loop was gone.)
+    {
+      uint64_t vote[2][8];
 #pragma unroll
-        for (int r = 0; r < 3; r++) { if (slot[r] == c0) val[r] = i0 + j; if (slot[3 + r] == c1) val[3 + r] = i0 + j; }
+      for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int b = 0; b < 8; b++) vote[c][b] = __ballot(act && ((slot[3 * c + 1] >> b) & 1u));
+      }
+      const uint64_t earlier = __ballot(act) & (((uint64_t)1 << lane) - 1);
+      uint64_t cand[6];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        uint64_t m = earlier;
+#pragma unroll
+        for (int b = 0; b < 8; b++) m &= ((slot[r] >> b) & 1u) ? vote[r / 3][b] : ~vote[r / 3][b];
+        cand[r] = act ? m : 0ull;
+      }
+      for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 6; r++) any = any || cand[r] != 0;
+        if (!__any(any)) break;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const uint32_t j = cand[r] ? 63u - (uint32_t)__builtin_clzll(cand[r]) : 0u;
+          const uint32_t theirs = (uint32_t)__shfl((int)slot[3 * (r / 3) + 1], (int)j, 64);   // (every lane takes part in the exchange)
+          if (cand[r]) {
+            if (theirs == slot[r]) { val[r] = i0 + j; cand[r] = 0; }
+            else cand[r] &= ~((uint64_t)1 << j);
+          }
+        }
       }
     }
+    LB_STAMP(1);
     if (act) { atomicMax((uint32_t*)&hash_tbl[slot[1]], ie); atomicMax((uint32_t*)&hash_tbl[slot[4]], ie); }
 #pragma unroll
     for (int r = 0; r < 6; r++) {
       const uint32_t lb = ie - val[r];
       const uint32_t pidx = 10 + r;
-      const uint32_t plb = lb <= window_n ? lb : (pidx < ie ? pidx : ie);
-      hp[lane * 6 + r] = plb;
-      // far proposals: their latent and their count (as of now) are fetched here, for the whole tile at once
-      if (act && plb >= kLbRing - 64) hp_other[lane * 6 + r] = (uint64_t)pre[ie - plb];
-      if (act && plb - 1 >= kLbCountsLds) hp_cnt[lane * 6 + r] = __hip_atomic_load(&gcounts[plb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      plb[r] = lb <= window_n ? lb : (pidx < ie ? pidx : ie);
     }
-    uint32_t n_big = 0;   // uniform
-    enc_wave_sync();
-    // ---- phase 2: element by element, lanes 0..15 = the 16 proposals ----
     uint32_t my_lb = 1;   // lane e keeps the lookback chosen for element e of the tile
-    for (uint32_t e = 0; e < tile_n; e++) {
-      const uint32_t i = i0 + e;
-      const L l = (L)ring[i & (kLbRing - 1)];   // uniform
-      if (i <= 16) { const uint32_t new_brute = i < 16 ? i : 16; if (lane == new_brute - 1) proposed = new_brute; }   // the brute-force lookbacks 1..16 fill up over the first 16 positions
-      if (lane >= 10 && lane < 16) proposed = hp[e * 6 + (lane - 10)];
-      uint32_t key = 0;
-      if (lane < 16) {
-        const uint32_t lb = proposed;
-        uint32_t cnt; L other;
-        const bool hashed = lane >= 10;
-        if (lb < kLbRing - 64) other = (L)ring[(i - lb) & (kLbRing - 1)];
-        else if (hashed) other = (L)hp_other[e * 6 + (lane - 10)];
-        else other = pre[i - lb];
-        if (lb - 1 < kLbCountsLds) cnt = lcounts[lb - 1];
-        else {  // count at the tile start + the times this lookback was chosen earlier in the tile
-          cnt = hashed ? hp_cnt[e * 6 + (lane - 10)] : __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (uint32_t k = 0; k < n_big; k++) cnt += big[k] == lb ? 1u : 0u;
-        }
-        const L d1 = (L)(l - other), d2 = (L)(other - l);
-        const L dlt = d1 < d2 ? d1 : d2;
-        const uint32_t lz = LBits<L>::v - bitlen<L>(dlt);
-        const uint32_t goodness = (32u - clz_u32(cnt)) + lz;
-        key = (goodness << 4) | (15u - lane);  // max key = max goodness, first proposal on ties (lookback.rs:88-96)
+    if (first_tile) {
+      // ---- the page's first tile, element by element: lanes 0..15 = the 16 proposals.  (The brute-force slots fill up over the first 16
+      //      positions and overwrite the "repeating" slots on the way: lookback.rs:129-130.  From the second tile on none of that happens.) ----
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        hp[lane * 6 + r] = plb[r];
+        if (act && plb[r] >= kLbRing - 64) hp_other[lane * 6 + r] = (uint64_t)pre[ie - plb[r]];
+        if (act && plb[r] - 1 >= kLbCountsLds) hp_cnt[lane * 6 + r] = __hip_atomic_load(&gcounts[plb[r] - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // arg-max over lanes 0..15 on the DPP network (row 0): after row_shr 1, 2, 4, 8 lane 15 holds the maximum
-      { uint32_t o = dpp0<0x111, 0xf>(key); key = o > key ? o : key; o = dpp0<0x112, 0xf>(key); key = o > key ? o : key;
-        o = dpp0<0x114, 0xf>(key); key = o > key ? o : key; o = dpp0<0x118, 0xf>(key); key = o > key ? o : key; }
-      const uint32_t best_p = 15u - ((uint32_t)__builtin_amdgcn_readlane((int)key, 15) & 15u);
-      const uint32_t new_best = (uint32_t)__builtin_amdgcn_readlane((int)proposed, (int)best_p);
-      if (new_best != best_lookback) repeating_idx++;
-      if (lane == 6 + (repeating_idx & 3u)) proposed = new_best;
-      best_lookback = new_best;
-      if (lane == e) my_lb = new_best;
-      if (new_best - 1 < kLbCountsLds) { if (lane == 0) lcounts[new_best - 1] += 1; }
-      else { if (lane == 0) big[n_big] = new_best; n_big++; }
+      uint32_t n_big = 0;   // uniform
       enc_wave_sync();
+      for (uint32_t e = 0; e < tile_n; e++) {
+        const uint32_t i = i0 + e;
+        const L l = (L)ring[i & (kLbRing - 1)];   // uniform
+        if (i <= 16) { const uint32_t new_brute = i < 16 ? i : 16; if (lane == new_brute - 1) proposed = new_brute; }
+        else if (lane == 15) proposed = 16;       // (slot 15 is a hash slot: rewritten below)
+        if (lane >= 10 && lane < 16) proposed = hp[e * 6 + (lane - 10)];
+        uint32_t key = 0;
+        if (lane < 16) {
+          const uint32_t lb = proposed;
+          uint32_t cnt; L other;
+          const bool hashed = lane >= 10;
+          if (lb < kLbRing - 64) other = (L)ring[(i - lb) & (kLbRing - 1)];
+          else if (hashed) other = (L)hp_other[e * 6 + (lane - 10)];
+          else other = pre[i - lb];
+          if (lb - 1 < kLbCountsLds) cnt = lcounts[lb - 1];
+          else {  // count at the tile start + the times this lookback was chosen earlier in the tile
+            cnt = hashed ? hp_cnt[e * 6 + (lane - 10)] : __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t k = 0; k < n_big; k++) cnt += big[k] == lb ? 1u : 0u;
+          }
+          const uint32_t goodness = (32u - clz_u32(cnt)) + lz_of(l, other);
+          key = (goodness << 4) | (15u - lane);  // max key = max goodness, first proposal on ties (lookback.rs:88-96)
+        }
+        // arg-max over lanes 0..15 on the DPP network (row 0): after row_shr 1, 2, 4, 8 lane 15 holds the maximum
+        { uint32_t o = dpp0<0x111, 0xf>(key); key = o > key ? o : key; o = dpp0<0x112, 0xf>(key); key = o > key ? o : key;
+          o = dpp0<0x114, 0xf>(key); key = o > key ? o : key; o = dpp0<0x118, 0xf>(key); key = o > key ? o : key; }
+        const uint32_t best_p = 15u - ((uint32_t)__builtin_amdgcn_readlane((int)key, 15) & 15u);
+        const uint32_t new_best = (uint32_t)__builtin_amdgcn_readlane((int)proposed, (int)best_p);
+        if (new_best != best_lookback) repeating_idx++;
+        if (lane == 6 + (repeating_idx & 3u)) proposed = new_best;
+        best_lookback = new_best;
+        if (lane == e) my_lb = new_best;
+        if (new_best - 1 < kLbCountsLds) { if (lane == 0) lcounts[new_best - 1] += 1; }
+        else { if (lane == 0) big[n_big] = new_best; n_big++; }
+        enc_wave_sync();
+      }
+      if (lane < n_big) atomicAdd((uint32_t*)&gcounts[big[lane] - 1], 1u);   // publish before the next tile prefetches counts
+      __threadfence_block();
+      enc_wave_sync();
+      // hand the state over to the tile-parallel path
+      ring_lb0 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 6); ring_lb1 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 7);
+      ring_lb2 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 8); ring_lb3 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 9);
+      auto count_now = [&](uint32_t lb) { return uni(lb - 1 < kLbCountsLds ? lcounts[lb - 1] : __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+      ring_c0 = count_now(ring_lb0); ring_c1 = count_now(ring_lb1); ring_c2 = count_now(ring_lb2); ring_c3 = count_now(ring_lb3);
+      cnt_best = count_now(best_lookback);
+    } else {
+      // ---- later tiles: one lane per element, all 64 decided together under the guess that every element repeats the lookback
+      //      of the one before it (B).  Under that guess the "repeating" slots never change and only B's count moves, so an element's
+      //      16 candidates and their counts are known without waiting for its predecessors.  The first element that decides
+      //      otherwise ends the round: everything before it, and its own decision, were made on the true state; the state is
+      //      brought up to date and the rest of the tile is decided again.  Exactly choose_lookbacks' sequence (lookback.rs:101-159),
+      //      one round per tile on periodic data instead of 64 dependent steps. ----
+      const L l = (L)lv;
+      uint32_t s_lb[12], s_lz[12], c_far[6], r_lz0, r_lz1, r_lz2, r_lz3;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s_lb[k] = (uint32_t)k + 1;           // brute force: 1..6 (the page is past position 16)
+#pragma unroll
+      for (int r = 0; r < 6; r++) s_lb[6 + r] = plb[r];
+#pragma unroll
+      for (int k = 0; k < 12; k++) s_lz[k] = act ? lz_of(l, latent_back(ie, s_lb[k])) : 0u;
+#pragma unroll
+      for (int r = 0; r < 6; r++) c_far[r] = act && plb[r] - 1 >= kLbCountsLds ? __hip_atomic_load(&gcounts[plb[r] - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      r_lz0 = act ? lz_of(l, latent_back(ie, ring_lb0)) : 0u; r_lz1 = act ? lz_of(l, latent_back(ie, ring_lb1)) : 0u;
+      r_lz2 = act ? lz_of(l, latent_back(ie, ring_lb2)) : 0u; r_lz3 = act ? lz_of(l, latent_back(ie, ring_lb3)) : 0u;
+      LB_STAMP(2);
+      uint32_t e_start = 0;
+      // count `lb` += k for everything that mirrors it
+      auto add_count = [&](uint32_t lb, uint32_t k) -> uint32_t {   // returns the new count
+        if (k == 0) return 0u;
+        uint32_t now;
+        if (lb - 1 < kLbCountsLds) { now = uni(lcounts[lb - 1]) + k; if (lane == 0) lcounts[lb - 1] = now; }
+        else {
+          uint32_t old = 0; if (lane == 0) old = atomicAdd((uint32_t*)&gcounts[lb - 1], k);
+          now = uni(old) + k;
+#pragma unroll
+          for (int r = 0; r < 6; r++) c_far[r] += plb[r] == lb ? k : 0u;
+        }
+        if (ring_lb0 == lb) ring_c0 = now; if (ring_lb1 == lb) ring_c1 = now; if (ring_lb2 == lb) ring_c2 = now; if (ring_lb3 == lb) ring_c3 = now;
+        return now;
+      };
+      for (;;) {
+#ifdef PCO_LB_TIMING
+        lb_rounds++;
+#endif
+        const uint32_t B = best_lookback;
+        const uint32_t cb = cnt_best + (lane - e_start);   // B's count as this element sees it
+        uint32_t best_g = 0, best = 0;
+        auto consider = [&](uint32_t lb, uint32_t lz, uint32_t cnt) { const uint32_t g = (32u - clz_u32(lb == B ? cb : cnt)) + lz; if (g > best_g) { best_g = g; best = lb; } };
+#pragma unroll
+        for (int k = 0; k < 6; k++) consider(s_lb[k], s_lz[k], lcounts[k]);
+        consider(ring_lb0, r_lz0, ring_c0); consider(ring_lb1, r_lz1, ring_c1); consider(ring_lb2, r_lz2, ring_c2); consider(ring_lb3, r_lz3, ring_c3);
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const uint32_t lb = plb[r];
+          const uint32_t idx = lb - 1 < kLbCountsLds ? lb - 1 : 0u;
+          const uint32_t near = lcounts[idx];
+          consider(lb, s_lz[6 + r], lb - 1 < kLbCountsLds ? near : c_far[r]);
+        }
+        uint64_t mism = __ballot(act && lane >= e_start && best != B);
+        const uint32_t e_star = mism ? (uint32_t)__builtin_ctzll(mism) : tile_n;
+        if (lane >= e_start && lane < e_star) my_lb = B;
+        enc_wave_sync();   // (the counts were read by every lane before lane 0 changes them)
+        const uint32_t nb = add_count(B, e_star - e_start);
+        if (nb) cnt_best = nb;
+        if (e_star >= tile_n) break;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)best, (int)e_star);
+        if (lane == e_star) my_lb = c;
+        repeating_idx++;
+        // the slot takes the new lookback BEFORE its count is bumped; add_count then mirrors the bump into the slot's count
+        const uint32_t rs = repeating_idx & 3u;
+        const uint32_t c_lz = act && lane > e_star ? lz_of(l, latent_back(ie, c)) : 0u;   // (only the elements still to be decided; c may reach before the page for earlier ones)
+        if (rs == 0) { ring_lb0 = c; r_lz0 = c_lz; } else if (rs == 1) { ring_lb1 = c; r_lz1 = c_lz; } else if (rs == 2) { ring_lb2 = c; r_lz2 = c_lz; } else { ring_lb3 = c; r_lz3 = c_lz; }
+        cnt_best = add_count(c, 1u);
+        best_lookback = c;
+        e_start = e_star + 1;
+        enc_wave_sync();
+        if (e_start >= tile_n) break;
+      }
+      __threadfence_block();
+      enc_wave_sync();
+      LB_STAMP(3);
     }
     if (act) lbs[ie] = my_lb;
-    if (lane < n_big) atomicAdd((uint32_t*)&gcounts[big[lane] - 1], 1u);   // publish before the next tile prefetches counts
-    __threadfence_block();   // (the atomics above and the agent-scope loads of the next tile are ordered per address)
     // ---- apply (lookback.rs:166-185): l[i] -= l[i - lb], + MID; reads the un-delta'd copy so it is parallel ----
     if (act) {
       const uint32_t lb = my_lb;
@@ -669,7 +801,11 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
       out[ie] = d;
       mn1 = d < mn1 ? d : mn1; mx1 = d > mx1 ? d : mx1; mn0 = lb < mn0 ? lb : mn0; mx0 = lb > mx0 ? lb : mx0;
     }
+    LB_STAMP(4);
   }
+#ifdef PCO_LB_TIMING
+  if (lane == 0) { for (int k = 0; k < 5; k++) atomicAdd(&g_lb_timing[k], lb_acc[k]); atomicAdd(&g_lb_timing[5], lb_rounds); atomicAdd(&g_lb_timing[6], (unsigned long long)((n - state_n + 63) / 64)); atomicAdd(&g_lb_timing[7], 1ull); }
+#endif
   for (int dlt = 32; dlt >= 1; dlt >>= 1) {
     L o1 = shfl_idx(mn1, (int)(lane ^ dlt)); mn1 = o1 < mn1 ? o1 : mn1;
     L o2 = shfl_idx(mx1, (int)(lane ^ dlt)); mx1 = o2 > mx1 ? o2 : mx1;
@@ -754,6 +890,31 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
     }
   }
   n_hist_out = n_hist;
+}
+
+// The histogram of one variable from its rank records, by the whole block (every thread calls this after the records are in LDS and a
+// barrier).  When no run of equal values straddles a bin end (ren[b] <= c_count(b) for every b: data without heavy ties) and there
+// are at least as many latents as bins, the state machine above visits the bins in order and emits bin b = ranks
+// [c_count(b-1), c_count(b)) with the bounds (value at its first rank, value at its last rank): that is done by one thread per
+// bin.  Otherwise one thread walks the state machine (a serial loop of up to 2 x bins steps, ~100 k cycles: most of a small chunk's
+// histogram time before this shortcut).
+template <class L>
+__device__ __forceinline__ void hist_emit(uint32_t n_lat, uint32_t bins_log, L first_value, const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
+                                          const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc, EncPlanVar PCO_GLOBAL* plan, EncVar PCO_GLOBAL* ev, uint32_t path) {
+  const uint32_t tid = threadIdx.x, B = 1u << bins_log;
+  const uint64_t n64 = n_lat;
+  auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
+  const bool mine_ok = tid >= B || ren[tid] <= c_count(tid);
+  const bool simple = __syncthreads_and(mine_ok && n_lat >= B) != 0;
+  if (simple) {
+    if (tid < B) {
+      const uint32_t c0 = tid == 0 ? 0u : c_count(tid - 1), c1 = c_count(tid);
+      plan->hcount[tid] = c1 - c0; plan->hlower[tid] = (uint64_t)(tid == 0 ? first_value : rnext[tid - 1]); plan->hupper[tid] = (uint64_t)rv[tid];
+    }
+    if (tid == 0) { ev->n_hist = B; ev->hist_path = path; }
+  } else if (tid == 0) {
+    uint32_t nh = 0; hist_state_machine<L>(n_lat, bins_log, first_value, rv, rst, ren, rnext, rpred, rsucc, plan, nh); ev->n_hist = nh; ev->hist_path = path;
+  }
 }
 
 // LDS layout of enc_hist_kernel
@@ -895,7 +1056,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
       if (en < n_lat) { lookup(en, x, a, b2); rsucc[tid] = x; } else rsucc[tid] = 0;
     }
     __syncthreads();
-    if (tid == 0) { uint32_t nh = 0; hist_state_machine<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, nh); ev->n_hist = nh; ev->hist_path = 0; }
+    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 0u);
     __syncthreads();
     return;
   }
@@ -1120,7 +1281,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     rsucc[tid] = en < n_lat ? value_at(en) : (L)0;
   }
   __syncthreads();
-  if (tid == 0) { uint32_t nh = 0; hist_state_machine<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, nh); ev->n_hist = nh; ev->hist_path = 1; }
+  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u);
   __syncthreads();
   }
 }

@@ -337,3 +337,10 @@ extern "C" int pco_gfx_debug_sel_timing(unsigned long long* out, int reset) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_sel_timing), 128);
 }
 #endif
+
+#ifdef PCO_LB_TIMING
+extern "C" int pco_gfx_debug_lb_timing(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(pcogfx::g_lb_timing), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_lb_timing), 128);
+}
+#endif

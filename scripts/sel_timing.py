@@ -22,3 +22,6 @@ run("u32 uniform random, no delta", [rng.integers(0, 1 << 32, 1 << 18, dtype=np.
 run("f32 normal, delta 1", [rng.standard_normal(1 << 18).astype(np.float32) for _ in range(nch)], dict(mode=1, delta=2, delta_order=1))
 run("i32 lomax, delta 1", [(rng.pareto(0.5, 1 << 18) * 10).clip(0, 2e9).astype(np.int32) for _ in range(nch)], dict(mode=1, delta=2, delta_order=1))
 run("i64 seasonal lookback", [U.synth("c4", seed=s) for s in range(64)], dict(mode=1, delta=3))
+
+run("small: 2048 x u64 uniform n=6600 (trial-sized)", [rng.integers(0, 1 << 62, 6600, dtype=np.uint64) for _ in range(2048)], dict(mode=1, delta=1))
+run("small: 2048 x u32 normal-ish n=6600", [(rng.standard_normal(6600) * 1e6).astype(np.int32) for _ in range(2048)], dict(mode=1, delta=1))
