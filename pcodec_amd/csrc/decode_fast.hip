@@ -195,7 +195,7 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
   if (mode_kind == kIntMult) { if (format_major == 0) { fail(PCO_GFX_CORRUPTION); return; } mode_base = (L)mr.read(LB); }
   else if (mode_kind == kFloatMult) mode_base = (L)mr.read(LB);
   else if (mode_kind == kFloatQuant) mode_k = (uint32_t)mr.read(kBitsQuantK);
-  else if (mode_kind == kDict) { fail(mr.in_bounds() ? PCO_GFX_UNSUPPORTED : PCO_GFX_INSUFFICIENT_DATA); return; }
+  else if (mode_kind == kDict) { fail(mr.in_bounds() ? kStatusRetryLegacy : PCO_GFX_INSUFFICIENT_DATA); return; }   // (the general kernel decodes Dict)
   else if (mode_kind != kClassic) { fail(mr.in_bounds() ? PCO_GFX_CORRUPTION : PCO_GFX_INSUFFICIENT_DATA); return; }
   if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
   uint32_t dkind = kDeltaNone, dorder = 0, wlog = 0, slog = 0; bool sec_uses_delta = false;
@@ -207,7 +207,7 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
       wlog = 1 + (uint32_t)mr.read(kBitsLookbackWindowLog); slog = (uint32_t)mr.read(kBitsLookbackStateLog);
       if (wlog > kMaxLookbackWindowLog || slog > wlog) { fail(PCO_GFX_CORRUPTION); return; }
       dkind = kDeltaLookback; sec_uses_delta = mr.read(1) != 0;
-    } else if (variant == 3) { fail(mr.in_bounds() ? PCO_GFX_UNSUPPORTED : PCO_GFX_INSUFFICIENT_DATA); return; }
+    } else if (variant == 3) { fail(mr.in_bounds() ? kStatusRetryLegacy : PCO_GFX_INSUFFICIENT_DATA); return; }   // Conv1: the general kernel
     else if (variant != 0) { fail(PCO_GFX_CORRUPTION); return; }
   }
   if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }

@@ -292,7 +292,43 @@ __device__ __forceinline__ L join_one(uint32_t mode_kind, uint32_t num_kind, L b
 struct PageParams {
   uint32_t mode_kind, mode_k, num_kind, n;
   uint64_t mode_base;
+  uint64_t dict_byte; uint32_t dict_n;     // Dict mode: the dictionary's first byte in src and its length (metadata/mode.rs:138-165)
+  uint32_t conv_order, conv_quant;         // Conv1 delta (metadata/delta_encoding.rs): weights and bias live in LDS (kLdsConvOff)
 };
+// Conv1 parameters in LDS, in the lookback path's "parent" area (the two deltas exclude each other): i64 bias | i64 weights[32]
+constexpr uint32_t kLdsConvOff = kLdsParentOff;
+
+// Conv1 delta decode of one batch (delta/conv1.rs:231-251,463-484): residuals = state ++ (deltas + MID); every residual past the state
+// gets max(0, bias + sum_k weights[k] * residuals[i - order + k]) >> quantization added, in the latent's "Conv" integer type (i16 / i32 /
+// i64 for 8- / 16- / 32-bit latents: sums formed in 64 bits and wrapped to that width); the batch's numbers are the first dst_n residuals,
+// the last `order` become the next state.  A serial recurrence: lane 0 walks it (this is the general kernel; Conv1 is rare).
+template <class L>
+__device__ __forceinline__ void conv1_decode(L x[4], uint32_t dst_n, uint32_t order, uint32_t quant) {
+  const uint32_t lane = lane_id();
+  uint32_t PCO_LDS* res = (uint32_t PCO_LDS*)(lds_base() + kLdsScratchOff);   // u32[32 + 256]: state, then this batch
+  const int64_t PCO_LDS* cw = (const int64_t PCO_LDS*)(lds_base() + kLdsConvOff);
+  constexpr int kConvBits = LBits<L>::v == 32 ? 64 : 2 * (int)LBits<L>::v;
+  auto wrap = [&](uint64_t v) -> int64_t { return kConvBits == 64 ? (int64_t)v : (int64_t)(v << (64 - kConvBits)) >> (64 - kConvBits); };
+#pragma unroll
+  for (int k = 0; k < 4; k++) res[order + 4 * lane + k] = (uint32_t)(L)(x[k] + lmid<L>());
+  wave_sync_lds();
+  if (lane == 0) {
+    const int64_t bias = wrap((uint64_t)cw[0]);
+    for (uint32_t i = 0; i < dst_n; i++) {
+      uint64_t sum = (uint64_t)bias;
+      for (uint32_t k = 0; k < order; k++) sum += (uint64_t)wrap((uint64_t)cw[1 + k]) * (uint64_t)res[i + k];
+      int64_t sc = wrap(sum);
+      if (sc < 0) sc = 0;
+      res[order + i] = (uint32_t)(L)((L)res[order + i] + (L)(uint64_t)(sc >> quant));
+    }
+  }
+  wave_sync_lds();
+#pragma unroll
+  for (int k = 0; k < 4; k++) x[k] = (L)res[4 * lane + k];
+  wave_sync_lds();
+  if (lane == 0) for (uint32_t j = 0; j < order; j++) res[j] = res[dst_n + j];   // (ascending: every source index is above its target)
+  wave_sync_lds();
+}
 
 // Decode one page (page meta + all batches) with number latent type L.
 template <class L, bool kLds>
@@ -317,7 +353,7 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
     present[vi] = uni(vinfo[vi].present); n_bins[vi] = uni(vinfo[vi].n_bins); max_ob[vi] = uni(vinfo[vi].max_ob);
     asl[vi] = uni(vinfo[vi].ans_size_log); dk[vi] = uni(vinfo[vi].delta_kind); dord[vi] = uni(vinfo[vi].delta_order);
     off_nodes[vi] = uni(vinfo[vi].off_nodes); off_lower[vi] = uni(vinfo[vi].off_lower); off_ob[vi] = uni(vinfo[vi].off_ob);
-    nlps[vi] = dk[vi] == kDeltaConsecutive ? dord[vi] : (dk[vi] == kDeltaLookback ? (1u << uni(vinfo[vi].state_n_log)) : 0u);
+    nlps[vi] = (dk[vi] == kDeltaConsecutive || dk[vi] == kDeltaConv1) ? dord[vi] : (dk[vi] == kDeltaLookback ? (1u << uni(vinfo[vi].state_n_log)) : 0u);
   }
   const uint32_t window_n_log = uni(vinfo[1].window_n_log);
   const uint32_t state_n = dk[1] == kDeltaLookback ? nlps[1] : 0u;
@@ -336,6 +372,7 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
     for (uint32_t i = 0; i < nlps[vi]; i++) {
       const L x = (L)mr.read(lbits);
       if (dk[vi] == kDeltaConsecutive) { if (lane == 0) { if (vi == 2) moments1[i] = x; else moments0[i] = x; } }
+      else if (dk[vi] == kDeltaConv1) { if (lane == 0 && i < 32) ((uint32_t PCO_LDS*)(smem + kLdsScratchOff))[i] = (uint32_t)x; }
       else if (vi == 1 && i < n && mr.in_bounds()) {  // lookback state = the first state_n latents (classic mode only)
         if (lane == 0) dst[i] = raw_hist ? x : from_latent_ordered<L>(x, num_kind);
       }
@@ -396,6 +433,9 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
       // delta decode (delta/mod.rs:125-159)
       if (vi >= 1 && dk[vi] == kDeltaConsecutive) {
         if (vi == 1) consecutive_decode<L>(prim, dord[1], moments0); else consecutive_decode<L>(sec, dord[2], moments1);
+      }
+      else if (vi == 1 && dk[1] == kDeltaConv1) {
+        if constexpr (sizeof(L) <= 4) conv1_decode<L>(prim, batch_n, dord[1], pp.conv_quant);
       }
     }
     if (dk[1] == kDeltaLookback && pass == 0) {
@@ -474,6 +514,64 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
   if (!mr.in_bounds()) status = PCO_GFX_INSUFFICIENT_DATA;
 }
 
+// Dict mode page (mode/dict.rs:70-90): the primary variable holds u32 indices into the chunk's dictionary (ChunkMeta, uncompressed, in
+// src); delta None or Consecutive on the indices.  num = from_latent_ordered(dict[index]); an index beyond the dictionary is corruption.
+template <class L, bool kLds>
+__device__ __noinline__ void decode_page_body_dict(gcptr_u8 src, uint64_t src_len, MetaReader& mr, tptr<kLds, uint8_t> tbl,
+                                                  const PageParams& pp, L PCO_GLOBAL* dst, uint32_t& status) {
+  const uint32_t lane = lane_id();
+  uint8_t PCO_LDS* smem = lds_base();
+  uint32_t PCO_LDS* moments = (uint32_t PCO_LDS*)(smem + kLdsMomOff);
+  VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(smem + kLdsVarOff);
+  const uint32_t n = pp.n, num_kind = pp.num_kind;
+  const uint32_t n_bins = uni(vinfo[1].n_bins), max_ob = uni(vinfo[1].max_ob), asl = uni(vinfo[1].ans_size_log), dk = uni(vinfo[1].delta_kind), dord = uni(vinfo[1].delta_order);
+  const uint32_t off_nodes = uni(vinfo[1].off_nodes), off_lower = uni(vinfo[1].off_lower), off_ob = uni(vinfo[1].off_ob);
+  const uint32_t nlps = dk == kDeltaConsecutive ? dord : 0u;
+  uint32_t st = 0;
+  for (uint32_t i = 0; i < nlps; i++) { const uint32_t x = (uint32_t)mr.read(32); if (lane == 0 && i < 8) moments[i] = x; }
+  { uint32_t mine = 0; for (uint32_t j = 0; j < 4; j++) { const uint32_t s = (uint32_t)mr.read(asl); if (lane == j) mine = s; } st = mine; }
+  if (!mr.drain_empty_byte()) { if (mr.in_bounds()) status = PCO_GFX_CORRUPTION; }
+  if (!mr.in_bounds()) { status = PCO_GFX_INSUFFICIENT_DATA; return; }
+  if (status) return;
+  if (n > nlps && n_bins == 0) { status = PCO_GFX_CORRUPTION; return; }
+  wave_sync_lds();
+  uint64_t bitpos = mr.bit;
+  uint32_t n_remaining = n, oob = 0;
+  constexpr uint32_t kBytes = sizeof(L);
+  for (uint32_t j0 = 0; j0 < n; j0 += kBatchN) {
+    const uint32_t batch_n = n_remaining < kBatchN ? n_remaining : kBatchN;
+    const uint32_t rem = n_remaining > nlps ? n_remaining - nlps : 0, cnt = rem < kBatchN ? rem : kBatchN;
+    uint32_t idx[4] = {0, 0, 0, 0};
+    if (cnt > 0) {
+      const bool single_bin = n_bins <= 1;
+      if (!single_bin) bitpos = walk_ans<kLds>(src, src_len, bitpos, cnt, (tptr<kLds, uint32_t>)(tbl + off_nodes), st);
+      tptr<kLds, uint32_t> lw = (tptr<kLds, uint32_t>)(tbl + off_lower);
+      if (max_ob != 0 || !single_bin) bitpos = unpack_offsets<uint32_t, kLds>(src, src_len, bitpos, cnt, lw, tbl + off_ob, single_bin, idx);
+      else { const uint32_t l0 = lw[0]; for (int k = 0; k < 4; k++) idx[k] = 4 * lane + k < cnt ? l0 : 0u; }
+      if (bitpos > src_len * 8) { status = PCO_GFX_INSUFFICIENT_DATA; return; }
+    }
+    if (dk == kDeltaConsecutive) consecutive_decode<uint32_t>(idx, dord, moments);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = 4 * lane + k;
+      if (i < batch_n) {
+        if (idx[k] >= pp.dict_n) oob = 1;
+        else {
+          L v = 0;
+          gcptr_u8 p = src + pp.dict_byte + (uint64_t)idx[k] * kBytes;
+          for (uint32_t b = 0; b < kBytes; b++) v |= (L)((L)p[b] << (8 * b));   // (the dictionary sits at an arbitrary byte offset)
+          dst[j0 + i] = from_latent_ordered<L>(v, num_kind);
+        }
+      }
+    }
+    n_remaining -= batch_n;
+  }
+  if (uni(wave_or_u32(oob))) { status = PCO_GFX_CORRUPTION; return; }
+  mr.bit = bitpos;
+  if (!mr.drain_empty_byte()) status = PCO_GFX_CORRUPTION;
+  if (!mr.in_bounds()) status = PCO_GFX_INSUFFICIENT_DATA;
+}
+
 template <class L>
 __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaReader& mr, uint32_t lds_table_budget,
                                          gptr_u8 tbl_ws, uint32_t format_major, uint32_t dtype, uint32_t n, L PCO_GLOBAL* dst, uint32_t& status,
@@ -484,15 +582,22 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
   VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(lds_base() + kLdsVarOff);
   // ---- ChunkMeta (metadata/chunk.rs:127-174) ----
   const uint32_t mode_kind = (uint32_t)mr.read(kBitsModeVariant);
-  L mode_base = 0; uint32_t mode_k = 0;
+  L mode_base = 0; uint32_t mode_k = 0, dict_n = 0, conv_quant = 0; uint64_t dict_byte = 0;
   if (mode_kind == kIntMult) {
     if (format_major == 0) { status = PCO_GFX_CORRUPTION; return; }
     mode_base = (L)mr.read(LB);
   } else if (mode_kind == kFloatMult) mode_base = (L)mr.read(LB);
   else if (mode_kind == kFloatQuant) mode_k = (uint32_t)mr.read(kBitsQuantK);
-  else if (mode_kind == kDict) { status = mr.in_bounds() ? PCO_GFX_UNSUPPORTED : PCO_GFX_INSUFFICIENT_DATA; return; }
+  else if (mode_kind == kDict) {   // metadata/mode.rs:138-165: 25-bit length, byte alignment, then the dictionary's latents, uncompressed
+    dict_n = (uint32_t)mr.read(kBitsDictLen);
+    if (!mr.in_bounds()) { status = PCO_GFX_INSUFFICIENT_DATA; return; }
+    if (!mr.drain_empty_byte()) { status = PCO_GFX_CORRUPTION; return; }
+    dict_byte = mr.bit >> 3;
+    mr.bit += (uint64_t)dict_n * LB;
+  }
   else if (mode_kind != kClassic) { status = mr.in_bounds() ? PCO_GFX_CORRUPTION : PCO_GFX_INSUFFICIENT_DATA; return; }
   if (!mr.in_bounds()) { status = PCO_GFX_INSUFFICIENT_DATA; return; }
+  const bool dict = mode_kind == kDict;
   // delta encoding (metadata/delta_encoding.rs:118-202)
   uint32_t dkind = kDeltaNone, dorder = 0, wlog = 0, slog = 0; bool sec_uses_delta = false;
   if (format_major < 3) {
@@ -508,7 +613,15 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
       wlog = 1 + (uint32_t)mr.read(kBitsLookbackWindowLog); slog = (uint32_t)mr.read(kBitsLookbackStateLog);
       if (wlog > kMaxLookbackWindowLog || slog > wlog) { status = PCO_GFX_CORRUPTION; return; }
       dkind = kDeltaLookback; sec_uses_delta = mr.read(1) != 0;
-    } else if (variant == 3) { status = mr.in_bounds() ? PCO_GFX_UNSUPPORTED : PCO_GFX_INSUFFICIENT_DATA; return; }
+    } else if (variant == 3) {   // Conv1 (metadata/delta_encoding.rs): 5-bit quantization, 64-bit bias, 5-bit weight count - 1, 32-bit weights
+      conv_quant = (uint32_t)mr.read(5);
+      const uint64_t bias = mr.read(64) ^ ((uint64_t)1 << 63);
+      dorder = 1 + (uint32_t)mr.read(5);
+      int64_t PCO_LDS* cw = (int64_t PCO_LDS*)(lds_base() + kLdsConvOff);
+      if (lane == 0) cw[0] = (int64_t)bias;
+      for (uint32_t k = 0; k < dorder; k++) { const uint32_t w = (uint32_t)mr.read(32) ^ 0x80000000u; if (lane == 0) cw[1 + k] = (int64_t)(int32_t)w; }
+      dkind = kDeltaConv1;
+    }
     else if (variant != 0) { status = PCO_GFX_CORRUPTION; return; }
   }
   if (!mr.in_bounds()) { status = PCO_GFX_INSUFFICIENT_DATA; return; }
@@ -522,7 +635,7 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
 #pragma unroll
     for (int vi = 0; vi < 3; vi++) {
       VarInfo v{};
-      v.present = present[vi]; v.latent_bits = vi == 0 ? 32u : LB;
+      v.present = present[vi]; v.latent_bits = (vi == 0 || (vi == 1 && dict)) ? 32u : LB;   // Dict: the primary holds u32 dictionary indices (mode.rs:197-202)
       if (vi == 1 || (vi == 2 && sec_uses_delta)) { v.delta_kind = dkind; v.delta_order = dorder; v.window_n_log = wlog; v.state_n_log = slog; }
       if (present[vi]) {
         const uint32_t a = (uint32_t)peek.read(kBitsAnsSizeLog), nb = (uint32_t)peek.read(kBitsNBins);
@@ -553,8 +666,9 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
     if (!present[vi]) continue;
     mr.bit += kBitsAnsSizeLog + kBitsNBins;
     bool ok;
-    if (lds_tables) ok = vi == 0 ? build_var_tables<uint32_t, true>(tbl_lds, vi, mr, status) : build_var_tables<L, true>(tbl_lds, vi, mr, status);
-    else ok = vi == 0 ? build_var_tables<uint32_t, false>(tbl_ws, vi, mr, status) : build_var_tables<L, false>(tbl_ws, vi, mr, status);
+    const bool u32_var = vi == 0 || (vi == 1 && dict);
+    if (lds_tables) ok = u32_var ? build_var_tables<uint32_t, true>(tbl_lds, vi, mr, status) : build_var_tables<L, true>(tbl_lds, vi, mr, status);
+    else ok = u32_var ? build_var_tables<uint32_t, false>(tbl_ws, vi, mr, status) : build_var_tables<L, false>(tbl_ws, vi, mr, status);
     if (!ok) return;
   }
   if (!mr.drain_empty_byte()) { if (mr.in_bounds()) { status = PCO_GFX_CORRUPTION; return; } }
@@ -585,8 +699,15 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
     }
     if (!valid) { status = PCO_GFX_CORRUPTION; return; }
   }
+  if (dkind == kDeltaConv1 && (LB > 32 || dict)) { status = LB > 32 ? PCO_GFX_CORRUPTION : PCO_GFX_UNSUPPORTED; return; }   // delta/conv1.rs: no 64-bit Conv type
+  if (dict && dkind == kDeltaLookback) { status = PCO_GFX_UNSUPPORTED; return; }   // (index history would need its own buffer; no encoder path produces it by default)
   if (meta_only) return;
-  PageParams pp{mode_kind, mode_k, num_kind, n, (uint64_t)mode_base};
+  PageParams pp{mode_kind, mode_k, num_kind, n, (uint64_t)mode_base, dict_byte, dict_n, dorder, conv_quant};
+  if (dict) {
+    if (lds_tables) decode_page_body_dict<L, true>(src, src_len, mr, tbl_lds, pp, dst, status);
+    else decode_page_body_dict<L, false>(src, src_len, mr, tbl_ws, pp, dst, status);
+    return;
+  }
   if (lds_tables) decode_page_body<L, true>(src, src_len, mr, tbl_lds, pp, dst, status);
   else decode_page_body<L, false>(src, src_len, mr, tbl_ws, pp, dst, status);
 }

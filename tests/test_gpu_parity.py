@@ -37,13 +37,26 @@ def fix_cfg(name):
 # ------------------------------------------------------------------------------------------------ decode
 def test_decode_reference_golden_assets(L):
     from test_oracle_golden import EXPECTED, asset
-    for name, exp in sorted(EXPECTED.items()):
+    from test_oracle_golden import EXPECTED_ORACLE_ONLY
+    every = dict(EXPECTED); every.update(EXPECTED_ORACLE_ONLY)   # all 13 files of pco/assets: Dict mode and Conv1 delta included
+    assert len(every) == 13
+    for name, exp in sorted(every.items()):
         got = U.gpu_simple_decompress(asset(name), exp.dtype, max(exp.size, 1))
         assert U.bits_equal(got, exp), name
-    for name, dt in (("v1_0_0_dict.pco", np.uint64), ("v1_0_0_conv1.pco", np.int32)):
-        with pytest.raises(G.PcoGfxError) as ei:
-            U.gpu_simple_decompress(asset(name), dt, 4096)
-        assert ei.value.status == G.ST_UNSUPPORTED
+    # Dict / Conv1 streams cut short or damaged: an error, never a crash or a hang (tests/stability.rs, tests/corruption.rs)
+    rng = np.random.default_rng(4)
+    for name in ("v1_0_0_dict.pco", "v1_0_0_conv1.pco"):
+        blob = asset(name); exp = every[name]
+        for cut in list(range(0, 60)) + [len(blob) // 2, len(blob) - 2]:
+            with pytest.raises(G.PcoGfxError) as ei:
+                U.gpu_simple_decompress(blob[:cut], exp.dtype, exp.size)
+            assert ei.value.status in (G.ST_INSUFFICIENT_DATA, G.ST_CORRUPTION), (name, cut)
+        for _ in range(60):
+            b = bytearray(blob); b[rng.integers(0, len(b))] ^= 1 << rng.integers(0, 8)
+            try:
+                U.gpu_simple_decompress(bytes(b), exp.dtype, exp.size)
+            except G.PcoGfxError as e:
+                assert e.status in (G.ST_CORRUPTION, G.ST_INSUFFICIENT_DATA, G.ST_INVALID_ARGUMENT, G.ST_UNSUPPORTED)
 
 
 @pytest.mark.parametrize("name", FIX_NAMES)
