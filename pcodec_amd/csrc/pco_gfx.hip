@@ -7,6 +7,8 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -27,7 +29,9 @@ void clear_error() { g_err.status = PCO_GFX_OK; g_err.msg.clear(); }
 
 struct WorkspaceHolder {
   Workspace ws;
-  ~WorkspaceHolder() { /* process teardown: the driver reclaims device memory */ }
+  // A worker thread that exits gives its device and pinned memory back.  The main thread's holder is destroyed during process
+  // teardown, when the HIP runtime may already be unloading: there the driver reclaims everything and nothing is touched.
+  ~WorkspaceHolder() { if ((long)syscall(SYS_gettid) != (long)getpid()) { ws.release_all(); if (ws.last_event) (void)hipEventDestroy(ws.last_event); } }
 };
 Workspace& workspace() {
   static thread_local WorkspaceHolder h;
@@ -253,7 +257,7 @@ enum PcoError pco_gfx_decompress_chunks(size_t n_tasks, const PcoGfxDecodeTask* 
   clear_error();
   try {
     require_device();
-    launch_decode(n_tasks, tasks, results, d_results, (hipStream_t)stream);
+    { WorkspaceUse use(workspace(), (hipStream_t)stream); launch_decode(n_tasks, tasks, results, d_results, (hipStream_t)stream); }
     if (results) for (size_t i = 0; i < n_tasks; i++) if (results[i].status != PCO_GFX_OK) {
       set_error((int)results[i].status, "decode task " + std::to_string(i) + " failed");
       return PcoDecompressionError;
@@ -271,6 +275,7 @@ enum PcoError pco_gfx_compact_chunks(size_t n_tasks, const PcoGfxEncodeTask* tas
     if (!d_results || !d_offsets || (!d_dst && dst_cap)) throw HostError{PCO_GFX_INVALID_ARGUMENT, "compact: null device array"};
     if (n_tasks >= (1ull << 31)) throw HostError{PCO_GFX_INVALID_ARGUMENT, "compact: too many chunks"};
     Workspace& ws = workspace();
+    WorkspaceUse use(ws, stream);
     uint8_t* d_base = (uint8_t*)ws.compact_tasks.ensure(n_tasks * sizeof(PcoGfxEncodeTask) + 64);
     uint32_t* d_over = (uint32_t*)d_base; PcoGfxEncodeTask* d_tasks = (PcoGfxEncodeTask*)(d_base + 64);
     uint64_t max_cap = 0;

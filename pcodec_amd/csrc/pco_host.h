@@ -25,7 +25,7 @@ void clear_error();
     if (_e != hipSuccess) throw pcogfx::HostError{PCO_GFX_DEVICE_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e)}; \
   } while (0)
 
-// A growable device buffer (never shrinks; freed by pco_gfx_release_workspace / thread exit).
+// A growable device buffer (never shrinks; freed by pco_gfx_release_workspace, and when a thread other than the main one exits).
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -61,6 +61,10 @@ struct HostBuf {
 
 struct Workspace {
   int device = -1;
+  // One workspace per (thread, device), shared by every call whatever its stream: a call on stream B while an asynchronous call on
+  // stream A still runs would overwrite buffers in use, so each call first makes its stream wait for the previous call's last
+  // kernel (an event recorded at that call's end; free when both calls use one stream, the documented pattern).
+  hipStream_t last_stream = nullptr; hipEvent_t last_event = nullptr; bool has_last = false;
   DevBuf tasks, results, tbl_ws;          // decode
   DevBuf dec_plans, dec_bins, dec_sym, dec_offpos;  // decode fast path
   DevBuf io_in, io_out;                   // staging for the host-buffer entry points
@@ -76,6 +80,16 @@ struct Workspace {
   }
 };
 Workspace& workspace();
+struct WorkspaceUse {   // RAII: orders the call after the workspace's previous user, records the hand-over event at scope exit
+  Workspace& ws; hipStream_t stream;
+  WorkspaceUse(Workspace& w, hipStream_t s) : ws(w), stream(s) {
+    if (ws.has_last && ws.last_stream != stream && ws.last_event) (void)hipStreamWaitEvent(stream, ws.last_event, 0);
+  }
+  ~WorkspaceUse() {
+    if (!ws.last_event && hipEventCreateWithFlags(&ws.last_event, hipEventDisableTiming) != hipSuccess) { ws.last_event = nullptr; return; }
+    if (hipEventRecord(ws.last_event, stream) == hipSuccess) { ws.last_stream = stream; ws.has_last = true; }
+  }
+};
 
 // ---- host-side bit writer for framing / size computations (O(metadata) work only) ----
 struct HostBitWriter {

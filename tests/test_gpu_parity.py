@@ -573,3 +573,40 @@ def test_many_chunk_properties_full_size(L):
     G.check(L.pco_gfx_decompress_chunks(nch, dt, dres, None, None))
     assert torch.equal(out, src)
     assert all(r.n_out <= L.pco_gfx_guarantee_chunk_size(base.size, dtb) for r in res)
+
+
+def test_workspace_budget_cuts_a_call_into_sub_batches(L):
+    """PCO_GFX_WORKSPACE_GB: a synchronous batched call whose scratch would exceed the budget runs as consecutive sub-batches through the
+    same buffers -- same bytes, same results order."""
+    import subprocess, sys
+    code = r'''
+import os, sys
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np, gpu_util as U, oracle_lib as O
+from pcodec_amd import _lib as G
+rng = np.random.default_rng(9)
+arrays = [(np.uint64(1 << 40) + np.uint64(1000) * np.arange(20000, dtype=np.uint64) + rng.integers(0, 512, 20000).astype(np.uint64)) for _ in range(300)]
+kw = dict(mode=1, delta=2, delta_order=1)
+chunks, back = U.gpu_batched(arrays, G.make_config(**kw))
+for a, ch, b in zip(arrays, chunks, back):
+    want = O.simple_compress(a, O.make_config(**kw))
+    assert ch == U.chunk_of_file(want, len(ch)) and U.bits_equal(a, b)
+print("ok")
+'''
+    env = dict(os.environ, PCO_GFX_WORKSPACE_GB="0.05")   # 50 MB: ~70 chunks of 20000 u64 per pass
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(HERE, ".."), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_chunks_beyond_one_page_of_the_standalone_writer(L):
+    """A batched task is one chunk of up to 2^24 numbers (the standalone writer would cut it at 2^18): 2^18 < n <= 2^22 against the
+    oracle's single-chunk file, u64 / f32 / i16."""
+    rng = np.random.default_rng(10)
+    arrays = [(np.uint64(1 << 40) + np.uint64(1000) * np.arange(n, dtype=np.uint64) + rng.integers(0, 512, n).astype(np.uint64)) for n in ((1 << 18) + 7, 1 << 20)]
+    arrays += [rng.standard_normal((1 << 19) + 1).astype(np.float32), (np.cumsum(rng.integers(-3, 4, 1 << 22)) % 30000).astype(np.int16)]
+    for kw in (dict(mode=1, delta=2, delta_order=1), dict(mode=1, delta=1)):
+        chunks, back = U.gpu_batched(arrays, G.make_config(**kw))
+        for a, ch, b in zip(arrays, chunks, back):
+            want = O.simple_compress(a, O.make_config(max_page_n=a.size, **kw))
+            assert ch == U.chunk_of_file(want, len(ch)), (a.dtype, a.size, kw)
+            assert U.bits_equal(a, b), (a.dtype, a.size, kw)
