@@ -135,14 +135,14 @@ __device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncF
   for (int v = 0; v < 3; v++) {
     use_lut[v] = false; rel0[v] = 0;
     if (!pv[v].present || pv[v].n_bins <= 1) continue;
-    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    const PlanRef plan = plan_ref(ws, t, v);
     const uint64_t range = uni((uint64_t)ch->v[v].maxv) - pv[v].minv;
     use_lut[v] = range < kDirectHistRange;
     rel0[v] = pv[v].compact ? pv[v].minv : 0ull;
     uint8_t PCO_LDS* vt = smem + v * kDisVarBytes;
     const uint32_t b = threadIdx.x;  // 256 threads: one padded bin each; lowers as u64 relative to rel0, padded with the maximum
-    ((uint64_t PCO_LDS*)vt)[b] = b < pv[v].n_bins ? (uint64_t)plan->blower[b] - rel0[v] : ~0ull;
-    (vt + 2048)[b] = b < pv[v].n_bins ? plan->bob[b] : 0;
+    ((uint64_t PCO_LDS*)vt)[b] = b < pv[v].n_bins ? (uint64_t)plan.blower()[b] - rel0[v] : ~0ull;
+    (vt + 2048)[b] = b < pv[v].n_bins ? plan.bob()[b] : 0;
   }
   __syncthreads();
 #pragma unroll
@@ -254,12 +254,12 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
     }
     if (stage != 0 && ew_fits16(pv.asl, pv.n_bins) != (stage == 1)) continue;   // the other stage's item
     const uint32_t kEwInfoOff = ew_info_off(pv.asl);
-    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    const PlanRef plan = plan_ref(ws, t, v);
     uint8_t PCO_LDS* sl = smem + q * kEwSlotBytes;
     const uint32_t T = 1u << pv.asl;
-    for (uint32_t i = lane; i < T; i += 64) ((uint16_t PCO_LDS*)(sl + kEwNsOff))[i] = plan->next_states[i];
+    for (uint32_t i = lane; i < T; i += 64) ((uint16_t PCO_LDS*)(sl + kEwNsOff))[i] = plan.next_states()[i];
     for (uint32_t b = lane; b < pv.n_bins; b += 64) {
-      const uint32_t si = plan->syminfo[b];   // cutoff(14) | min_renorm_bits(4) << 14 | (row + 8192)(14) << 18
+      const uint32_t si = plan.syminfo()[b];   // cutoff(14) | min_renorm_bits(4) << 14 | (row + 8192)(14) << 18
       const uint32_t cutoff = si & 0x3fffu, minb = (si >> 14) & 15u, row = (si >> 18) - 8192u;   // row may be "negative": wraps mod 2^32 below
       const uint32_t row_addr = lds0 + q * kEwSlotBytes + kEwNsOff + 2u * row;
       ((uint64_t PCO_LDS*)(sl + kEwInfoOff))[b] = (uint64_t)(((minb + 1u) << 16) - cutoff) | ((uint64_t)row_addr << 32);
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64) void enc_scan_kernel(EncWorkspace ws, EncFast f
     pv[v] = page_var(ch, v, page_n);
     ob0[v] = 0;
     if (!pv[v].present) continue;
-    if (pv[v].n_bins == 1) ob0[v] = uni((uint32_t)((const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v)->bob[0]);
+    if (pv[v].n_bins == 1) ob0[v] = uni((uint32_t)plan_ref(ws, t, v).bob()[0]);
     if (v == 1) page_meta += (uint64_t)LB * (delta_kind == kDeltaConsecutive ? uni(ch->delta_order) : (delta_kind == kDeltaLookback ? (1u << uni(ch->state_n_log)) : 0u));
     page_meta += 4ull * pv[v].asl;
   }
@@ -644,7 +644,7 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
 #pragma unroll
       for (int v = 0; v < 3; v++) {
         if (!pv[v].present) continue;
-        const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+        const PlanRef plan = plan_ref(ws, t, v);
         const uint32_t asl = pv[v].asl, nbins = pv[v].n_bins;
         const uint32_t lb = v == 0 ? 32u : LB, obb = offset_bits_bits(lb);
         sink.put_uniform(asl, kBitsAnsSizeLog); sink.put_uniform(nbins, kBitsNBins);
@@ -655,9 +655,9 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
           sink.reserve(64 * bin_bits);
           if (b < nbins) {
             const uint32_t rel = lane * bin_bits;
-            sink.put(rel, plan->bweight[b] - 1, asl);
-            sink.put(rel + asl, plan->blower[b], lb);
-            sink.put(rel + asl + lb, plan->bob[b], obb);
+            sink.put(rel, plan.bweight()[b] - 1, asl);
+            sink.put(rel + asl, plan.blower()[b], lb);
+            sink.put(rel + asl + lb, plan.bob()[b], obb);
           }
           sink.commit(nb * bin_bits);
         }
@@ -683,11 +683,11 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
   for (int v = 0; v < 3; v++) {
     on[v] = pv[v].present && !pv[v].trivial;
     if (!on[v]) continue;
-    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    const PlanRef plan = plan_ref(ws, t, v);
     uint8_t PCO_LDS* vt = smem + kPackLdsVar + ws.slot_of_var[v] * kPackVarBytes;
     const uint64_t rel0 = pv[v].compact ? pv[v].minv : 0ull;   // compact latents are relative to the minimum
     for (uint32_t b = lane; b < pv[v].n_bins; b += 64) {
-      const uint64_t lw = plan->blower[b] - rel0; const uint32_t ob = plan->bob[b];
+      const uint64_t lw = plan.blower()[b] - rel0; const uint32_t ob = plan.bob()[b];
       ((uint64_t PCO_LDS*)vt)[b] = lw; (vt + 2048)[b] = (uint8_t)ob;
       if (pv[v].compact) ((uint32_t PCO_LDS*)(vt + 2304))[b] = ((uint32_t)lw & 0xffffu) | (ob << 16);
     }

@@ -116,7 +116,7 @@ template <class L>
 __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log) {
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   EncVar PCO_GLOBAL* ev = &ch->v[var];
-  EncPlanVar PCO_GLOBAL* plan = (EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + var;
+  const PlanRef plan = plan_ref(ws, t, var);
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
   const uint32_t n_lat = ev->n_lat;
   if (n_lat == 0) return;

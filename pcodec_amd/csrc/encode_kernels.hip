@@ -73,16 +73,28 @@ __device__ __forceinline__ uint64_t page_start_of(uint64_t i, uint32_t low, uint
   return boundary + ((i - boundary) / low) * low;
 }
 
-// per (chunk, var) plan region
-struct EncPlanVar {
-  uint32_t hcount[kMaxBins]; uint64_t hlower[kMaxBins]; uint64_t hupper[kMaxBins];   // unoptimized histogram
-  uint32_t bweight[kMaxBins]; uint32_t bcount[kMaxBins]; uint64_t blower[kMaxBins]; uint8_t bob[kMaxBins];  // optimized bins
-  uint32_t syminfo[kMaxBins];                  // cutoff(14) | min_renorm_bits(4)<<14 | (ns_off - weight + 8192)(14)<<18
-  uint16_t next_states[1u << kMaxEncTableLog];
+// per (chunk, var) plan region: histogram bins, optimized bins, tANS encoder tables.  Its bin capacity is a property of the call:
+// 256 (compression levels whose unoptimized_bins_log stays at 8 or below: every level up to 8 at n >= 2^12) or 4096 (levels 9..12:
+// wrapped/chunk_compressor.rs:362-371, constants.rs:35).  Layout (cap = capacity): u64 hlower[cap] hupper[cap] blower[cap] |
+// u32 hcount[cap] bweight[cap] bcount[cap] syminfo[cap] | u16 next_states[4096] | u8 bob[cap].
+constexpr uint32_t kBigBins = 1u << 12;
+__host__ __device__ constexpr uint64_t plan_bytes_for(uint32_t cap) { return ((uint64_t)cap * (24 + 16 + 1) + (2ull << kMaxEncTableLog) + 63) & ~63ull; }
+struct PlanRef {
+  uint8_t PCO_GLOBAL* base; uint32_t cap;
+  __device__ __forceinline__ uint64_t PCO_GLOBAL* hlower() const { return (uint64_t PCO_GLOBAL*)base; }
+  __device__ __forceinline__ uint64_t PCO_GLOBAL* hupper() const { return (uint64_t PCO_GLOBAL*)base + cap; }
+  __device__ __forceinline__ uint64_t PCO_GLOBAL* blower() const { return (uint64_t PCO_GLOBAL*)base + 2 * (uint64_t)cap; }
+  __device__ __forceinline__ uint32_t PCO_GLOBAL* hcount() const { return (uint32_t PCO_GLOBAL*)(base + 24ull * cap); }
+  __device__ __forceinline__ uint32_t PCO_GLOBAL* bweight() const { return (uint32_t PCO_GLOBAL*)(base + 28ull * cap); }
+  __device__ __forceinline__ uint32_t PCO_GLOBAL* bcount() const { return (uint32_t PCO_GLOBAL*)(base + 32ull * cap); }
+  __device__ __forceinline__ uint32_t PCO_GLOBAL* syminfo() const { return (uint32_t PCO_GLOBAL*)(base + 36ull * cap); }   // cutoff(14) | min_renorm_bits(4)<<14 | (ns_off - weight + 8192)(14)<<18
+  __device__ __forceinline__ uint16_t PCO_GLOBAL* next_states() const { return (uint16_t PCO_GLOBAL*)(base + 40ull * cap); }
+  __device__ __forceinline__ uint8_t PCO_GLOBAL* bob() const { return (uint8_t PCO_GLOBAL*)(base + 40ull * cap + (2ull << kMaxEncTableLog)); }
 };
 struct EncWorkspace {
   EncChunk* chunks;
-  EncPlanVar* plans;        // [task][3]
+  uint8_t* plans;           // [task][3] plan regions of plan_bytes_for(plan_cap) bytes each (PlanRef)
+  uint32_t plan_cap, pad_cap;   // bin capacity of every plan region of this call: 256 or 4096
   EncPage* pages;           // [n_pages_total]
   uint8_t* lat;             // [task][n_slots][n_stride] 8-byte elements
   uint8_t* sort;            // [task][2][n_stride] 8-byte elements
@@ -103,6 +115,9 @@ __device__ __forceinline__ void enc_wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+__device__ __forceinline__ PlanRef plan_ref(const EncWorkspace& ws, uint32_t task, uint32_t var) {
+  return PlanRef{(uint8_t PCO_GLOBAL*)ws.plans + ((uint64_t)task * 3 + var) * plan_bytes_for(ws.plan_cap), ws.plan_cap};
+}
 template <class L> __device__ __forceinline__ L PCO_GLOBAL* lat_ptr(const EncWorkspace& ws, uint32_t task, uint32_t var) {
   return (L PCO_GLOBAL*)(ws.lat + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * ws.n_stride * 8);
 }
@@ -193,10 +208,10 @@ __global__ __launch_bounds__(256) void enc_trial_summary_kernel(EncWorkspace ws,
   TrialSummary* o = out + t;
   if (threadIdx.x == 0) { o->status = ch->status; o->fallback = ch->fallback; }
   for (int v = 0; v < 2; v++) {
-    const EncPlanVar* plan = ws.plans + (uint64_t)t * 3 + v;
+    const PlanRef plan = plan_ref(ws, t, v);
     const uint32_t nb = ch->v[v].present ? ch->v[v].n_bins : 0;
     if (threadIdx.x == 0) { o->asl[v] = ch->v[v].ans_size_log; o->n_bins[v] = nb; o->n_lat[v] = ch->v[v].present ? ch->v[v].n_lat : 0; }
-    for (uint32_t b = threadIdx.x; b < nb; b += 256) { o->w[v][b] = (uint16_t)plan->bweight[b]; o->ob[v][b] = plan->bob[b]; }
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) { o->w[v][b] = (uint16_t)plan.bweight()[b]; o->ob[v][b] = plan.bob()[b]; }
   }
 }
 
@@ -852,7 +867,7 @@ template <class L>
 __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins_log, L first_value,
                                                    const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
                                                    const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc,
-                                                   EncPlanVar PCO_GLOBAL* plan, uint32_t& n_hist_out) {
+                                                   const PlanRef& plan, uint32_t& n_hist_out) {
   // sequential (one lane); at most 2 * 2^bins_log iterations
   const uint64_t n = n_lat, B = (uint64_t)1 << bins_log;
   // floor((pos << bins_log) / n) by one multiplication: M = ceil(2^64 / n) is exact for dividends below 2^64 / n, and ours stay below
@@ -864,7 +879,7 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
   bool pending = false; uint32_t pending_start = 0; L pending_lower = 0;
   uint32_t next_avail = 0, n_hist = 0;
   auto emit = [&](uint32_t start, uint32_t end, L lower, L upper) {
-    plan->hcount[n_hist] = end - start; plan->hlower[n_hist] = (uint64_t)lower; plan->hupper[n_hist] = (uint64_t)upper; n_hist++;
+    plan.hcount()[n_hist] = end - start; plan.hlower()[n_hist] = (uint64_t)lower; plan.hupper()[n_hist] = (uint64_t)upper; n_hist++;
   };
   while (pos < n_lat) {
     const uint32_t target = bin_idx(pos);
@@ -900,7 +915,7 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
 // histogram time before this shortcut).
 template <class L>
 __device__ __forceinline__ void hist_emit(uint32_t n_lat, uint32_t bins_log, L first_value, const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
-                                          const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc, EncPlanVar PCO_GLOBAL* plan, EncVar PCO_GLOBAL* ev, uint32_t path) {
+                                          const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc, const PlanRef& plan, EncVar PCO_GLOBAL* ev, uint32_t path) {
   const uint32_t tid = threadIdx.x, B = 1u << bins_log;
   const uint64_t n64 = n_lat;
   auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
@@ -909,7 +924,7 @@ __device__ __forceinline__ void hist_emit(uint32_t n_lat, uint32_t bins_log, L f
   if (simple) {
     if (tid < B) {
       const uint32_t c0 = tid == 0 ? 0u : c_count(tid - 1), c1 = c_count(tid);
-      plan->hcount[tid] = c1 - c0; plan->hlower[tid] = (uint64_t)(tid == 0 ? first_value : rnext[tid - 1]); plan->hupper[tid] = (uint64_t)rv[tid];
+      plan.hcount()[tid] = c1 - c0; plan.hlower()[tid] = (uint64_t)(tid == 0 ? first_value : rnext[tid - 1]); plan.hupper()[tid] = (uint64_t)rv[tid];
     }
     if (tid == 0) { ev->n_hist = B; ev->hist_path = path; }
   } else if (tid == 0) {
@@ -949,14 +964,15 @@ template <class L, uint32_t T, uint32_t R, bool kWide, bool kSort>
 __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log) {
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   EncVar PCO_GLOBAL* ev = &ch->v[var];
-  EncPlanVar PCO_GLOBAL* plan = (EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + var;
+  const PlanRef plan = plan_ref(ws, t, var);
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
   const uint32_t n_lat = ev->n_lat;
   if (n_lat == 0) { if (tid == 0) ev->n_hist = 0; return; }
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   const L range = (L)(maxv - minv);
   // enc_hist_kernel: range < 4096; enc_hist_wide_kernel<16384>: [4096, 16384), <32768>: [16384, 32768); enc_hist_sort_kernel: the rest
-  if (!kSort && !kWide && (uint64_t)range >= kWideHistRange && tid == 0) atomicOr(ws.need_sort, 1u);
+  // (what the launcher has to run after this kernel: bit 0 the select / sort kernels, bit 1 the 16384-counter kernel, bit 2 the 32768-counter one)
+  if (!kSort && !kWide && (uint64_t)range >= kDirectHistRange && tid == 0) atomicOr(ws.need_sort, (uint64_t)range >= kWideHistRange ? 1u : ((uint64_t)range >= kMidHistRange ? 4u : 2u));
   if (kSort ? (uint64_t)range < kWideHistRange : (kWide ? ((uint64_t)range < (R == kWideHistRange ? kMidHistRange : kDirectHistRange) || (uint64_t)range >= R) : (uint64_t)range >= kDirectHistRange)) return;
   if (kSort && ev->hist_path != 2) return;   // the radix-sort path is the fallback of enc_hist_select_kernel (encode_hist_select.hip), which flags what it gave up on
   // Stored latents = every position that is not among the first `skip` of its page (wrapped/chunk_compressor.rs:129-140).
@@ -1360,7 +1376,7 @@ template <class L>
 __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   EncVar PCO_GLOBAL* ev = &ch->v[var];
-  EncPlanVar PCO_GLOBAL* plan = (EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + var;
+  const PlanRef plan = plan_ref(ws, t, var);
   const uint32_t lane = lane_id();
   uint8_t PCO_LDS* smem = enc_lds_base();
   uint32_t PCO_LDS* cc = (uint32_t PCO_LDS*)(smem + kTrainLdsCC);
@@ -1377,7 +1393,7 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
   const uint32_t n_lat = uni(ev->n_lat);
   const uint32_t nb = uni(ev->n_hist);
   if (n_lat == 0 || nb == 0) {  // train_infos: empty latents -> TrainedBins::default()
-    if (lane == 0) { ev->n_bins = 0; ev->ans_size_log = 0; ev->max_ob = 0; ev->is_trivial = 1; ev->needs_ans = 1; plan->next_states[0] = 1; }
+    if (lane == 0) { ev->n_bins = 0; ev->ans_size_log = 0; ev->max_ob = 0; ev->is_trivial = 1; ev->needs_ans = 1; plan.next_states()[0] = 1; }
     return;
   }
   const uint32_t ubl = uni(ch->unopt_bins_log);
@@ -1386,7 +1402,7 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
   uint32_t est = bins_log + 2; if (est > 12) est = 12; if (est > n_log_ceil) est = n_log_ceil;  // estimated_ans_size_log
   // load histogram bins
   enc_wave_sync();
-  for (uint32_t b = lane; b < nb; b += 64) { lows[b] = (L)plan->hlower[b]; ups[b] = (L)plan->hupper[b]; cc[b + 1] = plan->hcount[b]; }
+  for (uint32_t b = lane; b < nb; b += 64) { lows[b] = (L)plan.hlower()[b]; ups[b] = (L)plan.hupper()[b]; cc[b + 1] = plan.hcount()[b]; }
   if (lane == 0) { cc[0] = 0; best[0] = 0.0f; }
   enc_wave_sync();
   if (lane == 0) { uint32_t c = 0; for (uint32_t b = 0; b < nb; b++) { c += cc[b + 1]; cc[b + 1] = c; } }
@@ -1447,7 +1463,7 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
       const uint32_t count = cc[i + 1] - cc[j];
       const L lower = lows[j], upper = ups[i];
       const uint32_t ob = bitlen<L>((L)(upper - lower));
-      plan->bcount[s] = count; plan->blower[s] = (uint64_t)lower; plan->bob[s] = (uint8_t)ob;
+      plan.bcount()[s] = count; plan.blower()[s] = (uint64_t)lower; plan.bob()[s] = (uint8_t)ob;
       wts[s] = count; max_ob = max_ob > ob ? max_ob : ob;
     }
     // quantize_weights (ans/encoding.rs:95-175)
@@ -1485,10 +1501,10 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
       ans_size_log = size_log;
     }
     uint32_t c = 0;
-    for (uint32_t s = 0; s < n_opt; s++) { plan->bweight[s] = wts[s]; cum[s] = c; c += wts[s]; }
+    for (uint32_t s = 0; s < n_opt; s++) { plan.bweight()[s] = wts[s]; cum[s] = c; c += wts[s]; }
     cum[n_opt] = c;
     ev->n_bins = n_opt; ev->ans_size_log = ans_size_log; ev->max_ob = max_ob;
-    ev->is_trivial = (n_opt == 1 && plan->bob[0] == 0) ? 1u : 0u;
+    ev->is_trivial = (n_opt == 1 && plan.bob()[0] == 0) ? 1u : 0u;
     ev->needs_ans = n_opt != 1 ? 1u : 0u;
   }
   enc_wave_sync();
@@ -1508,7 +1524,7 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
     const uint32_t min_renorm_bits = ans_size_log - (31 - clz_u32(max_x_s));
     const uint32_t cutoff = (2 * w) << min_renorm_bits;
     const uint32_t adj = cum[s] - w + 8192u;  // next_states index = adj - 8192 + (state >> bits)
-    plan->syminfo[s] = cutoff | (min_renorm_bits << 14) | (adj << 18);
+    plan.syminfo()[s] = cutoff | (min_renorm_bits << 14) | (adj << 18);
   }
   // next_states: states of symbol s in ascending state order -> T + state_idx; fill counters reuse wts[] (set to cum)
   enc_wave_sync();
@@ -1527,7 +1543,7 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
     enc_wave_sync();
     if (act && rank == 0) wts[s] = basec + gcount;
     enc_wave_sync();
-    if (act) plan->next_states[basec + rank] = (uint16_t)(T + i);
+    if (act) plan.next_states()[basec + rank] = (uint16_t)(T + i);
   }
   enc_wave_sync();
 }
@@ -1561,10 +1577,10 @@ __global__ __launch_bounds__(64) void enc_train_kernel(EncWorkspace ws, uint32_t
       uint64_t page_meta_bits = 0;
       for (uint32_t var = 0; var < 3; var++) {
         if (!ch->v[var].present) continue;
-        const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + var;
+        const PlanRef plan = plan_ref(ws, t, var);
         const uint32_t lb = ch->v[var].latent_bits, asl = ch->v[var].ans_size_log, nbv = ch->v[var].n_bins;
         for (uint32_t s = 0; s < nbv; s++)
-          worst_bits += (uint64_t)plan->bcount[s] * (uint64_t)(plan->bob[s] + asl - (31 - clz_u32(plan->bweight[s])));
+          worst_bits += (uint64_t)plan.bcount()[s] * (uint64_t)(plan.bob()[s] + asl - (31 - clz_u32(plan.bweight()[s])));
         meta_bits += kBitsAnsSizeLog + kBitsNBins + (uint64_t)nbv * (asl + lb + offset_bits_bits(lb));
         uint32_t nlps = 0;
         if (var == 1) nlps = delta_kind == kDeltaConsecutive ? ch->delta_order : (delta_kind == kDeltaLookback ? (1u << ch->state_n_log) : 0u);
@@ -1651,7 +1667,7 @@ struct BitSink {
 };
 
 template <class LV>
-__device__ __forceinline__ void page_load_var_tables(uint8_t PCO_LDS* vt, const EncPlanVar PCO_GLOBAL* plan, uint32_t n_bins, uint32_t asl) {
+__device__ __forceinline__ void page_load_var_tables(uint8_t PCO_LDS* vt, const PlanRef& plan, uint32_t n_bins, uint32_t asl) {
   const uint32_t lane = lane_id();
   LV PCO_LDS* low = (LV PCO_LDS*)(vt + kPageVarLow);
   uint8_t PCO_LDS* ob = vt + kPageVarOb;
@@ -1659,12 +1675,12 @@ __device__ __forceinline__ void page_load_var_tables(uint8_t PCO_LDS* vt, const 
   uint16_t PCO_LDS* ns = (uint16_t PCO_LDS*)(vt + kPageVarNs);
   uint32_t padded = 1; while (padded < n_bins) padded <<= 1;
   for (uint32_t b = lane; b < padded && b < 256; b += 64) {
-    low[b] = b < n_bins ? (LV)plan->blower[b] : (LV)~(LV)0;   // padded with L::MAX (compression_table.rs:22-26)
-    ob[b] = b < n_bins ? plan->bob[b] : 0;
-    info[b] = b < n_bins ? plan->syminfo[b] : 0;
+    low[b] = b < n_bins ? (LV)plan.blower()[b] : (LV)~(LV)0;   // padded with L::MAX (compression_table.rs:22-26)
+    ob[b] = b < n_bins ? plan.bob()[b] : 0;
+    info[b] = b < n_bins ? plan.syminfo()[b] : 0;
   }
   const uint32_t T = 1u << asl;
-  for (uint32_t i = lane; i < T; i += 64) ns[i] = plan->next_states[i];
+  for (uint32_t i = lane; i < T; i += 64) ns[i] = plan.next_states()[i];
 }
 
 // Phase A1 for one variable: batches in reverse; binary search -> symbol; reverse tANS over 4 chains.
@@ -1793,7 +1809,7 @@ __device__ void page_write_chunk_meta(BitSink& sink, const EncWorkspace& ws, uin
 #pragma unroll
   for (int v = 0; v < 3; v++) {
     if (!uni(ch->v[v].present)) continue;
-    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    const PlanRef plan = plan_ref(ws, t, v);
     const uint32_t asl = uni(ch->v[v].ans_size_log), nbins = uni(ch->v[v].n_bins);
     const uint32_t lb = v == 0 ? 32u : LB, obb = offset_bits_bits(lb);
     sink.put_uniform(asl, kBitsAnsSizeLog); sink.put_uniform(nbins, kBitsNBins);
@@ -1803,9 +1819,9 @@ __device__ void page_write_chunk_meta(BitSink& sink, const EncWorkspace& ws, uin
       const uint32_t nb = nbins - b0 < 64 ? nbins - b0 : 64;
       if (b < nbins) {
         const uint32_t rel = lane * bin_bits;
-        sink.put(rel, plan->bweight[b] - 1, asl);
-        sink.put(rel + asl, plan->blower[b], lb);
-        sink.put(rel + asl + lb, plan->bob[b], obb);
+        sink.put(rel, plan.bweight()[b] - 1, asl);
+        sink.put(rel + asl, plan.blower()[b], lb);
+        sink.put(rel + asl + lb, plan.bob()[b], obb);
       }
       sink.advance(nb * bin_bits);
     }
@@ -1877,7 +1893,7 @@ __device__ void page_task(const EncWorkspace& ws, const PcoGfxEncodeTask& task, 
   for (int v = 0; v < 3; v++) {
     for (int j = 0; j < 4; j++) fs[v][j] = 1u << asl[v];
     if (!present[v] || trivial[v]) continue;
-    const EncPlanVar PCO_GLOBAL* plan = (const EncPlanVar PCO_GLOBAL*)ws.plans + (uint64_t)t * 3 + v;
+    const PlanRef plan = plan_ref(ws, t, v);
     if (v == 0) page_load_var_tables<uint32_t>(smem + voff[v], plan, n_bins[v], asl[v]); else page_load_var_tables<L>(smem + voff[v], plan, n_bins[v], asl[v]);
   }
   enc_wave_sync();
