@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kSelT) void enc_hist_select_kernel(EncWorkspace ws,
   const uint32_t t = blockIdx.x;
   if (t >= n_tasks) return;
   const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
-  if (uni(ch->status) != PCO_GFX_OK) return;
+  if (uni(ch->status) != PCO_GFX_OK || uni(ch->big) != 0) return;   // (more than 256 bins: the sort kernel)
   const int bits = dtype_bits(uni(ch->dtype));
   const uint32_t ubl = uni(ch->unopt_bins_log);
   for (uint32_t var = 0; var < 3; var++) {

@@ -51,7 +51,7 @@ struct EncChunk {
   uint32_t fast_ok;         // 1: the chunk's pages go through the dissect / walk / scan / pack kernels (encode_fast.hip)
   uint32_t c16_ok;          // speculative 16-bit latents (enc_split_kernel): 0 = off (full-width latents), 1 = on and holding, 2 = a tile did not fit
   uint32_t exact_paging;    // PagingSpec::Exact: page sizes are arbitrary, positions map to pages through the page list (ws.pages[page_first ...])
-  uint32_t pad0;
+  uint32_t big;             // more than 256 histogram bins (compression levels 9..12): the sort histogram, the block-wide bin DP and the page encoder with tables in HBM
   uint64_t c16_ref[2];      // what the 16-bit latents of variables 1 / 2 are relative to
   EncVar v[3];
 };
@@ -176,8 +176,9 @@ __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, 
   c.v[1].present = 1; c.v[1].latent_bits = lbits; c.v[1].lat_start = nlps; c.v[1].n_lat = (uint32_t)stored;
   c.v[2].present = mp.mode_kind == kIntMult || mp.mode_kind == kFloatMult || mp.mode_kind == kFloatQuant;
   c.v[2].latent_bits = lbits; c.v[2].lat_start = 0; c.v[2].n_lat = (uint32_t)n;
-  if (c.unopt_bins_log > kMaxUnoptBinsLog) c.status = PCO_GFX_UNSUPPORTED;
-  c.c16_ok = c16_enable && mp.delta_kind != kDeltaLookback ? 1u : 0u;   // (lookback reads the full-width primary back)
+  c.big = c.unopt_bins_log > kMaxUnoptBinsLog ? 1u : 0u;
+  if (c.unopt_bins_log > 12 || (c.big && ws.plan_cap < kBigBins)) c.status = PCO_GFX_INVALID_ARGUMENT;   // (cannot happen: levels stop at 12)
+  c.c16_ok = c16_enable && mp.delta_kind != kDeltaLookback && !c.big ? 1u : 0u;   // (lookback reads the full-width primary back; big chunks are histogrammed by the sort path)
   ws.chunks[t] = c;
 }
 
@@ -194,25 +195,35 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherTask* tasks) {
   else ((uint8_t*)g.dst)[k] = ((const uint8_t*)g.src)[i];
 }
 
-// compact per-task record of a trained plan, for the host-side size estimate of Auto delta trials
+// compact per-task record of a trained plan, for the host-side size estimate of Auto delta trials.  The average bits per latent
+// (metadata/chunk_latent_var.rs avg_bits_per_latent: a sum over the bins, in bin order, of f64 terms (ans_size_log - log2(weight) +
+// offset_bits) * weight / 2^ans_size_log) is formed here, by one lane per variable in the reference's order, with log2(weight) taken
+// from a table the HOST filled with its libm (weights are at most 4096): IEEE add / multiply / divide round the same on both
+// sides, so the host gets the reference's f64 bit for bit without 6 bytes per bin crossing PCIe.
 struct TrialSummary {
   uint32_t status, fallback;
   uint32_t asl[2], n_bins[2], n_lat[2];
-  uint16_t w[2][kMaxBins];
-  uint8_t ob[2][kMaxBins];
+  double avg[2];
 };
-__global__ __launch_bounds__(256) void enc_trial_summary_kernel(EncWorkspace ws, TrialSummary* out, uint32_t n_tasks) {
-  const uint32_t t = blockIdx.x;
+__global__ __launch_bounds__(64) void enc_trial_summary_kernel(EncWorkspace ws, TrialSummary* out, uint32_t n_tasks, const double* log2_of_weight) {
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
   if (t >= n_tasks) return;
   const EncChunk* ch = ws.chunks + t;
-  TrialSummary* o = out + t;
-  if (threadIdx.x == 0) { o->status = ch->status; o->fallback = ch->fallback; }
+  TrialSummary o;
+  o.status = ch->status; o.fallback = ch->fallback;
   for (int v = 0; v < 2; v++) {
     const PlanRef plan = plan_ref(ws, t, v);
-    const uint32_t nb = ch->v[v].present ? ch->v[v].n_bins : 0;
-    if (threadIdx.x == 0) { o->asl[v] = ch->v[v].ans_size_log; o->n_bins[v] = nb; o->n_lat[v] = ch->v[v].present ? ch->v[v].n_lat : 0; }
-    for (uint32_t b = threadIdx.x; b < nb; b += 256) { o->w[v][b] = (uint16_t)plan.bweight()[b]; o->ob[v][b] = plan.bob()[b]; }
+    const uint32_t nb = ch->v[v].present ? ch->v[v].n_bins : 0, asl = ch->v[v].ans_size_log;
+    o.asl[v] = asl; o.n_bins[v] = nb; o.n_lat[v] = ch->v[v].present ? ch->v[v].n_lat : 0;
+    double avg = 0.0; const double tw = (double)(1ull << asl);
+    for (uint32_t b = 0; b < nb; b++) {
+      const uint32_t wi = plan.bweight()[b];
+      const double w = (double)wi;
+      avg += ((double)asl - log2_of_weight[wi] + (double)plan.bob()[b]) * w / tw;
+    }
+    o.avg[v] = avg;
   }
+  out[t] = o;
 }
 
 // =========================================================================================================
@@ -863,32 +874,45 @@ __global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, uint3
 // =========================================================================================================
 struct HistRec { uint32_t st, en; };
 
+// The walk over the bins, resumable: with more than 256 bins (compression levels 9..12) the rank records are produced a window of 256
+// bins at a time and the walk stops when its next bin lies beyond the window.  Records are indexed by (bin - win_base).
+template <class L> struct HistWalk {
+  uint32_t pos = 0; L pos_value = 0; bool pending = false; uint32_t pending_start = 0; L pending_lower = 0; uint32_t next_avail = 0, n_hist = 0;
+};
+template <class L> __device__ __forceinline__ void walk_store(uint64_t PCO_LDS* a, const HistWalk<L>& w) {
+  a[0] = w.pos; a[1] = (uint64_t)w.pos_value; a[2] = w.pending ? 1u : 0u; a[3] = w.pending_start; a[4] = (uint64_t)w.pending_lower; a[5] = w.next_avail; a[6] = w.n_hist;
+}
+template <class L> __device__ __forceinline__ HistWalk<L> walk_load(const uint64_t PCO_LDS* a) {
+  HistWalk<L> w; w.pos = (uint32_t)a[0]; w.pos_value = (L)a[1]; w.pending = a[2] != 0; w.pending_start = (uint32_t)a[3]; w.pending_lower = (L)a[4]; w.next_avail = (uint32_t)a[5]; w.n_hist = (uint32_t)a[6];
+  return w;
+}
 template <class L>
-__device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins_log, L first_value,
-                                                   const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
-                                                   const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc,
-                                                   const PlanRef& plan, uint32_t& n_hist_out) {
-  // sequential (one lane); at most 2 * 2^bins_log iterations
+__device__ __forceinline__ void hist_walk(HistWalk<L>& w, uint32_t win_base, uint32_t win_end, uint32_t n_lat, uint32_t bins_log,
+                                          const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
+                                          const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc, const PlanRef& plan) {
+  // sequential (one lane); at most 2 * 2^bins_log iterations over all windows
   const uint64_t n = n_lat, B = (uint64_t)1 << bins_log;
   // floor((pos << bins_log) / n) by one multiplication: M = ceil(2^64 / n) is exact for dividends below 2^64 / n, and ours stay below
   // 2^36 with n <= 2^24 (the 64-bit divisions were most of this serial loop)
   const uint64_t magic = n > 1 ? (~0ull / n) + 1 : 0ull;
   auto bin_idx = [&](uint64_t pos) { return n > 1 ? (uint32_t)__umul64hi(pos << bins_log, magic) : (uint32_t)(pos << bins_log); };
   auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n + B - 1) >> bins_log); };
-  uint32_t pos = 0; L pos_value = first_value;
-  bool pending = false; uint32_t pending_start = 0; L pending_lower = 0;
-  uint32_t next_avail = 0, n_hist = 0;
+  uint32_t pos = w.pos; L pos_value = w.pos_value;
+  bool pending = w.pending; uint32_t pending_start = w.pending_start; L pending_lower = w.pending_lower;
+  uint32_t next_avail = w.next_avail, n_hist = w.n_hist;
   auto emit = [&](uint32_t start, uint32_t end, L lower, L upper) {
     plan.hcount()[n_hist] = end - start; plan.hlower()[n_hist] = (uint64_t)lower; plan.hupper()[n_hist] = (uint64_t)upper; n_hist++;
   };
   while (pos < n_lat) {
-    const uint32_t target = bin_idx(pos);
-    const uint32_t c = c_count(target);
+    const uint32_t target_abs = bin_idx(pos);
+    if (target_abs >= win_end) break;
+    const uint32_t target = target_abs - win_base;
+    const uint32_t c = c_count(target_abs);
     const L v = rv[target]; const uint32_t st = rst[target], en = ren[target];
     if (en <= c) {  // every run in [pos, c) fits: absorb and complete at c
       if (!pending) { pending_start = pos; pending_lower = pos_value; }
       emit(pending_start, c, pending_lower, v);
-      pending = false; next_avail = target + 1;
+      pending = false; next_avail = target_abs + 1;
       pos = c; pos_value = rnext[target];
     } else {        // the run [st, en) of value v straddles c: constant run
       if (st > pos && !pending) { pending = true; pending_start = pos; pending_lower = pos_value; }
@@ -904,7 +928,16 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
       pos = en; pos_value = rsucc[target];
     }
   }
-  n_hist_out = n_hist;
+  w.pos = pos; w.pos_value = pos_value; w.pending = pending; w.pending_start = pending_start; w.pending_lower = pending_lower; w.next_avail = next_avail; w.n_hist = n_hist;
+}
+template <class L>
+__device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins_log, L first_value,
+                                                   const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
+                                                   const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc,
+                                                   const PlanRef& plan, uint32_t& n_hist_out) {
+  HistWalk<L> w; w.pos_value = first_value;
+  hist_walk<L>(w, 0u, 1u << bins_log, n_lat, bins_log, rv, rst, ren, rnext, rpred, rsucc, plan);
+  n_hist_out = w.n_hist;
 }
 
 // The histogram of one variable from its rank records, by the whole block (every thread calls this after the records are in LDS and a
@@ -972,9 +1005,12 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   const L range = (L)(maxv - minv);
   // enc_hist_kernel: range < 4096; enc_hist_wide_kernel<16384>: [4096, 16384), <32768>: [16384, 32768); enc_hist_sort_kernel: the rest
   // (what the launcher has to run after this kernel: bit 0 the select / sort kernels, bit 1 the 16384-counter kernel, bit 2 the 32768-counter one)
-  if (!kSort && !kWide && (uint64_t)range >= kDirectHistRange && tid == 0) atomicOr(ws.need_sort, (uint64_t)range >= kWideHistRange ? 1u : ((uint64_t)range >= kMidHistRange ? 4u : 2u));
-  if (kSort ? (uint64_t)range < kWideHistRange : (kWide ? ((uint64_t)range < (R == kWideHistRange ? kMidHistRange : kDirectHistRange) || (uint64_t)range >= R) : (uint64_t)range >= kDirectHistRange)) return;
-  if (kSort && ev->hist_path != 2) return;   // the radix-sort path is the fallback of enc_hist_select_kernel (encode_hist_select.hip), which flags what it gave up on
+  if (!kSort && !kWide && ch->big != 0 && tid == 0) atomicOr(ws.need_sort, 1u);
+  if (!kSort && !kWide && ch->big == 0 && (uint64_t)range >= kDirectHistRange && tid == 0) atomicOr(ws.need_sort, (uint64_t)range >= kWideHistRange ? 1u : ((uint64_t)range >= kMidHistRange ? 4u : 2u));
+  const bool big = ch->big != 0;   // more than 256 bins: every variable of the chunk takes the sort path, whatever its range
+  if (!kSort && big) return;
+  if (!big && (kSort ? (uint64_t)range < kWideHistRange : (kWide ? ((uint64_t)range < (R == kWideHistRange ? kMidHistRange : kDirectHistRange) || (uint64_t)range >= R) : (uint64_t)range >= kDirectHistRange))) return;
+  if (kSort && !big && ev->hist_path != 2) return;   // the radix-sort path is the fallback of enc_hist_select_kernel (encode_hist_select.hip), which flags what it gave up on
   // Stored latents = every position that is not among the first `skip` of its page (wrapped/chunk_compressor.rs:129-140).
   const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
   const uint32_t n_all = (uint32_t)ch->n, skip = ev->lat_start, plow = ch->page_low, pr = ch->page_r;
@@ -1000,7 +1036,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   const uint64_t n64 = n_lat;
   auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
   __syncthreads();
-  if ((uint64_t)range < R) {
+  if ((uint64_t)range < R && !big) {
     // ---------------- direct path ----------------
     constexpr uint32_t PER = R / T;   // counters per thread in the prefix pass
     for (uint32_t i = tid; i < R + 8; i += T) counts[i] = 0;
@@ -1087,7 +1123,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   constexpr uint32_t NB = kSelBuckets;
   const uint32_t sig_bits = bitlen<L>(range);
   const uint32_t bshift = sig_bits > kSelBucketsLog ? sig_bits - kSelBucketsLog : 0u;
-  const uint32_t npass = (sig_bits + 7) / 8;
+  const uint32_t npass = sig_bits == 0 ? 1u : (sig_bits + 7) / 8;   // (a constant variable of a big chunk still goes through one pass: S must hold it)
   L PCO_GLOBAL* bufA = sort_ptr<L>(ws, t, 0);
   L PCO_GLOBAL* bufB = sort_ptr<L>(ws, t, 1);
   uint32_t PCO_LDS* cnt = counts;            // [4][256]
@@ -1132,8 +1168,8 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     return lo;
   };
   // (2) mark
-  if (tid < B) {
-    const uint32_t c = c_count(tid);
+  for (uint32_t bq = tid; bq < B; bq += 256) {
+    const uint32_t c = c_count(bq);
     for (uint32_t which = 0; which < 2; which++) {
       const uint32_t r = c - 1 + which;
       if (r >= n_lat) continue;
@@ -1288,17 +1324,59 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S[mid] <= value) lo = mid + 1; else hi = mid; }
     en = P[k] + (lo - oc);
   };
-  if (tid < B) {
-    const uint32_t c = c_count(tid);
-    L v; uint32_t st, en; lookup_sorted(c - 1, v, st, en);
-    rv[tid] = v; rst[tid] = st; ren[tid] = en;
-    rnext[tid] = c < n_lat ? value_at(c) : (L)0;
-    rpred[tid] = st > 0 ? value_at(st - 1) : (L)0;
-    rsucc[tid] = en < n_lat ? value_at(en) : (L)0;
+  if (B <= 256) {
+    if (tid < B) {
+      const uint32_t c = c_count(tid);
+      L v; uint32_t st, en; lookup_sorted(c - 1, v, st, en);
+      rv[tid] = v; rst[tid] = st; ren[tid] = en;
+      rnext[tid] = c < n_lat ? value_at(c) : (L)0;
+      rpred[tid] = st > 0 ? value_at(st - 1) : (L)0;
+      rsucc[tid] = en < n_lat ? value_at(en) : (L)0;
+    }
+    __syncthreads();
+    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u);
+    __syncthreads();
+  } else {
+    // more than 256 bins: rank records a window of 256 bins at a time.  A window none of whose bins is straddled by a run of equal
+    // values, entered with nothing pending at its first bin's start rank, is emitted by one thread per bin; otherwise one thread
+    // walks it (hist_walk).  The walk's state lives in LDS between windows.
+    uint64_t PCO_LDS* wst = (uint64_t PCO_LDS*)(smem + kHistLdsRecV + 10240 + 256);   // (behind the block-scan scratch)
+    if (tid == 0) { HistWalk<L> w0; w0.pos_value = minv; walk_store<L>(wst, w0); }
+    __syncthreads();
+    for (uint32_t wb = 0; wb < B; wb += 256) {
+      const uint32_t bq = wb + tid;
+      if (tid < 256 && bq < B) {
+        const uint32_t c = c_count(bq);
+        L v; uint32_t st, en; lookup_sorted(c - 1, v, st, en);
+        rv[tid] = v; rst[tid] = st; ren[tid] = en;
+        rnext[tid] = c < n_lat ? value_at(c) : (L)0;
+        rpred[tid] = st > 0 ? value_at(st - 1) : (L)0;
+        rsucc[tid] = en < n_lat ? value_at(en) : (L)0;
+      }
+      __syncthreads();
+      const uint32_t wn = B - wb < 256 ? B - wb : 256;
+      const HistWalk<L> w = walk_load<L>(wst);
+      const bool clean = !w.pending && n_lat >= B && w.pos == (wb == 0 ? 0u : c_count(wb - 1));
+      const bool mine_ok = tid >= wn || ren[tid] <= c_count(wb + tid);
+      const bool simple = __syncthreads_and(mine_ok && clean) != 0;
+      if (simple) {
+        if (tid < wn) {
+          const uint32_t c0 = bq == 0 ? 0u : c_count(bq - 1), c1 = c_count(bq);
+          const uint32_t at = w.n_hist + tid;
+          plan.hcount()[at] = c1 - c0; plan.hlower()[at] = (uint64_t)(tid == 0 ? w.pos_value : rnext[tid - 1]); plan.hupper()[at] = (uint64_t)rv[tid];
+        }
+        __syncthreads();
+        if (tid == 0) { HistWalk<L> w2 = w; w2.pos = c_count(wb + wn - 1); w2.pos_value = rnext[wn - 1]; w2.next_avail = wb + wn; w2.n_hist = w.n_hist + wn; walk_store<L>(wst, w2); }
+      } else if (tid == 0) {
+        HistWalk<L> w2 = w;
+        hist_walk<L>(w2, wb, wb + wn, n_lat, bins_log, rv, rst, ren, rnext, rpred, rsucc, plan);
+        walk_store<L>(wst, w2);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) { ev->n_hist = (uint32_t)wst[6]; ev->hist_path = 1; }
+    __syncthreads();
   }
-  __syncthreads();
-  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u);
-  __syncthreads();
   }
 }
 
@@ -1361,39 +1439,55 @@ __device__ __forceinline__ float bin_cost_dev(float meta, L lower, L upper, uint
   return __fadd_rn(meta, __fmul_rn(__fadd_rn(ans_cost, offset_cost), countf));
 }
 
-constexpr uint32_t kTrainLdsCC = 0;                  // u32[257] cumulative counts
-constexpr uint32_t kTrainLdsBest = 1040;             // f32[257]
-constexpr uint32_t kTrainLdsLow = 2080;              // u64[256]
-constexpr uint32_t kTrainLdsUp = 2080 + 2048;        // u64[256]
-constexpr uint32_t kTrainLdsBj = 2080 + 4096;        // u16[256]
-constexpr uint32_t kTrainLdsPart = kTrainLdsBj + 512;  // u16[256][2] partition
-constexpr uint32_t kTrainLdsW = kTrainLdsPart + 1024;  // u32[256] weights, f32[256] float weights
-constexpr uint32_t kTrainLdsSym = kTrainLdsW + 2048;   // u16[4096] state symbols
-constexpr uint32_t kTrainLdsCum = kTrainLdsSym + 8192; // u32[257]
-constexpr uint32_t kTrainLdsBytes = kTrainLdsCum + 1040;
+// LDS layout of the training kernels for a bin capacity CAP: 256 (one wave per chunk, enc_train_kernel) or 4096 (levels 9..12, one block
+// of 1024 threads per chunk, enc_train_big_kernel; there the float weights reuse the DP's cost array, the cumulative weights the
+// cumulative counts and the state symbols the back pointers, each dead by the time its tenant arrives: 138 KB instead of 178).
+template <uint32_t CAP> struct TrainLds {
+  static constexpr bool kAlias = CAP > 256;
+  static constexpr uint32_t cc = 0;                                   // u32[CAP + 1] cumulative counts
+  static constexpr uint32_t best = cc + (CAP + 4) * 4;                // f32[CAP + 1]
+  static constexpr uint32_t low = (best + (CAP + 4) * 4 + 7) & ~7u;   // u64[CAP]
+  static constexpr uint32_t up = low + CAP * 8;                       // u64[CAP]
+  static constexpr uint32_t bj = up + CAP * 8;                        // u16[CAP]
+  static constexpr uint32_t part = bj + CAP * 2;                      // u16[CAP][2] partition
+  static constexpr uint32_t w = part + CAP * 4;                       // u32[CAP] weights
+  static constexpr uint32_t fw = kAlias ? best : w + CAP * 4;         // f32[CAP] float weights
+  static constexpr uint32_t sym = kAlias ? bj : fw + CAP * 4;         // u16[4096] state symbols
+  static constexpr uint32_t cum = kAlias ? cc : sym + 8192;           // u32[CAP + 1]
+  static constexpr uint32_t red = kAlias ? w + CAP * 4 : cum + (CAP + 4) * 4;   // block reduction scratch: f32[16] u32[16]
+  static constexpr uint32_t bytes = red + 256;
+};
+constexpr uint32_t kTrainLdsBytes = TrainLds<256>::bytes;
+constexpr uint32_t kTrainBigLdsBytes = TrainLds<kBigBins>::bytes;
+static_assert(kTrainBigLdsBytes <= 160 * 1024, "one block per CU");
 
-template <class L>
+// NW waves per block: 1 (CAP 256) or 16 (CAP 4096).  Everything but the DP's inner loop is the work of wave 0.
+template <class L, uint32_t CAP, uint32_t NW>
 __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
+  typedef TrainLds<CAP> TL;
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   EncVar PCO_GLOBAL* ev = &ch->v[var];
   const PlanRef plan = plan_ref(ws, t, var);
-  const uint32_t lane = lane_id();
+  const uint32_t lane = lane_id(), tid = threadIdx.x, wave = tid >> 6;
+  auto block_sync = [&]() { if (NW > 1) __syncthreads(); else enc_wave_sync(); };
   uint8_t PCO_LDS* smem = enc_lds_base();
-  uint32_t PCO_LDS* cc = (uint32_t PCO_LDS*)(smem + kTrainLdsCC);
-  float PCO_LDS* best = (float PCO_LDS*)(smem + kTrainLdsBest);
-  L PCO_LDS* lows = (L PCO_LDS*)(smem + kTrainLdsLow);
-  L PCO_LDS* ups = (L PCO_LDS*)(smem + kTrainLdsUp);
-  uint16_t PCO_LDS* bj = (uint16_t PCO_LDS*)(smem + kTrainLdsBj);
-  uint16_t PCO_LDS* part = (uint16_t PCO_LDS*)(smem + kTrainLdsPart);
-  uint32_t PCO_LDS* wts = (uint32_t PCO_LDS*)(smem + kTrainLdsW);
-  float PCO_LDS* fw = (float PCO_LDS*)(smem + kTrainLdsW + 1024);
-  uint16_t PCO_LDS* ssym = (uint16_t PCO_LDS*)(smem + kTrainLdsSym);
-  uint32_t PCO_LDS* cum = (uint32_t PCO_LDS*)(smem + kTrainLdsCum);
+  uint32_t PCO_LDS* cc = (uint32_t PCO_LDS*)(smem + TL::cc);
+  float PCO_LDS* best = (float PCO_LDS*)(smem + TL::best);
+  L PCO_LDS* lows = (L PCO_LDS*)(smem + TL::low);
+  L PCO_LDS* ups = (L PCO_LDS*)(smem + TL::up);
+  uint16_t PCO_LDS* bj = (uint16_t PCO_LDS*)(smem + TL::bj);
+  uint16_t PCO_LDS* part = (uint16_t PCO_LDS*)(smem + TL::part);
+  uint32_t PCO_LDS* wts = (uint32_t PCO_LDS*)(smem + TL::w);
+  float PCO_LDS* fw = (float PCO_LDS*)(smem + TL::fw);
+  uint16_t PCO_LDS* ssym = (uint16_t PCO_LDS*)(smem + TL::sym);
+  uint32_t PCO_LDS* cum = (uint32_t PCO_LDS*)(smem + TL::cum);
+  float PCO_LDS* red_c = (float PCO_LDS*)(smem + TL::red);
+  uint32_t PCO_LDS* red_j = (uint32_t PCO_LDS*)(smem + TL::red + 64);
 
   const uint32_t n_lat = uni(ev->n_lat);
   const uint32_t nb = uni(ev->n_hist);
   if (n_lat == 0 || nb == 0) {  // train_infos: empty latents -> TrainedBins::default()
-    if (lane == 0) { ev->n_bins = 0; ev->ans_size_log = 0; ev->max_ob = 0; ev->is_trivial = 1; ev->needs_ans = 1; plan.next_states()[0] = 1; }
+    if (tid == 0) { ev->n_bins = 0; ev->ans_size_log = 0; ev->max_ob = 0; ev->is_trivial = 1; ev->needs_ans = 1; plan.next_states()[0] = 1; }
     return;
   }
   const uint32_t ubl = uni(ch->unopt_bins_log);
@@ -1401,12 +1495,12 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
   const uint32_t n_log_ceil = n_lat <= 1 ? 0 : (32 - clz_u32(n_lat - 1));
   uint32_t est = bins_log + 2; if (est > 12) est = 12; if (est > n_log_ceil) est = n_log_ceil;  // estimated_ans_size_log
   // load histogram bins
-  enc_wave_sync();
-  for (uint32_t b = lane; b < nb; b += 64) { lows[b] = (L)plan.hlower()[b]; ups[b] = (L)plan.hupper()[b]; cc[b + 1] = plan.hcount()[b]; }
-  if (lane == 0) { cc[0] = 0; best[0] = 0.0f; }
-  enc_wave_sync();
-  if (lane == 0) { uint32_t c = 0; for (uint32_t b = 0; b < nb; b++) { c += cc[b + 1]; cc[b + 1] = c; } }
-  enc_wave_sync();
+  block_sync();
+  for (uint32_t b = tid; b < nb; b += 64 * NW) { lows[b] = (L)plan.hlower()[b]; ups[b] = (L)plan.hupper()[b]; cc[b + 1] = plan.hcount()[b]; }
+  if (tid == 0) { cc[0] = 0; best[0] = 0.0f; }
+  block_sync();
+  if (tid == 0) { uint32_t c = 0; for (uint32_t b = 0; b < nb; b++) { c += cc[b + 1]; cc[b + 1] = c; } }
+  block_sync();
   const uint32_t total_count = cc[nb];
   const float total_log2 = log2_approx_dev((float)total_count);
   const float meta = (float)(est + LBits<L>::v + offset_bits_bits(LBits<L>::v));
@@ -1414,7 +1508,7 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
   for (uint32_t i = 0; i < nb; i++) {
     const L upper = ups[i]; const uint32_t cci = cc[i + 1];
     float bc = 3.402823466e+38f; uint32_t bjv = 0xffffffffu;
-    for (int32_t j = (int32_t)i - (int32_t)lane; j >= 0; j -= 64) {
+    for (int32_t j = (int32_t)i - (int32_t)tid; j >= 0; j -= 64 * NW) {
       const float cost = __fadd_rn(best[j], bin_cost_dev<L>(meta, lows[j], upper, cci - cc[j], total_log2));
       if (cost < bc) { bc = cost; bjv = (uint32_t)j; }
     }
@@ -1424,13 +1518,28 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
       const bool take = oj != 0xffffffffu && (bjv == 0xffffffffu || oc < bc || (oc == bc && oj > bjv));
       if (take) { bc = oc; bjv = oj; }
     }
-    enc_wave_sync();
-    if (lane == 0) { best[i + 1] = bc; bj[i] = (uint16_t)bjv; }
-    enc_wave_sync();
+    if (NW > 1) {   // across the block's waves (only those that had a j to look at)
+      const uint32_t n_act = (i >> 6) + 1 < NW ? (i >> 6) + 1 : NW;
+      if (lane == 0 && wave < n_act) { red_c[wave] = bc; red_j[wave] = bjv; }
+      __syncthreads();
+      if (tid == 0) {
+        for (uint32_t w = 1; w < n_act; w++) {
+          const float oc = red_c[w]; const uint32_t oj = red_j[w];
+          const bool take = oj != 0xffffffffu && (bjv == 0xffffffffu || oc < bc || (oc == bc && oj > bjv));
+          if (take) { bc = oc; bjv = oj; }
+        }
+        best[i + 1] = bc; bj[i] = (uint16_t)bjv;
+      }
+      __syncthreads();
+    } else {
+      enc_wave_sync();
+      if (lane == 0) { best[i + 1] = bc; bj[i] = (uint16_t)bjv; }
+      enc_wave_sync();
+    }
   }
-  // ---- partition choice + optimized bins + quantisation: sequential, tiny (lane 0) ----
+  // ---- partition choice + optimized bins + quantisation: sequential (thread 0) ----
   uint32_t n_opt = 0, ans_size_log = 0;
-  if (lane == 0) {
+  if (tid == 0) {
     const float best_cost = best[nb];
     const float bias = __fmul_rn(0.1f, (float)total_count);
     const float thr = __fadd_rn(best_cost, bias);
@@ -1507,18 +1616,19 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
     ev->is_trivial = (n_opt == 1 && plan.bob()[0] == 0) ? 1u : 0u;
     ev->needs_ans = n_opt != 1 ? 1u : 0u;
   }
-  enc_wave_sync();
+  __threadfence_block();
+  block_sync();
   n_opt = uni(ev->n_bins); ans_size_log = uni(ev->ans_size_log);
   // ---- tANS encoder tables (ans/spec.rs:37-59, ans/encoding.rs:28-63) ----
   const uint32_t T = 1u << ans_size_log;
   uint32_t stride = (3 * T) / 5; if ((stride & 1) == 0) stride += 1;
-  for (uint32_t tt = lane; tt < T; tt += 64) {
+  for (uint32_t tt = tid; tt < T; tt += 64 * NW) {
     uint32_t lo = 0, hi = n_opt;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= tt) lo = mid; else hi = mid; }
     ssym[(stride * tt) & (T - 1)] = (uint16_t)lo;
   }
-  enc_wave_sync();
-  for (uint32_t s = lane; s < n_opt; s += 64) {
+  block_sync();
+  for (uint32_t s = tid; s < n_opt; s += 64 * NW) {
     const uint32_t w = wts[s];
     const uint32_t max_x_s = 2 * w - 1;
     const uint32_t min_renorm_bits = ans_size_log - (31 - clz_u32(max_x_s));
@@ -1527,75 +1637,100 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
     plan.syminfo()[s] = cutoff | (min_renorm_bits << 14) | (adj << 18);
   }
   // next_states: states of symbol s in ascending state order -> T + state_idx; fill counters reuse wts[] (set to cum)
-  enc_wave_sync();
-  for (uint32_t s = lane; s < n_opt; s += 64) wts[s] = cum[s];
-  enc_wave_sync();
-  const uint32_t sym_bits = 32 - clz_u32(n_opt - 1 > 0 ? n_opt - 1 : 1);
-  for (uint32_t i0 = 0; i0 < T; i0 += 64) {
-    const uint32_t i = i0 + lane;
-    const bool act = i < T;
-    const uint32_t s = act ? (uint32_t)ssym[i] : 0xffffffffu;
-    uint64_t m = __ballot(act);
-    for (uint32_t bit = 0; bit < sym_bits; bit++) { const uint64_t bm = __ballot((s >> bit) & 1); m &= ((s >> bit) & 1) ? bm : ~bm; }
-    const uint64_t lt = ((uint64_t)1 << lane) - 1;
-    const uint32_t rank = __popcll(m & lt), gcount = __popcll(m);
-    const uint32_t basec = act ? wts[s] : 0;
-    enc_wave_sync();
-    if (act && rank == 0) wts[s] = basec + gcount;
-    enc_wave_sync();
-    if (act) plan.next_states()[basec + rank] = (uint16_t)(T + i);
+  block_sync();
+  for (uint32_t s = tid; s < n_opt; s += 64 * NW) wts[s] = cum[s];
+  block_sync();
+  if (wave == 0) {   // (state order matters: one wave walks the table)
+    const uint32_t sym_bits = 32 - clz_u32(n_opt - 1 > 0 ? n_opt - 1 : 1);
+    for (uint32_t i0 = 0; i0 < T; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const bool act = i < T;
+      const uint32_t s = act ? (uint32_t)ssym[i] : 0xffffffffu;
+      uint64_t m = __ballot(act);
+      for (uint32_t bit = 0; bit < sym_bits; bit++) { const uint64_t bm = __ballot((s >> bit) & 1); m &= ((s >> bit) & 1) ? bm : ~bm; }
+      const uint64_t lt = ((uint64_t)1 << lane) - 1;
+      const uint32_t rank = __popcll(m & lt), gcount = __popcll(m);
+      const uint32_t basec = act ? wts[s] : 0;
+      enc_wave_sync();
+      if (act && rank == 0) wts[s] = basec + gcount;
+      enc_wave_sync();
+      if (act) plan.next_states()[basec + rank] = (uint16_t)(T + i);
+    }
   }
-  enc_wave_sync();
+  block_sync();
+}
+
+// should_fallback (wrapped/chunk_compressor.rs:502-541) and the choice of page encoder, by one thread once every variable is trained
+__device__ void train_finish(const EncWorkspace& ws, uint32_t t) {
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  const int bits = dtype_bits(ch->dtype);
+  const uint32_t mode_kind = ch->mode_kind, delta_kind = ch->delta_kind;
+  uint32_t fallback = 0;
+  if (!(delta_kind == kDeltaNone && mode_kind == kClassic)) {
+    const uint64_t n = ch->n;
+    const uint64_t n_pages = ch->n_pages;
+    uint64_t worst_bits = 7 * n_pages;
+    uint64_t meta_bits = kBitsModeVariant + (mode_kind == kIntMult || mode_kind == kFloatMult ? (uint64_t)bits : (mode_kind == kFloatQuant ? kBitsQuantK : 0));
+    meta_bits += 4 + 5 + 5 + 64 + 32 * 32;  // DeltaEncoding::MAX_BIT_SIZE
+    uint64_t page_meta_bits = 0;
+    for (uint32_t var = 0; var < 3; var++) {
+      if (!ch->v[var].present) continue;
+      const PlanRef plan = plan_ref(ws, t, var);
+      const uint32_t lb = ch->v[var].latent_bits, asl = ch->v[var].ans_size_log, nbv = ch->v[var].n_bins;
+      for (uint32_t s = 0; s < nbv; s++)
+        worst_bits += (uint64_t)plan.bcount()[s] * (uint64_t)(plan.bob()[s] + asl - (31 - clz_u32(plan.bweight()[s])));
+      meta_bits += kBitsAnsSizeLog + kBitsNBins + (uint64_t)nbv * (asl + lb + offset_bits_bits(lb));
+      uint32_t nlps = 0;
+      if (var == 1) nlps = delta_kind == kDeltaConsecutive ? ch->delta_order : (delta_kind == kDeltaLookback ? (1u << ch->state_n_log) : 0u);
+      page_meta_bits += (uint64_t)asl * 4 + (uint64_t)lb * nlps;
+    }
+    const uint64_t worst = (meta_bits + 7) / 8 + n_pages * ((page_meta_bits + 7) / 8) + (worst_bits + 7) / 8;
+    const uint64_t base_meta_bits = kBitsModeVariant + (4 + 5 + 5 + 64 + 32 * 32) + kBitsAnsSizeLog + kBitsNBins + (uint64_t)bits + offset_bits_bits(bits);
+    const uint64_t baseline = (base_meta_bits + 7) / 8 + (n * (uint64_t)bits + 7) / 8;
+    fallback = worst > baseline ? 1u : 0u;
+  }
+  ch->fallback = fallback;
+  uint32_t fast_ok = fallback ? 0u : 1u;
+  for (uint32_t var = 0; var < 3; var++) if (ch->v[var].present && (ch->v[var].ans_size_log > kFastEncMaxAsl || ch->v[var].n_bins > kMaxBins)) fast_ok = 0;
+  ch->fast_ok = fast_ok;
 }
 
 __global__ __launch_bounds__(64) void enc_train_kernel(EncWorkspace ws, uint32_t n_tasks) {
   const uint32_t t = blockIdx.x;
   if (t >= n_tasks) return;
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
-  if (uni(ch->status) != PCO_GFX_OK) return;
+  if (uni(ch->status) != PCO_GFX_OK || uni(ch->big) != 0) return;   // (more than 256 bins: enc_train_big_kernel)
   const int bits = dtype_bits(uni(ch->dtype));
   for (uint32_t var = 0; var < 3; var++) {
     if (!uni(ch->v[var].present)) continue;
-    if (var == 0) train_var<uint32_t>(ws, t, var);
-    else if (bits == 64) train_var<uint64_t>(ws, t, var);
-    else if (bits == 32) train_var<uint32_t>(ws, t, var);
-    else if (bits == 16) train_var<uint16_t>(ws, t, var);
-    else train_var<uint8_t>(ws, t, var);
+    if (var == 0) train_var<uint32_t, kMaxBins, 1>(ws, t, var);
+    else if (bits == 64) train_var<uint64_t, kMaxBins, 1>(ws, t, var);
+    else if (bits == 32) train_var<uint32_t, kMaxBins, 1>(ws, t, var);
+    else if (bits == 16) train_var<uint16_t, kMaxBins, 1>(ws, t, var);
+    else train_var<uint8_t, kMaxBins, 1>(ws, t, var);
     __threadfence_block();
     enc_wave_sync();
   }
-  // should_fallback (wrapped/chunk_compressor.rs:502-541)
-  if (lane_id() == 0) {
-    const uint32_t mode_kind = ch->mode_kind, delta_kind = ch->delta_kind;
-    uint32_t fallback = 0;
-    if (!(delta_kind == kDeltaNone && mode_kind == kClassic)) {
-      const uint64_t n = ch->n;
-      const uint64_t n_pages = ch->n_pages;
-      uint64_t worst_bits = 7 * n_pages;
-      uint64_t meta_bits = kBitsModeVariant + (mode_kind == kIntMult || mode_kind == kFloatMult ? (uint64_t)bits : (mode_kind == kFloatQuant ? kBitsQuantK : 0));
-      meta_bits += 4 + 5 + 5 + 64 + 32 * 32;  // DeltaEncoding::MAX_BIT_SIZE
-      uint64_t page_meta_bits = 0;
-      for (uint32_t var = 0; var < 3; var++) {
-        if (!ch->v[var].present) continue;
-        const PlanRef plan = plan_ref(ws, t, var);
-        const uint32_t lb = ch->v[var].latent_bits, asl = ch->v[var].ans_size_log, nbv = ch->v[var].n_bins;
-        for (uint32_t s = 0; s < nbv; s++)
-          worst_bits += (uint64_t)plan.bcount()[s] * (uint64_t)(plan.bob()[s] + asl - (31 - clz_u32(plan.bweight()[s])));
-        meta_bits += kBitsAnsSizeLog + kBitsNBins + (uint64_t)nbv * (asl + lb + offset_bits_bits(lb));
-        uint32_t nlps = 0;
-        if (var == 1) nlps = delta_kind == kDeltaConsecutive ? ch->delta_order : (delta_kind == kDeltaLookback ? (1u << ch->state_n_log) : 0u);
-        page_meta_bits += (uint64_t)asl * 4 + (uint64_t)lb * nlps;
-      }
-      const uint64_t worst = (meta_bits + 7) / 8 + n_pages * ((page_meta_bits + 7) / 8) + (worst_bits + 7) / 8;
-      const uint64_t base_meta_bits = kBitsModeVariant + (4 + 5 + 5 + 64 + 32 * 32) + kBitsAnsSizeLog + kBitsNBins + (uint64_t)bits + offset_bits_bits(bits);
-      const uint64_t baseline = (base_meta_bits + 7) / 8 + (n * (uint64_t)bits + 7) / 8;
-      fallback = worst > baseline ? 1u : 0u;
-    }
-    ch->fallback = fallback;
-    uint32_t fast_ok = fallback ? 0u : 1u;
-    for (uint32_t var = 0; var < 3; var++) if (ch->v[var].present && ch->v[var].ans_size_log > kFastEncMaxAsl) fast_ok = 0;
-    ch->fast_ok = fast_ok;
+  if (lane_id() == 0) train_finish(ws, t);
+}
+// chunks with more than 256 histogram bins (compression levels 9..12): the O(bins^2) DP over up to 4096 bins by a block of 1024 threads
+__global__ __launch_bounds__(1024) void enc_train_big_kernel(EncWorkspace ws, uint32_t n_tasks) {
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tasks) return;
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (uni(ch->status) != PCO_GFX_OK || uni(ch->big) == 0) return;
+  const int bits = dtype_bits(uni(ch->dtype));
+  for (uint32_t var = 0; var < 3; var++) {
+    if (!uni(ch->v[var].present)) continue;
+    if (var == 0) train_var<uint32_t, kBigBins, 16>(ws, t, var);
+    else if (bits == 64) train_var<uint64_t, kBigBins, 16>(ws, t, var);
+    else if (bits == 32) train_var<uint32_t, kBigBins, 16>(ws, t, var);
+    else if (bits == 16) train_var<uint16_t, kBigBins, 16>(ws, t, var);
+    else train_var<uint8_t, kBigBins, 16>(ws, t, var);
+    __threadfence_block();
+    __syncthreads();
   }
+  if (threadIdx.x == 0) train_finish(ws, t);
 }
 
 // =========================================================================================================
@@ -1605,11 +1740,14 @@ constexpr uint32_t kStgDwords = 704;                       // staging for one se
 constexpr uint32_t kPageLdsStg = 0;                        // u32[704]
 constexpr uint32_t kPageLdsSym = 2816;                     // u32[256] dissect words of the batch
 constexpr uint32_t kPageLdsVar = kPageLdsSym + 1024;       // per-var tables follow
-constexpr uint32_t kPageVarLow = 0;                        // u64[256] search lowers
-constexpr uint32_t kPageVarOb = 2048;                      // u8[256]
-constexpr uint32_t kPageVarInfo = 2048 + 256;              // u32[256] syminfo
-constexpr uint32_t kPageVarNs = 2048 + 256 + 1024;         // u16[T]
-__host__ __device__ constexpr uint32_t page_var_bytes(uint32_t table_log) { return 2048 + 256 + 1024 + (2u << table_log); }
+// per-variable table area for a bin capacity `cap` (256, or the variable's bin count rounded up to a power of two when it has more:
+// levels 9..12): search lowers (8-byte stride) [cap] | offset bits u8[cap] | syminfo u32[cap] | next states u16[2^ans_size_log]
+constexpr uint32_t kPageVarLow = 0;
+__host__ __device__ constexpr uint32_t page_var_ob(uint32_t cap) { return cap * 8; }
+__host__ __device__ constexpr uint32_t page_var_info(uint32_t cap) { return cap * 9; }
+__host__ __device__ constexpr uint32_t page_var_ns(uint32_t cap) { return cap * 13; }
+__host__ __device__ constexpr uint32_t page_var_bytes(uint32_t table_log, uint32_t cap = 256) { return cap * 13 + (2u << table_log); }
+__device__ __forceinline__ uint32_t page_var_cap(uint32_t n_bins) { uint32_t c = 256; while (c < n_bins) c <<= 1; return c; }
 
 __device__ __forceinline__ void store_result(PcoGfxTaskResult PCO_GLOBAL* p, uint64_t n_out, uint32_t status, uint32_t aux) {
   p->n_out = n_out; p->consumed = 0; p->status = status; p->aux = aux;
@@ -1668,13 +1806,13 @@ struct BitSink {
 
 template <class LV>
 __device__ __forceinline__ void page_load_var_tables(uint8_t PCO_LDS* vt, const PlanRef& plan, uint32_t n_bins, uint32_t asl) {
-  const uint32_t lane = lane_id();
+  const uint32_t lane = lane_id(), cap = page_var_cap(n_bins);
   LV PCO_LDS* low = (LV PCO_LDS*)(vt + kPageVarLow);
-  uint8_t PCO_LDS* ob = vt + kPageVarOb;
-  uint32_t PCO_LDS* info = (uint32_t PCO_LDS*)(vt + kPageVarInfo);
-  uint16_t PCO_LDS* ns = (uint16_t PCO_LDS*)(vt + kPageVarNs);
+  uint8_t PCO_LDS* ob = vt + page_var_ob(cap);
+  uint32_t PCO_LDS* info = (uint32_t PCO_LDS*)(vt + page_var_info(cap));
+  uint16_t PCO_LDS* ns = (uint16_t PCO_LDS*)(vt + page_var_ns(cap));
   uint32_t padded = 1; while (padded < n_bins) padded <<= 1;
-  for (uint32_t b = lane; b < padded && b < 256; b += 64) {
+  for (uint32_t b = lane; b < padded; b += 64) {
     low[b] = b < n_bins ? (LV)plan.blower()[b] : (LV)~(LV)0;   // padded with L::MAX (compression_table.rs:22-26)
     ob[b] = b < n_bins ? plan.bob()[b] : 0;
     info[b] = b < n_bins ? plan.syminfo()[b] : 0;
@@ -1687,10 +1825,10 @@ __device__ __forceinline__ void page_load_var_tables(uint8_t PCO_LDS* vt, const 
 template <class LV>
 __device__ void page_dissect_var(const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, uint32_t PCO_GLOBAL* dis, uint32_t n_lat,
                                  uint32_t n_bins, uint32_t asl, uint32_t final_states[4]) {
-  const uint32_t lane = lane_id();
+  const uint32_t lane = lane_id(), cap = page_var_cap(n_bins);
   const LV PCO_LDS* low = (const LV PCO_LDS*)(vt + kPageVarLow);
-  const uint32_t PCO_LDS* info = (const uint32_t PCO_LDS*)(vt + kPageVarInfo);
-  const uint16_t PCO_LDS* ns = (const uint16_t PCO_LDS*)(vt + kPageVarNs);
+  const uint32_t PCO_LDS* info = (const uint32_t PCO_LDS*)(vt + page_var_info(cap));
+  const uint16_t PCO_LDS* ns = (const uint16_t PCO_LDS*)(vt + page_var_ns(cap));
   uint32_t PCO_LDS* words = (uint32_t PCO_LDS*)(enc_lds_base() + kPageLdsSym);
   uint32_t search_log = 0; while ((1u << search_log) < n_bins) search_log++;
   uint32_t state = 1u << asl;  // lanes 0..3: chain states (ans/encoding.rs:89-91)
@@ -1740,10 +1878,10 @@ __device__ void page_dissect_var(const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL*
 // Phase A2 for one variable's batch: pack 256 tANS fields then 256 offset fields.
 template <class LV>
 __device__ __forceinline__ void page_pack_batch(BitSink& sink, const uint8_t PCO_LDS* vt, const LV PCO_GLOBAL* lat, const uint32_t PCO_GLOBAL* dis,
-                                                uint32_t base, uint32_t cnt, bool needs_ans, uint32_t max_ob, bool single_bin) {
+                                                uint32_t base, uint32_t cnt, bool needs_ans, uint32_t max_ob, bool single_bin, uint32_t cap) {
   const uint32_t lane = lane_id();
   const LV PCO_LDS* low = (const LV PCO_LDS*)(vt + kPageVarLow);
-  const uint8_t PCO_LDS* obs = vt + kPageVarOb;
+  const uint8_t PCO_LDS* obs = vt + page_var_ob(cap);
   uint32_t w[4]; LV x[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -1885,7 +2023,7 @@ __device__ void page_task(const EncWorkspace& ws, const PcoGfxEncodeTask& task, 
     skip[v] = v == 2 ? 0u : uni(ch->v[v].lat_start);                 // the page's junk prefix (delta state lives in the page meta)
     if (skip[v] > page_n) skip[v] = page_n;
     n_lat[v] = page_n - skip[v];
-    voff[v] = off; if (present[v]) off += page_var_bytes(asl[v]);
+    voff[v] = off; if (present[v]) off += page_var_bytes(asl[v], page_var_cap(n_bins[v]));
   }
   // ---- load tables, phase A1 (reverse dissect) ----
   uint32_t fs[3][4];
@@ -1922,8 +2060,8 @@ __device__ void page_task(const EncWorkspace& ws, const PcoGfxEncodeTask& task, 
     for (int v = 0; v < 3; v++) {
       if (!present[v] || trivial[v] || base >= n_lat[v]) continue;
       const uint32_t cnt = n_lat[v] - base < kBatchN ? n_lat[v] - base : kBatchN;
-      if (v == 0) page_pack_batch<uint32_t>(sink, smem + voff[v], lat_ptr<uint32_t>(ws, t, 0) + pstart + skip[v], dissect_ptr(ws, t, 0) + pstart + skip[v], base, cnt, needs_ans[v] != 0, max_ob[v], n_bins[v] <= 1);
-      else page_pack_batch<L>(sink, smem + voff[v], lat_ptr<L>(ws, t, v) + pstart + skip[v], dissect_ptr(ws, t, v) + pstart + skip[v], base, cnt, needs_ans[v] != 0, max_ob[v], n_bins[v] <= 1);
+      if (v == 0) page_pack_batch<uint32_t>(sink, smem + voff[v], lat_ptr<uint32_t>(ws, t, 0) + pstart + skip[v], dissect_ptr(ws, t, 0) + pstart + skip[v], base, cnt, needs_ans[v] != 0, max_ob[v], n_bins[v] <= 1, page_var_cap(n_bins[v]));
+      else page_pack_batch<L>(sink, smem + voff[v], lat_ptr<L>(ws, t, v) + pstart + skip[v], dissect_ptr(ws, t, v) + pstart + skip[v], base, cnt, needs_ans[v] != 0, max_ob[v], n_bins[v] <= 1, page_var_cap(n_bins[v]));
     }
   }
   sink.finish_byte();

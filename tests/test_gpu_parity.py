@@ -218,7 +218,7 @@ def test_levels_and_histogram_paths(L):
         "normal_f32": rng.standard_normal(n).astype(np.float32),
         "lomax_i32": (rng.pareto(0.5, n) * 10).clip(0, 2e9).astype(np.int32),
     }
-    for level in (0, 1, 4, 8):
+    for level in (0, 1, 4, 8, 9, 10, 12):   # 9..12: more than 256 histogram bins at n >= 2^13 (sort histogram, block-wide DP, big page tables)
         for name, nums in datasets.items():
             kw = dict(level=level, mode=1, delta=1)
             want = O.simple_compress(nums, O.make_config(**kw))
@@ -301,7 +301,7 @@ def test_randomised_parity_sweep(L):
     is bounded and their reasons are listed: refusing more inputs does not pass.
     (This sweep found the 1-byte case missing from the Auto-delta sample gather, and the encode walker's divergent wave vote.)"""
     import fuzz_util
-    bad, skipped, _ = fuzz_util.run(400, 2024)
+    bad, skipped, _ = fuzz_util.run(400, 2024, max_level=12)
     assert not bad, bad[:10]
     check_skips(skipped, 400)
     bad, skipped, _ = fuzz_util.run(250, 2025, only_8bit=True)
@@ -312,7 +312,7 @@ def test_randomised_parity_sweep(L):
 def test_randomised_batched_sweep(L):
     """The same through the batched device API: up to 40 chunks of mixed dtypes and sizes per call, one config per call."""
     import fuzz_util
-    bad, skipped = fuzz_util.run_batched(12, 77)
+    bad, skipped = fuzz_util.run_batched(12, 77, max_level=12)
     assert not bad, bad[:10]
     assert not skipped, skipped
 
@@ -363,7 +363,7 @@ def test_two_variable_chunks_with_unequal_batch_counts(L):
 
 def test_unsupported_requests_fail_loudly(L):
     nums = np.arange(1000, dtype=np.uint32)
-    for kw in (dict(level=12, mode=1, delta=1), dict(mode=5, delta=1), dict(mode=1, delta=4, delta_order=2)):
+    for kw in (dict(mode=5, delta=1), dict(mode=1, delta=4, delta_order=2)):   # Dict / Conv1 ENCODE: outside the hot path
         with pytest.raises(G.PcoGfxError) as ei:
             U.gpu_simple_compress(np.tile(nums, 300), G.make_config(**kw))
         assert ei.value.status in (G.ST_UNSUPPORTED, G.ST_INVALID_ARGUMENT)
@@ -610,3 +610,25 @@ def test_chunks_beyond_one_page_of_the_standalone_writer(L):
             want = O.simple_compress(a, O.make_config(max_page_n=a.size, **kw))
             assert ch == U.chunk_of_file(want, len(ch)), (a.dtype, a.size, kw)
             assert U.bits_equal(a, b), (a.dtype, a.size, kw)
+
+
+@pytest.mark.parametrize("level", [9, 10, 11, 12])
+def test_levels_nine_to_twelve_full_size(L, level):
+    """unoptimized_bins_log 9..11 at n = 2^18 (wrapped/chunk_compressor.rs:362-371: level 12 gives 11 there; 12 needs n >= 2^20, below):
+    up to 2048 bins, tANS tables of up to 2^12 states -- every BASELINE config and a two-variable + lookback mix, byte-identical."""
+    for kind in ("c2", "c3", "c1", "c4"):
+        nums = U.synth(kind)
+        kw = {"c1": dict(mode=1, delta=1), "c2": dict(mode=1, delta=2, delta_order=1), "c3": dict(mode=2, mode_f64=0.01, delta=1), "c4": dict(mode=1, delta=3)}[kind]
+        want = O.simple_compress(nums, O.make_config(level=level, **kw))
+        got = U.gpu_simple_compress(nums, G.make_config(level=level, **kw))
+        assert got == want, (level, kind)
+        assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums), (level, kind)
+    rng = np.random.default_rng(level)
+    for nums, kw in (((rng.integers(0, 1 << 20, 9000) * 8 + rng.integers(0, 3, 9000)).astype(np.uint32), dict(mode=4, mode_u64=8, delta=2, delta_order=1)),
+                     (rng.standard_normal(70000).astype(np.float32), dict()),
+                     (np.where(rng.random(100000) < 0.5, 7, rng.integers(0, 1 << 40, 100000)).astype(np.uint64), dict(mode=1, delta=1)),
+                     (rng.integers(0, 1 << 62, (1 << 20) + 5, dtype=np.uint64), dict(mode=1, delta=1, max_page_n=1 << 21))):   # 4096 bins
+        want = O.simple_compress(nums, O.make_config(level=level, **kw))
+        got = U.gpu_simple_compress(nums, G.make_config(level=level, **kw))
+        assert got == want, (level, nums.dtype, nums.size, kw)
+        assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums), (level, nums.dtype, nums.size, kw)
