@@ -161,6 +161,9 @@ template <class L> inline L from_latent_ordered(L l, NumKind k) {
 }
 
 // float helpers (data_types/float.rs:135-252); only f32/f64 do arithmetic.
+}  // namespace pco_oracle
+#include "pco_oracle_half.hpp"
+namespace pco_oracle {
 template <class L> struct FloatOps;
 template <> struct FloatOps<uint32_t> {
   typedef float F; typedef uint32_t L;
@@ -181,6 +184,16 @@ template <> struct FloatOps<uint64_t> {
   static F round(F x) { return ::round(x); }
   static F fabs_(F x) { return ::fabs(x); }
   static F max_value() { return std::numeric_limits<double>::max(); }
+};
+template <> struct FloatOps<uint16_t> {   // f16 through the `half` crate's semantics (pco_oracle_half.hpp; data_types/float.rs:254-366)
+  typedef Half F; typedef uint16_t L;
+  static constexpr Bitlen PRECISION_BITS = 10; static constexpr int MANTISSA_DIGITS = 11;
+  static constexpr int EXP_OFFSET = 15;
+  static F from_bits(L b) { return Half::from_bits(b); }
+  static L to_bits(F f) { return f.b; }
+  static F round(F x) { return Half::from_f32(::roundf(x.to_f32())); }
+  static F fabs_(F x) { return Half::from_bits((uint16_t)(x.b & 0x7fffu)); }
+  static F max_value() { return Half::from_bits(0x7bffu); }
 };
 template <class L> inline typename FloatOps<L>::F float_from_latent_ordered(L l) {
   return FloatOps<L>::from_bits(from_latent_ordered<L>(l, kFloat));
@@ -224,7 +237,10 @@ template <class L> inline uint32_t float_trailing_zeros(typename FloatOps<L>::F 
   L b = FloatOps<L>::to_bits(x);
   return b == 0 ? LT<L>::BITS : (uint32_t)__builtin_ctzll((unsigned long long)b);
 }
-template <class L> inline bool float_is_normal(typename FloatOps<L>::F x) { return std::isnormal(x); }
+template <class L> inline bool float_is_normal(typename FloatOps<L>::F x) {
+  if constexpr (sizeof(L) == 2) { const uint32_t e = (x.b >> 10) & 0x1fu; return e != 0 && e != 0x1f; }
+  else return std::isnormal(x);
+}
 
 // ----------------------------------------------------------------------------
 // bit writer (bit_writer.rs:22-165).  Fields are LSB-first into a little

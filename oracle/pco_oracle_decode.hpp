@@ -188,7 +188,7 @@ template <class L> void join_latents(const Mode& mode, NumKind kind, const L* pr
       break;
     }
     case kFloatMult: {
-      if constexpr (LT<L>::BITS >= 32) {
+      if constexpr (LT<L>::BITS >= 16) {
         typedef FloatOps<L> FO; typedef typename FO::F F;
         F base = float_from_latent_ordered<L>((L)mode.base_latent);
         for (size_t i = 0; i < n; i++) {
@@ -196,7 +196,7 @@ template <class L> void join_latents(const Mode& mode, NumKind kind, const L* pr
           L l = (L)(float_to_latent_ordered<L>(unadjusted) + secondary[i] + MID<L>());
           dst_bits[i] = from_latent_ordered<L>(l, kFloat);
         }
-      } else fail(kUnsupported, "f16 float-mult arithmetic is not restated in the oracle");
+      } else fail(kCorruption, "float mult on an 8-bit type");
       break;
     }
     default: fail(kCorruption, "dict mode is joined by the chunk decoder");

@@ -977,8 +977,8 @@ template <class L> SplitLatents<L> choose_mode_and_split(const L* bits, size_t n
     if (mode.kind == kIntMult) return split_int_mult<L>(bits, n, kind, (L)mode.base_latent);
     return split_classic<L>(bits, n, kind);
   }
-  // floats
-  if constexpr (LT<L>::BITS >= 32) {
+  // floats (f16 through pco_oracle_half.hpp; there is no 8-bit float type)
+  if constexpr (LT<L>::BITS >= 16) {
     typedef FloatOps<L> FO; typedef typename FO::F F;
     FloatMultConfig<L> fm_cfg{};
     switch (cfg.mode_kind) {
@@ -1013,12 +1013,7 @@ template <class L> SplitLatents<L> choose_mode_and_split(const L* bits, size_t n
     if (mode.kind == kFloatMult) return split_float_mult<L>(bits, n, fm_cfg);
     if (mode.kind == kFloatQuant) return split_float_quant<L>(bits, n, mode.k);
     return split_classic<L>(bits, n, kFloat);
-  } else {
-    // f16: only the bit-level modes are restated
-    if (cfg.mode_kind == kModeTryFloatQuant) { mode.kind = kFloatQuant; mode.k = (Bitlen)cfg.mode_u64; if (!mode_is_valid(mode, dtype)) fail(kInvalidArgument, "invalid mode"); return split_float_quant<L>(bits, n, mode.k); }
-    if (cfg.mode_kind == kModeClassic) return split_classic<L>(bits, n, kFloat);
-    fail(kUnsupported, "f16 auto / float-mult detection is not restated in the oracle");
-  }
+  } else fail(kInvalidArgument, "no 8-bit float type");
 }
 
 // ----------------------------------------------------------------------------

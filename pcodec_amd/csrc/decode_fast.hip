@@ -261,7 +261,8 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
     else if (mode_kind == kFloatMult) {
       if (num_kind != kFloat) valid = false;
       else if constexpr (sizeof(L) >= 4) { typedef typename FloatOf<L>::F F; const F b = bits_to_float(from_latent_ordered<L>(mode_base, kFloat)); valid = isfinite(b) && b != (F)0; }
-      else { fail(PCO_GFX_UNSUPPORTED); return; }
+      else if constexpr (sizeof(L) == 2) { const uint32_t hb = (uint32_t)from_latent_ordered<L>(mode_base, kFloat); valid = (hb & 0x7c00u) != 0x7c00u && (hb & 0x7fffu) != 0; }
+      else valid = false;
     }
     if (!valid) { fail(PCO_GFX_CORRUPTION); return; }
   }

@@ -284,6 +284,11 @@ __device__ __forceinline__ L join_one(uint32_t mode_kind, uint32_t num_kind, L b
         const F unadjusted = int_float_from_latent<L>(p) * base;
         const L l = (L)(to_latent_ordered<L>(float_to_bits(unadjusted), kFloat) + s + lmid<L>());
         return from_latent_ordered<L>(l, kFloat);
+      } else if constexpr (sizeof(L) == 2) {   // f16 (pco_dev.h)
+        const uint32_t base = (uint32_t)from_latent_ordered<L>(base_latent, kFloat);
+        const uint32_t unadjusted = half_mul(half_int_float_from_latent((uint32_t)p), base);
+        const L l = (L)(to_latent_ordered<L>((L)unadjusted, kFloat) + s + lmid<L>());
+        return from_latent_ordered<L>(l, kFloat);
       } else return 0;
     }
   }
@@ -695,7 +700,8 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
         typedef typename FloatOf<L>::F F;
         const F b = bits_to_float(from_latent_ordered<L>(mode_base, kFloat));
         valid = isfinite(b) && b != (F)0;
-      } else { status = PCO_GFX_UNSUPPORTED; return; }
+      } else if constexpr (sizeof(L) == 2) { const uint32_t hb = (uint32_t)from_latent_ordered<L>(mode_base, kFloat); valid = (hb & 0x7c00u) != 0x7c00u && (hb & 0x7fffu) != 0; }
+      else valid = false;
     }
     if (!valid) { status = PCO_GFX_CORRUPTION; return; }
   }

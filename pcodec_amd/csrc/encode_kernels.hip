@@ -248,6 +248,10 @@ __device__ __forceinline__ void split_one(uint32_t num_kind, L mode_base, uint32
       const F mult = round_half_away(num * inv_base);
       p = int_float_to_latent<L>(mult);
       s = (L)(to_latent_ordered<L>(bits, kFloat) - to_latent_ordered<L>(float_to_bits(mult * base), kFloat) + lmid<L>());
+    } else if constexpr (sizeof(L) == 2) {   // f16: every product rounded to f16 (pco_dev.h)
+      const uint32_t mult = half_round(half_mul((uint32_t)bits, (uint32_t)aux_inv));
+      p = (L)half_int_float_to_latent(mult);
+      s = (L)(to_latent_ordered<L>(bits, kFloat) - to_latent_ordered<L>((L)half_mul(mult, (uint32_t)aux_base), kFloat) + lmid<L>());
     } else p = 0;
   }
 }

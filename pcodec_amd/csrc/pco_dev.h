@@ -77,7 +77,39 @@ template <class L> __device__ __forceinline__ uint32_t bitlen(L x) {
   else return 32u - clz_u32((uint32_t)x);
 }
 
-// ---- float <-> int-float latents (data_types/float.rs:208-244), f32/f64 only ----
+// ---- f16 (data_types/float.rs:254-366): the reference's f16 is the `half` crate's, whose arithmetic converts to f32, computes there
+//      and rounds back to nearest-even; the same is done here, with NaNs converted by bit manipulation (sign, all-ones exponent, quiet
+//      bit, top payload bits) so that they do not depend on the conversion instruction's NaN rule ----
+__device__ __forceinline__ float half_bits_to_f32(uint32_t h) {
+  if ((h & 0x7c00u) == 0x7c00u) return __uint_as_float(((h & 0x8000u) << 16) | 0x7f800000u | ((h & 0x3ffu) << 13));
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+}
+__device__ __forceinline__ uint32_t f32_to_half_bits(float f) {
+  const uint32_t u = __float_as_uint(f);
+  if ((u & 0x7f800000u) == 0x7f800000u) { const uint32_t man = u & 0x7fffffu; return ((u >> 16) & 0x8000u) | 0x7c00u | (man ? (0x200u | (man >> 13)) : 0u); }
+  return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);   // v_cvt_f16_f32: round to nearest even
+}
+__device__ __forceinline__ uint32_t half_mul(uint32_t a, uint32_t b) { return f32_to_half_bits(half_bits_to_f32(a) * half_bits_to_f32(b)); }
+__device__ __forceinline__ uint32_t half_round(uint32_t a) { return f32_to_half_bits(roundf(half_bits_to_f32(a))); }
+// int_float_from_latent / int_float_to_latent for f16 (float.rs:324-361): 11 mantissa digits
+__device__ __forceinline__ uint32_t half_int_float_from_latent(uint32_t l) {   // -> f16 bits
+  const uint32_t mid = 0x8000u; const bool negative = l < mid;
+  const uint32_t abs_int = negative ? mid - 1 - l : l - mid, gpi = 1u << 11;
+  uint32_t abs_bits;
+  if (abs_int < gpi) abs_bits = f32_to_half_bits((float)abs_int);
+  else abs_bits = (f32_to_half_bits((float)gpi) + (abs_int - gpi)) & 0xffffu;
+  return negative ? (abs_bits ^ 0x8000u) : abs_bits;
+}
+__device__ __forceinline__ uint32_t half_int_float_to_latent(uint32_t bits) {   // f16 bits -> latent
+  const uint32_t abs_bits = bits & 0x7fffu, gpi = 1u << 11, gpi_bits = 0x6800u;   // 2048.0
+  const float absf = half_bits_to_f32(abs_bits);
+  uint32_t abs_int;
+  if (absf < 2048.0f) abs_int = (uint32_t)absf;   // (NaN compares false and lands in the other branch, like the reference)
+  else abs_int = (gpi + (abs_bits - gpi_bits)) & 0xffffu;
+  return ((bits & 0x8000u) ? (0x8000u - 1 - abs_int) : (0x8000u + abs_int)) & 0xffffu;
+}
+
+// ---- float <-> int-float latents (data_types/float.rs:208-244), f32/f64 ----
 template <class L> struct FloatOf;
 template <> struct FloatOf<uint32_t> { typedef float F; static constexpr int kMantDigits = 24; };
 template <> struct FloatOf<uint64_t> { typedef double F; static constexpr int kMantDigits = 53; };

@@ -2,6 +2,7 @@
 // One translation unit: the gfx950 kernels are included below.  There is NO CPU codec here: without a
 // HIP device every compute entry point fails with PCO_GFX_DEVICE_ERROR.
 #include "pco_host.h"
+#include "pco_half.h"
 
 #include <algorithm>
 #include <atomic>

@@ -48,10 +48,9 @@ def draw_config(rng, dt, n, max_level=8):
     if m == 0: kw["mode"] = 0
     elif m == 1: kw["mode"] = 1
     elif m == 2 and not isf: kw.update(mode=4, mode_u64=int(rng.integers(1, 1000)))
-    elif m == 3 and isf and np.dtype(dt).itemsize >= 4: kw.update(mode=2, mode_f64=float(rng.choice([0.01, 0.1, 0.25, 1.0, 3.0])))
+    elif m == 3 and isf: kw.update(mode=2, mode_f64=float(rng.choice([0.01, 0.1, 0.25, 1.0, 3.0])))
     elif m == 4 and isf: kw.update(mode=3, mode_u64=int(rng.integers(1, 20 if np.dtype(dt).itemsize >= 4 else 10)))
     else: kw["mode"] = 1
-    if kw.get("mode") == 0 and np.dtype(dt) == np.float16: kw["mode"] = 1
     d = rng.integers(0, 5)
     if d == 0: kw["delta"] = 0
     elif d == 1: kw["delta"] = 1

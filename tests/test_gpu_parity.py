@@ -361,6 +361,46 @@ def test_two_variable_chunks_with_unequal_batch_counts(L):
         assert ch == U.chunk_of_file(want, len(ch)) and U.bits_equal(a, b), a.size
 
 
+def test_half_precision_floats(L):
+    """f16 (data_types/float.rs:254-366): Classic, FloatQuant, explicit FloatMult bases (arithmetic through f32, one rounding per operation) and
+    ModeSpec::Auto, on all 65536 bit patterns (NaN payloads, infinities, subnormals, signed zeros) and on structured data; also exhaustively:
+    every f16 value joined back from its own (mult, adjustment) pair."""
+    rng = np.random.default_rng(77)
+    every = np.arange(65536, dtype=np.uint16).view(np.float16)
+    n = 40000
+    with np.errstate(all="ignore"):
+        cases = {
+            "every_pattern": every,
+            "every_pattern_shuffled": rng.permutation(every),
+            "tenths": (rng.integers(0, 2000, n) * np.float16(0.1)).astype(np.float16),
+            "hundredths": (rng.integers(0, 500, n).astype(np.float32) * 0.01).astype(np.float16),
+            "integers": rng.integers(-2000, 2000, n).astype(np.float16),
+            "past_2048": rng.integers(-60000, 60000, n).astype(np.float16),      # beyond the greatest precise integer: the latent continues in bit steps
+            "quantised": (rng.normal(0, 100, n).astype(np.float16).view(np.uint16) & 0xFFE0).view(np.float16),
+            "normal": rng.normal(0, 1, n).astype(np.float16),
+            "sevenths": (rng.integers(1, 60, n).astype(np.float32) * 0.3).astype(np.float16),
+            "tiny": np.float16([0.5, -0.0, np.nan, np.inf, 6e-8, 65504, -65504]),
+        }
+    specs = [dict(mode=1), dict(), dict(mode=3, mode_u64=3), dict(mode=3, mode_u64=10)]
+    specs += [dict(mode=2, mode_f64=b) for b in (0.1, 0.01, 0.25, 3.0, 1.0 / 3.0, -0.3, 1e-7, 6e-8, 65504.0, 1000.0)]
+    bad = []
+    for name, nums in cases.items():
+        for kw in specs:
+            for dk in (dict(delta=1), dict(delta=2, delta_order=1), dict()):
+                okw = dict(kw); okw.update(dk)
+                want = O.simple_compress(nums, O.make_config(**okw))
+                got = U.gpu_simple_compress(nums, G.make_config(**okw))
+                if got != want: bad.append((name, okw)); continue
+                if not U.bits_equal(U.gpu_simple_decompress(got, np.float16, nums.size), nums): bad.append(("decode", name, okw))
+    assert not bad, bad[:10]
+    for b in (0.0, float("inf"), float("nan"), 1e-9, 1e6):      # a base that is zero / not finite once rounded to f16: refused like the reference
+        with pytest.raises(G.PcoGfxError) as ei:
+            U.gpu_simple_compress(cases["tenths"], G.make_config(mode=2, mode_f64=b, delta=1))
+        assert ei.value.status == G.ST_INVALID_ARGUMENT, b
+        with pytest.raises(O.OracleError):
+            O.simple_compress(cases["tenths"], O.make_config(mode=2, mode_f64=b, delta=1))
+
+
 def test_unsupported_requests_fail_loudly(L):
     nums = np.arange(1000, dtype=np.uint32)
     for kw in (dict(mode=5, delta=1), dict(mode=1, delta=4, delta_order=2)):   # Dict / Conv1 ENCODE: outside the hot path

@@ -16,9 +16,7 @@ ALL_DTYPES = ("f2", "f4", "f8", "i2", "i4", "i8", "u2", "u4", "u8")
 
 
 def cfg_for(P, dtype, **kw):
-    """The default ChunkConfig, except that ModeSpec::Auto on f16 is an open gap (refused loudly): f16 is compressed Classic."""
-    if dtype == "f2":
-        kw["mode_spec"] = P.ModeSpec.classic()
+    """The default ChunkConfig (every dtype, f16 included, goes through ModeSpec::Auto)."""
     return P.ChunkConfig(**kw)
 
 
@@ -104,7 +102,7 @@ def test_wrapped_compress(P, dtype):   # test_wrapped.py:11-52, with EqualPagesU
     page0, page1 = cc.write_page(0), cc.write_page(1)
     with pytest.raises(RuntimeError, match="page idx exceeds num pages"):
         cc.write_page(2)
-    want_meta, want_pages, want_ns = O.wrapped_compress(data, O.make_config(max_page_n=6, **({"mode": 1} if dtype == "f2" else {})))
+    want_meta, want_pages, want_ns = O.wrapped_compress(data, O.make_config(max_page_n=6))
     assert (chunk_meta, [page0, page1], [5, 5]) == (want_meta, want_pages, want_ns)
     fd, n_bytes_read = FileDecompressor.new(header)
     assert n_bytes_read == len(header)
