@@ -26,6 +26,7 @@ namespace pcogfx {
 constexpr uint32_t kSelT = 1024;
 constexpr uint32_t kSelSegs = 128, kSelSubLog = 6, kSelSample = 2048, kSelSortCap = 8192, kSelBigCap = 256, kSelWaveSortCap = 512;
 static_assert(kSelSegs << kSelSubLog == kSelBuckets, "segments x sub-buckets");
+static_assert(kSelSortCap == kSmallHistCap, "what enc_hist_small_kernel takes is what enc_hist_select_kernel leaves");
 static_assert(kSelWaveSortCap * (kSelT / 64) == kSelSortCap, "the block sort area is also the waves' private sort areas");
 constexpr uint32_t kSelLdsP = kHistLdsCounts;                                   // u32[8192 + 8] bucket counts, then exclusive prefix
 constexpr uint32_t kSelLdsNeed = kSelLdsP + (kSelBuckets + 8) * 4;              // u32[256] bitmap of the buckets to gather
@@ -89,6 +90,61 @@ template <class L> __device__ __forceinline__ void block_sort_lds(L PCO_LDS* a, 
   }
 }
 
+// Ascending LSD radix sort of a[0 .. n), n <= 8192, in place, by the whole block of 1024 threads: 8-bit digits, only the `sig_bits`
+// significant bits (the Auto-delta trial samples are a dense core plus a few dozen outliers at the seams of the sampled groups:
+// 3-4 passes where the bitonic network paid 91 barrier-separated stages whatever the data).  Array order is p = wave * 512 +
+// round * 64 + lane; a pass holds every key in registers between its counting and its scatter phase, so the array is its own
+// destination.  The stable rank of a key among its wave's equal digits comes from eight ballots per round (one per digit bit);
+// the waves' digit counts are scanned digit-major.  scratch: u16[256 * 17] counts (row stride 17: the 16 waves of one digit
+// sit in different banks) | u32[256] digit bases | u32[4].
+constexpr uint32_t kRadixScratchBytes = 256 * 17 * 2 + 64;
+template <class K> __device__ __forceinline__ void block_radix_sort_inplace(K PCO_LDS* a, uint8_t PCO_LDS* scratch, uint32_t n, uint32_t sig_bits) {
+  const uint32_t tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+  uint16_t PCO_LDS* cnt = (uint16_t PCO_LDS*)scratch;
+  uint32_t PCO_LDS* wsum = (uint32_t PCO_LDS*)(scratch + 256 * 17 * 2);
+  const uint64_t lt = ((uint64_t)1 << lane) - 1;
+  for (uint32_t s = 0; s < sig_bits; s += 8) {
+    for (uint32_t d = lane; d < 256; d += 64) cnt[d * 17 + w] = 0;
+    K key[8]; uint32_t rk[4];   // rank among the wave's keys of the same digit, two per word
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+      const uint32_t p = w * 512 + j * 64 + lane; const bool on = p < n;
+      key[j] = on ? a[p] : (K)0;
+      const uint32_t d = (uint32_t)(key[j] >> s) & 255u;
+      uint64_t m = __ballot(on);
+#pragma unroll
+      for (uint32_t bit = 0; bit < 8; bit++) {
+        const uint32_t mine = (d >> bit) & 1u;
+        const uint64_t bb = __ballot(mine != 0);
+        const uint32_t flip = mine - 1u;                       // all ones when my bit is clear: peers are the lanes NOT in the ballot
+        m &= bb ^ (((uint64_t)flip << 32) | flip);
+      }
+      const uint32_t before = (uint32_t)__popcll(m & lt);
+      uint32_t old = 0;
+      if (on) { old = cnt[d * 17 + w]; if (before == 0) cnt[d * 17 + w] = (uint16_t)(old + (uint32_t)__popcll(m)); }
+      if (j & 1) rk[j >> 1] |= (old + before) << 16; else rk[j >> 1] = old + before;
+    }
+    __syncthreads();
+    // digit-major exclusive scan of the 256 x 16 counts = a block-wide scan in thread order: thread 4 d + q owns digit d, waves 4 q .. 4 q + 3
+    const uint32_t ci = (tid >> 2) * 17 + (tid & 3) * 4;
+    const uint32_t c0 = cnt[ci], c1 = cnt[ci + 1], c2 = cnt[ci + 2], c3 = cnt[ci + 3];
+    const uint32_t mine4 = c0 + c1 + c2 + c3;
+    const uint32_t incl = wave_incl_scan(mine4);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    const uint32_t ws_incl = wave_incl_scan(lane < 16 ? wsum[lane] : 0u);
+    uint32_t base = incl - mine4 + (w == 0 ? 0u : shfl_idx(ws_incl, (int)w - 1));
+    cnt[ci] = (uint16_t)base; base += c0; cnt[ci + 1] = (uint16_t)base; base += c1; cnt[ci + 2] = (uint16_t)base; base += c2; cnt[ci + 3] = (uint16_t)base;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+      const uint32_t p = w * 512 + j * 64 + lane;
+      if (p < n) { const uint32_t d = (uint32_t)(key[j] >> s) & 255u; a[cnt[d * 17 + w] + ((rk[j >> 1] >> ((j & 1) * 16)) & 0xffffu)] = key[j]; }
+    }
+    __syncthreads();
+  }
+}
+
 #ifdef PCO_SEL_TIMING
 __device__ unsigned long long g_sel_timing[16];
 #define SEL_STAMP(idx) do { if (threadIdx.x == 0) { const unsigned long long _n = __builtin_readcyclecounter(); atomicAdd(&g_sel_timing[idx], _n - sel_t0); sel_t0 = _n; } } while (0)
@@ -122,6 +178,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   if (n_lat == 0) return;
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   if ((uint64_t)(L)(maxv - minv) < kWideHistRange) return;   // the LDS-counting kernels own it
+  if (n_lat <= kSelSortCap) return;                            // enc_hist_small_kernel orders the whole variable in LDS
   const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
   const uint32_t n_all = (uint32_t)ch->n, skip = ev->lat_start, plow = ch->page_low, pr = ch->page_r;
   const bool single_page = ch->n_pages == 1;
@@ -161,53 +218,6 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   unsigned long long sel_t0 = __builtin_readcyclecounter();
 #endif
   __syncthreads();
-  if (n_lat <= kSelSortCap) {
-    // ---- small variables (the 6.6 k-latent samples of the Auto-delta trials, short chunks): the whole variable is ordered in LDS ----
-    if (tid == 0) big[kSelBigCap] = 0;
-    __syncthreads();
-    if (single_page) {   // stored latents = positions skip ..
-      for (uint32_t i = skip + tid; i < n_all; i += kSelT) srt[i - skip] = lat[i];
-    } else {             // any order will do: one cursor bump per wave and round
-      for (uint32_t i0 = 0; i0 < n_all; i0 += kSelT) {
-        const uint32_t i = i0 + tid;
-        const bool on = i < n_all && stored(i);
-        const uint64_t m = __ballot(on);
-        uint32_t at = 0;
-        if (lane == 0 && m) at = atomicAdd((uint32_t*)&big[kSelBigCap], (uint32_t)__popcll(m));
-        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-        if (on) srt[at + __popcll(m & (((uint64_t)1 << lane) - 1))] = lat[i];
-      }
-    }
-    uint32_t p2 = 128; while (p2 < n_lat) p2 <<= 1;
-    for (uint32_t i = n_lat + tid; i < p2; i += kSelT) srt[i] = maxv;
-    __syncthreads();
-    SEL_STAMP(0);
-    block_sort_lds<L>(srt, p2);
-    SEL_STAMP(1);
-    if (tid < B) {
-      const uint32_t c = c_count(tid);
-      const L v = srt[c - 1];
-      uint32_t lo = 0, hi = c - 1;   // first index with srt[idx] >= v
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (srt[mid] < v) lo = mid + 1; else hi = mid; }
-      const uint32_t st = lo;
-      lo = c; hi = n_lat;            // first index with srt[idx] > v
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (srt[mid] <= v) lo = mid + 1; else hi = mid; }
-      const uint32_t en = lo;
-      rv[tid] = v; rst[tid] = st; ren[tid] = en;
-      rnext[tid] = c < n_lat ? srt[c] : (L)0;
-      rpred[tid] = st > 0 ? srt[st - 1] : (L)0;
-      rsucc[tid] = en < n_lat ? srt[en] : (L)0;
-    }
-    __syncthreads();
-    SEL_STAMP(6);
-    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u);
-    __syncthreads();
-    SEL_STAMP(7);
-#ifdef PCO_SEL_TIMING
-    if (tid == 0) atomicAdd(&g_sel_timing[8], 1ull);
-#endif
-    return;
-  }
   // ---- (A) sample: 2048 evenly spaced positions (positions that are not stored hold defined junk or, for lookback, possibly
   //      nothing at all: clamping into [min, max] makes any value a harmless boundary candidate), sorted by the block ----
   for (uint32_t k = tid; k < kSelSample; k += kSelT) {
@@ -585,6 +595,115 @@ __global__ __launch_bounds__(kSelT) void enc_hist_select_kernel(EncWorkspace ws,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// enc_hist_small_kernel: wide-range variables of at most kSelSortCap latents (the 6.6 k-latent samples of the Auto-delta trials,
+// short chunks).  The whole variable is ordered in LDS: keys are x - min, 32 bits wide whenever the range allows, sorted in
+// place by block_radix_sort_inplace, and the <= 256 rank queries read the sorted array directly.  LDS = the record area +
+// n keys (launcher: small_lds_bytes), so two to four blocks share a CU and hide each other's barriers and loads.
+// ---------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr uint32_t small_lds_bytes(uint32_t n, uint32_t key_bytes) { return kHistLdsCounts + ((n * key_bytes + 15u) & ~15u); }
+
+template <class L, class K>
+__device__ __forceinline__ void small_body(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log, EncChunk PCO_GLOBAL* ch, EncVar PCO_GLOBAL* ev,
+                                           uint32_t n_lat, L minv, L maxv) {
+  const PlanRef plan = plan_ref(ws, t, var);
+  const uint32_t tid = threadIdx.x, lane = lane_id();
+  const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
+  const uint32_t n_all = (uint32_t)ch->n, skip = ev->lat_start, plow = ch->page_low, pr = ch->page_r;
+  const bool single_page = ch->n_pages == 1;
+  const bool exact_paging = ch->exact_paging != 0; const uint32_t n_pg = ch->n_pages;
+  const EncPage PCO_GLOBAL* pgl = (const EncPage PCO_GLOBAL*)ws.pages + ch->page_first;
+  auto exact_start = [&](uint32_t i) {
+    uint32_t lo = 0, hi = n_pg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)pgl[mid].start <= i) lo = mid; else hi = mid; }
+    return (uint64_t)pgl[lo].start;
+  };
+  auto stored = [&](uint32_t i) { return skip == 0 || (single_page ? i >= skip : (uint64_t)i - (exact_paging ? exact_start(i) : page_start_of(i, plow, pr)) >= skip); };
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  L PCO_LDS* rv = (L PCO_LDS*)(smem + kHistLdsRecV);
+  L PCO_LDS* rnext = (L PCO_LDS*)(smem + kHistLdsRecV + 2048);
+  L PCO_LDS* rpred = (L PCO_LDS*)(smem + kHistLdsRecV + 4096);
+  L PCO_LDS* rsucc = (L PCO_LDS*)(smem + kHistLdsRecV + 6144);
+  uint32_t PCO_LDS* rst = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 8192);
+  uint32_t PCO_LDS* ren = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 9216);
+  uint32_t PCO_LDS* cursor = (uint32_t PCO_LDS*)(smem + kRadixScratchBytes);
+  K PCO_LDS* srt = (K PCO_LDS*)(smem + kHistLdsCounts);
+  const uint32_t B = 1u << bins_log;
+  const uint64_t n64 = n_lat;
+  auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
+  __syncthreads();   // (the previous variable's records are done with)
+  if (single_page) {   // stored latents = positions skip ..
+    for (uint32_t i = skip + tid; i < n_all; i += kSelT) srt[i - skip] = (K)(L)(lat[i] - minv);
+  } else {             // any order will do: one cursor bump per wave and round
+    if (tid == 0) *cursor = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n_all; i0 += kSelT) {
+      const uint32_t i = i0 + tid;
+      const bool on = i < n_all && stored(i);
+      const uint64_t m = __ballot(on);
+      uint32_t at = 0;
+      if (lane == 0 && m) at = atomicAdd((uint32_t*)cursor, (uint32_t)__popcll(m));
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+      if (on) srt[at + __popcll(m & (((uint64_t)1 << lane) - 1))] = (K)(L)(lat[i] - minv);
+    }
+  }
+  __syncthreads();
+  block_radix_sort_inplace<K>(srt, smem + kHistLdsRecV, n_lat, bitlen<L>((L)(maxv - minv)));
+  if (tid < B) {
+    const uint32_t c = c_count(tid);
+    const K v = srt[c - 1];
+    uint32_t lo = 0, hi = c - 1;   // first index with srt[idx] >= v
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (srt[mid] < v) lo = mid + 1; else hi = mid; }
+    const uint32_t st = lo;
+    lo = c; hi = n_lat;            // first index with srt[idx] > v
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (srt[mid] <= v) lo = mid + 1; else hi = mid; }
+    const uint32_t en = lo;
+    const K nx = c < n_lat ? srt[c] : (K)0, pd = st > 0 ? srt[st - 1] : (K)0, sc = en < n_lat ? srt[en] : (K)0;
+    rv[tid] = (L)(minv + (L)v); rst[tid] = st; ren[tid] = en;
+    rnext[tid] = c < n_lat ? (L)(minv + (L)nx) : (L)0;
+    rpred[tid] = st > 0 ? (L)(minv + (L)pd) : (L)0;
+    rsucc[tid] = en < n_lat ? (L)(minv + (L)sc) : (L)0;
+  }
+  __syncthreads();
+  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u);
+}
+
+template <class L>
+__device__ void small_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log) {
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  EncVar PCO_GLOBAL* ev = &ch->v[var];
+  const uint32_t n_lat = ev->n_lat;
+  if (n_lat == 0 || n_lat > kSelSortCap) return;
+  const L minv = (L)ev->minv, maxv = (L)ev->maxv;
+  const uint64_t range = (uint64_t)(L)(maxv - minv);
+  if (range < kWideHistRange) return;   // the LDS-counting kernels own it
+  if constexpr (sizeof(L) == 8) { if (range >> 32) { small_body<L, uint64_t>(ws, t, var, bins_log, ch, ev, n_lat, minv, maxv); return; } }
+  small_body<L, uint32_t>(ws, t, var, bins_log, ch, ev, n_lat, minv, maxv);
+}
+
+// grid = chunks, 1024 threads, dynamic LDS = small_lds_bytes(largest small variable, its key width)
+__global__ __launch_bounds__(kSelT, 8) void enc_hist_small_kernel(EncWorkspace ws, uint32_t n_tasks) {
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tasks) return;
+  const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (uni(ch->status) != PCO_GFX_OK || uni(ch->big) != 0) return;   // (more than 256 bins: the sort kernel)
+  const int bits = dtype_bits(uni(ch->dtype));
+  const uint32_t ubl = uni(ch->unopt_bins_log);
+  for (uint32_t var = 0; var < 3; var++) {
+    if (!uni(ch->v[var].present)) continue;
+    const uint32_t bl = var == 2 ? (ubl < 6 ? ubl : 6) : ubl;
+    if (var == 0) small_var<uint32_t>(ws, t, var, bl);
+    else if (bits == 64) small_var<uint64_t>(ws, t, var, bl);
+    else if (bits == 32) small_var<uint32_t>(ws, t, var, bl);
+    else if (bits == 16) small_var<uint16_t>(ws, t, var, bl);
+    else small_var<uint8_t>(ws, t, var, bl);
+  }
+}
+
+#ifdef PCO_RADIX_PROBE
+__global__ __launch_bounds__(kSelT, 8) void radix_probe32(uint32_t n, uint32_t sig) { block_radix_sort_inplace<uint32_t>((uint32_t PCO_LDS*)(enc_lds_base() + kHistLdsCounts), enc_lds_base(), n, sig); }
+__global__ __launch_bounds__(kSelT, 8) void radix_probe64(uint32_t n, uint32_t sig) { block_radix_sort_inplace<uint64_t>((uint64_t PCO_LDS*)(enc_lds_base() + kHistLdsCounts), enc_lds_base(), n, sig); }
+#endif
 // A/B switch (PCO_GFX_NO_HIST_SELECT): hand every wide-range variable to the radix-sort kernel
 __global__ void enc_hist_flag_kernel(EncWorkspace ws, uint32_t n_tasks) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -256,6 +256,31 @@ __device__ __forceinline__ void split_one(uint32_t num_kind, L mode_base, uint32
   }
 }
 
+// Primary latents at sampled positions only (the Auto-delta sample, sampling.rs:27-60: 2.5 % of a chunk): what a full split pass
+// would have produced there, without touching the other 97.5 %.  grid = (ceil(max n_idx / 256), tasks)
+struct SplitGatherTask { const void* src; void* dst; const uint32_t* idx; uint32_t n_idx, dtype, mode_kind, mode_k; uint64_t mode_base, mode_aux, mode_aux2; };
+template <class L> __device__ __forceinline__ void split_gather_one(const SplitGatherTask& g, uint32_t k, uint32_t num_kind) {
+  const L bits = ((const L PCO_GLOBAL*)g.src)[g.idx[k]];
+  L p = 0, s = 0;
+  switch (g.mode_kind) {
+    case kIntMult: split_one<L, kIntMult>(num_kind, (L)g.mode_base, g.mode_k, g.mode_aux, g.mode_aux2, bits, p, s); break;
+    case kFloatMult: split_one<L, kFloatMult>(num_kind, (L)g.mode_base, g.mode_k, g.mode_aux, g.mode_aux2, bits, p, s); break;
+    case kFloatQuant: split_one<L, kFloatQuant>(num_kind, (L)g.mode_base, g.mode_k, g.mode_aux, g.mode_aux2, bits, p, s); break;
+    default: split_one<L, kClassic>(num_kind, (L)g.mode_base, g.mode_k, g.mode_aux, g.mode_aux2, bits, p, s); break;
+  }
+  ((L PCO_GLOBAL*)g.dst)[k] = p;
+}
+__global__ __launch_bounds__(256) void split_gather_kernel(const SplitGatherTask* tasks) {
+  const SplitGatherTask g = tasks[blockIdx.y];
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= g.n_idx) return;
+  const uint32_t num_kind = dtype_kind(g.dtype); const int bits = dtype_bits(g.dtype);
+  if (bits == 64) split_gather_one<uint64_t>(g, k, num_kind);
+  else if (bits == 32) split_gather_one<uint32_t>(g, k, num_kind);
+  else if (bits == 16) split_gather_one<uint16_t>(g, k, num_kind);
+  else split_gather_one<uint8_t>(g, k, num_kind);
+}
+
 // One thread owns kSplitE contiguous numbers (all of its loads are issued before anything is used), a block owns a
 // tile of kSplitTile.  The `order` preceding primaries a thread needs for the finite differences come from its left
 // neighbour through LDS; the block's halo (the 7 numbers before the tile) is split by threads 249..255.
@@ -976,6 +1001,7 @@ constexpr uint32_t kHistLdsRecV = 0;
 constexpr uint32_t kHistLdsCounts = 4 * 2048 + 2 * 1024 + 2048;
 constexpr uint32_t kWideHistRange = 32768, kMidHistRange = 16384;   // the two LDS-counting tiers above kDirectHistRange (2 resp. 1 block per CU)
 constexpr uint32_t kSelBucketsLog = 13, kSelBuckets = 1u << kSelBucketsLog, kSelMaxNeeded = 1600;
+constexpr uint32_t kSmallHistCap = 8192;   // wide-range variables of at most this many latents are ordered whole in LDS (enc_hist_small_kernel)
 __host__ __device__ constexpr uint32_t hist_lds_bytes(uint32_t range) { return kHistLdsCounts + (range + 8) * 4; }
 constexpr uint32_t kHistLdsBytes = hist_lds_bytes(kDirectHistRange);
 // enc_hist_sort_kernel: radix counters u32[2048] | bucket prefix u32[8200] | marks u32[256] | marked-bucket list u32[2][1600 + 1]
@@ -1008,9 +1034,10 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   const L range = (L)(maxv - minv);
   // enc_hist_kernel: range < 4096; enc_hist_wide_kernel<16384>: [4096, 16384), <32768>: [16384, 32768); enc_hist_sort_kernel: the rest
-  // (what the launcher has to run after this kernel: bit 0 the select / sort kernels, bit 1 the 16384-counter kernel, bit 2 the 32768-counter one)
+  // (what the launcher has to run after this kernel: bit 0 the select / sort kernels, bit 1 the 16384-counter kernel, bit 2 the 32768-counter one,
+  //  bit 3 the whole-variable-in-LDS kernel)
   if (!kSort && !kWide && ch->big != 0 && tid == 0) atomicOr(ws.need_sort, 1u);
-  if (!kSort && !kWide && ch->big == 0 && (uint64_t)range >= kDirectHistRange && tid == 0) atomicOr(ws.need_sort, (uint64_t)range >= kWideHistRange ? 1u : ((uint64_t)range >= kMidHistRange ? 4u : 2u));
+  if (!kSort && !kWide && ch->big == 0 && (uint64_t)range >= kDirectHistRange && tid == 0) atomicOr(ws.need_sort, (uint64_t)range >= kWideHistRange ? (n_lat <= kSmallHistCap ? 8u : 1u) : ((uint64_t)range >= kMidHistRange ? 4u : 2u));
   const bool big = ch->big != 0;   // more than 256 bins: every variable of the chunk takes the sort path, whatever its range
   if (!kSort && big) return;
   if (!big && (kSort ? (uint64_t)range < kWideHistRange : (kWide ? ((uint64_t)range < (R == kWideHistRange ? kMidHistRange : kDirectHistRange) || (uint64_t)range >= R) : (uint64_t)range >= kDirectHistRange))) return;
