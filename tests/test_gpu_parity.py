@@ -163,6 +163,92 @@ def test_auto_specs(L):
     np.testing.assert_array_equal(P.standalone.simple_decompress(P.standalone.simple_compress(nums, P.ChunkConfig())), nums)
 
 
+def test_auto_mode_device_screens_agree_with_the_oracle(L):
+    """ModeSpec::Auto with part of the decision taken on the device (triple-GCD counts for ints, the float screen): data that is
+    structured only in part -- a fraction of multiples / decimals / quantised numbers among noise -- sits on either side of every
+    gate (sample too small, fewer than half with trailing zeros, too few converging pairs, no k saving bits)."""
+    rng = np.random.default_rng(2024)
+    bad = []
+    for n in (40, 300, 5000, 30000):
+        for frac in (0.0, 0.02, 0.2, 0.45, 0.5, 0.55, 0.8, 1.0):
+            pick = rng.random(n) < frac
+            noise64 = rng.standard_normal(n) * 100
+            cases = {
+                "f64_decimals": np.where(pick, np.round(noise64, 1), noise64),
+                "f32_decimals": np.where(pick, np.round(noise64, 2), noise64).astype(np.float32),
+                "f64_thirds": np.where(pick, rng.integers(-3000, 3000, n) / 3.0, noise64),
+                "f32_pow2_steps": np.where(pick, rng.integers(-3000, 3000, n) * 0.125, noise64).astype(np.float32),
+                "f64_quantised": np.where(pick, (noise64.view(np.uint64) & ~np.uint64(0xFFFFFF)).view(np.float64), noise64),
+                "f32_quantised": np.where(pick, (noise64.astype(np.float32).view(np.uint32) & ~np.uint32(0x3FF)).view(np.float32), noise64.astype(np.float32)),
+                "f32_specials": np.where(pick, np.float32(np.inf), noise64.astype(np.float32)),
+                "f64_huge": np.where(pick, 1e308, noise64),
+                "i64_multiples": np.where(pick, rng.integers(-10**6, 10**6, n) * 7919, rng.integers(-10**12, 10**12, n)).astype(np.int64),
+                "u32_multiples": np.where(pick, rng.integers(0, 10**6, n) * 100, rng.integers(0, 1 << 32, n)).astype(np.uint32),
+                "i16_multiples": np.where(pick, rng.integers(-1000, 1000, n) * 12, rng.integers(-(1 << 15), 1 << 15, n)).astype(np.int16),
+                "u64_two_bases": np.where(pick, rng.integers(0, 10**6, n) * 6, rng.integers(0, 10**6, n) * 10).astype(np.uint64),
+            }
+            for name, nums in cases.items():
+                want = O.simple_compress(nums, O.make_config(delta=1))
+                got = U.gpu_simple_compress(nums, G.make_config(delta=1))
+                if got != want: bad.append((name, n, frac))
+    assert not bad, bad[:12]
+
+
+def _pair_gcd(hi, lo, F, prec):
+    """mode/float_mult.rs:101-142 in numpy scalars of type F: one IEEE operation per step, as the device does them"""
+    tiny, eps, p16, p6 = F(2.0) ** F(-(prec - 6)), F(2.0) ** F(-prec), F(2.0) ** F(-16), F(64.0)
+    if lo <= hi * tiny or lo == hi: return None
+    gv, ge, lv, le = hi, F(0), lo, F(0)
+    while True:
+        prev = gv
+        q = F(gv / lv)
+        fl = F(np.floor(q))
+        ratio = F(fl + F(1)) if F(q - fl) >= F(0.5) else fl        # round half away from zero (q > 0; q - floor(q) is exact)
+        ge = F(ge + F(F(ratio * le) + F(gv * eps)))
+        gv = F(abs(F(gv - F(ratio * lv))))
+        if gv <= F(prev * p16) or gv <= ge: return lv
+        if gv <= F(hi * tiny) or gv <= F(ge * p6): return None
+        gv, lv = lv, gv; ge, le = le, ge
+
+
+def test_auto_float_screen_matches_an_ieee_reference(L):
+    """The device-side screen of Auto mode detection on floats: its sample filter, trailing-zeros histogram, the converging
+    approximate-GCD pairs and the percentile similarity counts against the same steps in numpy scalars (every operation rounded
+    once, no contraction)."""
+    L.pco_gfx_debug_float_screen.restype = C.c_int
+    rng = np.random.default_rng(606)
+    for dt, prec, dtype_id in ((np.float32, 23, G.DTYPE_BYTE["float32"]), (np.float64, 52, G.DTYPE_BYTE["float64"])):
+        F = dt
+        for kind in range(6):
+            n = 4000
+            base = rng.standard_normal(n) * 50
+            with np.errstate(all="ignore"):
+                vals = [base, np.round(base, 1), rng.integers(-500, 500, n) * 0.3 + (rng.random(n) < 0.3) * rng.standard_normal(n) * 1e-3,
+                        rng.integers(1, 2000, n) * 0.125, np.where(rng.random(n) < 0.1, np.nan, base * 1e30), rng.integers(1, 40, n) / 7.0][kind].astype(dt)
+            vals[::97] = dt(0.0); vals[5::131] = dt(np.inf); vals[7::113] = np.finfo(dt).tiny / dt(4)
+            out = (C.c_uint32 * 64)()
+            G.check(L.pco_gfx_debug_float_screen(vals.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.c_uint32(dtype_id), out))
+            with np.errstate(all="ignore"):
+                a = np.abs(vals)
+                keep = np.isfinite(a) & (a >= np.finfo(dt).tiny) & (a <= np.finfo(dt).max / dt(2))
+            s = a[keep]
+            bits = s.view(np.uint32 if dt == np.float32 else np.uint64).astype(np.uint64)
+            tz_raw = np.array([(int(b) & -int(b)).bit_length() - 1 for b in bits])
+            hist = np.bincount(np.minimum(tz_raw, prec), minlength=56)[:56]
+            with np.errstate(all="ignore"):
+                g = [_pair_gcd(max(s[i], s[i + 1]), min(s[i], s[i + 1]), F, prec) for i in range(0, len(s) - 1, 2)]
+            g = sorted(x for x in g if x is not None)
+            sims = []
+            for pct in (0.1, 0.3, 0.5):
+                c = g[int(pct * len(g))] if g else F(0)
+                sims.append(sum(1 for x in g if F(abs(F(x - c))) < F(F(0.01) * c)))
+            assert out[0] == len(s), (dt, kind)
+            assert out[1] == int((tz_raw >= 5).sum()), (dt, kind)
+            assert list(out[6:62]) == list(hist), (dt, kind)
+            assert out[2] == len(g), (dt, kind, out[2], len(g))
+            assert list(out[3:6]) == sims, (dt, kind, list(out[3:6]), sims)
+
+
 def test_encode_matrix_small(L):
     rng = np.random.default_rng(99)
     bad = []
