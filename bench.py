@@ -53,6 +53,7 @@ WORKLOADS = {
     "c1": (["u32rand"], dict(mode=1, delta=1), "u32", "u32 classic no-delta uniform random, 2^18-element chunks (BASELINE configs[0], incompressible)"),
     "c4": (["i64season"], dict(mode=1, delta=3), "i64", "i64 seasonal (period 365) lookback delta, 2^18-element chunks (BASELINE configs[3])"),
     "c2auto": (["u64ramp"], dict(), "u64", "u64 noisy ramp, default ChunkConfig (Auto mode + Auto delta), 2^18-element chunks"),
+    "c3auto": (["f64cents"], dict(), "f64", "f64 decimals, default ChunkConfig (Auto mode + Auto delta), 2^18-element chunks (SURVEY 8d C3, Auto)"),
     "c5": (["u64ramp", "f32normal", "i32lomax"], dict(mode=1, delta=2, delta_order=1), "u64/f32/i32",
            "mixed u64 ramp / f32 normal / i32 lomax chunks of 2^18, one call per rank, Classic + TryConsecutive(1) (BASELINE configs[4], explicit specs)"),
     "c5auto": (["u64ramp", "f32normal", "i32lomax"], dict(), "u64/f32/i32",

@@ -195,191 +195,6 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherTask* tasks) {
   else ((uint8_t*)g.dst)[k] = ((const uint8_t*)g.src)[i];
 }
 
-// Auto mode detection on integer chunks, the bulk of it (mode/int_mult.rs:56-127): the GCD of every sorted triple of the Floyd sample,
-// and how often each value above 1 occurs.  The host scores the (gcd, count) list -- a few dozen entries, with libm -- and only asks
-// for a chunk's sample when a candidate base survives; for data without a common multiple nothing else crosses PCIe.
-// grid = tasks, 256 threads; LDS: 2048-slot open-addressing table (u64 keys | u32 counts | u32 first triple).
-struct IntGcdTask { const void* src; const uint32_t* idx; uint32_t n_idx, dtype; };
-constexpr uint32_t kGcdSlots = 2048, kGcdMaxEntries = 192;
-struct IntGcdEntry { uint64_t gcd; uint32_t count, first; };
-struct IntGcdResult { uint32_t n_entries, overflow; uint64_t pad; IntGcdEntry e[kGcdMaxEntries]; };
-__device__ __forceinline__ uint64_t gcd_u64(uint64_t a, uint64_t b) {   // binary GCD
-  if (a == 0) return b;
-  if (b == 0) return a;
-  const int shift = __builtin_ctzll(a | b);
-  a >>= __builtin_ctzll(a);
-  do { b >>= __builtin_ctzll(b); if (a > b) { const uint64_t t = a; a = b; b = t; } b -= a; } while (b != 0);
-  return a << shift;
-}
-template <class L> __device__ __forceinline__ uint64_t triple_gcd(const IntGcdTask& g, uint32_t tri, uint32_t num_kind) {
-  const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)g.src;
-  L x = to_latent_ordered<L>(src[g.idx[3 * tri]], num_kind), y = to_latent_ordered<L>(src[g.idx[3 * tri + 1]], num_kind), z = to_latent_ordered<L>(src[g.idx[3 * tri + 2]], num_kind);
-  if (x > y) { const L t = x; x = y; y = t; }
-  if (y > z) { const L t = y; y = z; z = t; }
-  if (x > y) { const L t = x; x = y; y = t; }
-  return gcd_u64((uint64_t)(L)(y - x), (uint64_t)(L)(z - x));
-}
-__global__ __launch_bounds__(256) void auto_int_gcd_kernel(const IntGcdTask* tasks, IntGcdResult* out) {
-  __shared__ uint64_t keys[kGcdSlots];
-  __shared__ uint32_t counts[kGcdSlots], firsts[kGcdSlots];
-  __shared__ uint32_t n_used, n_out;
-  const IntGcdTask g = tasks[blockIdx.x];
-  const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < kGcdSlots; i += 256) { keys[i] = 0; counts[i] = 0; firsts[i] = 0xffffffffu; }
-  if (tid == 0) { n_used = 0; n_out = 0; }
-  __syncthreads();
-  const uint32_t num_kind = dtype_kind(g.dtype); const int bits = dtype_bits(g.dtype);
-  const uint32_t n_tri = g.n_idx / 3;
-  for (uint32_t tri = tid; tri < n_tri; tri += 256) {
-    const uint64_t v = bits == 64 ? triple_gcd<uint64_t>(g, tri, num_kind) : (bits == 32 ? triple_gcd<uint32_t>(g, tri, num_kind) : (bits == 16 ? triple_gcd<uint16_t>(g, tri, num_kind) : triple_gcd<uint8_t>(g, tri, num_kind)));
-    if (v <= 1) continue;
-    uint32_t slot = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 53) & (kGcdSlots - 1);
-    for (uint32_t probe = 0; probe < kGcdSlots; probe++, slot = (slot + 1) & (kGcdSlots - 1)) {
-      const uint64_t old = atomicCAS((unsigned long long*)&keys[slot], 0ull, (unsigned long long)v);
-      if (old == 0) atomicAdd(&n_used, 1u);
-      if (old == 0 || old == v) { atomicAdd(&counts[slot], 1u); atomicMin(&firsts[slot], tri); break; }
-    }
-  }
-  __syncthreads();
-  IntGcdResult* r = out + blockIdx.x;
-  // A value seen once can never become the candidate (score_gcd: its lower confidence bound w - sqrt(w) is 0), and the long tail of
-  // large accidental GCDs is all such values: they stay on the device.
-  const bool table_full = n_used >= kGcdSlots;
-  if (!table_full) for (uint32_t i = tid; i < kGcdSlots; i += 256) if (keys[i] != 0 && counts[i] > 1) { const uint32_t at = atomicAdd(&n_out, 1u); if (at < kGcdMaxEntries) r->e[at] = IntGcdEntry{keys[i], counts[i], firsts[i]}; }
-  __syncthreads();
-  const bool overflow = table_full || n_out > kGcdMaxEntries;
-  if (tid == 0) { r->n_entries = overflow ? 0u : n_out; r->overflow = overflow ? 1u : 0u; }
-}
-
-// Auto mode detection on float chunks, the screening part (data_types/float.rs:82-132): whether a float-mult or float-quant bid is
-// possible at all.  On the |x| of the normal, not-too-large numbers of the Floyd sample (in sample order) it counts
-//   * the numbers with >= 5 trailing zero mantissa bits (mode/float_mult.rs:145-160: fewer than half of them ends that strategy),
-//   * the neighbouring pairs whose approximate Euclidean GCD converges, and how many of those GCDs lie within 1 % of the ones at
-//     their 10th / 30th / 50th percentile (float_mult.rs:101-142, 197-229: fewer than 1 + ceil(n / 1000) ends that strategy; noise
-//     converges for a tenth of its pairs, onto scattered values) -- the same IEEE operations in the same order as the host (division
-//     and rounding are correctly rounded on both sides, contraction is off),
-//   * the trailing-zeros histogram float-quant starts from (mode/float_quant.rs:73-100).
-// Unstructured floats fail all three and never cross PCIe; everything else goes to the host with its sample.  grid = tasks, 256 threads.
-struct FloatStatsTask { const void* src; const uint32_t* idx; uint32_t n_idx, dtype; };
-constexpr uint32_t kFloatScreenMaxSample = 8192;
-struct FloatStatsResult { uint32_t s_size, tz5, n_gcd, pad; uint32_t sim[4]; uint32_t hist[56]; };
-template <class F> struct FloatScreen;
-template <> struct FloatScreen<float> {
-  typedef uint32_t L; static constexpr int kPrec = 23, kBias = 127;
-  static __device__ __forceinline__ float from_bits(uint32_t b) { return __uint_as_float(b); }
-  static __device__ __forceinline__ float rnd(float x) { return roundf(x); }
-};
-template <> struct FloatScreen<double> {
-  typedef uint64_t L; static constexpr int kPrec = 52, kBias = 1023;
-  static __device__ __forceinline__ double from_bits(uint64_t b) { return __longlong_as_double((long long)b); }
-  static __device__ __forceinline__ double rnd(double x) { return round(x); }
-};
-template <class F> __device__ __forceinline__ F screen_pow2(int p) { typedef FloatScreen<F> S; return S::from_bits((typename S::L)(S::kBias + p) << S::kPrec); }
-template <class F> __device__ __forceinline__ bool screen_pair_gcd(F hi, F lo, F& out) {
-  typedef FloatScreen<F> S;
-  const F tiny = screen_pow2<F>(-(S::kPrec - 6)), eps = screen_pow2<F>(-S::kPrec), p16 = screen_pow2<F>(-16), p6 = screen_pow2<F>(6);
-  if (lo <= hi * tiny || lo == hi) return false;
-  F gv = hi, ge = 0, lv = lo, le = 0;
-  for (;;) {
-    const F prev = gv, ratio = S::rnd(gv / lv);
-    ge += ratio * le + gv * eps;
-    gv = fabs(gv - ratio * lv);
-    if (gv <= prev * p16 || gv <= ge) { out = lv; return true; }
-    if (gv <= hi * tiny || gv <= ge * p6) return false;
-    const F t = gv; gv = lv; lv = t; const F u = ge; ge = le; le = u;
-  }
-}
-template <class F> __device__ __forceinline__ void float_stats(const FloatStatsTask& g, FloatStatsResult* r, uint8_t PCO_LDS* smem) {
-  typedef FloatScreen<F> S; typedef typename S::L L;
-  L PCO_LDS* samp = (L PCO_LDS*)smem;                                   // |x| bits of the kept numbers, in sample order
-  uint32_t PCO_LDS* hist = (uint32_t PCO_LDS*)(smem + 8192 * 8);         // u32[56] | kept | tz5 | n_gcd
-  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-  if (tid < 64) hist[tid] = 0;
-  __syncthreads();
-  const L PCO_GLOBAL* src = (const L PCO_GLOBAL*)g.src;
-  const L mid = (L)1 << (sizeof(L) * 8 - 1), exp_all = (L)((1u << (sizeof(L) * 8 - 1 - S::kPrec)) - 1);
-  const L max_bits = (L)(mid - 1 - ((L)1 << S::kPrec)), lim = (L)(max_bits - ((L)1 << S::kPrec));   // MAX_FOR_SAMPLING = half the largest finite value
-  uint32_t PCO_LDS* wcnt = hist + 60;   // u32[4] per-wave counts of a round
-  uint32_t base = 0;                    // kept so far (every thread keeps the same running total)
-  for (uint32_t k0 = 0; k0 < g.n_idx; k0 += 256) {                      // order-preserving compaction, 256 at a time
-    const uint32_t k = k0 + tid;
-    L a = 0; bool keep = false;
-    if (k < g.n_idx) { a = (L)(src[g.idx[k]] & (L)~mid); const L e = (L)(a >> S::kPrec); keep = e != 0 && e != exp_all && a <= lim; }
-    const uint64_t m = __ballot(keep);
-    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t before = base;
-    for (uint32_t w = 0; w < wave; w++) before += wcnt[w];
-    if (keep) {
-      samp[before + (uint32_t)__popcll(m & (((uint64_t)1 << lane) - 1))] = a;
-      const uint32_t tz = (uint32_t)__builtin_ctzll((unsigned long long)a | ((unsigned long long)1 << 63));
-      atomicAdd((uint32_t*)&hist[tz < (uint32_t)S::kPrec ? tz : (uint32_t)S::kPrec], 1u);
-      if (tz >= 5) atomicAdd((uint32_t*)&hist[57], 1u);
-    }
-    base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    __syncthreads();
-  }
-  const uint32_t kept = base;
-  // approximate GCD of every neighbouring pair; the converged ones are compacted in place (a round's 256 pairs are read before its
-  // results are written, and the dense output never runs ahead of the pairs still to be read)
-  uint32_t n_g = 0;
-  for (uint32_t p0 = 0; 2 * p0 + 1 < kept; p0 += 256) {
-    const uint32_t pr = p0 + tid;
-    F gval = 0; bool ok = false;
-    if (2 * pr + 1 < kept) {
-      const F x = S::from_bits(samp[2 * pr]), y = S::from_bits(samp[2 * pr + 1]);
-      ok = screen_pair_gcd<F>(x > y ? x : y, x > y ? y : x, gval);
-    }
-    const uint64_t m = __ballot(ok);
-    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t before = n_g;
-    for (uint32_t w = 0; w < wave; w++) before += wcnt[w];
-    if (ok) { L gb; if constexpr (sizeof(F) == 4) gb = __float_as_uint(gval); else gb = (L)__double_as_longlong(gval); samp[before + (uint32_t)__popcll(m & (((uint64_t)1 << lane) - 1))] = gb; }
-    n_g += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    __syncthreads();
-  }
-  // euclid_gcd (float_mult.rs:197-229): sort them (positive floats order like their bits), take the values at the 10th / 30th / 50th
-  // percentile and count, for each, the values within 1 % of it
-  uint32_t p2 = 2; while (p2 < n_g) p2 <<= 1;
-  for (uint32_t i = n_g + tid; i < p2; i += 256) samp[i] = (L)~(L)0;
-  __syncthreads();
-  for (uint32_t k = 2; k <= p2; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = tid; i < (p2 >> 1); i += 256) {
-        const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), rr = l | j;
-        const L x = samp[l], y = samp[rr];
-        if ((x > y) == ((l & k) == 0)) { samp[l] = y; samp[rr] = x; }
-      }
-      __syncthreads();
-    }
-  }
-  if (tid < 3) hist[tid == 0 ? 56 : 57 + tid] = 0;   // [56], [58], [59]: similar-value counts of the three candidates
-  __syncthreads();
-  if (n_g > 0) {
-    const double pct[3] = {0.1, 0.3, 0.5};
-    F c[3];
-    for (int q = 0; q < 3; q++) c[q] = S::from_bits(samp[(uint32_t)(pct[q] * (double)n_g)]);
-    uint32_t sim[3] = {0, 0, 0};
-    for (uint32_t i = tid; i < n_g; i += 256) {
-      const F x = S::from_bits(samp[i]);
-      for (int q = 0; q < 3; q++) if (fabs(x - c[q]) < (F)0.01 * c[q]) sim[q]++;
-    }
-    if (sim[0]) atomicAdd((uint32_t*)&hist[56], sim[0]);
-    if (sim[1]) atomicAdd((uint32_t*)&hist[58], sim[1]);
-    if (sim[2]) atomicAdd((uint32_t*)&hist[59], sim[2]);
-  }
-  __syncthreads();
-  if (tid < 56) r->hist[tid] = hist[tid];
-  if (tid == 0) { r->s_size = kept; r->tz5 = hist[57]; r->n_gcd = n_g; r->sim[0] = hist[56]; r->sim[1] = hist[58]; r->sim[2] = hist[59]; r->sim[3] = 0; r->pad = 0; }
-}
-__global__ __launch_bounds__(256) void auto_float_stats_kernel(const FloatStatsTask* tasks, FloatStatsResult* out) {
-  __shared__ __attribute__((aligned(16))) uint8_t smem[8192 * 8 + 64 * 4];
-  const FloatStatsTask g = tasks[blockIdx.x];
-  if (dtype_bits(g.dtype) == 64) float_stats<double>(g, out + blockIdx.x, (uint8_t PCO_LDS*)smem);
-  else float_stats<float>(g, out + blockIdx.x, (uint8_t PCO_LDS*)smem);
-}
-
 // compact per-task record of a trained plan, for the host-side size estimate of Auto delta trials.  The average bits per latent
 // (metadata/chunk_latent_var.rs avg_bits_per_latent: a sum over the bins, in bin order, of f64 terms (ans_size_log - log2(weight) +
 // offset_bits) * weight / 2^ans_size_log) is formed here, by one lane per variable in the reference's order, with log2(weight) taken

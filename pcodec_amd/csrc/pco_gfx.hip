@@ -23,6 +23,7 @@
 #include "decode_fast.hip"
 #include "encode_kernels.hip"
 #include "encode_hist_select.hip"
+#include "auto_mode_kernels.hip"
 #include "encode_fast.hip"
 #include "stream_kernels.hip"
 
@@ -341,27 +342,32 @@ extern "C" int pco_gfx_debug_walk_timing(unsigned long long* out) {
 }
 #endif
 
-// Test hook: the float screen of Auto mode detection (auto_float_stats_kernel) on a host array taken as the sample, in order.
-// out: s_size, tz5, n_gcd, sim[3], hist[56] (out[3 .. 6) are the similar-value counts).  Lets the GPU tests check the device's pair arithmetic against an IEEE reference (numpy).
+// Test hook: stage 1 of Auto mode detection on floats (auto_float_stats_kernel) on a host array taken as the sample, in order.
+// out: s_size, tz5, n_gcd, sim[3], hist[56], then has_euclid, k, n_ints, base_c (lo, hi).  Lets the GPU tests check the device's
+// arithmetic against an IEEE reference (numpy).
 extern "C" int pco_gfx_debug_float_screen(const void* values, size_t n, uint32_t dtype, uint32_t* out) {
   using namespace pcogfx;
-  if (n == 0 || n > kFloatScreenMaxSample || dtype_kind(dtype) != kFloat || dtype_bits(dtype) < 32) return PCO_GFX_INVALID_ARGUMENT;
+  if (n == 0 || n > kAutoCap || dtype_kind(dtype) != kFloat || dtype_bits(dtype) < 32) return PCO_GFX_INVALID_ARGUMENT;
   const size_t eb = dtype_bits(dtype) / 8;
-  void* d_vals = nullptr; uint32_t* d_idx = nullptr; FloatStatsTask* d_task = nullptr; FloatStatsResult* d_res = nullptr;
+  void* d_vals = nullptr; void* d_sbuf = nullptr; uint32_t* d_idx = nullptr; FloatStatsTask* d_task = nullptr; FloatStatsResult* d_res = nullptr;
   std::vector<uint32_t> idx(n); for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
   int rc = PCO_GFX_OK;
-  if (hipMalloc(&d_vals, n * eb) != hipSuccess || hipMalloc((void**)&d_idx, n * 4) != hipSuccess || hipMalloc((void**)&d_task, sizeof(FloatStatsTask)) != hipSuccess || hipMalloc((void**)&d_res, sizeof(FloatStatsResult)) != hipSuccess) rc = PCO_GFX_DEVICE_ERROR;
+  if (hipFuncSetAttribute((const void*)auto_float_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAutoStage1LdsBytes) != hipSuccess) return PCO_GFX_DEVICE_ERROR;
+  if (hipMalloc(&d_vals, n * eb) != hipSuccess || hipMalloc(&d_sbuf, kAutoCap * 8) != hipSuccess || hipMalloc((void**)&d_idx, n * 4) != hipSuccess || hipMalloc((void**)&d_task, sizeof(FloatStatsTask)) != hipSuccess || hipMalloc((void**)&d_res, sizeof(FloatStatsResult)) != hipSuccess) rc = PCO_GFX_DEVICE_ERROR;
   if (rc == PCO_GFX_OK) {
-    const FloatStatsTask t{d_vals, d_idx, (uint32_t)n, dtype};
-    FloatStatsResult r{};
+    const FloatStatsTask t{d_vals, d_idx, d_sbuf, (uint32_t)n, dtype};
+    static FloatStatsResult r;
     if (hipMemcpy(d_vals, values, n * eb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_task, &t, sizeof(t), hipMemcpyHostToDevice) != hipSuccess) rc = PCO_GFX_DEVICE_ERROR;
     else {
-      hipLaunchKernelGGL(auto_float_stats_kernel, dim3(1), dim3(256), 0, 0, d_task, d_res);
+      hipLaunchKernelGGL(auto_float_stats_kernel, dim3(1), dim3(256), kAutoStage1LdsBytes, 0, d_task, d_res);
       if (hipMemcpy(&r, d_res, sizeof(r), hipMemcpyDeviceToHost) != hipSuccess) rc = PCO_GFX_DEVICE_ERROR;
-      else { out[0] = r.s_size; out[1] = r.tz5; out[2] = r.n_gcd; out[3] = r.sim[0]; out[4] = r.sim[1]; out[5] = r.sim[2]; for (int i = 0; i < 56; i++) out[6 + i] = r.hist[i]; }
+      else {
+        out[0] = r.s_size; out[1] = r.tz5; out[2] = r.n_gcd; out[3] = r.sim[0]; out[4] = r.sim[1]; out[5] = r.sim[2]; for (int i = 0; i < 56; i++) out[6 + i] = r.hist[i];
+        out[62] = r.has_euclid; out[63] = (uint32_t)r.k; out[64] = r.n_ints; out[65] = (uint32_t)r.base_c; out[66] = (uint32_t)(r.base_c >> 32);
+      }
     }
   }
-  (void)hipFree(d_vals); (void)hipFree(d_idx); (void)hipFree(d_task); (void)hipFree(d_res);
+  (void)hipFree(d_vals); (void)hipFree(d_sbuf); (void)hipFree(d_idx); (void)hipFree(d_task); (void)hipFree(d_res);
   return rc;
 }
 

@@ -212,41 +212,70 @@ def _pair_gcd(hi, lo, F, prec):
 
 
 def test_auto_float_screen_matches_an_ieee_reference(L):
-    """The device-side screen of Auto mode detection on floats: its sample filter, trailing-zeros histogram, the converging
-    approximate-GCD pairs and the percentile similarity counts against the same steps in numpy scalars (every operation rounded
-    once, no contraction)."""
+    """Stage 1 of Auto mode detection on floats (auto_float_stats_kernel): its sample filter, trailing-zeros histogram and power of two,
+    the converging approximate-GCD pairs, the percentile similarity counts, the picked GCD and its centring against the same steps in
+    numpy scalars (every operation rounded once, no contraction)."""
+    import math
     L.pco_gfx_debug_float_screen.restype = C.c_int
     rng = np.random.default_rng(606)
     for dt, prec, dtype_id in ((np.float32, 23, G.DTYPE_BYTE["float32"]), (np.float64, 52, G.DTYPE_BYTE["float64"])):
-        F = dt
-        for kind in range(6):
+        F = dt; bits_n = 32 if dt == np.float32 else 64; bias = 127 if dt == np.float32 else 1023
+        for kind in range(7):
             n = 4000
             base = rng.standard_normal(n) * 50
             with np.errstate(all="ignore"):
                 vals = [base, np.round(base, 1), rng.integers(-500, 500, n) * 0.3 + (rng.random(n) < 0.3) * rng.standard_normal(n) * 1e-3,
-                        rng.integers(1, 2000, n) * 0.125, np.where(rng.random(n) < 0.1, np.nan, base * 1e30), rng.integers(1, 40, n) / 7.0][kind].astype(dt)
+                        rng.integers(1, 2000, n) * 0.125, np.where(rng.random(n) < 0.1, np.nan, base * 1e30), rng.integers(1, 40, n) / 7.0,
+                        rng.integers(1, 3000, n) * 0.01][kind].astype(dt)
             vals[::97] = dt(0.0); vals[5::131] = dt(np.inf); vals[7::113] = np.finfo(dt).tiny / dt(4)
-            out = (C.c_uint32 * 64)()
+            out = (C.c_uint32 * 80)()
             G.check(L.pco_gfx_debug_float_screen(vals.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.c_uint32(dtype_id), out))
             with np.errstate(all="ignore"):
                 a = np.abs(vals)
                 keep = np.isfinite(a) & (a >= np.finfo(dt).tiny) & (a <= np.finfo(dt).max / dt(2))
             s = a[keep]
-            bits = s.view(np.uint32 if dt == np.float32 else np.uint64).astype(np.uint64)
-            tz_raw = np.array([(int(b) & -int(b)).bit_length() - 1 for b in bits])
+            ubits = [int(b) for b in s.view(np.uint32 if dt == np.float32 else np.uint64)]
+            tz_raw = np.array([(b & -b).bit_length() - 1 for b in ubits])
             hist = np.bincount(np.minimum(tz_raw, prec), minlength=56)[:56]
             with np.errstate(all="ignore"):
                 g = [_pair_gcd(max(s[i], s[i + 1]), min(s[i], s[i + 1]), F, prec) for i in range(0, len(s) - 1, 2)]
             g = sorted(x for x in g if x is not None)
-            sims = []
+            need = 1 + math.ceil(len(s) * 0.001); required = max(math.ceil(len(s) * 0.5), 10)
+            sims, cands = [], []
             for pct in (0.1, 0.3, 0.5):
                 c = g[int(pct * len(g))] if g else F(0)
-                sims.append(sum(1 for x in g if F(abs(F(x - c))) < F(F(0.01) * c)))
+                cands.append(c); sims.append(sum(1 for x in g if F(abs(F(x - c))) < F(F(0.01) * c)))
             assert out[0] == len(s), (dt, kind)
             assert out[1] == int((tz_raw >= 5).sum()), (dt, kind)
             assert list(out[6:62]) == list(hist), (dt, kind)
             assert out[2] == len(g), (dt, kind, out[2], len(g))
             assert list(out[3:6]) == sims, (dt, kind, list(out[3:6]), sims)
+            # trailing zeros: the common power of two and how many numbers are whole multiples of it
+            if out[1] >= required:
+                exps = [(b >> prec) - bias for b in ubits]
+                divp = [e - max(prec - int(t), 0) for e, t in zip(exps, tz_raw)]
+                k = min(d for d, t in zip(divp, tz_raw) if t >= 5)
+                assert np.int32(np.uint32(out[63])) == k, (dt, kind)
+                assert out[64] == sum(1 for d, e in zip(divp, exps) if d >= k and e < k + bits_n), (dt, kind)
+            # Euclid: the first percentile value enough GCDs agree with, centred
+            has = len(g) >= need and any(x >= need for x in sims)
+            assert out[62] == int(has), (dt, kind)
+            if has:
+                basev = cands[[x >= need for x in sims].index(True)]
+                inv = F(F(1.0) / basev); tsum = F(0); tw = F(0)
+                with np.errstate(all="ignore"):
+                    for x in s:
+                        q = F(x * inv); fl = F(np.floor(q)); mult = F(fl + F(1)) if F(q - fl) >= F(0.5) else fl
+                        mb = int(np.array([mult]).view(np.uint32 if dt == np.float32 else np.uint64)[0]) & ((1 << (bits_n - 1)) - 1)
+                        me = (mb >> prec) - bias
+                        if 0 <= me < prec and mult != 0:
+                            over = F(F(mult * basev) - x)
+                            w = F(prec - me)
+                            tsum = F(tsum + F(w * F(over / mult))); tw = F(tw + w)
+                    want = F(basev - F(tsum / tw))
+                got_bits = out[65] | (out[66] << 32)
+                want_bits = int(np.array([want]).view(np.uint32 if dt == np.float32 else np.uint64)[0])
+                assert got_bits == want_bits or (np.isnan(want) and True), (dt, kind, hex(got_bits), hex(want_bits))
 
 
 def test_encode_matrix_small(L):
