@@ -19,6 +19,7 @@
 
 namespace pcogfx {
 
+constexpr uint32_t kAutoT = 512;      // threads per block of the float statistics kernel
 constexpr uint32_t kAutoCap = 6656;   // largest sample handled here: chunks of up to 2^18 + 3720 numbers (beyond: the host path)
 constexpr uint32_t kGcdSlots = 2048, kGcdMaxEntries = 192;
 struct IntGcdEntry { uint64_t gcd; uint32_t count, first; };
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void auto_int_gcd_kernel(const IntGcdTask* tas
 //   * approx_sample_gcd_euclidean (float_mult.rs:101-142, 197-229): the approximate GCD of every neighbouring pair, sorted; the value
 //     at the first of the 10th / 30th / 50th percentile that 1 + ceil(n / 1000) values lie within 1 % of; then center_sample_base
 //     (float_mult.rs:239-258) of that value: the per-number terms in parallel, the two running sums by one lane in sample order.
-// s goes to the task's scratch buffer for stage 2.  grid = tasks, 256 threads, dynamic LDS kAutoStage1LdsBytes.
+// s goes to the task's scratch buffer for stage 2.  grid = tasks, kAutoT threads, dynamic LDS kAutoStage1LdsBytes.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct FloatStatsTask { const void* src; const uint32_t* idx; void* sbuf; uint32_t n_idx, dtype; };
 struct FloatStatsResult {
@@ -163,11 +164,13 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
   constexpr uint32_t kBits = sizeof(L) * 8;
   L PCO_LDS* A = (L PCO_LDS*)(smem + kAutoLdsA);                        // s: |x| bits of the kept numbers, in sample order
   L PCO_LDS* B = (L PCO_LDS*)(smem + kAutoLdsB);                        // by turns: the 2^k-unit integers, the pair GCDs, the centring terms
-  uint32_t PCO_LDS* misc = (uint32_t PCO_LDS*)(smem + kAutoLdsMisc);    // [0, 56) tz histogram | 56 tz5 | 57 k | 58, 59 table counters | 60.. per-wave counts | 64.. sims
+  uint32_t PCO_LDS* misc = (uint32_t PCO_LDS*)(smem + kAutoLdsMisc);    // [0, 56) tz histogram | 56 tz5 | 57 k | 58, 59 table counters | 64.. sims | 68.. per-wave counts
   uint8_t PCO_LDS* wq = smem + kAutoLdsKeys;                            // (after the GCD table is done with) centring weights, one byte per number
   const GcdTable tab{(uint64_t PCO_LDS*)(smem + kAutoLdsKeys), (uint32_t PCO_LDS*)(smem + kAutoLdsCounts), (uint32_t PCO_LDS*)(smem + kAutoLdsFirsts), misc + 58, misc + 59};
-  uint32_t PCO_LDS* wcnt = misc + 60;
+  uint32_t PCO_LDS* wcnt = misc + 68;   // u32[NW]
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+  constexpr uint32_t T = kAutoT, NW = kAutoT / 64;
+  auto wave_total = [&]() { uint32_t t = 0; for (uint32_t w = 0; w < NW; w++) t += wcnt[w]; return t; };
   if (tid < 128) misc[tid] = 0;
   if (tid == 0) ((int PCO_LDS*)misc)[57] = 0x7fffffff;
   gcd_table_clear(tab);
@@ -180,7 +183,7 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
   auto div_pow = [](int e, uint32_t tz) { return e - (int)((uint32_t)S::kPrec > tz ? (uint32_t)S::kPrec - tz : 0u); };
   // ---- 1. the sample: order-preserving compaction, 256 at a time ----
   uint32_t kept = 0;
-  for (uint32_t k0 = 0; k0 < g.n_idx; k0 += 256) {
+  for (uint32_t k0 = 0; k0 < g.n_idx; k0 += T) {
     const uint32_t k = k0 + tid;
     L a = 0; bool keep = false;
     if (k < g.n_idx) { a = (L)(src[g.idx[k]] & (L)~mid); const L e = (L)(a >> S::kPrec); keep = e != 0 && e != exp_all && a <= lim; }
@@ -195,11 +198,11 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
       atomicAdd((uint32_t*)&misc[tz < (uint32_t)S::kPrec ? tz : (uint32_t)S::kPrec], 1u);
       if (tz >= 5) { atomicAdd((uint32_t*)&misc[56], 1u); atomicMin((int*)&misc[57], div_pow(exp_of(a), tz)); }
     }
-    kept += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    kept += wave_total();
     __syncthreads();
   }
   L PCO_GLOBAL* sbuf = (L PCO_GLOBAL*)g.sbuf;
-  for (uint32_t i = tid; i < kept; i += 256) sbuf[i] = A[i];
+  for (uint32_t i = tid; i < kept; i += T) sbuf[i] = A[i];
   const uint32_t tz5 = misc[56];
   const int kpow = ((int PCO_LDS*)misc)[57];
   const uint32_t required = max((uint32_t)ceil((double)kept * 0.5), 10u), need = 1u + (uint32_t)ceil((double)kept * 0.001);
@@ -207,7 +210,7 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
   uint32_t n_ints = 0;
   if (tz5 >= required) {
     constexpr uint32_t lshift = kBits - S::kPrec - 1;
-    for (uint32_t i0 = 0; i0 < kept; i0 += 256) {
+    for (uint32_t i0 = 0; i0 < kept; i0 += T) {
       const uint32_t i = i0 + tid;
       bool on = false; L v = 0;
       if (i < kept) {
@@ -220,15 +223,15 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
       uint32_t before = n_ints;
       for (uint32_t w = 0; w < wave; w++) before += wcnt[w];
       if (on) B[before + (uint32_t)__popcll(m & (((uint64_t)1 << lane) - 1))] = v;
-      n_ints += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      n_ints += wave_total();
       __syncthreads();
     }
-    if (n_ints >= required) for (uint32_t tri = tid; tri < n_ints / 3; tri += 256) gcd_table_add(tab, sorted_triple_gcd<L>(B[3 * tri], B[3 * tri + 1], B[3 * tri + 2]), tri);
+    if (n_ints >= required) for (uint32_t tri = tid; tri < n_ints / 3; tri += T) gcd_table_add(tab, sorted_triple_gcd<L>(B[3 * tri], B[3 * tri + 1], B[3 * tri + 2]), tri);
   }
   gcd_table_emit(tab, r->e, &r->n_entries, &r->overflow);   // (barriers inside: B and the table are free afterwards)
   // ---- 3. Euclid: the pairs' approximate GCDs, compacted into B, sorted (positive floats order like their bits) ----
   uint32_t n_g = 0;
-  for (uint32_t p0 = 0; 2 * p0 + 1 < kept; p0 += 256) {
+  for (uint32_t p0 = 0; 2 * p0 + 1 < kept; p0 += T) {
     const uint32_t pr = p0 + tid;
     F gval = 0; bool ok = false;
     if (2 * pr + 1 < kept) {
@@ -241,15 +244,15 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
     uint32_t before = n_g;
     for (uint32_t w = 0; w < wave; w++) before += wcnt[w];
     if (ok) B[before + (uint32_t)__popcll(m & (((uint64_t)1 << lane) - 1))] = S::to_bits(gval);
-    n_g += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    n_g += wave_total();
     __syncthreads();
   }
   uint32_t p2 = 2; while (p2 < n_g) p2 <<= 1;
-  for (uint32_t i = n_g + tid; i < p2; i += 256) B[i] = (L)~(L)0;
+  for (uint32_t i = n_g + tid; i < p2; i += T) B[i] = (L)~(L)0;
   __syncthreads();
   for (uint32_t k = 2; k <= p2; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = tid; i < (p2 >> 1); i += 256) {
+      for (uint32_t i = tid; i < (p2 >> 1); i += T) {
         const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), rr = l | j;
         const L x = B[l], y = B[rr];
         if ((x > y) == ((l & k) == 0)) { B[l] = y; B[rr] = x; }
@@ -262,7 +265,7 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
     const double pct[3] = {0.1, 0.3, 0.5};
     for (int q = 0; q < 3; q++) c[q] = S::from_bits(B[(uint32_t)(pct[q] * (double)n_g)]);
     uint32_t sim[3] = {0, 0, 0};
-    for (uint32_t i = tid; i < n_g; i += 256) {
+    for (uint32_t i = tid; i < n_g; i += T) {
       const F x = S::from_bits(B[i]);
       for (int q = 0; q < 3; q++) if (fabs(x - c[q]) < (F)0.01 * c[q]) sim[q]++;
     }
@@ -276,7 +279,7 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
   F base_c = 0;
   if (has_euclid) {
     const F base = gcd_pick, inv = (F)1.0 / base;
-    for (uint32_t i = tid; i < kept; i += 256) {
+    for (uint32_t i = tid; i < kept; i += T) {
       const F x = S::from_bits(A[i]);
       const F mult = S::rnd(x * inv);
       const uint32_t me = (uint32_t)screen_exponent<F>(mult);
@@ -290,15 +293,17 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
     }
     __syncthreads();
     if (wave == 0) {
-      F tsum = 0, tw = 0;
+      // the weights are whole numbers <= 52 and their running sums stay below 2^24: every partial sum is exact in F, so the sum is the
+      // integer sum; the terms are added one by one in sample order
+      F tsum = 0; uint32_t wsum = 0;
       for (uint32_t i0 = 0; i0 < kept; i0 += 64) {
         const uint32_t i = i0 + lane;
         const uint32_t wb = i < kept ? (uint32_t)wq[i] : 0u;
         const F term = i < kept ? S::from_bits(B[i]) : (F)0;
-        const uint64_t valid = __ballot(wb != 0);
-        tsum = seq_add_lanes<F>(tsum, term, valid);
-        tw = seq_add_lanes<F>(tw, (F)(double)wb, valid);
+        tsum = seq_add_lanes<F>(tsum, term, __ballot(wb != 0));
+        wsum += wb;
       }
+      const F tw = (F)(double)wave_sum(wsum);
       base_c = base - tsum / tw;
     }
   }
@@ -308,7 +313,7 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
     r->has_euclid = has_euclid ? 1u : 0u; r->k = kpow; r->pad = 0; r->base_c = (uint64_t)S::to_bits(base_c);
   }
 }
-__global__ __launch_bounds__(256) void auto_float_stats_kernel(const FloatStatsTask* tasks, FloatStatsResult* out) {
+__global__ __launch_bounds__(kAutoT) void auto_float_stats_kernel(const FloatStatsTask* tasks, FloatStatsResult* out) {
   const FloatStatsTask g = tasks[blockIdx.x];
   if (dtype_bits(g.dtype) == 64) float_stage1<double>(g, out + blockIdx.x, enc_lds_base());
   else float_stage1<float>(g, out + blockIdx.x, enc_lds_base());

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kSelT) void enc_hist_select_kernel(EncWorkspace ws,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// enc_hist_small_kernel: wide-range variables of at most kSelSortCap latents (the 6.6 k-latent samples of the Auto-delta trials,
+// enc_hist_small_kernel: variables of at most kSelSortCap latents whose value range is beyond enc_hist_kernel's counters (>= 4096) (the 6.6 k-latent samples of the Auto-delta trials,
 // short chunks).  The whole variable is ordered in LDS: keys are x - min, 32 bits wide whenever the range allows, sorted in
 // place by block_radix_sort_inplace, and the <= 256 rank queries read the sorted array directly.  LDS = the record area +
 // n keys (launcher: small_lds_bytes), so two to four blocks share a CU and hide each other's barriers and loads.
@@ -632,8 +632,15 @@ __device__ __forceinline__ void small_body(const EncWorkspace& ws, uint32_t t, u
   const uint64_t n64 = n_lat;
   auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
   __syncthreads();   // (the previous variable's records are done with)
+  // A chunk whose split left 16-bit latents (EncChunk::c16_ok == 1; its ranges are below 32768) has no full-width latents: like the
+  // counting kernels, read the 16-bit ones, leave them relative to the minimum and report the compact layout (hist_path 0).
+  const bool c16 = uni(ch->c16_ok) == 1 && var != 0;
+  uint16_t PCO_GLOBAL* clat = clat_ptr(ws, t, var);
+  const uint16_t c16_off = (uint16_t)((uint64_t)minv - (uint64_t)ch->c16_ref[var == 2 ? 1 : 0]);
+  auto value_at = [&](uint32_t i) { if (c16) { const uint16_t c = (uint16_t)(clat[i] - c16_off); clat[i] = c; return (K)c; } return (K)(L)(lat[i] - minv); };
   if (single_page) {   // stored latents = positions skip ..
-    for (uint32_t i = skip + tid; i < n_all; i += kSelT) srt[i - skip] = (K)(L)(lat[i] - minv);
+    for (uint32_t i = skip + tid; i < n_all; i += kSelT) srt[i - skip] = value_at(i);
+    if (c16) for (uint32_t i = tid; i < skip && i < n_all; i += kSelT) (void)value_at(i);
   } else {             // any order will do: one cursor bump per wave and round
     if (tid == 0) *cursor = 0;
     __syncthreads();
@@ -644,7 +651,9 @@ __device__ __forceinline__ void small_body(const EncWorkspace& ws, uint32_t t, u
       uint32_t at = 0;
       if (lane == 0 && m) at = atomicAdd((uint32_t*)cursor, (uint32_t)__popcll(m));
       at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-      if (on) srt[at + __popcll(m & (((uint64_t)1 << lane) - 1))] = (K)(L)(lat[i] - minv);
+      K v = 0;
+      if (i < n_all && (on || c16)) v = value_at(i);
+      if (on) srt[at + __popcll(m & (((uint64_t)1 << lane) - 1))] = v;
     }
   }
   __syncthreads();
@@ -665,7 +674,7 @@ __device__ __forceinline__ void small_body(const EncWorkspace& ws, uint32_t t, u
     rsucc[tid] = en < n_lat ? (L)(minv + (L)sc) : (L)0;
   }
   __syncthreads();
-  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u);
+  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, c16 ? 0u : 1u);
 }
 
 template <class L>
@@ -676,7 +685,7 @@ __device__ void small_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint
   if (n_lat == 0 || n_lat > kSelSortCap) return;
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   const uint64_t range = (uint64_t)(L)(maxv - minv);
-  if (range < kWideHistRange) return;   // the LDS-counting kernels own it
+  if (range < kDirectHistRange) return;   // enc_hist_kernel's value-space counting owns it
   if constexpr (sizeof(L) == 8) { if (range >> 32) { small_body<L, uint64_t>(ws, t, var, bins_log, ch, ev, n_lat, minv, maxv); return; } }
   small_body<L, uint32_t>(ws, t, var, bins_log, ch, ev, n_lat, minv, maxv);
 }
@@ -704,13 +713,13 @@ __global__ __launch_bounds__(kSelT, 8) void enc_hist_small_kernel(EncWorkspace w
 __global__ __launch_bounds__(kSelT, 8) void radix_probe32(uint32_t n, uint32_t sig) { block_radix_sort_inplace<uint32_t>((uint32_t PCO_LDS*)(enc_lds_base() + kHistLdsCounts), enc_lds_base(), n, sig); }
 __global__ __launch_bounds__(kSelT, 8) void radix_probe64(uint32_t n, uint32_t sig) { block_radix_sort_inplace<uint64_t>((uint64_t PCO_LDS*)(enc_lds_base() + kHistLdsCounts), enc_lds_base(), n, sig); }
 #endif
-// A/B switch (PCO_GFX_NO_HIST_SELECT): hand every wide-range variable to the radix-sort kernel
+// A/B switch (PCO_GFX_NO_HIST_SELECT): hand every long wide-range variable to the radix-sort kernel
 __global__ void enc_hist_flag_kernel(EncWorkspace ws, uint32_t n_tasks) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_tasks) return;
   EncChunk* ch = ws.chunks + t;
   if (ch->status != PCO_GFX_OK) return;
-  for (uint32_t var = 0; var < 3; var++) if (ch->v[var].present && ch->v[var].n_lat != 0 && ch->v[var].maxv - ch->v[var].minv >= kWideHistRange) ch->v[var].hist_path = 2;
+  for (uint32_t var = 0; var < 3; var++) if (ch->v[var].present && ch->v[var].n_lat > kSmallHistCap && ch->v[var].maxv - ch->v[var].minv >= kWideHistRange) ch->v[var].hist_path = 2;
 }
 
 }  // namespace pcogfx

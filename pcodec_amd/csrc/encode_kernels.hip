@@ -1037,9 +1037,12 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   // (what the launcher has to run after this kernel: bit 0 the select / sort kernels, bit 1 the 16384-counter kernel, bit 2 the 32768-counter one,
   //  bit 3 the whole-variable-in-LDS kernel)
   if (!kSort && !kWide && ch->big != 0 && tid == 0) atomicOr(ws.need_sort, 1u);
-  if (!kSort && !kWide && ch->big == 0 && (uint64_t)range >= kDirectHistRange && tid == 0) atomicOr(ws.need_sort, (uint64_t)range >= kWideHistRange ? (n_lat <= kSmallHistCap ? 8u : 1u) : ((uint64_t)range >= kMidHistRange ? 4u : 2u));
+  if (!kSort && !kWide && ch->big == 0 && (uint64_t)range >= kDirectHistRange && tid == 0) atomicOr(ws.need_sort, n_lat <= kSmallHistCap ? 8u : ((uint64_t)range >= kWideHistRange ? 1u : ((uint64_t)range >= kMidHistRange ? 4u : 2u)));
   const bool big = ch->big != 0;   // more than 256 bins: every variable of the chunk takes the sort path, whatever its range
   if (!kSort && big) return;
+  // short variables beyond the first counting tier (the Auto-delta trial samples, mostly) are cheaper to order whole in LDS than to count in
+  // 16 k - 32 k counters: enc_hist_small_kernel
+  if (!big && (kWide || kSort) && n_lat <= kSmallHistCap) return;
   if (!big && (kSort ? (uint64_t)range < kWideHistRange : (kWide ? ((uint64_t)range < (R == kWideHistRange ? kMidHistRange : kDirectHistRange) || (uint64_t)range >= R) : (uint64_t)range >= kDirectHistRange))) return;
   if (kSort && !big && ev->hist_path != 2) return;   // the radix-sort path is the fallback of enc_hist_select_kernel (encode_hist_select.hip), which flags what it gave up on
   // Stored latents = every position that is not among the first `skip` of its page (wrapped/chunk_compressor.rs:129-140).

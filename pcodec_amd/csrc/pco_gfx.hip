@@ -359,7 +359,7 @@ extern "C" int pco_gfx_debug_float_screen(const void* values, size_t n, uint32_t
     static FloatStatsResult r;
     if (hipMemcpy(d_vals, values, n * eb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_idx, idx.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_task, &t, sizeof(t), hipMemcpyHostToDevice) != hipSuccess) rc = PCO_GFX_DEVICE_ERROR;
     else {
-      hipLaunchKernelGGL(auto_float_stats_kernel, dim3(1), dim3(256), kAutoStage1LdsBytes, 0, d_task, d_res);
+      hipLaunchKernelGGL(auto_float_stats_kernel, dim3(1), dim3(kAutoT), kAutoStage1LdsBytes, 0, d_task, d_res);
       if (hipMemcpy(&r, d_res, sizeof(r), hipMemcpyDeviceToHost) != hipSuccess) rc = PCO_GFX_DEVICE_ERROR;
       else {
         out[0] = r.s_size; out[1] = r.tz5; out[2] = r.n_gcd; out[3] = r.sim[0]; out[4] = r.sim[1]; out[5] = r.sim[2]; for (int i = 0; i < 56; i++) out[6 + i] = r.hist[i];
