@@ -44,7 +44,7 @@ __device__ __forceinline__ uint16_t PCO_GLOBAL* fansw_ptr(const EncWorkspace& ws
 }
 
 // The page's view of one variable (as in page_task)
-struct PageVar { uint32_t present, n_bins, asl, max_ob, needs_ans, trivial, skip, n_lat, compact; uint64_t minv; };
+struct PageVar { uint32_t present, n_bins, asl, max_ob, needs_ans, trivial, skip, n_lat, compact; uint64_t minv, rel; };   // rel: what the compact (16-bit) latents are relative to
 __device__ __forceinline__ PageVar page_var(const EncChunk PCO_GLOBAL* ch, uint32_t v, uint32_t page_n) {
   PageVar r;
   r.present = uni(ch->v[v].present); r.n_bins = uni(ch->v[v].n_bins); r.asl = uni(ch->v[v].ans_size_log); r.max_ob = uni(ch->v[v].max_ob);
@@ -54,6 +54,8 @@ __device__ __forceinline__ PageVar page_var(const EncChunk PCO_GLOBAL* ch, uint3
   r.n_lat = page_n - r.skip;
   r.compact = uni(ch->v[v].hist_path) == 0 ? 1u : 0u;   // histogram by LDS counting: compact latents exist (clat_ptr)
   r.minv = uni((uint64_t)ch->v[v].minv);
+  // compact latents: the histogram's copy relative to the minimum, or -- when the split speculated on 16-bit latents and held -- the split's own, relative to c16_ref
+  r.rel = v != 0 && uni(ch->c16_ok) == 1 ? uni(ch->c16_ref[v == 2 ? 1 : 0]) : r.minv;
   return r;
 }
 
@@ -138,7 +140,7 @@ __device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncF
     const PlanRef plan = plan_ref(ws, t, v);
     const uint64_t range = uni((uint64_t)ch->v[v].maxv) - pv[v].minv;
     use_lut[v] = range < kDirectHistRange;
-    rel0[v] = pv[v].compact ? pv[v].minv : 0ull;
+    rel0[v] = pv[v].compact ? pv[v].rel : 0ull;
     uint8_t PCO_LDS* vt = smem + v * kDisVarBytes;
     const uint32_t b = threadIdx.x;  // 256 threads: one padded bin each; lowers as u64 relative to rel0, padded with the maximum
     ((uint64_t PCO_LDS*)vt)[b] = b < pv[v].n_bins ? (uint64_t)plan.blower()[b] - rel0[v] : ~0ull;
@@ -685,7 +687,7 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
     if (!on[v]) continue;
     const PlanRef plan = plan_ref(ws, t, v);
     uint8_t PCO_LDS* vt = smem + kPackLdsVar + ws.slot_of_var[v] * kPackVarBytes;
-    const uint64_t rel0 = pv[v].compact ? pv[v].minv : 0ull;   // compact latents are relative to the minimum
+    const uint64_t rel0 = pv[v].compact ? pv[v].rel : 0ull;   // compact latents are relative to the minimum
     for (uint32_t b = lane; b < pv[v].n_bins; b += 64) {
       const uint64_t lw = plan.blower()[b] - rel0; const uint32_t ob = plan.bob()[b];
       ((uint64_t PCO_LDS*)vt)[b] = lw; (vt + 2048)[b] = (uint8_t)ob;

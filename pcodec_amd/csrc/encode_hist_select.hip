@@ -633,14 +633,13 @@ __device__ __forceinline__ void small_body(const EncWorkspace& ws, uint32_t t, u
   auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
   __syncthreads();   // (the previous variable's records are done with)
   // A chunk whose split left 16-bit latents (EncChunk::c16_ok == 1; its ranges are below 32768) has no full-width latents: like the
-  // counting kernels, read the 16-bit ones, leave them relative to the minimum and report the compact layout (hist_path 0).
+  // counting kernels, read the 16-bit ones (relative to c16_ref) and report the compact layout (hist_path 0).
   const bool c16 = uni(ch->c16_ok) == 1 && var != 0;
   uint16_t PCO_GLOBAL* clat = clat_ptr(ws, t, var);
   const uint16_t c16_off = (uint16_t)((uint64_t)minv - (uint64_t)ch->c16_ref[var == 2 ? 1 : 0]);
-  auto value_at = [&](uint32_t i) { if (c16) { const uint16_t c = (uint16_t)(clat[i] - c16_off); clat[i] = c; return (K)c; } return (K)(L)(lat[i] - minv); };
+  auto value_at = [&](uint32_t i) { return c16 ? (K)(uint16_t)(clat[i] - c16_off) : (K)(L)(lat[i] - minv); };
   if (single_page) {   // stored latents = positions skip ..
     for (uint32_t i = skip + tid; i < n_all; i += kSelT) srt[i - skip] = value_at(i);
-    if (c16) for (uint32_t i = tid; i < skip && i < n_all; i += kSelT) (void)value_at(i);
   } else {             // any order will do: one cursor bump per wave and round
     if (tid == 0) *cursor = 0;
     __syncthreads();
@@ -651,9 +650,7 @@ __device__ __forceinline__ void small_body(const EncWorkspace& ws, uint32_t t, u
       uint32_t at = 0;
       if (lane == 0 && m) at = atomicAdd((uint32_t*)cursor, (uint32_t)__popcll(m));
       at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-      K v = 0;
-      if (i < n_all && (on || c16)) v = value_at(i);
-      if (on) srt[at + __popcll(m & (((uint64_t)1 << lane) - 1))] = v;
+      if (on) srt[at + __popcll(m & (((uint64_t)1 << lane) - 1))] = value_at(i);
     }
   }
   __syncthreads();

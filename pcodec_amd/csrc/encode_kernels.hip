@@ -371,8 +371,8 @@ __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const Pco
     auto clamp_ref = [&](L x) { return sizeof(L) == 1 ? (L)0 : (x < kBias ? kBias : (x > (L)(kLmax - kBias) ? (L)(kLmax - kBias) : x)); };
     L ref1 = sizeof(L) == 1 ? (L)0 : toggle, ref2 = 0;
     if (order == 0 || has_sec) { L p0, s0; split_one<L, MODE>(num_kind, mode_base, mode_k, aux_inv, aux_base, ((const L PCO_GLOBAL*)task.src)[0], p0, s0); if (order == 0) ref1 = clamp_ref(p0); ref2 = clamp_ref(s0); }
-    if (pstart == 0 && e0 == 0) { ch->c16_ref[0] = (uint64_t)ref1; ch->c16_ref[1] = (uint64_t)ref2; }
-    const L lo1 = (L)(ref1 - kBias), lo2 = (L)(ref2 - kBias);
+    const L lo1 = (L)(ref1 - kBias), lo2 = (L)(ref2 - kBias);   // what the 16-bit latents are relative to: they lie in [0, 2^15)
+    if (pstart == 0 && e0 == 0) { ch->c16_ref[0] = (uint64_t)lo1; ch->c16_ref[1] = (uint64_t)lo2; }
     uint16_t PCO_GLOBAL* c1 = clat_ptr(ws, t, 1) + pstart;
     uint16_t PCO_GLOBAL* c2 = has_sec ? clat_ptr(ws, t, 2) + pstart : nullptr;
     uint32_t bad = 0, rmin1 = 0xffffffffu, rmax1 = 0, rmin2 = 0xffffffffu, rmax2 = 0;
@@ -382,12 +382,12 @@ __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const Pco
       const uint64_t i = e0 + k;
       const L t1 = (L)(d[k] - lo1);
       const uint32_t u1 = (uint32_t)t1;
-      w1[k] = (uint16_t)(u1 - (uint32_t)kBias);
+      w1[k] = (uint16_t)u1;
       if (i < n && i >= order) { if ((uint64_t)t1 >= 32768u) bad = 1; rmin1 = u1 < rmin1 ? u1 : rmin1; rmax1 = u1 > rmax1 ? u1 : rmax1; }
       if (has_sec) {
         const L t2 = (L)(sec[k] - lo2);
         const uint32_t u2 = (uint32_t)t2;
-        w2[k] = (uint16_t)(u2 - (uint32_t)kBias);
+        w2[k] = (uint16_t)u2;
         if (i < n) { if ((uint64_t)t2 >= 32768u) bad = 1; rmin2 = u2 < rmin2 ? u2 : rmin2; rmax2 = u2 > rmax2 ? u2 : rmax2; }
       }
     }
@@ -1078,10 +1078,10 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     {  // counting: 8 loads in flight per thread; the compact copy (x - min, u16) is written on the way
       uint16_t PCO_GLOBAL* clat = clat_ptr(ws, t, var);
       const bool agg = uni((uint32_t)((uint64_t)range < 256 ? 1u : 0u)) != 0;   // (wave-uniform) few distinct values: same-address atomics would serialise, aggregate per wave
-      const bool c16 = uni(ch->c16_ok) == 1;   // the split left 16-bit latents relative to c16_ref (in the compact copy's place)
+      const bool c16 = uni(ch->c16_ok) == 1 && var != 0;   // the split left 16-bit latents relative to c16_ref (in the compact copy's place)
       const uint16_t c16_off = (uint16_t)((uint64_t)minv - (uint64_t)ch->c16_ref[var == 2 ? 1 : 0]);
       uint32_t base = 0;
-      if (c16) {
+      if (c16) {   // (the 16-bit latents stay as the split wrote them, relative to c16_ref: the page kernels take that as their reference)
         for (; base + 8 * T <= n_all; base += 8 * T) {
           uint16_t x[8];
 #pragma unroll
@@ -1089,9 +1089,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
 #pragma unroll
           for (int k = 0; k < 8; k++) {
             const uint32_t i = base + k * T + tid;
-            const uint32_t c = (uint16_t)(x[k] - c16_off);
-            clat[i] = (uint16_t)c;
-            hist_count(counts, c, stored(i), agg);
+            hist_count(counts, (uint32_t)(uint16_t)(x[k] - c16_off), stored(i), agg);
           }
         }
       } else {
@@ -1111,7 +1109,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
       for (uint32_t i0 = base; i0 < n_all; i0 += T) {   // whole waves enter hist_count
         const uint32_t i = i0 + tid;
         const uint32_t c = i < n_all ? (c16 ? (uint32_t)(uint16_t)(clat[i] - c16_off) : (uint32_t)(lat[i] - minv)) : 0u;
-        if (i < n_all) clat[i] = (uint16_t)c;
+        if (i < n_all && !c16) clat[i] = (uint16_t)c;
         hist_count(counts, c, i < n_all && stored(i), agg);
       }
     }
