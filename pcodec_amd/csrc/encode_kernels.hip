@@ -651,24 +651,44 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
 #ifdef PCO_LB_TIMING
   unsigned long long lb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lb_t0 = __builtin_readcyclecounter(), lb_rounds = 0;
 #endif
+  // A tile's latents and the last-index table entries of its six hash proposals per element: two dependent HBM round trips.  They are
+  // fetched one tile ahead -- right after the previous tile has sent its own table updates, which the reads must observe (same wave,
+  // same addresses, in order at L2) -- so that they travel while that tile is being decided.
+  auto tile_slots = [&](uint64_t lv_, uint32_t (&slot_)[6]) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const uint64_t bucket = lv_ >> (c == 0 ? 0 : 8);
+      slot_[3 * c + 0] = c * hash_table_n + hash_fn(bucket - 1);
+      slot_[3 * c + 1] = c * hash_table_n + hash_fn(bucket);
+      slot_[3 * c + 2] = c * hash_table_n + hash_fn(bucket + 1);
+    }
+  };
+  auto tile_fetch = [&](uint32_t i0t, uint64_t& lv_, uint32_t (&val_)[6]) {
+    const bool a = i0t < n && lane < n - i0t;
+    lv_ = a ? (uint64_t)pre[i0t + lane] : 0ull;
+    uint32_t sl[6]; tile_slots(lv_, sl);
+#pragma unroll
+    for (int r = 0; r < 6; r++) val_[r] = a ? __hip_atomic_load(&hash_tbl[sl[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // L2-served: earlier tiles updated it with atomics
+  };
+  uint64_t pf_lv; uint32_t pf_val[6];
+  tile_fetch(state_n, pf_lv, pf_val);
+  bool pend_act = false; uint32_t pend_ie = 0; L pend_lv = 0, pend_other = 0;   // the previous tile's apply step, its read in flight
+  auto apply_pending = [&]() {
+    if (pend_act) { const L d = (L)(pend_lv - pend_other + lmid<L>()); out[pend_ie] = d; mn1 = d < mn1 ? d : mn1; mx1 = d > mx1 ? d : mx1; }
+    pend_act = false;
+  };
   for (uint32_t i0 = state_n; i0 < n; i0 += 64) {
     const uint32_t tile_n = n - i0 < 64 ? n - i0 : 64;
     const bool first_tile = i0 == state_n;
     // ---- phase 1: hash proposals of the whole tile ----
     const uint32_t ie = i0 + lane;
     const bool act = lane < tile_n;
-    const uint64_t lv = act ? (uint64_t)pre[ie] : 0ull;
+    const uint64_t lv = pf_lv;
     if (act) ring[ie & (kLbRing - 1)] = lv;
     uint32_t slot[6], val[6], plb[6];
+    tile_slots(lv, slot);
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-      const uint64_t bucket = lv >> (c == 0 ? 0 : 8);
-      slot[3 * c + 0] = c * hash_table_n + hash_fn(bucket - 1);
-      slot[3 * c + 1] = c * hash_table_n + hash_fn(bucket);
-      slot[3 * c + 2] = c * hash_table_n + hash_fn(bucket + 1);
-    }
-#pragma unroll
-    for (int r = 0; r < 6; r++) val[r] = act ? __hip_atomic_load(&hash_tbl[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // L2-served: earlier tiles updated it with atomics
+    for (int r = 0; r < 6; r++) val[r] = pf_val[r];
     LB_STAMP(0);
     // in-tile hazards: an earlier element of the tile wrote its centre bucket (slot[1] / slot[4]) before we read: each of my six
     // slots needs the LAST earlier lane whose centre slot (same table) equals it.  Eight wave votes per table give every lane the set
@@ -709,6 +729,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
     }
     LB_STAMP(1);
     if (act) { atomicMax((uint32_t*)&hash_tbl[slot[1]], ie); atomicMax((uint32_t*)&hash_tbl[slot[4]], ie); }
+    tile_fetch(i0 + 64, pf_lv, pf_val);   // the next tile's (nothing past the page's end)
 #pragma unroll
     for (int r = 0; r < 6; r++) {
       const uint32_t lb = ie - val[r];
@@ -784,12 +805,34 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
       for (int k = 0; k < 6; k++) s_lb[k] = (uint32_t)k + 1;           // brute force: 1..6 (the page is past position 16)
 #pragma unroll
       for (int r = 0; r < 6; r++) s_lb[6 + r] = plb[r];
+      // Every candidate's latent, and the far candidates' counts: all the reads are issued before any is used.  Both the LDS ring and HBM
+      // are read for every candidate, unconditionally -- the HBM read of a near candidate goes to the element itself, a cache hit -- because a
+      // per-lane "near or far" branch around each read made the 22 reads of a tile wait for one another (12 k cycles per tile at four
+      // pages per CU: scripts/lb_timing.py).
+      {
+        const uint32_t ie_s = act ? ie : i0;   // (lanes past the page's end read a valid position)
+        uint32_t all_lb[16];
 #pragma unroll
-      for (int k = 0; k < 12; k++) s_lz[k] = act ? lz_of(l, latent_back(ie, s_lb[k])) : 0u;
+        for (int k = 0; k < 12; k++) all_lb[k] = s_lb[k];
+        all_lb[12] = ring_lb0; all_lb[13] = ring_lb1; all_lb[14] = ring_lb2; all_lb[15] = ring_lb3;
+        L c_near[16], c_hbm[16]; uint32_t far_cnt[6];
 #pragma unroll
-      for (int r = 0; r < 6; r++) c_far[r] = act && plb[r] - 1 >= kLbCountsLds ? __hip_atomic_load(&gcounts[plb[r] - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      r_lz0 = act ? lz_of(l, latent_back(ie, ring_lb0)) : 0u; r_lz1 = act ? lz_of(l, latent_back(ie, ring_lb1)) : 0u;
-      r_lz2 = act ? lz_of(l, latent_back(ie, ring_lb2)) : 0u; r_lz3 = act ? lz_of(l, latent_back(ie, ring_lb3)) : 0u;
+        for (int k = 0; k < 16; k++) {
+          const bool far = act && all_lb[k] >= kLbRing - 64;
+          c_near[k] = (L)ring[(ie_s - all_lb[k]) & (kLbRing - 1)];
+          c_hbm[k] = pre[ie_s - (far ? all_lb[k] : 0u)];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) far_cnt[r] = __hip_atomic_load(&gcounts[act && plb[r] - 1 >= kLbCountsLds ? plb[r] - 1 : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t lz_all[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) lz_all[k] = act ? lz_of(l, all_lb[k] >= kLbRing - 64 ? c_hbm[k] : c_near[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < 12; k++) s_lz[k] = lz_all[k];
+        r_lz0 = lz_all[12]; r_lz1 = lz_all[13]; r_lz2 = lz_all[14]; r_lz3 = lz_all[15];
+#pragma unroll
+        for (int r = 0; r < 6; r++) c_far[r] = act && plb[r] - 1 >= kLbCountsLds ? far_cnt[r] : 0u;
+      }
       LB_STAMP(2);
       uint32_t e_start = 0;
       // count `lb` += k for everything that mirrors it
@@ -848,16 +891,14 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
       enc_wave_sync();
       LB_STAMP(3);
     }
-    if (act) lbs[ie] = my_lb;
-    // ---- apply (lookback.rs:166-185): l[i] -= l[i - lb], + MID; reads the un-delta'd copy so it is parallel ----
-    if (act) {
-      const uint32_t lb = my_lb;
-      const L d = (L)((L)lv - pre[ie - lb] + lmid<L>());
-      out[ie] = d;
-      mn1 = d < mn1 ? d : mn1; mx1 = d > mx1 ? d : mx1; mn0 = lb < mn0 ? lb : mn0; mx0 = lb > mx0 ? lb : mx0;
-    }
+    if (act) { lbs[ie] = my_lb; mn0 = my_lb < mn0 ? my_lb : mn0; mx0 = my_lb > mx0 ? my_lb : mx0; }
+    // ---- apply (lookback.rs:166-185): l[i] -= l[i - lb], + MID; reads the un-delta'd copy so it is parallel.  The read of l[i - lb] is
+    //      sent now and used one tile later, after that tile's own reads have gone out: nothing waits for it on its own ----
+    apply_pending();
+    pend_act = act; pend_ie = ie; pend_lv = (L)lv; pend_other = pre[act ? ie - my_lb : i0];
     LB_STAMP(4);
   }
+  apply_pending();
 #ifdef PCO_LB_TIMING
   if (lane == 0) { for (int k = 0; k < 5; k++) atomicAdd(&g_lb_timing[k], lb_acc[k]); atomicAdd(&g_lb_timing[5], lb_rounds); atomicAdd(&g_lb_timing[6], (unsigned long long)((n - state_n + 63) / 64)); atomicAdd(&g_lb_timing[7], 1ull); }
 #endif

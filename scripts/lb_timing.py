@@ -20,3 +20,5 @@ run("i64 seasonal x1024", [U.synth("c4", seed=s) for s in range(1024)], dict(mod
 run("i64 seasonal x64", [U.synth("c4", seed=s) for s in range(64)], dict(mode=1, delta=3))
 run("u32 random x256", [rng.integers(0, 1 << 32, 1 << 18, dtype=np.uint64).astype(np.uint32) for _ in range(256)], dict(mode=1, delta=3))
 run("u64 ramp x256", [U.synth("c2", seed=s) for s in range(256)], dict(mode=1, delta=3))
+run("trial-sized: 2048 x u64 random ints 1000..10000 n=6563", [rng.integers(1000, 10000, 6563).astype(np.uint64) for _ in range(2048)], dict(mode=1, delta=3))
+run("trial-sized: 2048 x u64 noisy ramp n=6563", [U.synth("c2", seed=s)[:6563] for s in range(2048)], dict(mode=1, delta=3))
