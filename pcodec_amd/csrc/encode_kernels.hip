@@ -586,7 +586,7 @@ __global__ __launch_bounds__(64) void enc_presample_kernel(EncWorkspace ws, cons
 // once per tile.  Other state: last-index hash tables in HBM (2 x 2^(w+1) u32).
 // =========================================================================================================
 // LDS layout, in two sizes: the full one for real pages, and a small one for the 6.6 k-number sample pages of the Auto-delta
-// trials (thousands of them per call: at 12 KB instead of 31 KB per wave, 13 instead of 5 of them share a CU)
+// trials (thousands of them per call: at 9 KB instead of 18 KB per wave, 16 instead of 8 of them share a CU)
 template <uint32_t kCounts, uint32_t kRingN> struct LbCfg {
   static constexpr uint32_t kLbCountsLds = kCounts;
   static constexpr uint32_t kLbRing = kRingN;                        // must be >= 64 + the largest lookback served from LDS
@@ -599,7 +599,7 @@ template <uint32_t kCounts, uint32_t kRingN> struct LbCfg {
   static constexpr uint32_t kLbLdsBytes = kLbLdsBig + 64 * 4;
 };
 typedef LbCfg<1024, 1024> LbFull;   // 18 KB of LDS per page: eight pages per CU (lookbacks beyond ~960 read their latent and count from HBM)
-typedef LbCfg<512, 512> LbSmall;
+typedef LbCfg<256, 256> LbSmall;   // 9 KB: sixteen pages per CU (the register budget allows no more)
 constexpr uint32_t kLbSmallMaxPage = 8192;   // pages up to this size take the small layout
 
 struct LookbackScratch { uint32_t* hash; uint32_t* counts; };  // per page: hash[2 << (wlog+1)], counts[1 << wlog]
