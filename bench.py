@@ -295,6 +295,7 @@ def main():
             dist.barrier()
 
     # warm-up, with the reference bench's bitwise round-trip assertion (pco_cli/src/bench/codecs/mod.rs:176-189)
+    L.pco_gfx_profile_begin()   # (warm-up also fills the library's pool of timing events, so the timed steps create none)
     for w in range(max(args.warmup, 1)):
         encode(); decode()
     torch.cuda.synchronize()

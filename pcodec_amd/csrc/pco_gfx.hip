@@ -82,6 +82,9 @@ struct KernelProfile {
   bool on = false;
   struct Rec { const char* name; hipEvent_t a, b; };
   std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;   // events are reused from one profiled region to the next: creating two per launch showed up in host time
+  bool take(hipEvent_t& e) { if (!pool.empty()) { e = pool.back(); pool.pop_back(); return true; } return hipEventCreate(&e) == hipSuccess; }
+  void give(hipEvent_t e) { pool.push_back(e); }
 };
 static thread_local KernelProfile g_prof;
 struct ScopedKernelTimer {
@@ -89,7 +92,8 @@ struct ScopedKernelTimer {
   ScopedKernelTimer(const char* name, hipStream_t stream) : s(stream) {
     if (!g_prof.on) return;
     hipEvent_t a;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    if (!g_prof.take(a)) return;
+    if (!g_prof.take(b)) { g_prof.give(a); return; }
     (void)hipEventRecord(a, s);
     g_prof.recs.push_back({name, a, b}); live = true;
   }
@@ -189,7 +193,7 @@ void pco_gfx_release_workspace(void) { try { workspace().release_all(); } catch 
 // Kernel timing: begin() arms per-launch HIP events on this thread; end() synchronises and returns one
 // (name, milliseconds) pair per kernel launched since begin().  Names are written NUL-separated.
 void pco_gfx_profile_begin(void) {
-  for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto& r : g_prof.recs) { g_prof.give(r.a); g_prof.give(r.b); }
   g_prof.recs.clear(); g_prof.on = true;
 }
 int pco_gfx_profile_end(char* names, size_t names_cap, float* ms, int cap) {
@@ -205,7 +209,7 @@ int pco_gfx_profile_end(char* names, size_t names_cap, float* ms, int cap) {
       if (ms) ms[n] = t;
       n++;
     }
-    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    g_prof.give(r.a); g_prof.give(r.b);
   }
   g_prof.recs.clear();
   return n;
