@@ -191,6 +191,17 @@ def test_auto_mode_device_screens_agree_with_the_oracle(L):
                 want = O.simple_compress(nums, O.make_config(delta=1))
                 got = U.gpu_simple_compress(nums, G.make_config(delta=1))
                 if got != want: bad.append((name, n, frac))
+    # full-size chunks: 2^18 (a 6563-number sample, decided on the device) and 300 000 (7509: beyond the device kernels' capacity, host path),
+    # both specs Auto
+    for n in (1 << 18, 300000):
+        noise = rng.standard_normal(n) * 100
+        for name, nums in (("f64_decimals", np.round(noise, 2)), ("f32_eighths", (rng.integers(-30000, 30000, n) * 0.125).astype(np.float32)),
+                           ("f64_noise", noise), ("i64_multiples", (rng.integers(-10**6, 10**6, n) * 7919).astype(np.int64)),
+                           ("u32_noise", rng.integers(0, 1 << 32, n).astype(np.uint32))):
+            kw = dict(max_page_n=1 << 19)
+            want = O.simple_compress(nums, O.make_config(**kw))
+            got = U.gpu_simple_compress(nums, G.make_config(**kw))
+            if got != want: bad.append((name, n, "full size"))
     assert not bad, bad[:12]
 
 
@@ -276,6 +287,29 @@ def test_auto_float_screen_matches_an_ieee_reference(L):
                 got_bits = out[65] | (out[66] << 32)
                 want_bits = int(np.array([want]).view(np.uint32 if dt == np.float32 else np.uint64)[0])
                 assert got_bits == want_bits or (np.isnan(want) and True), (dt, kind, hex(got_bits), hex(want_bits))
+
+
+def test_auto_mode_host_path_stays_in_step(L):
+    """The host path of Auto mode detection (f16, samples beyond the device kernels' capacity, overflowing GCD lists) is the same code the
+    A/B switch PCO_GFX_AUTO_MODE_ON_HOST forces for everything: under it the same inputs must give the same bytes."""
+    import subprocess, sys
+    code = r'''
+import os, sys
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np, gpu_util as U, oracle_lib as O
+from pcodec_amd import _lib as G
+rng = np.random.default_rng(77)
+n = 40000
+noise = rng.standard_normal(n) * 100
+cases = [np.round(noise, 2), np.round(noise, 1).astype(np.float32), noise, (rng.integers(-10**6, 10**6, n) * 7919).astype(np.int64),
+         rng.integers(0, 1 << 32, n).astype(np.uint32), (noise.view(np.uint64) & ~np.uint64(0xFFFFFF)).view(np.float64), (rng.integers(0, 2000, n) * np.float16(0.1)).astype(np.float16)]
+for nums in cases:
+    assert U.gpu_simple_compress(nums, G.make_config()) == O.simple_compress(nums, O.make_config()), nums.dtype
+print("ok")
+'''
+    env = dict(os.environ, PCO_GFX_AUTO_MODE_ON_HOST="1")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(HERE, ".."), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_encode_matrix_small(L):
