@@ -610,6 +610,14 @@ __device__ unsigned long long g_lb_timing[16];
 #else
 #define LB_STAMP(idx) do { } while (0)
 #endif
+// One wave owns a page, and the LDS traffic of a wave is processed in order: between the steps of the search only the compiler has
+// to be kept from reordering.  (A workgroup-scope fence here also waited for every outstanding HBM read -- the next tile's latents and
+// table entries, the apply step's read -- and so undid the overlap they were sent early for.  HBM ordering that matters is between an
+// atomic and a later read of the same address by the same wave, which the memory pipeline keeps.)
+__device__ __forceinline__ void lb_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 template <class L, class Cfg>
 __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, uint32_t PCO_GLOBAL* hash_tbl, uint32_t PCO_GLOBAL* gcounts) {
   constexpr uint32_t kLbCountsLds = Cfg::kLbCountsLds, kLbRing = Cfg::kLbRing, kLbLdsCounts = Cfg::kLbLdsCounts, kLbLdsHp = Cfg::kLbLdsHp, kLbLdsRing = Cfg::kLbLdsRing;
@@ -663,14 +671,16 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
       slot_[3 * c + 2] = c * hash_table_n + hash_fn(bucket + 1);
     }
   };
-  auto tile_fetch = [&](uint32_t i0t, uint64_t& lv_, uint32_t (&val_)[6]) {
+  // (the latents do not depend on anything the search does, so they are read two tiles ahead: when the table reads of the next tile are
+  //  due, their addresses can be formed without waiting)
+  auto tile_latent = [&](uint32_t i0t) { return i0t < n && lane < n - i0t ? (uint64_t)pre[i0t + lane] : 0ull; };
+  auto tile_fetch = [&](uint32_t i0t, uint64_t lv_, uint32_t (&val_)[6]) {
     const bool a = i0t < n && lane < n - i0t;
-    lv_ = a ? (uint64_t)pre[i0t + lane] : 0ull;
     uint32_t sl[6]; tile_slots(lv_, sl);
 #pragma unroll
     for (int r = 0; r < 6; r++) val_[r] = a ? __hip_atomic_load(&hash_tbl[sl[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // L2-served: earlier tiles updated it with atomics
   };
-  uint64_t pf_lv; uint32_t pf_val[6];
+  uint64_t pf_lv = tile_latent(state_n), pf2_lv = tile_latent(state_n + 64); uint32_t pf_val[6];
   tile_fetch(state_n, pf_lv, pf_val);
   bool pend_act = false; uint32_t pend_ie = 0; L pend_lv = 0, pend_other = 0;   // the previous tile's apply step, its read in flight
   auto apply_pending = [&]() {
@@ -729,6 +739,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
     }
     LB_STAMP(1);
     if (act) { atomicMax((uint32_t*)&hash_tbl[slot[1]], ie); atomicMax((uint32_t*)&hash_tbl[slot[4]], ie); }
+    pf_lv = pf2_lv; pf2_lv = tile_latent(i0 + 128);
     tile_fetch(i0 + 64, pf_lv, pf_val);   // the next tile's (nothing past the page's end)
 #pragma unroll
     for (int r = 0; r < 6; r++) {
@@ -747,7 +758,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
         if (act && plb[r] - 1 >= kLbCountsLds) hp_cnt[lane * 6 + r] = __hip_atomic_load(&gcounts[plb[r] - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       uint32_t n_big = 0;   // uniform
-      enc_wave_sync();
+      lb_sync();
       for (uint32_t e = 0; e < tile_n; e++) {
         const uint32_t i = i0 + e;
         const L l = (L)ring[i & (kLbRing - 1)];   // uniform
@@ -781,11 +792,11 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
         if (lane == e) my_lb = new_best;
         if (new_best - 1 < kLbCountsLds) { if (lane == 0) lcounts[new_best - 1] += 1; }
         else { if (lane == 0) big[n_big] = new_best; n_big++; }
-        enc_wave_sync();
+        lb_sync();
       }
       if (lane < n_big) atomicAdd((uint32_t*)&gcounts[big[lane] - 1], 1u);   // publish before the next tile prefetches counts
-      __threadfence_block();
-      enc_wave_sync();
+      
+      lb_sync();
       // hand the state over to the tile-parallel path
       ring_lb0 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 6); ring_lb1 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 7);
       ring_lb2 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 8); ring_lb3 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 9);
@@ -870,7 +881,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
         uint64_t mism = __ballot(act && lane >= e_start && best != B);
         const uint32_t e_star = mism ? (uint32_t)__builtin_ctzll(mism) : tile_n;
         if (lane >= e_start && lane < e_star) my_lb = B;
-        enc_wave_sync();   // (the counts were read by every lane before lane 0 changes them)
+        lb_sync();   // (the counts were read by every lane before lane 0 changes them)
         const uint32_t nb = add_count(B, e_star - e_start);
         if (nb) cnt_best = nb;
         if (e_star >= tile_n) break;
@@ -884,11 +895,11 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
         cnt_best = add_count(c, 1u);
         best_lookback = c;
         e_start = e_star + 1;
-        enc_wave_sync();
+        lb_sync();
         if (e_start >= tile_n) break;
       }
-      __threadfence_block();
-      enc_wave_sync();
+      
+      lb_sync();
       LB_STAMP(3);
     }
     if (act) { lbs[ie] = my_lb; mn0 = my_lb < mn0 ? my_lb : mn0; mx0 = my_lb > mx0 ? my_lb : mx0; }

@@ -19,6 +19,6 @@ run c5gather --workload c5 --gather --steps 5 --warmup 1 --no-cpu-baseline "$@"
 run c3 --workload c3 --steps 5 --warmup 1 "$@"
 run c1 --workload c1 --steps 5 --warmup 1 --chunks 8192 "$@"
 run c4 --workload c4 --steps 3 --warmup 1 --chunks 1024 "$@"
-run c2auto --workload c2auto --steps 5 --warmup 1 --chunks 8192 --no-cpu-baseline "$@"
-run c3auto --workload c3auto --steps 5 --warmup 1 --chunks 8192 --no-cpu-baseline "$@"
-run c5auto --workload c5auto --steps 5 --warmup 1 --no-cpu-baseline "$@"
+run c2auto --workload c2auto --steps 5 --warmup 2 --chunks 8192 --no-cpu-baseline "$@"
+run c3auto --workload c3auto --steps 5 --warmup 2 --chunks 8192 --no-cpu-baseline "$@"
+run c5auto --workload c5auto --steps 5 --warmup 2 --no-cpu-baseline "$@"
