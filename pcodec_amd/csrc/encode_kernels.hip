@@ -614,6 +614,10 @@ __device__ unsigned long long g_lb_timing[16];
 // to be kept from reordering.  (A workgroup-scope fence here also waited for every outstanding HBM read -- the next tile's latents and
 // table entries, the apply step's read -- and so undid the overlap they were sent early for.  HBM ordering that matters is between an
 // atomic and a later read of the same address by the same wave, which the memory pipeline keeps.)
+// The last-index tables and far counts of a page are private to the wave that owns the page for the whole kernel: workgroup scope is all
+// their atomics and reads need.  (At agent scope every access went past the XCD's L2 to the memory side for cross-XCD coherence nobody
+// asked for.)
+constexpr int kLbScope = __HIP_MEMORY_SCOPE_WORKGROUP;
 __device__ __forceinline__ void lb_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -678,7 +682,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
     const bool a = i0t < n && lane < n - i0t;
     uint32_t sl[6]; tile_slots(lv_, sl);
 #pragma unroll
-    for (int r = 0; r < 6; r++) val_[r] = a ? __hip_atomic_load(&hash_tbl[sl[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // L2-served: earlier tiles updated it with atomics
+    for (int r = 0; r < 6; r++) val_[r] = a ? __hip_atomic_load(&hash_tbl[sl[r]], __ATOMIC_RELAXED, kLbScope) : 0u;  // L2-served: earlier tiles updated it with atomics
   };
   uint64_t pf_lv = tile_latent(state_n), pf2_lv = tile_latent(state_n + 64); uint32_t pf_val[6];
   tile_fetch(state_n, pf_lv, pf_val);
@@ -738,7 +742,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
       }
     }
     LB_STAMP(1);
-    if (act) { atomicMax((uint32_t*)&hash_tbl[slot[1]], ie); atomicMax((uint32_t*)&hash_tbl[slot[4]], ie); }
+    if (act) { (void)__hip_atomic_fetch_max(&hash_tbl[slot[1]], ie, __ATOMIC_RELAXED, kLbScope); (void)__hip_atomic_fetch_max(&hash_tbl[slot[4]], ie, __ATOMIC_RELAXED, kLbScope); }
     pf_lv = pf2_lv; pf2_lv = tile_latent(i0 + 128);
     tile_fetch(i0 + 64, pf_lv, pf_val);   // the next tile's (nothing past the page's end)
 #pragma unroll
@@ -755,7 +759,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
       for (int r = 0; r < 6; r++) {
         hp[lane * 6 + r] = plb[r];
         if (act && plb[r] >= kLbRing - 64) hp_other[lane * 6 + r] = (uint64_t)pre[ie - plb[r]];
-        if (act && plb[r] - 1 >= kLbCountsLds) hp_cnt[lane * 6 + r] = __hip_atomic_load(&gcounts[plb[r] - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (act && plb[r] - 1 >= kLbCountsLds) hp_cnt[lane * 6 + r] = __hip_atomic_load(&gcounts[plb[r] - 1], __ATOMIC_RELAXED, kLbScope);
       }
       uint32_t n_big = 0;   // uniform
       lb_sync();
@@ -775,7 +779,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
           else other = pre[i - lb];
           if (lb - 1 < kLbCountsLds) cnt = lcounts[lb - 1];
           else {  // count at the tile start + the times this lookback was chosen earlier in the tile
-            cnt = hashed ? hp_cnt[e * 6 + (lane - 10)] : __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cnt = hashed ? hp_cnt[e * 6 + (lane - 10)] : __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, kLbScope);
             for (uint32_t k = 0; k < n_big; k++) cnt += big[k] == lb ? 1u : 0u;
           }
           const uint32_t goodness = (32u - clz_u32(cnt)) + lz_of(l, other);
@@ -794,13 +798,13 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
         else { if (lane == 0) big[n_big] = new_best; n_big++; }
         lb_sync();
       }
-      if (lane < n_big) atomicAdd((uint32_t*)&gcounts[big[lane] - 1], 1u);   // publish before the next tile prefetches counts
+      if (lane < n_big) (void)__hip_atomic_fetch_add(&gcounts[big[lane] - 1], 1u, __ATOMIC_RELAXED, kLbScope);   // publish before the next tile prefetches counts
       
       lb_sync();
       // hand the state over to the tile-parallel path
       ring_lb0 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 6); ring_lb1 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 7);
       ring_lb2 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 8); ring_lb3 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 9);
-      auto count_now = [&](uint32_t lb) { return uni(lb - 1 < kLbCountsLds ? lcounts[lb - 1] : __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+      auto count_now = [&](uint32_t lb) { return uni(lb - 1 < kLbCountsLds ? lcounts[lb - 1] : __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, kLbScope)); };
       ring_c0 = count_now(ring_lb0); ring_c1 = count_now(ring_lb1); ring_c2 = count_now(ring_lb2); ring_c3 = count_now(ring_lb3);
       cnt_best = count_now(best_lookback);
     } else {
@@ -834,7 +838,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
           c_hbm[k] = pre[ie_s - (far ? all_lb[k] : 0u)];
         }
 #pragma unroll
-        for (int r = 0; r < 6; r++) far_cnt[r] = __hip_atomic_load(&gcounts[act && plb[r] - 1 >= kLbCountsLds ? plb[r] - 1 : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = 0; r < 6; r++) far_cnt[r] = __hip_atomic_load(&gcounts[act && plb[r] - 1 >= kLbCountsLds ? plb[r] - 1 : 0u], __ATOMIC_RELAXED, kLbScope);
         uint32_t lz_all[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) lz_all[k] = act ? lz_of(l, all_lb[k] >= kLbRing - 64 ? c_hbm[k] : c_near[k]) : 0u;
@@ -852,7 +856,7 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
         uint32_t now;
         if (lb - 1 < kLbCountsLds) { now = uni(lcounts[lb - 1]) + k; if (lane == 0) lcounts[lb - 1] = now; }
         else {
-          uint32_t old = 0; if (lane == 0) old = atomicAdd((uint32_t*)&gcounts[lb - 1], k);
+          uint32_t old = 0; if (lane == 0) old = __hip_atomic_fetch_add(&gcounts[lb - 1], k, __ATOMIC_RELAXED, kLbScope);
           now = uni(old) + k;
 #pragma unroll
           for (int r = 0; r < 6; r++) c_far[r] += plb[r] == lb ? k : 0u;
