@@ -11,7 +11,7 @@ import fuzz_util
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-bad, skipped, fails = fuzz_util.run(n_cases, seed, only_8bit=os.environ.get("FUZZ_8BIT") is not None)
+bad, skipped, fails = fuzz_util.run(n_cases, seed, only_8bit=os.environ.get("FUZZ_8BIT") is not None, max_level=12)
 print(f"cases {n_cases} skipped {sum(skipped.values())} {skipped} bad {len(bad)}")
 if fails:
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
