@@ -930,15 +930,17 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
 }
 
 template <class Cfg>
-__global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, uint32_t n_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32) {
-  const uint32_t p = blockIdx.x;
-  if (p >= n_pages) return;
+// grid = the lookback pages only (page_ids lists them): a launch over all pages left the blocks of the other pages to exit at once, and
+// with the lookback trial at every 4th page of an Auto-delta wave all the work landed on the two XCDs that blocks 1 and 5 (mod 8) go to.
+__global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32) {
+  if (blockIdx.x >= n_lb_pages) return;
+  const uint32_t p = page_ids[blockIdx.x];
   EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
   if (uni(pg->flags) & kPageFlagMetaOnly) return;
   const uint32_t t = uni(pg->chunk);
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   if (uni(ch->status) != PCO_GFX_OK || uni(ch->delta_kind) != kDeltaLookback) return;
-  uint32_t PCO_GLOBAL* base = (uint32_t PCO_GLOBAL*)lb_scratch + (uint64_t)p * scratch_stride_u32;
+  uint32_t PCO_GLOBAL* base = (uint32_t PCO_GLOBAL*)lb_scratch + (uint64_t)blockIdx.x * scratch_stride_u32;
   const uint32_t wlog = uni(ch->window_n_log);
   uint32_t PCO_GLOBAL* hash_tbl = base; uint32_t PCO_GLOBAL* gcounts = base + (4ull << wlog);
   const int bits = dtype_bits(uni(ch->dtype));
