@@ -1,0 +1,116 @@
+"""-m "not gpu": the product's HOST-side arithmetic that never touches the device, compiled on its own with g++ and checked on the CPU:
+the binary16 type behind explicit f16 float-mult bases and f16 Auto (pcodec_amd/csrc/pco_half.h) against numpy's float16, and the
+host path of Auto mode detection (pco_auto_host.inc: f16, oversized samples, overflowing GCD lists) against the oracle's bids."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "pcodec_amd", "csrc")
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+
+
+def _build(tmp_path, name, source, extra=()):
+    src = tmp_path / (name + ".cpp"); src.write_text(source)
+    out = tmp_path / ("lib" + name + ".so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-w", "-o", str(out), str(src), *extra])
+    return C.CDLL(str(out))
+
+
+def test_host_binary16_matches_numpy(tmp_path):
+    lib = _build(tmp_path, "half", f'''
+#include "{CSRC}/pco_half.h"
+using namespace pcogfx;
+extern "C" {{
+  uint16_t h_from_f32(float f) {{ return F16::from_f32(f).bits; }}
+  uint16_t h_from_f64(double d) {{ return F16::from_f64(d).bits; }}
+  float h_to_f32(uint16_t b) {{ return F16::raw(b).to_f32(); }}
+  uint16_t h_mul(uint16_t a, uint16_t b) {{ return (F16::raw(a) * F16::raw(b)).bits; }}
+  uint16_t h_div(uint16_t a, uint16_t b) {{ return (F16::raw(a) / F16::raw(b)).bits; }}
+}}''')
+    lib.h_from_f32.restype = C.c_uint16; lib.h_from_f32.argtypes = [C.c_float]
+    lib.h_from_f64.restype = C.c_uint16; lib.h_from_f64.argtypes = [C.c_double]
+    lib.h_to_f32.restype = C.c_float; lib.h_to_f32.argtypes = [C.c_uint16]
+    for f in (lib.h_mul, lib.h_div): f.restype = C.c_uint16; f.argtypes = [C.c_uint16, C.c_uint16]
+    every = np.arange(65536, dtype=np.uint16)
+    with np.errstate(all="ignore"):
+        ref32 = every.view(np.float16).astype(np.float32)
+        for b in range(65536):   # every bit pattern widens exactly
+            got = np.float32(lib.h_to_f32(b))
+            assert np.isnan(ref32[b]) and np.isnan(got) or got.view(np.uint32) == ref32[b].view(np.uint32), b
+        rng = np.random.default_rng(0)
+        f32 = np.concatenate([rng.integers(0, 1 << 32, 60000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+                              (ref32[rng.integers(0, 65536, 60000)].astype(np.float64) * (1 + rng.uniform(-1e-3, 1e-3, 60000))).astype(np.float32),
+                              np.float32([65504, 65519.99, 65520, 65520.01, 6e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 2.981e-8, 1e-10, 0, -0.0])])
+        want = f32.astype(np.float16).view(np.uint16)
+        for v, w in zip(f32, want):
+            if not np.isnan(v): assert lib.h_from_f32(float(v)) == w, float(v)
+        f64 = np.concatenate([rng.uniform(-70000, 70000, 40000), rng.uniform(-1e-4, 1e-4, 20000), rng.uniform(-1e-7, 1e-7, 20000),
+                              ref32[rng.integers(0, 65536, 40000)].astype(np.float64) * (1 + rng.uniform(-1e-9, 1e-9, 40000))])
+        f64 = f64[np.isfinite(f64)]
+        want = f64.astype(np.float16).view(np.uint16)
+        for v, w in zip(f64, want): assert lib.h_from_f64(float(v)) == w, float(v)
+        a = rng.integers(0, 65536, 40000).astype(np.uint16); b = rng.integers(0, 65536, 40000).astype(np.uint16)
+        fa, fb = a.view(np.float16), b.view(np.float16)
+        for x, y, m, d in zip(a, b, (fa.astype(np.float32) * fb.astype(np.float32)).astype(np.float16).view(np.uint16),
+                              (fa.astype(np.float32) / fb.astype(np.float32)).astype(np.float16).view(np.uint16)):
+            fm, fd = np.uint16(m).view(np.float16), np.uint16(d).view(np.float16)
+            if not np.isnan(fm): assert lib.h_mul(int(x), int(y)) == m
+            if not np.isnan(fd): assert lib.h_div(int(x), int(y)) == d
+
+
+def test_host_mode_detection_agrees_with_the_oracle_bids(tmp_path):
+    """FloatDetect<L>::mult_bid / quant_bid of pco_auto_host.inc on f16, f32 and f64 samples against the oracle's FM<L>::compute_bid /
+    quant_compute_bid (two independent restatements of mode/float_mult.rs:62-374 and mode/float_quant.rs:73-149)."""
+    lib = _build(tmp_path, "autocmp", f'''
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include <cmath>
+#include <random>
+#include "{CSRC}/pco_half.h"
+#include "{CSRC}/pco_auto_host.inc"
+#include "{ROOT}/oracle/pco_oracle.hpp"
+#include "{ROOT}/oracle/pco_oracle_encode.hpp"
+using namespace pcogfx::autodetect;
+template <class L, class OF> static int run(int n_iter, int* n_found) {{
+  typedef typename FloatTraits<L>::F F;
+  std::mt19937_64 rng(7);
+  int mism = 0; *n_found = 0;
+  for (int it = 0; it < n_iter; it++) {{
+    const size_t n = 10 + rng() % 3000; const int kind = it % 8;
+    const double basef = kind == 0 ? 0.1 : kind == 1 ? 0.01 : kind == 2 ? 3.0 : kind == 3 ? 0.125 : kind == 4 ? (double)(1 + rng() % 50) / 7.0 : kind == 5 ? 0.05 : kind == 6 ? 1e-3 : 0.3;
+    const int maxk = 2 + (int)(rng() % (kind == 7 ? 60 : 3000));
+    std::vector<F> s; std::vector<OF> so;
+    for (size_t i = 0; i < n; i++) {{
+      F x = (F)((double)(1 + rng() % maxk) * basef);
+      if (rng() % 50 == 0) {{ L b = (L)rng(); std::memcpy(&x, &b, sizeof(L)); }}
+      if (kind == 5 && rng() % 3 == 0) {{ L b; std::memcpy(&b, &x, sizeof(L)); b &= ~(L)0x1f; std::memcpy(&x, &b, sizeof(L)); }}
+      if (!is_normal<L>(x)) continue;
+      const F a = fabsx<L>(x); if (!(a <= max_for_sampling<L>())) continue;
+      s.push_back(a); OF o; std::memcpy(&o, &a, sizeof(L)); so.push_back(o);
+    }}
+    if (s.size() < 10) continue;
+    MultConfig<L> c{{}}; double v = 0; const bool ok = FloatDetect<L>::mult_bid(s, c, v);
+    pco_oracle::FloatMultConfig<L> oc{{}}; double ov = 0; const bool ook = pco_oracle::FM<L>::compute_bid(so, oc, ov);
+    uint32_t k = 0; double qv = 0, oqv = 0; const bool q = FloatDetect<L>::quant_bid(s, k, qv); pco_oracle::Bitlen okk = 0; const bool oq = pco_oracle::FM<L>::quant_compute_bid(so, okk, oqv);
+    *n_found += ok;
+    if (ok != ook || (ok && (std::memcmp(&c.base, &oc.base, sizeof(L)) || std::memcmp(&c.inv_base, &oc.inv_base, sizeof(L)) || v != ov)) || q != oq || (q && (k != okk || qv != oqv))) mism++;
+  }}
+  return mism;
+}}
+extern "C" int cmp16(int n, int* f) {{ return run<uint16_t, pco_oracle::Half>(n, f); }}
+extern "C" int cmp32(int n, int* f) {{ return run<uint32_t, float>(n, f); }}
+extern "C" int cmp64(int n, int* f) {{ return run<uint64_t, double>(n, f); }}
+''')
+    for fn, min_found in ((lib.cmp16, 1), (lib.cmp32, 50), (lib.cmp64, 50)):
+        found = C.c_int(0)
+        assert fn(1200, C.byref(found)) == 0
+        assert found.value >= min_found, found.value   # the generator really produces float-mult bids
