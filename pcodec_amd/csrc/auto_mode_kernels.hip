@@ -148,6 +148,16 @@ template <class F> __device__ __forceinline__ bool screen_pair_gcd(F hi, F lo, F
 }
 // one value per lane (index i0 + lane) added into a running sum in index order: what a sequential loop over the array would compute
 template <class F> __device__ __forceinline__ F seq_add_lanes(F acc, F v, uint64_t valid) {
+  if (valid == ~(uint64_t)0) {   // a full row: no per-lane test in the dependent chain
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+      F vj;
+      if constexpr (sizeof(F) == 4) vj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), j));
+      else { const uint64_t b = (uint64_t)__double_as_longlong(v); vj = __longlong_as_double((long long)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, j))); }
+      acc += vj;
+    }
+    return acc;
+  }
 #pragma unroll 8
   for (int j = 0; j < 64; j++) {
     if (!((valid >> j) & 1)) continue;
@@ -182,11 +192,19 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
   auto exp_of = [](L a) { return (int)(a >> S::kPrec) - S::kBias; };
   auto div_pow = [](int e, uint32_t tz) { return e - (int)((uint32_t)S::kPrec > tz ? (uint32_t)S::kPrec - tz : 0u); };
   // ---- 1. the sample: order-preserving compaction, 256 at a time ----
+  // (all of a thread's sample numbers are requested before the first is used: the gather is two dependent HBM reads per number)
+  constexpr uint32_t kRounds = (kAutoCap + T - 1) / T;
+  L fetched[kRounds];
+#pragma unroll
+  for (uint32_t rr = 0; rr < kRounds; rr++) { const uint32_t k = rr * T + tid; fetched[rr] = k < g.n_idx ? src[g.idx[k]] : (L)0; }
   uint32_t kept = 0;
-  for (uint32_t k0 = 0; k0 < g.n_idx; k0 += T) {
+#pragma unroll
+  for (uint32_t rr = 0; rr < kRounds; rr++) {
+    const uint32_t k0 = rr * T;
+    if (k0 >= g.n_idx) break;
     const uint32_t k = k0 + tid;
     L a = 0; bool keep = false;
-    if (k < g.n_idx) { a = (L)(src[g.idx[k]] & (L)~mid); const L e = (L)(a >> S::kPrec); keep = e != 0 && e != exp_all && a <= lim; }
+    if (k < g.n_idx) { a = (L)(fetched[rr] & (L)~mid); const L e = (L)(a >> S::kPrec); keep = e != 0 && e != exp_all && a <= lim; }
     const uint64_t m = __ballot(keep);
     if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
     __syncthreads();
@@ -300,7 +318,7 @@ template <class F> __device__ void float_stage1(const FloatStatsTask& g, FloatSt
         const uint32_t i = i0 + lane;
         const uint32_t wb = i < kept ? (uint32_t)wq[i] : 0u;
         const F term = i < kept ? S::from_bits(B[i]) : (F)0;
-        tsum = seq_add_lanes<F>(tsum, term, __ballot(wb != 0));
+        tsum = seq_add_lanes<F>(tsum, term, __ballot(i < kept));   // (a number without a term carries +0.0: adding it changes nothing, the running sum is never -0.0)
         wsum += wb;
       }
       const F tw = (F)(double)wave_sum(wsum);
