@@ -568,7 +568,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   }
   __syncthreads();
   SEL_STAMP(6);
-  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u);
+  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts));
   __syncthreads();
   SEL_STAMP(7);
 #ifdef PCO_SEL_TIMING
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kSelT) void enc_hist_select_kernel(EncWorkspace ws,
 // place by block_radix_sort_inplace, and the <= 256 rank queries read the sorted array directly.  LDS = the record area +
 // n keys (launcher: small_lds_bytes), so two to four blocks share a CU and hide each other's barriers and loads.
 // ---------------------------------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr uint32_t small_lds_bytes(uint32_t n, uint32_t key_bytes) { return kHistLdsCounts + ((n * key_bytes + 15u) & ~15u); }
+__host__ __device__ constexpr uint32_t small_lds_bytes(uint32_t n, uint32_t key_bytes) { return kHistLdsCounts + (n * key_bytes > 11280u ? ((n * key_bytes + 15u) & ~15u) : 11280u); }   // (at least hist_emit's 11 KB of scratch)
 
 template <class L, class K>
 __device__ __forceinline__ void small_body(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log, EncChunk PCO_GLOBAL* ch, EncVar PCO_GLOBAL* ev,
@@ -671,7 +671,7 @@ __device__ __forceinline__ void small_body(const EncWorkspace& ws, uint32_t t, u
     rsucc[tid] = en < n_lat ? (L)(minv + (L)sc) : (L)0;
   }
   __syncthreads();
-  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, c16 ? 0u : 1u);
+  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, c16 ? 0u : 1u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts));
 }
 
 template <class L>

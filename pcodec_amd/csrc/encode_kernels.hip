@@ -960,6 +960,9 @@ __global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, const
 //   * sorted path  (otherwise): stable LSD radix sort (8-bit digits, significant digits only).
 // =========================================================================================================
 struct HistRec { uint32_t st, en; };
+#ifdef PCO_HIST_TIMING
+__device__ unsigned long long g_hist_timing[16];   // [0..4]: narrow kernel (count, prefix, lookups, emit, vars); [8..12]: the wide kernels
+#endif
 
 // The walk over the bins, resumable: with more than 256 bins (compression levels 9..12) the rank records are produced a window of 256
 // bins at a time and the walk stops when its next bin lies beyond the window.  Records are indexed by (bin - win_base).
@@ -1027,6 +1030,60 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
   n_hist_out = w.n_hist;
 }
 
+// The same walk for one window covering every bin, with everything that costs a 64-bit multiplication taken out of the serial loop
+// (bin_idx and c_count were 100 instructions of a 130-instruction step: 280 k cycles per variable, 44 % of enc_hist_kernel on the
+// benchmark's data, 70 % of the 16 k-counter kernel's on float-mult primaries -- scripts/hist_timing.py).  One thread per bin fills,
+// before the walk:  pre[0][b] = c_count(b);  pre[1][b] = bin_idx(c_count(b)), the bin the walk stands in after completing bin b;
+// pre[2][b] = bin_idx(en_b), ... after a constant run;  pre[3][b] = bin_idx(middle of the run);  pre[4][b] = c_count(pre[3][b]);
+// pre[5][b] = c_count(pre[3][b] - 1).
+template <class L>
+__device__ __forceinline__ void hist_precompute(uint32_t b, uint32_t n_lat, uint32_t bins_log, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren, uint32_t PCO_LDS* pre) {
+  const uint64_t n = n_lat, B = (uint64_t)1 << bins_log;
+  const uint64_t magic = n > 1 ? (~0ull / n) + 1 : 0ull;
+  auto bin_idx = [&](uint64_t pos) { return n > 1 ? (uint32_t)__umul64hi(pos << bins_log, magic) : (uint32_t)(pos << bins_log); };
+  auto c_count = [&](uint32_t bb) { return (uint32_t)((((uint64_t)bb + 1) * n + B - 1) >> bins_log); };
+  const uint32_t c = c_count(b), st = rst[b], en = ren[b];
+  const uint32_t bm = bin_idx(st + (en - st) / 2);
+  pre[b] = c; pre[B + b] = bin_idx(c); pre[2 * B + b] = bin_idx(en); pre[3 * B + b] = bm; pre[4 * B + b] = c_count(bm); pre[5 * B + b] = bm > 0 ? c_count(bm - 1) : 0u;
+}
+template <class L>
+__device__ __forceinline__ uint32_t hist_walk_pre(uint32_t n_lat, uint32_t bins_log, L first_value, const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
+                                                  const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc, const uint32_t PCO_LDS* pre, const PlanRef& plan) {
+  const uint32_t B = 1u << bins_log;
+  uint32_t pos = 0, target = 0; L pos_value = first_value;
+  bool pending = false; uint32_t pending_start = 0; L pending_lower = 0;
+  uint32_t next_avail = 0, n_hist = 0;
+  // (bins are emitted into LDS -- u32 counts after the six tables, then u64 lowers and uppers -- and copied out by the block afterwards)
+  uint32_t PCO_LDS* o_cnt = (uint32_t PCO_LDS*)(pre + 6 * B); uint64_t PCO_LDS* o_lo = (uint64_t PCO_LDS*)(pre + 7 * B); uint64_t PCO_LDS* o_hi = o_lo + B;
+  auto emit = [&](uint32_t start, uint32_t end, L lower, L upper) { o_cnt[n_hist] = end - start; o_lo[n_hist] = (uint64_t)lower; o_hi[n_hist] = (uint64_t)upper; n_hist++; };
+  while (pos < n_lat) {
+    // everything this step may need, read at once (one LDS round trip per step instead of one per dependent use)
+    const uint32_t c = pre[target], nb_c = pre[B + target], nb_en = pre[2 * B + target], bm = pre[3 * B + target], c_bm = pre[4 * B + target], c_bm1 = pre[5 * B + target];
+    const L v = rv[target], vnext = rnext[target], vpred = rpred[target], vsucc = rsucc[target];
+    const uint32_t st = rst[target], en = ren[target];
+    if (en <= c) {  // every run in [pos, c) fits: absorb and complete at c
+      if (!pending) { pending_start = pos; pending_lower = pos_value; }
+      emit(pending_start, c, pending_lower, v);
+      pending = false; next_avail = target + 1;
+      pos = c; pos_value = vnext;
+      target = nb_c;
+    } else {        // the run [st, en) of value v straddles c: constant run
+      if (st > pos && !pending) { pending = true; pending_start = pos; pending_lower = pos_value; }
+      uint32_t b = bm, cb = c_bm;
+      if (b > next_avail) {
+        const uint32_t spare = b - 1;
+        if (pending) { emit(pending_start, st, pending_lower, vpred); pending = false; next_avail = spare + 1; }
+        else { b = spare; cb = c_bm1; }
+      }
+      if (!pending) { pending = true; pending_start = st; pending_lower = v; }
+      if (en >= cb) { emit(pending_start, en, pending_lower, v); pending = false; next_avail = b + 1; }
+      pos = en; pos_value = vsucc;
+      target = nb_en;
+    }
+  }
+  return n_hist;
+}
+
 // The histogram of one variable from its rank records, by the whole block (every thread calls this after the records are in LDS and a
 // barrier).  When no run of equal values straddles a bin end (ren[b] <= c_count(b) for every b: data without heavy ties) and there
 // are at least as many latents as bins, the state machine above visits the bins in order and emits bin b = ranks
@@ -1035,7 +1092,8 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
 // histogram time before this shortcut).
 template <class L>
 __device__ __forceinline__ void hist_emit(uint32_t n_lat, uint32_t bins_log, L first_value, const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
-                                          const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc, const PlanRef& plan, EncVar PCO_GLOBAL* ev, uint32_t path) {
+                                          const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc, const PlanRef& plan, EncVar PCO_GLOBAL* ev, uint32_t path,
+                                          uint32_t PCO_LDS* pre /* u32[11 << bins_log + 1] of scratch (the counters / sort area: done with by now) */) {
   const uint32_t tid = threadIdx.x, B = 1u << bins_log;
   const uint64_t n64 = n_lat;
   auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
@@ -1047,8 +1105,14 @@ __device__ __forceinline__ void hist_emit(uint32_t n_lat, uint32_t bins_log, L f
       plan.hcount()[tid] = c1 - c0; plan.hlower()[tid] = (uint64_t)(tid == 0 ? first_value : rnext[tid - 1]); plan.hupper()[tid] = (uint64_t)rv[tid];
     }
     if (tid == 0) { ev->n_hist = B; ev->hist_path = path; }
-  } else if (tid == 0) {
-    uint32_t nh = 0; hist_state_machine<L>(n_lat, bins_log, first_value, rv, rst, ren, rnext, rpred, rsucc, plan, nh); ev->n_hist = nh; ev->hist_path = path;
+  } else {
+    if (tid < B) hist_precompute<L>(tid, n_lat, bins_log, rst, ren, pre);
+    if (tid == 0) pre[11 * B] = 0;
+    __syncthreads();
+    if (tid == 0) { const uint32_t nh = hist_walk_pre<L>(n_lat, bins_log, first_value, rv, rst, ren, rnext, rpred, rsucc, pre, plan); ev->n_hist = nh; ev->hist_path = path; pre[11 * B] = nh; }
+    __syncthreads();
+    const uint32_t nh = pre[11 * B];
+    if (tid < nh) { plan.hcount()[tid] = pre[6 * B + tid]; plan.hlower()[tid] = ((const uint64_t PCO_LDS*)(pre + 7 * B))[tid]; plan.hupper()[tid] = ((const uint64_t PCO_LDS*)(pre + 7 * B))[B + tid]; }
   }
 }
 
@@ -1130,6 +1194,12 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
   __syncthreads();
   if ((uint64_t)range < R && !big) {
     // ---------------- direct path ----------------
+#ifdef PCO_HIST_TIMING
+    unsigned long long ht0 = __builtin_readcyclecounter();
+#define HIST_STAMP(idx) do { __syncthreads(); if (tid == 0) { const unsigned long long _n = __builtin_readcyclecounter(); atomicAdd(&g_hist_timing[(kWide ? 8 : 0) + idx], _n - ht0); ht0 = _n; } } while (0)
+#else
+#define HIST_STAMP(idx) do { } while (0)
+#endif
     constexpr uint32_t PER = R / T;   // counters per thread in the prefix pass
     for (uint32_t i = tid; i < R + 8; i += T) counts[i] = 0;
     __syncthreads();
@@ -1172,6 +1242,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
       }
     }
     __syncthreads();
+    HIST_STAMP(0);
     // exclusive prefix over R counters: PER per thread + block scan
     uint32_t s = 0;
     for (uint32_t k = 0; k < PER; k++) s += counts[tid * PER + k];
@@ -1183,6 +1254,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     for (uint32_t k = 0; k < PER; k++) { const uint32_t c = counts[tid * PER + k]; counts[tid * PER + k] = run; run += c; }
     if (tid == T - 1) counts[R] = run;  // == n_lat
     __syncthreads();
+    HIST_STAMP(1);
     auto lookup = [&](uint32_t r, L& value, uint32_t& st, uint32_t& en) {
       uint32_t lo = 0, hi = R;  // last v with P[v] <= r
       while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (counts[mid] <= r) lo = mid; else hi = mid; }
@@ -1198,8 +1270,13 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
       if (en < n_lat) { lookup(en, x, a, b2); rsucc[tid] = x; } else rsucc[tid] = 0;
     }
     __syncthreads();
-    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 0u);
+    HIST_STAMP(2);
+    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 0u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts));
     __syncthreads();
+    HIST_STAMP(3);
+#ifdef PCO_HIST_TIMING
+    if (tid == 0) atomicAdd(&g_hist_timing[(kWide ? 8 : 0) + 4], 1ull);
+#endif
     return;
   }
   if constexpr (!kSort) return;
@@ -1424,7 +1501,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
       rsucc[tid] = en < n_lat ? value_at(en) : (L)0;
     }
     __syncthreads();
-    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u);
+    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts));
     __syncthreads();
   } else {
     // more than 256 bins: rank records a window of 256 bins at a time.  A window none of whose bins is straddled by a run of equal

@@ -382,6 +382,13 @@ extern "C" int pco_gfx_debug_sel_timing(unsigned long long* out, int reset) {
 }
 #endif
 
+#ifdef PCO_HIST_TIMING
+extern "C" int pco_gfx_debug_hist_timing(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(pcogfx::g_hist_timing), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_hist_timing), 128);
+}
+#endif
+
 #ifdef PCO_LB_TIMING
 extern "C" int pco_gfx_debug_lb_timing(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[16] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(pcogfx::g_lb_timing), z, sizeof(z)); }
