@@ -568,7 +568,8 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   }
   __syncthreads();
   SEL_STAMP(6);
-  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts));
+  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts),
+               ws.walk != nullptr ? (uint8_t PCO_GLOBAL*)ws.walk + ((uint64_t)t * 3 + var) * kWalkRecBytes : (uint8_t PCO_GLOBAL*)nullptr);
   __syncthreads();
   SEL_STAMP(7);
 #ifdef PCO_SEL_TIMING
@@ -671,7 +672,8 @@ __device__ __forceinline__ void small_body(const EncWorkspace& ws, uint32_t t, u
     rsucc[tid] = en < n_lat ? (L)(minv + (L)sc) : (L)0;
   }
   __syncthreads();
-  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, c16 ? 0u : 1u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts));
+  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, c16 ? 0u : 1u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts),
+               ws.walk != nullptr ? (uint8_t PCO_GLOBAL*)ws.walk + ((uint64_t)t * 3 + var) * kWalkRecBytes : (uint8_t PCO_GLOBAL*)nullptr);
 }
 
 template <class L>

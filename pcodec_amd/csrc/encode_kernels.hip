@@ -35,7 +35,7 @@ struct EncVar {
   uint32_t present, latent_bits, n_lat, lat_start;
   unsigned long long minv, maxv;
   uint32_t n_hist, n_bins, ans_size_log, max_ob;
-  uint32_t is_trivial, needs_ans, hist_path, pad;
+  uint32_t is_trivial, needs_ans, hist_path, walk_pending;   // walk_pending: the bin walk was left to enc_hist_walk_kernel
 };
 static_assert(sizeof(EncVar) == 64, "EncVar");
 struct EncChunk {
@@ -98,6 +98,7 @@ struct EncWorkspace {
   EncPage* pages;           // [n_pages_total]
   uint8_t* lat;             // [task][n_slots][n_stride] 8-byte elements
   uint8_t* sort;            // [task][2][n_stride] 8-byte elements
+  uint8_t* walk;            // [task][3] kWalkRecBytes: rank records + tables of a deferred bin walk (enc_hist_walk_kernel), or null
   uint32_t* dissect;        // [task][n_slots][n_stride]
   uint64_t n_stride;
   uint32_t n_slots;         // latent slots allocated per task
@@ -960,6 +961,7 @@ __global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, const
 //   * sorted path  (otherwise): stable LSD radix sort (8-bit digits, significant digits only).
 // =========================================================================================================
 struct HistRec { uint32_t st, en; };
+constexpr uint32_t kWalkRecBytes = 16384;   // u32[6][256] tables | u32[256] run starts | u32[256] run ends | u64[4][256] value, next, predecessor, successor
 #ifdef PCO_HIST_TIMING
 __device__ unsigned long long g_hist_timing[16];   // [0..4]: narrow kernel (count, prefix, lookups, emit, vars); [8..12]: the wide kernels
 #endif
@@ -1093,7 +1095,8 @@ __device__ __forceinline__ uint32_t hist_walk_pre(uint32_t n_lat, uint32_t bins_
 template <class L>
 __device__ __forceinline__ void hist_emit(uint32_t n_lat, uint32_t bins_log, L first_value, const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
                                           const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc, const PlanRef& plan, EncVar PCO_GLOBAL* ev, uint32_t path,
-                                          uint32_t PCO_LDS* pre /* u32[11 << bins_log + 1] of scratch (the counters / sort area: done with by now) */) {
+                                          uint32_t PCO_LDS* pre /* u32[11 << bins_log + 1] of scratch (the counters / sort area: done with by now) */,
+                                          uint8_t PCO_GLOBAL* defer = nullptr /* where to leave records + tables for enc_hist_walk_kernel instead of walking here */) {
   const uint32_t tid = threadIdx.x, B = 1u << bins_log;
   const uint64_t n64 = n_lat;
   auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
@@ -1109,6 +1112,18 @@ __device__ __forceinline__ void hist_emit(uint32_t n_lat, uint32_t bins_log, L f
     if (tid < B) hist_precompute<L>(tid, n_lat, bins_log, rst, ren, pre);
     if (tid == 0) pre[11 * B] = 0;
     __syncthreads();
+    if (defer != nullptr) {   // the walk is one thread's work: with two 1024-thread blocks per CU it was most of the kernel's time; it gets a wave of its own later
+      if (tid < B) {
+        uint32_t PCO_GLOBAL* g32 = (uint32_t PCO_GLOBAL*)defer;
+#pragma unroll
+        for (uint32_t k = 0; k < 6; k++) g32[k * 256 + tid] = pre[k * B + tid];
+        g32[6 * 256 + tid] = rst[tid]; g32[7 * 256 + tid] = ren[tid];
+        uint64_t PCO_GLOBAL* g64 = (uint64_t PCO_GLOBAL*)(defer + 8192);
+        g64[tid] = (uint64_t)rv[tid]; g64[256 + tid] = (uint64_t)rnext[tid]; g64[512 + tid] = (uint64_t)rpred[tid]; g64[768 + tid] = (uint64_t)rsucc[tid];
+      }
+      if (tid == 0) { ev->hist_path = path; ev->walk_pending = 1u; }
+      return;
+    }
     if (tid == 0) { const uint32_t nh = hist_walk_pre<L>(n_lat, bins_log, first_value, rv, rst, ren, rnext, rpred, rsucc, pre, plan); ev->n_hist = nh; ev->hist_path = path; pre[11 * B] = nh; }
     __syncthreads();
     const uint32_t nh = pre[11 * B];
@@ -1271,7 +1286,8 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     }
     __syncthreads();
     HIST_STAMP(2);
-    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 0u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts));
+    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 0u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts),
+                 kWide && ws.walk != nullptr ? (uint8_t PCO_GLOBAL*)ws.walk + ((uint64_t)t * 3 + var) * kWalkRecBytes : (uint8_t PCO_GLOBAL*)nullptr);   // (five 256-thread blocks per CU hide their own walks: measured, no gain from deferring)
     __syncthreads();
     HIST_STAMP(3);
 #ifdef PCO_HIST_TIMING
@@ -1501,7 +1517,8 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
       rsucc[tid] = en < n_lat ? value_at(en) : (L)0;
     }
     __syncthreads();
-    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts));
+    hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts),
+                 ws.walk != nullptr ? (uint8_t PCO_GLOBAL*)ws.walk + ((uint64_t)t * 3 + var) * kWalkRecBytes : (uint8_t PCO_GLOBAL*)nullptr);
     __syncthreads();
   } else {
     // more than 256 bins: rank records a window of 256 bins at a time.  A window none of whose bins is straddled by a run of equal
@@ -1575,6 +1592,43 @@ __global__ __launch_bounds__(256) void enc_hist_sort_kernel(EncWorkspace ws, uin
 template <uint32_t R>
 __global__ __launch_bounds__(1024) void enc_hist_wide_kernel(EncWorkspace ws, uint32_t n_tasks) {
   if (blockIdx.x < n_tasks) hist_chunk<1024, R, true, false>(ws, blockIdx.x);
+}
+
+// The bin walks the 1024-thread histogram kernels left behind (EncVar::walk_pending): one wave per chunk, records and tables from HBM
+// into LDS, the walk by one lane, the bins copied out by the wave.  Thousands of walks at once instead of one per resident block.
+constexpr uint32_t kWalkLdsBytes = (11 * 256 + 4) * 4 + 2 * 1024 + 4 * 2048;   // hist_walk_pre's tables + emit area | run starts, ends | four value arrays
+__global__ __launch_bounds__(64) void enc_hist_walk_kernel(EncWorkspace ws, uint32_t n_tasks) {
+  const uint32_t t = blockIdx.x;
+  if (t >= n_tasks) return;
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (uni(ch->status) != PCO_GFX_OK) return;
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  uint32_t PCO_LDS* pre = (uint32_t PCO_LDS*)smem;
+  uint32_t PCO_LDS* rst = (uint32_t PCO_LDS*)(smem + (11 * 256 + 4) * 4); uint32_t PCO_LDS* ren = rst + 256;
+  uint64_t PCO_LDS* rv = (uint64_t PCO_LDS*)(ren + 256);
+  const uint32_t lane = lane_id(), ubl = uni(ch->unopt_bins_log);
+  for (uint32_t var = 0; var < 3; var++) {
+    EncVar PCO_GLOBAL* ev = &ch->v[var];
+    if (!uni(ev->present) || !uni(ev->walk_pending)) continue;
+    const uint32_t bins_log = var == 2 ? (ubl < 6 ? ubl : 6) : ubl, B = 1u << bins_log;
+    const uint8_t PCO_GLOBAL* src = (const uint8_t PCO_GLOBAL*)ws.walk + ((uint64_t)t * 3 + var) * kWalkRecBytes;
+    const uint32_t PCO_GLOBAL* g32 = (const uint32_t PCO_GLOBAL*)src; const uint64_t PCO_GLOBAL* g64 = (const uint64_t PCO_GLOBAL*)(src + 8192);
+    for (uint32_t i = lane; i < B; i += 64) {
+#pragma unroll
+      for (uint32_t k = 0; k < 6; k++) pre[k * B + i] = g32[k * 256 + i];
+      rst[i] = g32[6 * 256 + i]; ren[i] = g32[7 * 256 + i];
+      rv[i] = g64[i]; rv[256 + i] = g64[256 + i]; rv[512 + i] = g64[512 + i]; rv[768 + i] = g64[768 + i];
+    }
+    enc_wave_sync();
+    const PlanRef plan = plan_ref(ws, t, var);
+    uint32_t nh = 0;
+    if (lane == 0) nh = hist_walk_pre<uint64_t>(uni(ev->n_lat), bins_log, (uint64_t)ev->minv, rv, rst, ren, rv + 256, rv + 512, rv + 768, pre, plan);
+    nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)nh);
+    enc_wave_sync();
+    for (uint32_t i = lane; i < nh; i += 64) { plan.hcount()[i] = pre[6 * B + i]; plan.hlower()[i] = ((const uint64_t PCO_LDS*)(pre + 7 * B))[i]; plan.hupper()[i] = ((const uint64_t PCO_LDS*)(pre + 7 * B))[B + i]; }
+    if (lane == 0) { ev->n_hist = nh; ev->walk_pending = 0u; }
+    enc_wave_sync();
+  }
 }
 
 // =========================================================================================================
