@@ -121,6 +121,12 @@ int pco_gfx_device_count(void);
 enum PcoError pco_gfx_simple_compress_into_ex(const void* nums, size_t n, unsigned char dtype,
                                               const PcoChunkConfigEx* config, int uniform_type,
                                               void* dst, size_t dst_cap, size_t* n_written);
+/* The same under PagingSpec::Exact (chunk_config.rs:124,162-180): standalone::simple_compress cuts one chunk per entry of the
+ * paging spec (standalone/simple.rs:32-45), so `page_sizes` are the chunk sizes; they must be non-zero and sum to n.
+ * dst_cap: header + footer + sum of pco_gfx_guarantee_chunk_size(page_sizes[i]). */
+enum PcoError pco_gfx_simple_compress_into_exact(const void* nums, size_t n, unsigned char dtype, const PcoChunkConfigEx* config,
+                                                 int uniform_type, const size_t* page_sizes, size_t n_pages, void* dst,
+                                                 size_t dst_cap, size_t* n_written);
 size_t pco_gfx_guarantee_file_size(size_t n, unsigned char dtype, uint64_t max_page_n);
 /* standalone/guarantee.rs:21-23: bound for one standalone chunk of n numbers */
 size_t pco_gfx_guarantee_chunk_size(size_t n, unsigned char dtype);

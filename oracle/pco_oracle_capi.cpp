@@ -79,6 +79,24 @@ int pco_oracle_simple_compress(const void* nums, size_t n, uint8_t dtype, const 
   });
 }
 
+// simple_compress under PagingSpec::Exact (standalone/simple.rs:32-45: one chunk per entry of the paging spec)
+int pco_oracle_simple_compress_exact(const void* nums, size_t n, uint8_t dtype, const PcoOracleConfig* config, int uniform_type,
+                                     const size_t* exact_pages, size_t n_exact, uint8_t* dst, size_t dst_cap, size_t* n_written) {
+  return guard([&] {
+    if (!dtype_valid(dtype)) fail(kInvalidArgument, "invalid dtype");
+    ChunkConfig cfg = to_cfg(config);
+    cfg.paging_exact = true; if (n_exact) cfg.exact_pages.assign(exact_pages, exact_pages + n_exact);
+    std::vector<uint8_t> out;
+    dispatch_bits(dtype_bits(dtype), [&](auto tag) {
+      typedef decltype(tag) LTYPE;
+      out = simple_compress_t<LTYPE>((const LTYPE*)nums, n, dtype, cfg, uniform_type != 0);
+    });
+    if (out.size() > dst_cap) fail(kInvalidArgument, "destination too small");
+    std::memcpy(dst, out.data(), out.size());
+    *n_written = out.size();
+  });
+}
+
 // wrapped::ChunkCompressor (wrapped/chunk_compressor.rs:442-705): ChunkMeta bytes, then every page's bytes back to back.
 // sizes[0] = meta bytes, sizes[1 + i] = bytes of page i, page_ns[i] = numbers in page i; *n_pages <= cap_pages.
 static int wrapped_compress_impl(const void* nums, size_t n, uint8_t dtype, const PcoOracleConfig* config, const size_t* exact_pages, size_t n_exact,

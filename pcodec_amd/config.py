@@ -72,10 +72,7 @@ class ChunkConfig:  # chunk_config.rs:191-235, pco_python/src/config.rs:108-159
     enable_8_bit: bool = False
 
     def to_c(self, wrapped=False):
-        if self.paging_spec.exact is not None and not wrapped:
-            # standalone::simple_compress hands the paging spec to every chunk it cuts (standalone/simple.rs:62-91); exact sizes only
-            # make sense on the wrapped surface, where the caller owns the chunking
-            raise ValueError("PagingSpec.exact_page_sizes is only meaningful for the wrapped API")
+        # (PagingSpec.exact travels beside the struct: pco_chunk_compressor_new_exact / pco_gfx_simple_compress_into_exact)
         return G.make_config(level=self.compression_level, mode=self.mode_spec.kind, mode_f64=self.mode_spec.f64,
                              mode_u64=self.mode_spec.u64, delta=self.delta_spec.kind, delta_order=self.delta_spec.order,
                              max_page_n=self.paging_spec.max_page_n, enable_8_bit=self.enable_8_bit)

@@ -23,12 +23,21 @@ def simple_compress(nums, config=None):
     nums = np.ascontiguousarray(nums)
     if nums.ndim != 1:
         raise TypeError("nums must be a 1D array")
-    cfg = (config or ChunkConfig()).to_c()
+    config = config or ChunkConfig()
+    cfg = config.to_c()
     L = G.lib()
     dt = _dtype_byte(nums)
+    n = C.c_size_t(0)
+    exact = config.paging_spec.exact
+    if exact is not None:   # PagingSpec::Exact: one chunk per entry (standalone/simple.rs:32-45)
+        cap = L.pco_gfx_guarantee_file_size(0, dt, 0) + sum(L.pco_gfx_guarantee_chunk_size(max(int(s), 1), dt) for s in exact) + 64
+        dst = np.empty(cap, np.uint8)
+        sizes = (C.c_size_t * max(len(exact), 1))(*exact)
+        G.check(L.pco_gfx_simple_compress_into_exact(nums.ctypes.data_as(C.c_void_p), C.c_size_t(nums.size), C.c_ubyte(dt), C.byref(cfg), C.c_int(0), sizes,
+                                                     C.c_size_t(len(exact)), dst.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(n)))
+        return dst[: n.value].tobytes()
     cap = L.pco_gfx_guarantee_file_size(nums.size, dt, cfg.max_page_n) + 64
     dst = np.empty(cap, np.uint8)
-    n = C.c_size_t(0)
     G.check(L.pco_gfx_simple_compress_into_ex(nums.ctypes.data_as(C.c_void_p), nums.size, dt, C.byref(cfg), 0,
                                               dst.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
     return dst[: n.value].tobytes()

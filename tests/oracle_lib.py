@@ -101,6 +101,21 @@ def simple_compress(arr, config=None, uniform_type=False):
     return dst[: n_written.value].tobytes()
 
 
+def simple_compress_exact(arr, config, exact_pages, uniform_type=False):
+    """simple_compress under PagingSpec::Exact: one standalone chunk per entry of exact_pages (standalone/simple.rs:32-45)."""
+    arr = np.ascontiguousarray(arr)
+    dt = dtype_byte(arr)
+    cap = file_size_bound(0, dt, 0) + sum(file_size_bound(max(int(p), 1), dt, 0) for p in exact_pages) + 64
+    dst = np.empty(cap, dtype=np.uint8)
+    n_written = C.c_size_t(0)
+    ex = (C.c_size_t * max(len(exact_pages), 1))(*[int(x) for x in exact_pages])
+    rc = lib().pco_oracle_simple_compress_exact(arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.size), C.c_uint8(dt), C.byref(config),
+                                                C.c_int(1 if uniform_type else 0), ex, C.c_size_t(len(exact_pages)),
+                                                dst.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(n_written))
+    _check(rc)
+    return dst[: n_written.value].tobytes()
+
+
 def simple_decompress(data, np_dtype, cap=None):
     dt = DTYPE_BYTE[{"uint32": "u32", "uint64": "u64", "int32": "i32", "int64": "i64", "float32": "f32",
                      "float64": "f64", "uint16": "u16", "int16": "i16", "float16": "f16", "uint8": "u8",

@@ -120,8 +120,7 @@ def test_python_surface_host_side(lib):
         FileCompressor().chunk_compressor(np.zeros((2, 2)), P.ChunkConfig())
     with pytest.raises(RuntimeError, match="unknown number type"):
         fd.chunk_decompressor(b"", "U128")
-    with pytest.raises(ValueError):
-        P.ChunkConfig(paging_spec=P.PagingSpec.exact_page_sizes([6, 4])).to_c()
+    assert P.ChunkConfig(paging_spec=P.PagingSpec.exact_page_sizes([6, 4])).paging_spec.exact == (6, 4)
     if lib.pco_gfx_device_count() == 0:
         with pytest.raises(G.PcoGfxError) as ei:
             P.standalone.simple_compress(np.arange(10, dtype=np.uint32), P.ChunkConfig())

@@ -121,6 +121,79 @@ def test_wrapped_compress(P, dtype):   # test_wrapped.py:11-52, with EqualPagesU
     assert n_bytes_read == len(page0)
 
 
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_wrapped_compress_exact_page_sizes(P, dtype):   # test_wrapped.py:11-52 as written: PagingSpec.exact_page_sizes([6, 4])
+    import oracle_lib as O
+    from pcodec_amd.wrapped import FileCompressor, FileDecompressor
+    rng = np.random.default_rng(12345)
+    data = rng.uniform(0, 1000, size=[10]).astype(dtype)
+    pco_number_type = dtype[0].upper() + str(int(dtype[1]) * 8)
+    page_sizes = [6, 4]  # so there are 2 pages
+    fc = FileCompressor()
+    header = fc.write_header()
+    cc = fc.chunk_compressor(data, P.ChunkConfig(paging_spec=P.PagingSpec.exact_page_sizes(page_sizes)))
+    assert cc.n_per_page() == page_sizes
+    chunk_meta = cc.write_meta()
+    page0 = cc.write_page(0)
+    page1 = cc.write_page(1)
+    with pytest.raises(RuntimeError, match="page idx exceeds num pages"):
+        cc.write_page(2)
+    assert (chunk_meta, [page0, page1], page_sizes) == O.wrapped_compress(data, O.make_config(), exact_pages=page_sizes)
+    fd, n_bytes_read = FileDecompressor.new(header)
+    assert n_bytes_read == len(header)
+    cd, n_bytes_read = fd.chunk_decompressor(chunk_meta, pco_number_type)
+    assert n_bytes_read == len(chunk_meta)
+    # page 1, which has elements 6-10
+    dst1 = np.zeros(100).astype(dtype)
+    _progress, n_bytes_read = cd.read_page_into(page1, 4, dst1)
+    np.testing.assert_array_equal(dst1[4:], np.zeros(96))
+    np.testing.assert_array_equal(dst1[:4], data[6:])
+    assert n_bytes_read == len(page1)
+    # page 0, which has elements 0-6
+    dst0 = np.zeros(6).astype(dtype)
+    _progress, n_bytes_read = cd.read_page_into(page0, 6, dst0)
+    np.testing.assert_array_equal(dst0, data[:6])
+    assert n_bytes_read == len(page0)
+    # a wrong sum is the reference's InvalidArgument (chunk_config.rs:166-171)
+    from pcodec_amd import _lib as G
+    with pytest.raises(G.PcoGfxError, match="paging spec suggests 9 numbers but 10 were given"):
+        fc.chunk_compressor(data, P.ChunkConfig(paging_spec=P.PagingSpec.exact_page_sizes([5, 4])))
+
+
+def test_standalone_exact_page_sizes(P):   # standalone/simple.rs:32-45: the paging spec decides where the CHUNKS are cut
+    import oracle_lib as O
+    rng = np.random.default_rng(9)
+    data = (rng.normal(size=3000) * 1000).astype(np.int32)
+    sizes = [1000, 1, 1999]
+    comp = P.standalone.simple_compress(data, P.ChunkConfig(paging_spec=P.PagingSpec.exact_page_sizes(sizes)))
+    assert comp == O.simple_compress_exact(data, O.make_config(), sizes)
+    np.testing.assert_array_equal(P.standalone.simple_decompress(comp), data)
+
+
+def test_page_decompressor_partial_reads(P):   # page_decompressor.rs:193-221 through the Python mirror
+    from pcodec_amd.wrapped import FileCompressor, FileDecompressor
+    rng = np.random.default_rng(10)
+    data = np.cumsum(rng.integers(-3, 9, 5000)).astype(np.int64)
+    fc = FileCompressor()
+    cc = fc.chunk_compressor(data, P.ChunkConfig(paging_spec=P.PagingSpec.exact_page_sizes([5000])))
+    fd, _ = FileDecompressor.new(fc.write_header())
+    cd, _ = fd.chunk_decompressor(cc.write_meta(), "I64")
+    page = cc.write_page(0)
+    pd = cd.page_decompressor(page, 5000)
+    out = np.zeros(5120, np.int64); pos = 0
+    for k in (256, 2048, 512):
+        pr = pd.read(out[pos:pos + k])
+        assert pr.n_processed == k and not pr.finished
+        pos += k
+    from pcodec_amd import _lib as G
+    with pytest.raises(G.PcoGfxError, match="multiple of 256"):
+        pd.read(np.zeros(100, np.int64))
+    pr = pd.read(out[pos:pos + 2304])   # 2184 left: a multiple of 256 that is longer than the rest
+    assert pr.n_processed == 5000 - pos and pr.finished
+    np.testing.assert_array_equal(out[:5000], data)
+    assert pd.n_bytes_read() == len(page)
+
+
 def test_argument_errors(P):   # test_standalone.py:185-199
     rng = np.random.default_rng(1)
     with pytest.raises(TypeError, match="1D"):
