@@ -183,6 +183,274 @@ def spawn_ranks(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def csrc_sha16():
+    """Hash of the product's kernel sources: a committed PMC traffic table is only quoted for the build it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pcodec_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(workload, nch, kernel_names):
+    """HBM bytes per kernel from the committed PMC passes (profiles/rNN_traffic_<workload>.json), scaled to this run's chunk count --
+    or (None, why) when there is no table for this workload, when it was measured on other kernel sources (csrc_sha16), or when the
+    kernels it lists are not the kernels that just ran."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{workload}.json")), reverse=True)
+    if not cands:
+        return None, "no PMC table committed for this workload"
+    try:
+        tj = json.load(open(cands[0]))
+        if tj.get("workload") != workload:
+            return None, "table names another workload"
+        if tj.get("csrc_sha16") != csrc_sha16():
+            return None, f"{os.path.basename(cands[0])} was measured on other kernel sources (csrc_sha16 {tj.get('csrc_sha16')}); re-run scripts/pmc_run.sh"
+        tab = {k: int((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * nch / tj["chunks"]) for k, v in tj["kernels"].items()}
+        missing = [k for k in kernel_names if k not in tab and not k.startswith(("pco_decode_kernel", "enc_page_kernel", "enc_init", "enc_presample", "enc_scan", "dec_walk4"))]
+        if missing:
+            return None, f"{os.path.basename(cands[0])} lacks kernels that ran: {missing}"
+        return tab, os.path.basename(cands[0])
+    except (OSError, ValueError, KeyError) as e:
+        return None, f"unreadable table: {e}"
+
+
+class Bench:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from pcodec_amd import _lib as G
+        from pcodec_amd import sharding as S
+        self.torch, self.dist, self.G, self.S, self.args = torch, dist, G, S, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: pcodec_amd has no CPU fallback")
+        if self.world != args.gpus and self.rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; reporting n_gpus={self.world}", file=sys.stderr)
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+        self.L = G.lib()
+        self.L.pco_gfx_compact_chunks.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def sync_all(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+
+    def verify_against_oracle(self, kinds, cfg_kw, kind_of, row_of, data, comp, cap_off, n_out, k_verify):
+        """Rank 0, warm-up: `k_verify` randomly drawn chunks, compressed by the oracle on every host CPU this process owns (native
+        threads: oracle/pco_oracle_capi.cpp pco_oracle_verify_chunks) and compared byte for byte with what the GPU wrote."""
+        import oracle_lib as O
+        torch = self.torch
+        nch = len(kind_of)
+        pick = np.sort(np.random.default_rng(99).choice(nch, size=min(k_verify, nch), replace=False))
+        info = cpu_info()
+        threads = int(min(info["logical_cpus"], info.get("affinity_cpus", 1 << 30), max(1, int(info.get("cgroup_cpu_quota", 1 << 30)))))
+        OL = O.lib(); ocfg = O.make_config(**cfg_kw)
+        checked = 0
+        for k, kind in enumerate(kinds):
+            idx = pick[kind_of[pick] == k]
+            if len(idx) == 0:
+                continue
+            rows = torch.from_numpy(row_of[idx]).to(self.device)
+            host = data[k][rows].cpu().numpy()   # [len(idx), 2^18] of the kind's torch dtype: same bits as the pco dtype
+            offs = np.zeros(len(idx), np.uint64); lens = n_out[idx].astype(np.uint64)
+            offs[1:] = np.cumsum(lens[:-1])
+            got = torch.empty(int(lens.sum()) + 64, dtype=torch.uint8, device=self.device)
+            # (gather the picked chunks' bytes on the device, one copy back)
+            for j, i in enumerate(idx):
+                got[int(offs[j]): int(offs[j]) + int(lens[j])] = comp[int(cap_off[i]): int(cap_off[i]) + int(lens[j])]
+            got_h = got.cpu().numpy()
+            n_bad = C.c_uint64(0); first = C.c_int64(-1)
+            rc = OL.pco_oracle_verify_chunks(host.ctypes.data_as(C.c_void_p), C.c_size_t(len(idx)), C.c_size_t(N18), C.c_size_t(host.strides[0]), C.c_uint8(KINDS[kind][1]),
+                                             C.byref(ocfg), got_h.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                                             C.c_uint32(threads), C.byref(n_bad), C.byref(first))
+            if rc != 0:
+                raise RuntimeError("oracle verify failed: " + OL.pco_oracle_last_error().decode())
+            assert n_bad.value == 0, f"{n_bad.value} GPU chunks of kind {kind} differ from the oracle's bytes (first: chunk {int(idx[first.value])})"
+            checked += len(idx)
+        return checked
+
+    def run(self, workload, chunks, steps, warmup, gather, verify_chunks, with_cpu, cpu_seconds=14.0):
+        """One workload: data generation, warm-up (round-trip assertion + oracle spot check), K timed steps.  Returns rank 0's record."""
+        torch, dist, G, S, L = self.torch, self.dist, self.G, self.S, self.L
+        world, rank, device = self.world, self.rank, self.device
+        kinds, cfg_kw, dtype_label, desc = WORKLOADS[workload]
+        gcfg = G.make_config(**cfg_kw)
+        elem = [np.dtype(KINDS[k][0]).itemsize for k in kinds]
+        if chunks is None:   # 16 GiB of numbers per GPU
+            per_cycle = sum(N18 * e for e in elem)
+            chunks = max(len(kinds), int((16 << 30) // per_cycle) * len(kinds))
+        nch = -(-chunks // len(kinds)) * len(kinds)   # whole cycles of the kinds: every rank owns the same mix
+        # this rank's block of the global chunk sequence (contiguous blocks, sharding.shard_range); kinds cycle over the GLOBAL index
+        c0, c1 = S.shard_range(nch * world, rank, world)
+        assert c1 - c0 == nch
+        g = torch.Generator(device=device); g.manual_seed(1234 + 7919 * rank)
+        kind_of = np.array([(c0 + i) % len(kinds) for i in range(nch)])
+        data = {}; row_of = np.zeros(nch, np.int64)
+        for k, kind in enumerate(kinds):
+            idx = np.nonzero(kind_of == k)[0]
+            row_of[idx] = np.arange(len(idx))
+            if len(idx): data[k] = make_kind(torch, kind, len(idx), g, device).contiguous()
+        out = {k: torch.empty_like(v) for k, v in data.items()}
+        chunk_bytes = np.array([N18 * elem[k] for k in kind_of], dtype=np.uint64)
+        dtb = np.array([KINDS[kinds[k]][1] for k in kind_of], dtype=np.uint32)
+        caps = np.array([(L.pco_gfx_guarantee_chunk_size(N18, int(b)) + 64 + 15) // 16 * 16 for b in dtb], dtype=np.uint64)
+        cap_off = np.concatenate([[0], np.cumsum(caps)]).astype(np.uint64)
+        comp = torch.zeros(int(cap_off[-1]), dtype=torch.uint8, device=device)
+        src_ptr = np.array([data[k].data_ptr() + int(r) * N18 * elem[k] for k, r in zip(kind_of, row_of)], dtype=np.uint64)
+        out_ptr = np.array([out[k].data_ptr() + int(r) * N18 * elem[k] for k, r in zip(kind_of, row_of)], dtype=np.uint64)
+
+        enc_tasks = np.zeros(nch, ENC_TASK)
+        enc_tasks["src"] = src_ptr; enc_tasks["n"] = N18; enc_tasks["dtype"] = dtb; enc_tasks["dst_cap"] = caps
+        enc_tasks["dst"] = np.uint64(comp.data_ptr()) + cap_off[:-1]
+        dec_tasks = np.zeros(nch, DEC_TASK)
+        dec_tasks["src"] = enc_tasks["dst"]; dec_tasks["dst"] = out_ptr; dec_tasks["dst_cap"] = N18; dec_tasks["dtype"] = dtb
+        enc_res = np.zeros(nch, RESULT); dec_res = np.zeros(nch, RESULT)
+        d_res = torch.zeros(nch * RESULT.itemsize, dtype=torch.uint8, device=device)
+        # --gather buffers: this rank's compacted stream, its offsets, the scattered copy the decoders read, and (rank 0) the file body
+        if gather:
+            stream_cap = int(cap_off[-1]) + 64
+            payload = torch.zeros(stream_cap, dtype=torch.uint8, device=device)
+            d_offs = torch.zeros(nch + 1, dtype=torch.int64, device=device)
+            recv = torch.zeros(stream_cap, dtype=torch.uint8, device=device)
+            file_body = torch.zeros(stream_cap * world, dtype=torch.uint8, device=device) if rank == 0 and world > 1 else None
+        gather_ms = []
+        state = {"n_bytes": 0, "offs": None}
+
+        def encode():
+            G.check(L.pco_gfx_compress_chunks(nch, enc_tasks.ctypes.data, C.byref(gcfg), enc_res.ctypes.data, d_res.data_ptr() if gather else None, None))
+            if gather:   # device-side compaction (no Python loop), then the exact-size gather-v to rank 0
+                t = time.perf_counter()
+                total = C.c_uint64(0)
+                G.check(L.pco_gfx_compact_chunks(nch, enc_tasks.ctypes.data, d_res.data_ptr(), payload.data_ptr(), stream_cap - 64, 0, d_offs.data_ptr(), C.byref(total), None))
+                state["n_bytes"] = int(total.value)
+                if world > 1:
+                    totals = S.exchange_totals(state["n_bytes"], device)
+                    _, state["offs"] = S.gather_stream(payload, state["n_bytes"], dst=0, out=file_body, totals=totals)
+                    torch.cuda.synchronize()
+                gather_ms.append((time.perf_counter() - t) * 1e3)
+
+        def decode():
+            if gather:   # decoders read the byte ranges the root hands out
+                if world > 1:
+                    S.scatter_stream(file_body, state["offs"], recv, src=0)
+                    base = recv.data_ptr()
+                else:
+                    base = payload.data_ptr()
+                sizes = enc_res["n_out"]
+                dec_tasks["src"] = np.uint64(base) + np.concatenate([[0], np.cumsum(sizes[:-1])]).astype(np.uint64)
+                dec_tasks["src_len"] = sizes
+            else:
+                dec_tasks["src_len"] = enc_res["n_out"]
+            G.check(L.pco_gfx_decompress_chunks(nch, dec_tasks.ctypes.data, dec_res.ctypes.data, None, None))
+
+        # warm-up, with the reference bench's bitwise round-trip assertion (pco_cli/src/bench/codecs/mod.rs:176-189)
+        L.pco_gfx_profile_begin()   # (warm-up also fills the library's pool of timing events, so the timed steps create none)
+        for w in range(max(warmup, 1)):
+            encode(); decode()
+        torch.cuda.synchronize()
+        for k in data:
+            assert torch.equal(out[k].view(torch.uint8), data[k].view(torch.uint8)), "decode(encode(x)) != x"
+        verified = 0
+        if rank == 0 and verify_chunks > 0:   # parity spot check against the oracle's bytes (native threads)
+            verified = self.verify_against_oracle(kinds, cfg_kw, kind_of, row_of, data, comp, cap_off, enc_res["n_out"], verify_chunks)
+
+        # timed region: exactly K steps, bracketed by barrier + synchronize
+        self.sync_all()
+        gather_ms.clear()
+        L.pco_gfx_profile_begin()
+        t_enc = t_dec = 0.0
+        step_ms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a = time.perf_counter(); encode(); b = time.perf_counter(); decode(); c = time.perf_counter()
+            t_enc += b - a; t_dec += c - b; step_ms.append((c - a) * 1e3)
+        self.sync_all()
+        elapsed = time.perf_counter() - t0
+        names = C.create_string_buffer(1 << 18); ms = (C.c_float * 65536)()
+        nk = L.pco_gfx_profile_end(names, len(names), ms, 65536)
+        el = torch.tensor([elapsed, t_enc, t_dec], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed, t_enc, t_dec = (float(x) for x in el.tolist())
+        ms_per_step = elapsed * 1e3 / steps
+        rank_bytes = int(chunk_bytes.sum())
+        total_bytes = world * rank_bytes   # (every rank owns the same mix: kinds cycle with a period that divides nch)
+        value = 2 * total_bytes / (ms_per_step * 1e-3) / 1e9
+        rec = None
+        if rank == 0:
+            raw = names.raw; kn = []; pos = 0
+            for _ in range(nk):
+                e = raw.index(b"\0", pos); kn.append(raw[pos:e].decode()); pos = e + 1
+            per = {}
+            for nm, t in zip(kn, ms[:nk]):
+                per.setdefault(nm, []).append(float(t))
+            kavg = {k: sum(v) / len(v) for k, v in per.items()}                 # per launch
+            kstep = {k: sum(v) / steps for k, v in per.items()}                 # per step (a kernel may launch several times per step)
+            comp_bytes = int(enc_res["n_out"].sum())
+            # algorithmic bytes per launch (SURVEY.md 8d): encode = n*sizeof(T) read + C written; decode = C read + n*sizeof(T) written
+            alg = rank_bytes + comp_bytes
+            dom = max(kavg, key=kavg.get)
+            traffic_tab, traffic_src = load_traffic(workload, nch, list(kstep))
+
+            def direction(prefixes):
+                ks = [k for k in kstep if k.startswith(prefixes)]
+                t = sum(kstep[k] for k in ks)
+                tr = sum(traffic_tab.get(k, 0) for k in ks) if traffic_tab else None
+                return {"kernel_ms": round(t, 4), "achieved": round(alg / (t * 1e-3) / 1e9, 1) if t > 0 else None,
+                        "frac": round(alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None, "traffic": tr,
+                        "traffic_over_algorithmic": round(tr / alg, 2) if tr else None}
+
+            enc_d = direction(("enc_", "gather_", "compact_", "auto_", "split_gather")); dec_d = direction(("dec_", "pco_decode"))
+            both_t = enc_d["kernel_ms"] + dec_d["kernel_ms"]
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(alg / (kavg[dom] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(alg / (kavg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_tab.get(dom) if traffic_tab else None,
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4),
+                    # the honest numbers: a direction's algorithmic bytes over the SUM of its kernels' time (the dominant-kernel
+                    # figure above credits one kernel with the whole direction's bytes)
+                    "direction": {"encode": enc_d, "decode": dec_d,
+                                  "step": {"kernel_ms": round(both_t, 4), "achieved": round(2 * alg / (both_t * 1e-3) / 1e9, 1), "frac": round(2 * alg / (both_t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+                    "per_kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kstep.items())}}
+            rec = {
+                "workload": workload, "value": round(value, 2), "ms_per_step": round(ms_per_step, 3), "dtype": dtype_label, "steps": steps, "warmup": warmup,
+                "config": {"workload": desc, "chunks_per_gpu": nch, "chunk_n": N18, "compression_level": 8,
+                           "mode_spec": MODE_NAMES[cfg_kw.get("mode", 0)] + (f"({cfg_kw['mode_f64']})" if "mode_f64" in cfg_kw else ""),
+                           "delta_spec": DELTA_NAMES[cfg_kw.get("delta", 0)] + (f"({cfg_kw['delta_order']})" if "delta_order" in cfg_kw else ""),
+                           "parallelism": f"chunk-sharded x{world}, contiguous chunk blocks" + (", device compaction + RCCL gather-v / scatter of the chunk bytes" if gather else ", no data-path collective"),
+                           "compressed_bytes_per_chunk": comp_bytes // nch,
+                           "encode_GBps": round(total_bytes * steps / t_enc / 1e9, 2),
+                           "decode_GBps": round(total_bytes * steps / t_dec / 1e9, 2),
+                           "median_step_ms_rank0": round(float(np.median(step_ms)), 3),
+                           "oracle_verified_chunks": verified},
+                "roofline": roof,
+            }
+            if gather:
+                rec["config"]["gather_ms_per_step_rank0"] = round(float(np.mean(gather_ms)), 3) if gather_ms else None
+                rec["config"]["stream_bytes_per_rank"] = state["n_bytes"]
+            if with_cpu and world == 1:
+                rec["cpu_baseline"] = cpu_baseline(kinds, cfg_kw, seconds=cpu_seconds)
+        # give the memory back before the next workload (the library's workspace is ~8 B per input byte)
+        del data, out, comp, d_res
+        if gather:
+            del payload, d_offs, recv, file_body
+        L.pco_gfx_release_workspace()
+        torch.cuda.empty_cache()
+        return rec
+
+
+# what the default invocation times after the headline workload (BASELINE.json's other configs + the default ChunkConfig on the
+# headline's and the f64 data): name -> chunks per GPU (None = 16 GiB of numbers), steps
+OTHER_WORKLOADS = [("c3", None, 4), ("c4", 4096, 3), ("c5", None, 3), ("c2auto", None, 3), ("c3auto", None, 3), ("c1", None, 3)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,214 +459,42 @@ def main():
     ap.add_argument("--chunks", type=int, default=None, help="chunks per GPU per step (default: 16 GiB of numbers per GPU)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--gather", action="store_true", help="file assembly: compact on device, gather-v the chunk bytes to rank 0 over RCCL, scatter them back for the decode")
-    ap.add_argument("--verify-chunks", type=int, default=64, help="chunks (drawn at random) whose bytes rank 0 compares with the oracle during warm-up")
+    ap.add_argument("--verify-chunks", type=int, default=1024, help="chunks (drawn at random) whose bytes rank 0 compares with the oracle during warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="only the headline workload (default: BASELINE's other configs are timed after it and attached as config.other_workloads)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
 
-    import torch
-    import torch.distributed as dist
-    from pcodec_amd import _lib as G
-    from pcodec_amd import sharding as S
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: pcodec_amd has no CPU fallback")
-    if world != args.gpus and rank == 0:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    L = G.lib()
-    L.pco_gfx_compact_chunks.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
-
-    kinds, cfg_kw, dtype_label, desc = WORKLOADS[args.workload]
-    gcfg = G.make_config(**cfg_kw)
-    elem = [np.dtype(KINDS[k][0]).itemsize for k in kinds]
-    if args.chunks is None:   # 16 GiB of numbers per GPU
-        per_cycle = sum(N18 * e for e in elem)
-        args.chunks = max(len(kinds), int((16 << 30) // per_cycle) * len(kinds))
-    nch = args.chunks = -(-args.chunks // len(kinds)) * len(kinds)   # whole cycles of the kinds: every rank owns the same mix
-    # this rank's block of the global chunk sequence (contiguous blocks, sharding.shard_range); kinds cycle over the GLOBAL index
-    c0, c1 = S.shard_range(nch * world, rank, world)
-    assert c1 - c0 == nch
-    g = torch.Generator(device=device); g.manual_seed(1234 + 7919 * rank)
-    kind_of = np.array([(c0 + i) % len(kinds) for i in range(nch)])
-    data = {}; row_of = np.zeros(nch, np.int64)
-    for k, kind in enumerate(kinds):
-        idx = np.nonzero(kind_of == k)[0]
-        row_of[idx] = np.arange(len(idx))
-        if len(idx): data[k] = make_kind(torch, kind, len(idx), g, device).contiguous()
-    out = {k: torch.empty_like(v) for k, v in data.items()}
-    chunk_bytes = np.array([N18 * elem[k] for k in kind_of], dtype=np.uint64)
-    dtb = np.array([KINDS[kinds[k]][1] for k in kind_of], dtype=np.uint32)
-    caps = np.array([(L.pco_gfx_guarantee_chunk_size(N18, int(b)) + 64 + 15) // 16 * 16 for b in dtb], dtype=np.uint64)
-    cap_off = np.concatenate([[0], np.cumsum(caps)]).astype(np.uint64)
-    comp = torch.zeros(int(cap_off[-1]), dtype=torch.uint8, device=device)
-    src_ptr = np.array([data[k].data_ptr() + int(r) * N18 * elem[k] for k, r in zip(kind_of, row_of)], dtype=np.uint64)
-    out_ptr = np.array([out[k].data_ptr() + int(r) * N18 * elem[k] for k, r in zip(kind_of, row_of)], dtype=np.uint64)
-
-    enc_tasks = np.zeros(nch, ENC_TASK)
-    enc_tasks["src"] = src_ptr; enc_tasks["n"] = N18; enc_tasks["dtype"] = dtb; enc_tasks["dst_cap"] = caps
-    enc_tasks["dst"] = np.uint64(comp.data_ptr()) + cap_off[:-1]
-    dec_tasks = np.zeros(nch, DEC_TASK)
-    dec_tasks["src"] = enc_tasks["dst"]; dec_tasks["dst"] = out_ptr; dec_tasks["dst_cap"] = N18; dec_tasks["dtype"] = dtb
-    enc_res = np.zeros(nch, RESULT); dec_res = np.zeros(nch, RESULT)
-    d_res = torch.zeros(nch * RESULT.itemsize, dtype=torch.uint8, device=device)
-    # --gather buffers: this rank's compacted stream, its offsets, the scattered copy the decoders read, and (rank 0) the file body
-    if args.gather:
-        stream_cap = int(cap_off[-1]) + 64
-        payload = torch.zeros(stream_cap, dtype=torch.uint8, device=device)
-        d_offs = torch.zeros(nch + 1, dtype=torch.int64, device=device)
-        recv = torch.zeros(stream_cap, dtype=torch.uint8, device=device)
-        file_body = torch.zeros(stream_cap * world, dtype=torch.uint8, device=device) if rank == 0 and world > 1 else None
-    gather_ms = []
-
-    def encode():
-        G.check(L.pco_gfx_compress_chunks(nch, enc_tasks.ctypes.data, C.byref(gcfg), enc_res.ctypes.data, d_res.data_ptr() if args.gather else None, None))
-        if args.gather:   # device-side compaction (no Python loop), then the exact-size gather-v to rank 0
-            t = time.perf_counter()
-            total = C.c_uint64(0)
-            G.check(L.pco_gfx_compact_chunks(nch, enc_tasks.ctypes.data, d_res.data_ptr(), payload.data_ptr(), stream_cap - 64, 0, d_offs.data_ptr(), C.byref(total), None))
-            state["n_bytes"] = int(total.value)
-            if world > 1:
-                totals = S.exchange_totals(state["n_bytes"], device)
-                _, state["offs"] = S.gather_stream(payload, state["n_bytes"], dst=0, out=file_body, totals=totals)
-                torch.cuda.synchronize()
-            gather_ms.append((time.perf_counter() - t) * 1e3)
-
-    def decode():
-        if args.gather:   # decoders read the byte ranges the root hands out
-            if world > 1:
-                S.scatter_stream(file_body, state["offs"], recv, src=0)
-                base = recv.data_ptr()
-            else:
-                base = payload.data_ptr()
-            sizes = enc_res["n_out"]
-            dec_tasks["src"] = np.uint64(base) + np.concatenate([[0], np.cumsum(sizes[:-1])]).astype(np.uint64)
-            dec_tasks["src_len"] = sizes
-        else:
-            dec_tasks["src_len"] = enc_res["n_out"]
-        G.check(L.pco_gfx_decompress_chunks(nch, dec_tasks.ctypes.data, dec_res.ctypes.data, None, None))
-
-    state = {"n_bytes": 0, "offs": None}
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    # warm-up, with the reference bench's bitwise round-trip assertion (pco_cli/src/bench/codecs/mod.rs:176-189)
-    L.pco_gfx_profile_begin()   # (warm-up also fills the library's pool of timing events, so the timed steps create none)
-    for w in range(max(args.warmup, 1)):
-        encode(); decode()
-    torch.cuda.synchronize()
-    for k in data:
-        assert torch.equal(out[k].view(torch.uint8), data[k].view(torch.uint8)), "decode(encode(x)) != x"
-    if rank == 0 and args.verify_chunks > 0:   # parity spot check: randomly drawn chunks against the oracle's bytes
-        import oracle_lib as O
-        pick = np.random.default_rng(99).choice(nch, size=min(args.verify_chunks, nch), replace=False)
-        for i in pick:
-            k = int(kind_of[i]); r = int(row_of[i])
-            host = data[k][r].cpu().numpy().view(KINDS[kinds[k]][0])
-            want = O.simple_compress(host, O.make_config(**cfg_kw))
-            n_out = int(enc_res["n_out"][i]); o = int(cap_off[i])
-            got = bytes(comp[o: o + n_out].cpu().numpy())
-            assert got == want[len(want) - 1 - n_out:-1], f"GPU chunk {i} ({kinds[k]}) differs from the oracle's bytes"
-
-    # timed region: exactly K steps, bracketed by barrier + synchronize
-    sync_all()
-    gather_ms.clear()
-    L.pco_gfx_profile_begin()
-    t_enc = t_dec = 0.0
-    step_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        a = time.perf_counter(); encode(); b = time.perf_counter(); decode(); c = time.perf_counter()
-        t_enc += b - a; t_dec += c - b; step_ms.append((c - a) * 1e3)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    names = C.create_string_buffer(1 << 18); ms = (C.c_float * 65536)()
-    nk = L.pco_gfx_profile_end(names, len(names), ms, 65536)
-    el = torch.tensor([elapsed, t_enc, t_dec], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed, t_enc, t_dec = (float(x) for x in el.tolist())
-    ms_per_step = elapsed * 1e3 / args.steps
-    rank_bytes = int(chunk_bytes.sum())
-    total_bytes = world * rank_bytes   # (every rank owns the same mix: kinds cycle with a period that divides nch)
-    value = 2 * total_bytes / (ms_per_step * 1e-3) / 1e9
-
-    if rank == 0:
-        raw = names.raw; kn = []; pos = 0
-        for _ in range(nk):
-            e = raw.index(b"\0", pos); kn.append(raw[pos:e].decode()); pos = e + 1
-        per = {}
-        for nm, t in zip(kn, ms[:nk]):
-            per.setdefault(nm, []).append(float(t))
-        kavg = {k: sum(v) / len(v) for k, v in per.items()}                 # per launch
-        kstep = {k: sum(v) / args.steps for k, v in per.items()}            # per step (a kernel may launch several times per step)
-        comp_bytes = int(enc_res["n_out"].sum())
-        # algorithmic bytes per launch: encode = n*sizeof(T) read + C written; decode = C read + n*sizeof(T) written
-        alg = rank_bytes + comp_bytes
-        dom = max(kavg, key=kavg.get)
-        traffic_tab = {}
-        for tag in ("r02", "r01"):   # HBM bytes per kernel from the committed PMC passes (profiles/), scaled to this run's chunk count
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_traffic_{args.workload}.json" if tag != "r01" else "r01_traffic.json")))
-                if tj.get("workload") == args.workload:
-                    traffic_tab = {k: int((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * nch / tj["chunks"]) for k, v in tj["kernels"].items()}
-                    break
-            except (OSError, ValueError, KeyError):
-                continue
-
-        def direction(prefixes):
-            ks = [k for k in kstep if k.startswith(prefixes)]
-            t = sum(kstep[k] for k in ks)
-            tr = sum(traffic_tab.get(k, 0) for k in ks) if traffic_tab else None
-            return {"kernel_ms": round(t, 4), "achieved": round(alg / (t * 1e-3) / 1e9, 1) if t > 0 else None,
-                    "frac": round(alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None, "traffic": tr,
-                    "traffic_over_algorithmic": round(tr / alg, 2) if tr else None}
-
-        enc_d = direction(("enc_", "gather_", "compact_")); dec_d = direction(("dec_", "pco_decode"))
-        both_t = enc_d["kernel_ms"] + dec_d["kernel_ms"]
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(alg / (kavg[dom] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(alg / (kavg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_tab.get(dom),
-                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4),
-                # the honest numbers: a direction's algorithmic bytes over the SUM of its kernels' time (the dominant-kernel
-                # figure above credits one kernel with the whole direction's bytes)
-                "direction": {"encode": enc_d, "decode": dec_d,
-                              "step": {"kernel_ms": round(both_t, 4), "achieved": round(2 * alg / (both_t * 1e-3) / 1e9, 1), "frac": round(2 * alg / (both_t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
-                "per_kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kstep.items())}}
-        line = {
-            "metric": "encode+decode GB/s (uncompressed) per chunk, u64/f64 2^18-elem", "value": round(value, 2), "unit": "GB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
-            "config": {"workload": desc, "chunks_per_gpu": nch, "chunk_n": N18, "compression_level": 8,
-                       "mode_spec": MODE_NAMES[cfg_kw.get("mode", 0)] + (f"({cfg_kw['mode_f64']})" if "mode_f64" in cfg_kw else ""),
-                       "delta_spec": DELTA_NAMES[cfg_kw.get("delta", 0)] + (f"({cfg_kw['delta_order']})" if "delta_order" in cfg_kw else ""),
-                       "parallelism": f"chunk-sharded x{world}, contiguous chunk blocks" + (", device compaction + RCCL gather-v / scatter of the chunk bytes" if args.gather else ", no data-path collective"),
-                       "compressed_bytes_per_chunk": comp_bytes // nch,
-                       "encode_GBps": round(total_bytes * args.steps / t_enc / 1e9, 2),
-                       "decode_GBps": round(total_bytes * args.steps / t_dec / 1e9, 2),
-                       "median_step_ms_rank0": round(float(np.median(step_ms)), 3),
-                       "oracle_verified_chunks": min(args.verify_chunks, nch)},
-            "roofline": roof,
-        }
-        if args.gather:
-            line["config"]["gather_ms_per_step_rank0"] = round(float(np.mean(gather_ms)), 3) if gather_ms else None
-            line["config"]["stream_bytes_per_rank"] = state["n_bytes"]
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(kinds, cfg_kw)
+    B = Bench(args)
+    head = B.run(args.workload, args.chunks, args.steps, args.warmup, args.gather, args.verify_chunks, not args.no_cpu_baseline)
+    others = []
+    if args.workload == "c2" and args.chunks is None and not args.no_others and not args.gather:
+        for name, chunks, steps in OTHER_WORKLOADS:
+            r = B.run(name, chunks, steps, 1, False, min(args.verify_chunks, 256), not args.no_cpu_baseline, cpu_seconds=6.0)
+            if r is not None:
+                cb = r.get("cpu_baseline")
+                others.append({"workload": name, "description": r["config"]["workload"], "dtype": r["dtype"], "value": r["value"], "unit": "GB/s", "steps": steps,
+                               "chunks_per_gpu": r["config"]["chunks_per_gpu"], "ms_per_step": r["ms_per_step"],
+                               "encode_GBps": r["config"]["encode_GBps"], "decode_GBps": r["config"]["decode_GBps"],
+                               "compressed_bytes_per_chunk": r["config"]["compressed_bytes_per_chunk"], "oracle_verified_chunks": r["config"]["oracle_verified_chunks"],
+                               "roofline": {"kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"], "avg_launch_ms": r["roofline"]["avg_launch_ms"],
+                                            "direction": r["roofline"]["direction"], "per_kernel_ms_per_step": r["roofline"]["per_kernel_ms_per_step"]},
+                               "cpu_baseline": None if cb is None else {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                                                       "single_thread": cb["single_thread"], "linear_extrapolation_one_socket": cb["linear_extrapolation_one_socket"]}})
+    if B.rank == 0:
+        line = {"metric": "encode+decode GB/s (uncompressed) per chunk, u64/f64 2^18-elem", "value": head["value"], "unit": "GB/s",
+                "n_gpus": B.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+                "config": head["config"], "roofline": head["roofline"]}
+        if others:
+            line["config"]["other_workloads"] = others
+        if "cpu_baseline" in head:
+            line["cpu_baseline"] = head["cpu_baseline"]
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if B.world > 1:
+        B.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -188,7 +188,9 @@ enum PcoError pco_gfx_decompress_chunks(size_t n_tasks, const PcoGfxDecodeTask* 
  * d_results array to that call; it is filled in synchronous calls too).  Chunk i's bytes are copied to
  * d_dst[d_offsets[i] .. d_offsets[i+1]) with d_offsets[0] = dst_offset; d_offsets is a DEVICE array of n_tasks + 1 entries.
  * If `total` is non-NULL the call synchronises `stream` and stores d_offsets[n_tasks] (the end of the stream) there, failing
- * with PCO_GFX_INVALID_ARGUMENT when it exceeds dst_cap (nothing is copied in that case); with total == NULL it is asynchronous. */
+ * with PCO_GFX_INVALID_ARGUMENT when it exceeds dst_cap (nothing is copied in that case); with total == NULL it is asynchronous
+ * and a destination that is too small shows as d_offsets[n_tasks] == ~0 (again nothing is copied).  At most 2^31 / ceil(max
+ * dst_cap / 64 KiB) chunks per call. */
 enum PcoError pco_gfx_compact_chunks(size_t n_tasks, const PcoGfxEncodeTask* tasks, const PcoGfxTaskResult* d_results, void* d_dst,
                                      uint64_t dst_cap, uint64_t dst_offset, uint64_t* d_offsets, uint64_t* total, void* stream);
 
@@ -249,6 +251,14 @@ enum PcoError pco_page_decompressor_new(PcoGfxChunkDecompressor*, const void* sr
 enum PcoError pco_page_decompressor_read(PcoGfxPageDecompressor*, void* dst, size_t dst_len, size_t* n_processed, int* finished);
 size_t pco_page_decompressor_consumed(const PcoGfxPageDecompressor*);
 void pco_page_decompressor_free(PcoGfxPageDecompressor*);
+
+/* ------------------------------------------------------------------------------------------
+ * 5. Test hook (NOT part of the drop-in surface; exported so that the GPU tests can check the device's arithmetic operation by
+ *    operation against an IEEE reference).  Stage 1 of ModeSpec::Auto detection on floats (mode/float_mult.rs:145-275,
+ *    mode/float_quant.rs:73-118) run on a host array taken as the sample, in order.  out[0..66]: s_size, tz5, n_gcd, sim[3],
+ *    hist[56], has_euclid, k, n_ints, base_c (lo, hi).  Returns a PcoGfxStatus.
+ * ---------------------------------------------------------------------------------------- */
+int pco_gfx_debug_float_screen(const void* values, size_t n, uint32_t dtype, uint32_t* out);
 
 #if defined(__cplusplus)
 }

@@ -547,6 +547,17 @@ inline void validate_chunk_meta(const ChunkMeta& m) {
     uint64_t window_n = (uint64_t)1 << m.delta.window_n_log;
     for (const DynBin& b : m.vars[kVarDelta].bins)
       if (b.lower < 1 || b.lower > window_n) fail(kCorruption, "delta lookback bin had invalid lower bound");
+  } else if (m.delta.kind == kDeltaConv1) {  // chunk.rs:58-94: the primary latent type bounds the Conv type (data_types/unsigned.rs:132-138)
+    const int l_bits = m.vars[kVarPrimary].latent_bits;
+    if (l_bits > 32) fail(kCorruption, "Conv1 delta encodings are not supported on types larger than 32 bits");
+    const int conv_bits = l_bits == 32 ? 64 : 2 * l_bits;
+    const Bitlen max_quantization = std::min<Bitlen>((1u << BITS_TO_ENCODE_DELTA_CONV_QUANTIZATION) - 1, (Bitlen)(conv_bits - 1));
+    if (m.delta.quantization > max_quantization) fail(kCorruption, "Conv1 delta encoding quantization exceeds max");
+    double sum_abs = 0.0;   // (i64::abs as f64, summed in order)
+    for (int64_t wgt : m.delta.weights) sum_abs += (double)(wgt < 0 ? (uint64_t)0 - (uint64_t)wgt : (uint64_t)wgt);
+    const double bias_abs = std::fabs((double)m.delta.bias);
+    const double max_pred = bias_abs + std::ldexp(1.0, l_bits) * sum_abs;
+    if (max_pred >= std::ldexp(1.0, conv_bits - 1)) fail(kCorruption, "Conv1 delta encoding weights and bias risk overflowing");
   }
 }
 inline ChunkMeta read_chunk_meta(BitReader& r, uint8_t format_major, int latent_bits) {

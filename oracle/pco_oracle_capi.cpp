@@ -6,6 +6,7 @@
 #include "pco_oracle.hpp"
 #include "pco_oracle_decode.hpp"
 #include "pco_oracle_encode.hpp"
+#include "pco_oracle_testenc.hpp"
 #include <memory>
 
 using namespace pco_oracle;
@@ -90,6 +91,24 @@ int pco_oracle_simple_compress_exact(const void* nums, size_t n, uint8_t dtype, 
     dispatch_bits(dtype_bits(dtype), [&](auto tag) {
       typedef decltype(tag) LTYPE;
       out = simple_compress_t<LTYPE>((const LTYPE*)nums, n, dtype, cfg, uniform_type != 0);
+    });
+    if (out.size() > dst_cap) fail(kInvalidArgument, "destination too small");
+    std::memcpy(dst, out.data(), out.size());
+    *n_written = out.size();
+  });
+}
+
+// TEST-ONLY stream generator (pco_oracle_testenc.hpp): a standalone file of one chunk per entry of `chunks`, written with features the
+// restated encoder lacks (Dict mode, Conv1 delta, delta'd secondary variable, lookback state); any valid stream will do for decode sweeps.
+int pco_oracle_test_encode(const void* nums, size_t n, uint8_t dtype, const TestEncSpec* spec, const size_t* chunks, size_t n_chunks,
+                           uint8_t* dst, size_t dst_cap, size_t* n_written) {
+  return guard([&] {
+    if (!dtype_valid(dtype)) fail(kInvalidArgument, "invalid dtype");
+    std::vector<size_t> cs(chunks, chunks + n_chunks);
+    std::vector<uint8_t> out;
+    dispatch_bits(dtype_bits(dtype), [&](auto tag) {
+      typedef decltype(tag) LTYPE;
+      out = test_encode_file<LTYPE>((const LTYPE*)nums, n, dtype, *spec, cs);
     });
     if (out.size() > dst_cap) fail(kInvalidArgument, "destination too small");
     std::memcpy(dst, out.data(), out.size());
@@ -400,5 +419,45 @@ extern "C" int pco_oracle_bench(const void* nums, size_t n, uint8_t dtype, const
     if (failed.load()) fail(kCorruption, "oracle bench: round trip failed");
     double se = 0, sd = 0; for (uint32_t k = 0; k < n_threads; k++) { se += t_enc[k]; sd += t_dec[k]; }
     out[0] = (double)done.load(); out[1] = wall; out[2] = se; out[3] = sd;
+  });
+}
+
+// ---------------------------------------------------------------------------
+// Parity spot check of bench.py's warm-up step: `n_chunks` chunks of n numbers each (numbers at nums + i * stride_bytes) are
+// compressed by the restated reference on `n_threads` host threads and compared with the standalone chunks the GPU produced
+// (got + got_off[i], got_len[i] bytes: dtype byte | n - 1 | ChunkMeta | page, i.e. the oracle's file minus header and terminator).
+// *n_bad = chunks that differ, *first_bad = the first of them (or -1).
+// ---------------------------------------------------------------------------
+extern "C" int pco_oracle_verify_chunks(const void* nums, size_t n_chunks, size_t n, size_t stride_bytes, uint8_t dtype, const PcoOracleConfig* config,
+                                        const uint8_t* got, const uint64_t* got_off, const uint64_t* got_len, uint32_t n_threads,
+                                        uint64_t* n_bad, int64_t* first_bad) {
+  return guard([&] {
+    if (!dtype_valid(dtype)) fail(kInvalidArgument, "invalid dtype");
+    if (n_threads == 0) n_threads = 1;
+    mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_ARENA_MAX, (int)n_threads + 8);
+    const ChunkConfig cfg = to_cfg(config);
+    const int bits = dtype_bits(dtype);
+    std::atomic<size_t> next{0}; std::atomic<uint64_t> bad{0}; std::atomic<int64_t> first{-1}; std::atomic<int> failed{0};
+    auto worker = [&]() {
+      try {
+        dispatch_bits(bits, [&](auto tag) {
+          typedef decltype(tag) LTYPE;
+          for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n_chunks) break;
+            const std::vector<uint8_t> want = simple_compress_t<LTYPE>((const LTYPE*)((const uint8_t*)nums + i * stride_bytes), n, dtype, cfg, false);
+            const size_t len = (size_t)got_len[i];
+            const bool same = want.size() >= len + 1 && std::memcmp(want.data() + (want.size() - 1 - len), got + got_off[i], len) == 0 &&
+                              want.size() - 1 - len == standalone_header_len(n);
+            if (!same) { bad.fetch_add(1); int64_t cur = first.load(); while ((cur < 0 || (int64_t)i < cur) && !first.compare_exchange_weak(cur, (int64_t)i)) {} }
+          }
+        });
+      } catch (...) { failed.store(1); }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < n_threads; k++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    if (failed.load()) fail(kCorruption, "oracle verify: the oracle failed to compress a chunk");
+    *n_bad = bad.load(); *first_bad = first.load();
   });
 }

@@ -1115,6 +1115,7 @@ inline void write_standalone_header(BitWriter& w, size_t n_hint, uint8_t uniform
   const uint8_t ver[2] = {FORMAT_MAJOR, FORMAT_MINOR};
   w.write_aligned_bytes(ver, 2);
 }
+inline size_t standalone_header_len(size_t n_hint) { BitWriter w; write_standalone_header(w, n_hint, 0); return w.byte_len(); }
 template <class L> void write_standalone_chunk(const ChunkCompressor<L>& cc, BitWriter& w) {
   w.write_aligned_bytes(&cc.dtype, 1);
   w.write_uint(cc.page_infos[0].page_n - 1, BITS_TO_ENCODE_N_ENTRIES);

@@ -520,56 +520,136 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
 }
 
 // Dict mode page (mode/dict.rs:70-90): the primary variable holds u32 indices into the chunk's dictionary (ChunkMeta, uncompressed, in
-// src); delta None or Consecutive on the indices.  num = from_latent_ordered(dict[index]); an index beyond the dictionary is corruption.
+// src), under any delta encoding (None, Consecutive, Conv1 on the u32 indices; Lookback with its own u32 delta variable).
+// num = from_latent_ordered(dict[index]); an index beyond the dictionary is corruption.  Lookback keeps its history -- the indices --
+// in dst and maps them through the dictionary in place once the page is decoded (decode_chunk has made sure an index fits a number).
 template <class L, bool kLds>
 __device__ __noinline__ void decode_page_body_dict(gcptr_u8 src, uint64_t src_len, MetaReader& mr, tptr<kLds, uint8_t> tbl,
                                                   const PageParams& pp, L PCO_GLOBAL* dst, uint32_t& status) {
   const uint32_t lane = lane_id();
   uint8_t PCO_LDS* smem = lds_base();
   uint32_t PCO_LDS* moments = (uint32_t PCO_LDS*)(smem + kLdsMomOff);
+  uint32_t PCO_LDS* dlat = (uint32_t PCO_LDS*)(smem + kLdsDlatOff);
+  uint32_t PCO_LDS* scratch = (uint32_t PCO_LDS*)(smem + kLdsScratchOff);
+  uint32_t PCO_LDS* parent = (uint32_t PCO_LDS*)(smem + kLdsParentOff);
   VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(smem + kLdsVarOff);
   const uint32_t n = pp.n, num_kind = pp.num_kind;
-  const uint32_t n_bins = uni(vinfo[1].n_bins), max_ob = uni(vinfo[1].max_ob), asl = uni(vinfo[1].ans_size_log), dk = uni(vinfo[1].delta_kind), dord = uni(vinfo[1].delta_order);
-  const uint32_t off_nodes = uni(vinfo[1].off_nodes), off_lower = uni(vinfo[1].off_lower), off_ob = uni(vinfo[1].off_ob);
-  const uint32_t nlps = dk == kDeltaConsecutive ? dord : 0u;
-  uint32_t st = 0;
-  for (uint32_t i = 0; i < nlps; i++) { const uint32_t x = (uint32_t)mr.read(32); if (lane == 0 && i < 8) moments[i] = x; }
-  { uint32_t mine = 0; for (uint32_t j = 0; j < 4; j++) { const uint32_t s = (uint32_t)mr.read(asl); if (lane == j) mine = s; } st = mine; }
+  const uint32_t dk = uni(vinfo[1].delta_kind), dord = uni(vinfo[1].delta_order);
+  const bool lookback = dk == kDeltaLookback;
+  const uint32_t window_n = 1u << uni(vinfo[1].window_n_log);
+  uint32_t n_bins[2], max_ob[2], asl[2], off_nodes[2], off_lower[2], off_ob[2];
+#pragma unroll
+  for (int vi = 0; vi < 2; vi++) {
+    n_bins[vi] = uni(vinfo[vi].n_bins); max_ob[vi] = uni(vinfo[vi].max_ob); asl[vi] = uni(vinfo[vi].ans_size_log);
+    off_nodes[vi] = uni(vinfo[vi].off_nodes); off_lower[vi] = uni(vinfo[vi].off_lower); off_ob[vi] = uni(vinfo[vi].off_ob);
+  }
+  const uint32_t nlps = (dk == kDeltaConsecutive || dk == kDeltaConv1) ? dord : (lookback ? (1u << uni(vinfo[1].state_n_log)) : 0u);
+  const uint32_t state_n = lookback ? nlps : 0u;
+  // ---- page meta (metadata/page.rs:36-57): [delta variable: 4 tANS states] then [primary: delta state, 4 tANS states] ----
+  uint32_t st[2] = {0, 0};
+#pragma unroll
+  for (int vi = 0; vi < 2; vi++) {
+    if (vi == 0 && !lookback) continue;
+    if (vi == 1) for (uint32_t i = 0; i < nlps; i++) {
+      const uint32_t x = (uint32_t)mr.read(32);
+      if (dk == kDeltaConsecutive) { if (lane == 0 && i < 8) moments[i] = x; }
+      else if (dk == kDeltaConv1) { if (lane == 0 && i < 32) scratch[i] = x; }
+      else if (i < n && mr.in_bounds()) { if (lane == 0) dst[i] = (L)x; }   // lookback state = the first state_n indices
+    }
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < 4; j++) { const uint32_t s = (uint32_t)mr.read(asl[vi]); if (lane == j) mine = s; }
+    st[vi] = mine;
+  }
   if (!mr.drain_empty_byte()) { if (mr.in_bounds()) status = PCO_GFX_CORRUPTION; }
   if (!mr.in_bounds()) { status = PCO_GFX_INSUFFICIENT_DATA; return; }
   if (status) return;
-  if (n > nlps && n_bins == 0) { status = PCO_GFX_CORRUPTION; return; }
+  if (n > nlps && (n_bins[1] == 0 || (lookback && n_bins[0] == 0))) { status = PCO_GFX_CORRUPTION; return; }
   wave_sync_lds();
   uint64_t bitpos = mr.bit;
-  uint32_t n_remaining = n, oob = 0;
+  uint32_t n_remaining = n, oob = 0, lb_oob = 0;
   constexpr uint32_t kBytes = sizeof(L);
+  auto dict_value = [&](uint32_t index) -> L {
+    L v = 0;
+    gcptr_u8 p = src + pp.dict_byte + (uint64_t)index * kBytes;
+    for (uint32_t b = 0; b < kBytes; b++) v |= (L)((L)p[b] << (8 * b));   // (the dictionary sits at an arbitrary byte offset)
+    return from_latent_ordered<L>(v, num_kind);
+  };
   for (uint32_t j0 = 0; j0 < n; j0 += kBatchN) {
     const uint32_t batch_n = n_remaining < kBatchN ? n_remaining : kBatchN;
     const uint32_t rem = n_remaining > nlps ? n_remaining - nlps : 0, cnt = rem < kBatchN ? rem : kBatchN;
     uint32_t idx[4] = {0, 0, 0, 0};
-    if (cnt > 0) {
-      const bool single_bin = n_bins <= 1;
-      if (!single_bin) bitpos = walk_ans<kLds>(src, src_len, bitpos, cnt, (tptr<kLds, uint32_t>)(tbl + off_nodes), st);
-      tptr<kLds, uint32_t> lw = (tptr<kLds, uint32_t>)(tbl + off_lower);
-      if (max_ob != 0 || !single_bin) bitpos = unpack_offsets<uint32_t, kLds>(src, src_len, bitpos, cnt, lw, tbl + off_ob, single_bin, idx);
-      else { const uint32_t l0 = lw[0]; for (int k = 0; k < 4; k++) idx[k] = 4 * lane + k < cnt ? l0 : 0u; }
+#pragma unroll
+    for (int vi = 0; vi < 2; vi++) {
+      if (vi == 0 && !lookback) continue;
+      const uint32_t c = vi == 0 ? (cnt < batch_n ? cnt : batch_n) : cnt;
+      if (c == 0) { if (vi == 0) for (int k = 0; k < 4; k++) dlat[4 * lane + k] = 0u; continue; }
+      uint32_t tmp[4];
+      const bool single_bin = n_bins[vi] <= 1;
+      if (!single_bin) bitpos = walk_ans<kLds>(src, src_len, bitpos, c, (tptr<kLds, uint32_t>)(tbl + off_nodes[vi]), st[vi]);
+      tptr<kLds, uint32_t> lw = (tptr<kLds, uint32_t>)(tbl + off_lower[vi]);
+      if (max_ob[vi] != 0 || !single_bin) bitpos = unpack_offsets<uint32_t, kLds>(src, src_len, bitpos, c, lw, tbl + off_ob[vi], single_bin, tmp);
+      else { const uint32_t l0 = lw[0]; for (int k = 0; k < 4; k++) tmp[k] = 4 * lane + k < c ? l0 : 0u; }
       if (bitpos > src_len * 8) { status = PCO_GFX_INSUFFICIENT_DATA; return; }
+      if (vi == 0) { for (int k = 0; k < 4; k++) dlat[4 * lane + k] = 4 * lane + k < c ? tmp[k] : 0u; }
+      else { for (int k = 0; k < 4; k++) idx[k] = tmp[k]; }
     }
     if (dk == kDeltaConsecutive) consecutive_decode<uint32_t>(idx, dord, moments);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t i = 4 * lane + k;
-      if (i < batch_n) {
-        if (idx[k] >= pp.dict_n) oob = 1;
-        else {
-          L v = 0;
-          gcptr_u8 p = src + pp.dict_byte + (uint64_t)idx[k] * kBytes;
-          for (uint32_t b = 0; b < kBytes; b++) v |= (L)((L)p[b] << (8 * b));   // (the dictionary sits at an arbitrary byte offset)
-          dst[j0 + i] = from_latent_ordered<L>(v, num_kind);
+    else if (dk == kDeltaConv1) conv1_decode<uint32_t>(idx, batch_n, dord, pp.conv_quant);
+    if (lookback) {
+      // F[state_n + k] = delta_k + MID + F[state_n + k - lb_k] (delta/lookback.rs:200-246), the indices F living in dst
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t kbase = (uint64_t)j0;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t i = 4 * lane + k;
+        uint32_t val = idx[k] + 0x80000000u, par = 0xffffffffu;
+        if (i < cnt) {
+          uint32_t lb = dlat[i];
+          if (lb > window_n) { lb_oob = 1; lb = 1; }
+          if (lb == 0) {
+            // (the slot's stale window content in the reference; only reachable from corrupt bins, which ChunkMeta validation rejects)
+          } else if (lb <= i) par = i - lb;
+          else {
+            const int64_t jsrc = (int64_t)(state_n + kbase + i) - (int64_t)lb;
+            if (jsrc >= 0) val += (uint32_t)__hip_atomic_load(&dst[jsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
+        scratch[i] = val; parent[i] = par;
+      }
+      wave_sync_lds();
+      for (int round = 0; round < 8; round++) {  // pointer jumping: resolves in-batch chains of length <= 256
+        uint32_t nv[4], np[4];
+        for (int k = 0; k < 4; k++) {
+          const uint32_t i = 4 * lane + k; const uint32_t p = parent[i];
+          nv[k] = scratch[i]; np[k] = p;
+          if (p != 0xffffffffu) { nv[k] += scratch[p]; np[k] = parent[p]; }
+        }
+        wave_sync_lds();
+        for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; scratch[i] = nv[k]; parent[i] = np[k]; }
+        wave_sync_lds();
+      }
+      for (int k = 0; k < 4; k++) {
+        const uint32_t i = 4 * lane + k;
+        if (i < cnt) { const uint32_t f = scratch[i]; if (f >= pp.dict_n) oob = 1; dst[state_n + kbase + i] = (L)f; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t i = 4 * lane + k;
+        if (i < batch_n) { if (idx[k] >= pp.dict_n) oob = 1; else dst[j0 + i] = dict_value(idx[k]); }
       }
     }
     n_remaining -= batch_n;
+  }
+  if (uni(wave_or_u32(lb_oob))) { status = PCO_GFX_CORRUPTION; return; }
+  if (lookback) {   // the page's indices are complete: map them through the dictionary in place
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t j = lane; j < n; j += 64) {
+      const L f = __hip_atomic_load(&dst[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint64_t)f >= (uint64_t)pp.dict_n) oob = 1; else dst[j] = dict_value((uint32_t)f);
+    }
   }
   if (uni(wave_or_u32(oob))) { status = PCO_GFX_CORRUPTION; return; }
   mr.bit = bitpos;
@@ -687,7 +767,7 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
       if (lw < 1 || lw > (1u << wlog)) bad = 1;
     }
     if (uni(wave_or_u32(bad))) { status = PCO_GFX_CORRUPTION; return; }
-    if (sec_uses_delta) { status = PCO_GFX_UNSUPPORTED; return; }  // (no encoder writes it; the history of a second variable would need its own buffer)
+    if (sec_uses_delta && present[2]) { status = PCO_GFX_UNSUPPORTED; return; }  // (no encoder writes it; the history of a second variable would need its own buffer)
   }
   // mode validity for the number type (data_types/unsigned.rs:65-71, float.rs:377-390)
   {
@@ -705,8 +785,21 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
     }
     if (!valid) { status = PCO_GFX_CORRUPTION; return; }
   }
-  if (dkind == kDeltaConv1 && (LB > 32 || dict)) { status = LB > 32 ? PCO_GFX_CORRUPTION : PCO_GFX_UNSUPPORTED; return; }   // delta/conv1.rs: no 64-bit Conv type
-  if (dict && dkind == kDeltaLookback) { status = PCO_GFX_UNSUPPORTED; return; }   // (index history would need its own buffer; no encoder path produces it by default)
+  if (dkind == kDeltaConv1) {   // ChunkMeta::new validation (metadata/chunk.rs:58-94); the primary variable's latent type decides (u32 in Dict mode)
+    const uint32_t plb = dict ? 32u : LB;
+    if (plb > 32) { status = PCO_GFX_CORRUPTION; return; }   // "Conv1 delta encodings are not supported on types larger than 32 bits"
+    const uint32_t conv_bits = plb == 32 ? 64u : 2 * plb;   // Conv = i16 / i32 / i64 (data_types/unsigned.rs:132-134)
+    const uint32_t max_quant = conv_bits - 1 < 31u ? conv_bits - 1 : 31u;
+    if (conv_quant > max_quant) { status = PCO_GFX_CORRUPTION; return; }
+    const int64_t PCO_LDS* cw = (const int64_t PCO_LDS*)(lds_base() + kLdsConvOff);
+    double sum_abs = 0.0;
+    for (uint32_t k = 0; k < dorder; k++) { const int64_t wk = cw[1 + k]; sum_abs += (double)(wk < 0 ? -wk : wk); }
+    const double max_pred = fabs((double)cw[0]) + ldexp(1.0, (int)plb) * sum_abs;
+    if (max_pred >= ldexp(1.0, (int)conv_bits - 1)) { status = PCO_GFX_CORRUPTION; return; }   // "weights and bias risk overflowing"
+  }
+  // Dict + Lookback keeps the u32 indices in dst until the page is done: they must fit a number.  A dictionary of distinct latents
+  // (the only kind an encoder writes, mode/dict.rs:12-33) always does; a padded one on an 8- / 16-bit type is refused.
+  if (dict && dkind == kDeltaLookback && LB < 32 && dict_n > (1u << LB)) { status = PCO_GFX_UNSUPPORTED; return; }
   if (meta_only) return;
   PageParams pp{mode_kind, mode_k, num_kind, n, (uint64_t)mode_base, dict_byte, dict_n, dorder, conv_quant};
   if (dict) {

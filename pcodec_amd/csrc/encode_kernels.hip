@@ -185,9 +185,10 @@ __global__ void enc_init_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, 
 
 // gather: out[k] = src[idx[k]]  (Auto sampling: sampling.rs:27-100)
 struct GatherTask { const void* src; void* dst; const uint32_t* idx; uint32_t n_idx, elem_bytes; };
-__global__ __launch_bounds__(256) void gather_kernel(const GatherTask* tasks) {
-  const GatherTask g = tasks[blockIdx.y];
-  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void gather_kernel(const GatherTask* tasks, uint32_t blocks_per_task) {   // (linear grid: gridDim.y stops at 65535)
+  const uint32_t t = blockIdx.x / blocks_per_task;
+  const GatherTask g = tasks[t];
+  const uint32_t k = (blockIdx.x - t * blocks_per_task) * 256 + threadIdx.x;
   if (k >= g.n_idx) return;
   const uint32_t i = g.idx[k];
   if (g.elem_bytes == 8) ((uint64_t*)g.dst)[k] = ((const uint64_t*)g.src)[i];
@@ -271,9 +272,10 @@ template <class L> __device__ __forceinline__ void split_gather_one(const SplitG
   }
   ((L PCO_GLOBAL*)g.dst)[k] = p;
 }
-__global__ __launch_bounds__(256) void split_gather_kernel(const SplitGatherTask* tasks) {
-  const SplitGatherTask g = tasks[blockIdx.y];
-  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void split_gather_kernel(const SplitGatherTask* tasks, uint32_t blocks_per_task) {
+  const uint32_t t = blockIdx.x / blocks_per_task;
+  const SplitGatherTask g = tasks[t];
+  const uint32_t k = (blockIdx.x - t * blocks_per_task) * 256 + threadIdx.x;
   if (k >= g.n_idx) return;
   const uint32_t num_kind = dtype_kind(g.dtype); const int bits = dtype_bits(g.dtype);
   if (bits == 64) split_gather_one<uint64_t>(g, k, num_kind);

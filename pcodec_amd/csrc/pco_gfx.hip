@@ -12,11 +12,13 @@
 #include <condition_variable>
 #include <functional>
 #include <sched.h>
+#include <pthread.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <unordered_map>
 
 #include "pco_auto_host.inc"
 #include "decode_kernel.hip"
@@ -34,18 +36,25 @@ void set_error(int status, const std::string& msg) { g_err.status = status; g_er
 void clear_error() { g_err.status = PCO_GFX_OK; g_err.msg.clear(); }
 
 struct WorkspaceHolder {
-  Workspace ws;
+  std::unordered_map<int, std::unique_ptr<Workspace>> by_device;   // one workspace per (thread, device)
   // A worker thread that exits gives its device and pinned memory back.  The main thread's holder is destroyed during process
   // teardown, when the HIP runtime may already be unloading: there the driver reclaims everything and nothing is touched.
-  ~WorkspaceHolder() { if ((long)syscall(SYS_gettid) != (long)getpid()) { ws.release_all(); if (ws.last_event) (void)hipEventDestroy(ws.last_event); } }
+  ~WorkspaceHolder() {
+    const bool worker = (long)syscall(SYS_gettid) != (long)getpid();
+    for (auto& kv : by_device) {
+      if (worker) { int cur = 0; const bool sw = hipGetDevice(&cur) == hipSuccess && cur != kv.first && hipSetDevice(kv.first) == hipSuccess; kv.second->release_all(); if (kv.second->last_event) (void)hipEventDestroy(kv.second->last_event); if (sw) (void)hipSetDevice(cur); }
+      else (void)kv.second.release();   // (leaked on purpose, see above)
+    }
+  }
 };
+static thread_local WorkspaceHolder g_ws_holder;
 Workspace& workspace() {
-  static thread_local WorkspaceHolder h;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) throw HostError{PCO_GFX_DEVICE_ERROR, std::string("no HIP device: ") + hipGetErrorString(e)};
-  if (h.ws.device != dev) { h.ws.release_all(); h.ws.device = dev; }
-  return h.ws;
+  std::unique_ptr<Workspace>& slot = g_ws_holder.by_device[dev];
+  if (!slot) { slot.reset(new Workspace()); slot->device = dev; }
+  return *slot;
 }
 
 static void require_device() {
@@ -188,7 +197,9 @@ extern "C" {
 int pco_gfx_last_status(void) { return g_err.status; }
 const char* pco_gfx_last_error(void) { return g_err.msg.c_str(); }
 int pco_gfx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
-void pco_gfx_release_workspace(void) { try { workspace().release_all(); } catch (...) {} }
+void pco_gfx_release_workspace(void) {   // this thread's workspace on the current device
+  try { Workspace& w = workspace(); if (w.has_last && w.last_event) (void)hipEventSynchronize(w.last_event); w.release_all(); } catch (...) {}
+}
 
 // Kernel timing: begin() arms per-launch HIP events on this thread; end() synchronises and returns one
 // (name, milliseconds) pair per kernel launched since begin().  Names are written NUL-separated.
@@ -295,7 +306,8 @@ enum PcoError pco_gfx_compact_chunks(size_t n_tasks, const PcoGfxEncodeTask* tas
     if (n_tasks) {
       const uint64_t slice = 64 * 1024;   // one block per 64 KiB of a chunk: >> 256 blocks in flight for any many-chunk call
       const uint32_t slices = (uint32_t)std::max<uint64_t>(1, (max_cap + slice - 1) / slice);
-      PCO_TIMED_LAUNCH("compact_copy_kernel", stream, compact_copy_kernel, dim3(slices, (uint32_t)n_tasks), dim3(256), 0, stream, d_tasks, d_results, d_offsets, (uint8_t*)d_dst, d_over, (uint32_t)n_tasks, slice);
+      if ((uint64_t)slices * n_tasks >= (1ull << 31)) throw HostError{PCO_GFX_INVALID_ARGUMENT, "compact: too many chunks for one call"};
+      PCO_TIMED_LAUNCH("compact_copy_kernel", stream, compact_copy_kernel, dim3((uint32_t)(slices * n_tasks)), dim3(256), 0, stream, d_tasks, d_results, d_offsets, (uint8_t*)d_dst, d_over, (uint32_t)n_tasks, slice, slices);
     }
     PCO_HIP_CHECK(hipGetLastError());
     if (total) {
@@ -317,6 +329,7 @@ enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size
   try {
     require_device();
     Workspace& ws = workspace();
+    WorkspaceUse use(ws, 0);   // (ordered behind an asynchronous batched call of this thread that may still be running on another stream)
     uint8_t* d_in = (uint8_t*)ws.io_in.ensure(compressed_len + 64);
     const size_t out_bytes = dst_cap * (size_t)(bits / 8);
     uint8_t* d_out = (uint8_t*)ws.io_out.ensure(out_bytes + 64);

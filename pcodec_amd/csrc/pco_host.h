@@ -14,6 +14,7 @@ namespace pcogfx {
 struct HostError {
   int status;
   std::string msg;
+  bool oom = false;   // a device / pinned allocation failed: the sub-batching encoder retries with fewer chunks per pass
 };
 
 void set_error(int status, const std::string& msg);
@@ -34,7 +35,7 @@ struct DevBuf {
       if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
       size_t want = bytes + bytes / 8 + 256;
       hipError_t e = hipMalloc(&p, want);
-      if (e != hipSuccess) { p = nullptr; throw HostError{PCO_GFX_DEVICE_ERROR, std::string("hipMalloc failed: ") + hipGetErrorString(e)}; }
+      if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); throw HostError{PCO_GFX_DEVICE_ERROR, std::string("hipMalloc failed: ") + hipGetErrorString(e), true}; }
       cap = want;
     }
     return p;
@@ -51,7 +52,7 @@ struct HostBuf {
       if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
       size_t want = bytes + bytes / 8 + 256;
       hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-      if (e != hipSuccess) { p = nullptr; throw HostError{PCO_GFX_DEVICE_ERROR, std::string("hipHostMalloc failed: ") + hipGetErrorString(e)}; }
+      if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); throw HostError{PCO_GFX_DEVICE_ERROR, std::string("hipHostMalloc failed: ") + hipGetErrorString(e), true}; }
       cap = want;
     }
     return p;

@@ -31,17 +31,19 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(const PcoGfxTaskResu
     if (tid == 1023) carry_s = before + incl;
     __syncthreads();
   }
-  if (tid == 0) { offsets[n] = carry_s; *overflow = carry_s > dst_cap ? 1u : 0u; }
+  // (an asynchronous caller never sees `overflow`: the end offset it is handed reads ~0 when the destination is too small)
+  if (tid == 0) { const bool over = carry_s > dst_cap; offsets[n] = over ? ~0ull : carry_s; *overflow = over ? 1u : 0u; }
 }
 
-// grid (slices_per_chunk, n): slice s of chunk i copies bytes [s * slice, (s + 1) * slice) of the chunk
+// linear grid of n * slices_per_chunk blocks (gridDim.y stops at 65535): block b copies slice b % slices of chunk b / slices,
+// i.e. bytes [s * slice, (s + 1) * slice) of the chunk
 __global__ __launch_bounds__(256) void compact_copy_kernel(const PcoGfxEncodeTask* tasks, const PcoGfxTaskResult* res, const uint64_t* offsets, uint8_t* dst,
-                                                           const uint32_t* overflow, uint32_t n, uint64_t slice_bytes) {
-  const uint32_t i = blockIdx.y;
+                                                           const uint32_t* overflow, uint32_t n, uint64_t slice_bytes, uint32_t slices) {
+  const uint32_t i = blockIdx.x / slices, sl = blockIdx.x - i * slices;
   if (i >= n || *overflow) return;
   if (res[i].status != PCO_GFX_OK) return;
   const uint64_t len = res[i].n_out;
-  const uint64_t s0 = (uint64_t)blockIdx.x * slice_bytes;
+  const uint64_t s0 = (uint64_t)sl * slice_bytes;
   if (s0 >= len) return;
   const uint64_t s1 = s0 + slice_bytes < len ? s0 + slice_bytes : len;
   gcptr_u8 src = (gcptr_u8)tasks[i].dst;

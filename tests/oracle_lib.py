@@ -116,6 +116,40 @@ def simple_compress_exact(arr, config, exact_pages, uniform_type=False):
     return dst[: n_written.value].tobytes()
 
 
+class TestEncSpec(C.Structure):
+    """oracle/pco_oracle_testenc.hpp: the TEST-ONLY stream generator's spec."""
+    __test__ = False
+    _fields_ = [("mode_kind", C.c_uint32), ("delta_kind", C.c_uint32), ("mode_f64", C.c_double), ("mode_u64", C.c_uint64),
+                ("order", C.c_uint32), ("secondary_uses_delta", C.c_uint32), ("window_n_log", C.c_uint32), ("state_n_log", C.c_uint32),
+                ("lookback_seed", C.c_uint32), ("quantization", C.c_uint32), ("bias", C.c_int64), ("weights", C.c_int32 * 32),
+                ("level", C.c_uint32), ("dict_first_appearance", C.c_uint32)]
+
+
+TE_DELTA_NONE, TE_DELTA_CONSECUTIVE, TE_DELTA_LOOKBACK, TE_DELTA_CONV1 = range(4)
+
+
+def test_encode(arr, chunks=None, mode=MODE_CLASSIC, mode_f64=0.0, mode_u64=0, delta=TE_DELTA_NONE, order=0, secondary_uses_delta=False,
+                window_n_log=0, state_n_log=0, lookback_seed=0, quantization=0, bias=0, weights=(), level=8, dict_first_appearance=False):
+    """A VALID standalone file written by the test-only generator (Dict mode, Conv1 delta, delta'd secondary, lookback state):
+    one chunk per entry of `chunks`."""
+    arr = np.ascontiguousarray(arr)
+    chunks = [arr.size] if chunks is None else [int(c) for c in chunks]
+    spec = TestEncSpec(mode, delta, mode_f64, mode_u64, order if delta != TE_DELTA_CONV1 else len(weights), 1 if secondary_uses_delta else 0,
+                       window_n_log, state_n_log, lookback_seed, quantization, bias, (C.c_int32 * 32)(*[int(w) for w in weights]), level,
+                       1 if dict_first_appearance else 0)
+    dt = dtype_byte(arr)
+    cap = 64 + arr.nbytes * 2 + 4096 * len(chunks) + 65536
+    dst = np.empty(cap, np.uint8); n_written = C.c_size_t(0)
+    cs = (C.c_size_t * len(chunks))(*chunks)
+    rc = lib().pco_oracle_test_encode(arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.size), C.c_uint8(dt), C.byref(spec), cs, C.c_size_t(len(chunks)),
+                                      dst.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(n_written))
+    _check(rc)
+    return dst[: n_written.value].tobytes()
+
+
+test_encode.__test__ = False
+
+
 def simple_decompress(data, np_dtype, cap=None):
     dt = DTYPE_BYTE[{"uint32": "u32", "uint64": "u64", "int32": "i32", "int64": "i64", "float32": "f32",
                      "float64": "f64", "uint16": "u16", "int16": "i16", "float16": "f16", "uint8": "u8",

@@ -121,3 +121,16 @@ def test_invalid_arguments():
     with pytest.raises(O.OracleError) as ei:
         O.simple_decompress(enc, np.int32)
     assert ei.value.kind == O.ERR_CORRUPTION
+
+
+@pytest.mark.parametrize("kind,count", [("dict", 220), ("conv1", 220), ("extra", 160)])
+def test_test_only_generator_streams_decode_on_the_oracle(kind, count):
+    """oracle/pco_oracle_testenc.hpp writes VALID streams with features the restated encoder lacks (Dict mode, Conv1 delta, a
+    delta'd secondary variable, lookback state); the restated DECODER (pinned by the reference's v1_0_0_dict.pco / v1_0_0_conv1.pco)
+    must give the input back.  The same streams are what the GPU decode sweep runs on (tests/test_gpu_decode_sweep.py)."""
+    import decode_sweep_util as S
+    for label, x, kw in S.cases(kind, count, 4242):
+        data = O.test_encode(x, **kw)
+        back = O.simple_decompress(data, x.dtype, cap=x.size + 8)
+        u = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[x.dtype.itemsize]
+        assert back.size == x.size and np.array_equal(back.view(u), x.view(u)), label
