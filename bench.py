@@ -189,7 +189,8 @@ def csrc_sha16():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "pcodec_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+        if os.path.isfile(os.path.join(d, f)) and f.endswith((".hip", ".inc", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -935,8 +935,9 @@ __device__ void lookback_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GL
 template <class Cfg>
 // grid = the lookback pages only (page_ids lists them): a launch over all pages left the blocks of the other pages to exit at once, and
 // with the lookback trial at every 4th page of an Auto-delta wave all the work landed on the two XCDs that blocks 1 and 5 (mod 8) go to.
-__global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32) {
+__global__ __launch_bounds__(64) void enc_lookback_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32, const uint32_t* only_if) {
   if (blockIdx.x >= n_lb_pages) return;
+  if (only_if && uni(only_if[blockIdx.x]) == 0) return;   // (behind enc_lookback_pipe_kernel: only the pages it handed back)
   const uint32_t p = page_ids[blockIdx.x];
   EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
   if (uni(pg->flags) & kPageFlagMetaOnly) return;

@@ -1,0 +1,462 @@
+// encode_lookback.hip -- the lookback search (delta/lookback.rs:22-185) as a five-wave pipeline per page.
+//
+// choose_lookbacks is greedy and strictly element-ordered, but only a small part of an element's work depends on what its
+// predecessors chose.  enc_lookback_kernel (encode_kernels.hip) gives a page to ONE wave, which walks a tile of 64 elements through
+// hash proposals -> candidate latents -> decision rounds -> delta application: a ~12 k-cycle chain of dependent LDS / HBM round trips
+// per tile with nothing else on the SIMD to hide it.  Here a page belongs to a workgroup of five waves, each owning one stage and all
+// advancing one tile per step (s_barrier between steps), so a step costs the slowest stage, not their sum:
+//
+//   wave 0 / 1  H0 / H1  tile s     the three hash proposals from the fine (l) / coarse (l >> 8) last-index table (lookback.rs:22-64):
+//                                    independent of every decision, ordered only against their own table's earlier updates
+//   wave 2      C        tile s-1   the latent and leading-zero count of the twelve decision-independent candidates (6 brute force, 6 hashed)
+//   wave 3      D        tile s-2   the decisions (find_best_lookback + the repeating slots + the counts, lookback.rs:67-159), a tile at
+//                                    a time under the guess that every element repeats its predecessor's lookback (exact: see
+//                                    lookback_page in encode_kernels.hip, whose formulation this stage keeps)
+//   wave 4      A        tile s-3   lookback.rs:166-185: l[i] - l[i - lookback] + MID, the chosen lookbacks, the variables' ranges
+//
+// Hand-over through LDS: the latents of the last kRing positions (ring), the proposals (u16), the leading-zero counts (u8) and the
+// chosen lookbacks, double / triple buffered by tile parity.
+//
+// The last-index tables are what the search's random accesses go to (six reads and two updates per element into 2 x 2^(w+1) entries),
+// and with u32 entries a 2^18-number page owns 640 KB of them: beyond ~256 pages in flight the tables no longer fit the 256 MB memory-side
+// cache and every access is an HBM access -- the kernel then does 7 G elements/s whatever else is done (scripts/lb_scaling.py).  So:
+//   * entries are u16, the position mod 2^16.  Only entries within window_n <= 2^15 positions matter (lookback.rs:52-56), and a sweep
+//     every 2^14 positions rewrites every entry older than the window to "window_n + 1 positions old", so no entry ever ages past 2^16
+//     and (position - entry) mod 2^16 IS its age.  Tables: 256 KB per page instead of 512;
+//   * a launch keeps at most as many pages in flight as fit the cache (the grid is a pool of page slots, each block takes pages until
+//     none are left);
+//   * pages of at most 8192 numbers (the Auto-delta trial samples: thousands per call) keep their tables in LDS -- a position fits 13
+//     bits, nothing ever goes stale -- and with them every random access of the search.
+// Data on which the "repeats its predecessor" guess fails for nearly every element (small random integers: ~49 rounds per tile) makes stage D
+// the whole cost; there one wave per page and sixteen pages per CU (enc_lookback_kernel) is the better shape, so a page that averages more
+// than kLbAbortRounds rounds per tile early on is handed back to that kernel (redo list), which runs after this one.  Small pages go to
+// this kernel only on request (PCO_GFX_LB_PIPE_SMALL=1): with their tables in LDS one page fills a CU, and a degenerate page costs it a
+// twelfth of the throughput sixteen one-wave pages get.
+#pragma once
+// (included by pco_gfx.hip after encode_kernels.hip, whose workspace types and lookback helpers it uses)
+
+namespace pcogfx {
+
+template <bool kSmall> struct LbPipe {
+  static constexpr bool kLdsTables = kSmall;
+  static constexpr uint32_t kWaves = 5, kThreads = 64 * kWaves;
+  static constexpr uint32_t kRing = kSmall ? 1024u : 2048u;            // latents of the last kRing positions (u64 each)
+  static constexpr uint32_t kNear = kRing - 64 * kWaves;               // lookbacks below this are served from the ring by every stage (they run up to four tiles apart)
+  static constexpr uint32_t kCounts = kSmall ? 8192u : 4096u;          // lookback_counts kept in LDS (small pages: all of them, as u16)
+  typedef std::conditional_t<kSmall, uint16_t, uint32_t> CountT;
+  static constexpr uint32_t kTableSlots = kSmall ? (1u << 14) : 0u;    // per table: 2 << window_n_log, window_n_log <= 13 for n <= 8192
+  static constexpr uint32_t kOffCounts = 0;
+  static constexpr uint32_t kOffRing = kOffCounts + kCounts * sizeof(CountT);
+  static constexpr uint32_t kOffPlb = kOffRing + kRing * 8;             // u16[3][6][64]
+  static constexpr uint32_t kOffLz = kOffPlb + 3 * 6 * 64 * 2;          // u8[2][12][64]
+  static constexpr uint32_t kOffLb = kOffLz + 2 * 12 * 64;              // u32[2][64]
+  static constexpr uint32_t kOffTables = kOffLb + 2 * 64 * 4 + 16;      // (abort flag), then u16[2][kTableSlots] (small pages only)
+  static constexpr uint32_t kLdsBytes = kOffTables + 2 * kTableSlots * 2;
+};
+constexpr uint32_t kLbPipeSmallMaxPage = 8192;
+constexpr uint32_t kLbSweepPeriod = 1u << 14;      // positions between two sweeps of the u16 tables (window_n + 1 + period + a tile < 2^16)
+// more than kLbAbortRounds rounds per tile over tiles [kLbAbortFrom, kLbAbortAt) -- past the page's opening, where nothing has a history
+// yet and every element decides differently whatever the data -- sends the page to enc_lookback_kernel
+constexpr uint32_t kLbAbortFrom = 8, kLbAbortAt = 16, kLbAbortRounds = 8;
+
+#ifdef PCO_LBP_TIMING
+__device__ unsigned long long g_lbp_timing[16];
+#endif
+
+template <class L, class Cfg>
+__device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, uint16_t PCO_GLOBAL* hash_tbl, uint32_t PCO_GLOBAL* gcounts) {
+  typedef typename Cfg::CountT CountT;
+  constexpr uint32_t kRing = Cfg::kRing, kNear = Cfg::kNear, kCounts = Cfg::kCounts;
+  constexpr bool kLdsTables = Cfg::kLdsTables;
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = uni(tid >> 6);
+  const uint32_t wlog = uni(ch->window_n_log), state_n = 1u << uni(ch->state_n_log);
+  const uint32_t window_n = 1u << wlog, hash_table_n = 2u << wlog, hash_mask = hash_table_n - 1;
+  const uint32_t n = (uint32_t)uni((uint64_t)pg->n); const uint64_t pstart = uni((uint64_t)pg->start);
+  const L PCO_GLOBAL* pre = sort_ptr<L>(ws, t, 0) + pstart;
+  uint32_t PCO_GLOBAL* lbs = lat_ptr<uint32_t>(ws, t, 0) + pstart;
+  L PCO_GLOBAL* out = lat_ptr<L>(ws, t, 1) + pstart;
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  CountT PCO_LDS* lcounts = (CountT PCO_LDS*)(smem + Cfg::kOffCounts);
+  uint64_t PCO_LDS* ring = (uint64_t PCO_LDS*)(smem + Cfg::kOffRing);
+  uint16_t PCO_LDS* q_plb = (uint16_t PCO_LDS*)(smem + Cfg::kOffPlb);
+  uint8_t PCO_LDS* q_lz = (uint8_t PCO_LDS*)(smem + Cfg::kOffLz);
+  uint32_t PCO_LDS* q_lb = (uint32_t PCO_LDS*)(smem + Cfg::kOffLb);
+  uint16_t PCO_LDS* ltab = (uint16_t PCO_LDS*)(smem + Cfg::kOffTables);
+  uint32_t PCO_LDS* abort_flag = q_lb + 2 * 64;   // (one word behind the lookback queue)
+  // delta state = the first state_n latents, right aligned (lookback.rs:179-181); state_n == 1 from this encoder
+  if (tid == 0) for (uint32_t i = 0; i < state_n && i < 8; i++) pg->moments[i] = i < n ? (uint64_t)pre[i] : 0ull;
+  if (n <= state_n) return false;   // (uniform over the block)
+  if (tid == 0) *abort_flag = 0;
+  for (uint32_t i = tid; i < state_n; i += Cfg::kThreads) ring[i & (kRing - 1)] = (uint64_t)pre[i];   // the positions before the first tile
+  const uint32_t n_counts = window_n < n ? window_n : n;
+  for (uint32_t i = tid; i < kCounts; i += Cfg::kThreads) lcounts[i] = (CountT)1;
+  if constexpr (kLdsTables) { for (uint32_t i = tid; i < 2 * hash_table_n; i += Cfg::kThreads) ltab[i] = 0; }
+  else {
+    for (uint32_t i = kCounts + tid; i < n_counts; i += Cfg::kThreads) gcounts[i] = 1;
+    for (uint32_t i = tid; i < hash_table_n / 2; i += Cfg::kThreads) ((uint64_t PCO_GLOBAL*)hash_tbl)[i] = 0ull;   // 2 tables x hash_table_n u16
+  }
+  __threadfence_block();
+  __syncthreads();
+  const uint32_t n_tiles = (n - state_n + 63) / 64;
+  auto hash_fn = [&](uint64_t x) { x = (x ^ (x >> 32)) * 11400714819323197441ull; x = x ^ (x >> 32); return (uint32_t)x & hash_mask; };
+  auto lz_of = [&](L l, L other) { const L d1 = (L)(l - other), d2 = (L)(other - l); const L dlt = d1 < d2 ? d1 : d2; return LBits<L>::v - bitlen<L>(dlt); };
+  // the latent `lb` positions before position i (i in the tile a stage is working on): the ring serves the recent ones
+  auto latent_back = [&](uint32_t i, uint32_t lb) { return lb < kNear ? (L)ring[(i - lb) & (kRing - 1)] : pre[i - lb]; };
+  auto tile_latent = [&](uint32_t i0t) { return i0t < n && lane < n - i0t ? (uint64_t)pre[i0t + lane] : 0ull; };
+
+  // ------------------------------------------------------------------ per-stage state (each wave uses its own part)
+  // H: the next two tiles' latents and (HBM tables) the next tile's three table entries, in flight
+  uint64_t h_lv = 0, h_lv2 = 0; uint32_t h_val[3] = {0, 0, 0};
+  // D: choose_lookbacks' running state (wave-uniform) -- the current best lookback and its count, the four "repeating" proposals and theirs
+  uint32_t proposed = 1, best_lookback = 1, repeating_idx = 0;
+  uint32_t ring_lb0 = 1, ring_lb1 = 1, ring_lb2 = 1, ring_lb3 = 1, ring_c0 = 1, ring_c1 = 1, ring_c2 = 1, ring_c3 = 1, cnt_best = 1;
+  // A: the ranges of the delta'd primary and of the lookbacks
+  L mn1 = (L)~(L)0, mx1 = 0; uint32_t mn0 = 0xffffffffu, mx0 = 0;
+  if (wave < 2) {
+    h_lv = tile_latent(state_n); h_lv2 = tile_latent(state_n + 64);
+    if constexpr (!kLdsTables) {
+      const uint32_t c = wave;
+      const uint64_t bucket = h_lv >> (c == 0 ? 0 : 8);
+      const bool a = lane < n - state_n;
+      const uint32_t s0 = c * hash_table_n + hash_fn(bucket - 1), s1 = c * hash_table_n + hash_fn(bucket), s2 = c * hash_table_n + hash_fn(bucket + 1);
+      h_val[0] = a ? (uint32_t)__hip_atomic_load(&hash_tbl[s0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      h_val[1] = a ? (uint32_t)__hip_atomic_load(&hash_tbl[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      h_val[2] = a ? (uint32_t)__hip_atomic_load(&hash_tbl[s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+  }
+  uint32_t next_sweep = kLbSweepPeriod;   // (H waves)
+  uint32_t d_rounds = 0;                  // (D wave) rounds over the page's first tiles
+  if (wave == 3 && lane < 16) proposed = (lane + 1) < state_n ? (lane + 1) : state_n;
+#ifdef PCO_LBP_TIMING
+  unsigned long long tm_acc = 0, tm_rounds = 0;
+#endif
+
+  for (uint32_t step = 0; step < n_tiles + 3; step++) {
+#ifdef PCO_LBP_TIMING
+    const unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
+    if (wave < 2) {
+      // ============================================================ H0 / H1: hash proposals of tile `step` from table `wave`
+      const uint32_t c = wave;
+      if (step < n_tiles) {
+        const uint32_t i0 = state_n + 64 * step, tile_n = n - i0 < 64 ? n - i0 : 64, ie = i0 + lane;
+        const bool act = lane < tile_n;
+        const uint64_t lv = h_lv;
+        if (c == 0 && act) ring[ie & (kRing - 1)] = lv;
+        if constexpr (!kLdsTables) {
+          if (i0 >= next_sweep) {
+            // sweep of this wave's table: every entry older than the window becomes "window_n + 1 positions old" (stale either way), so that
+            // no entry's age can reach 2^16 before the next sweep.  (The entries prefetched for this tile were read before the sweep: a
+            // stale one is stale in both forms.)  8-byte L2-served reads: the table's lines were written two bytes at a time by this wave.
+            const uint32_t T = i0 & 0xffffu, marker = (i0 - window_n - 1) & 0xffffu;
+            uint64_t PCO_GLOBAL* tv = (uint64_t PCO_GLOBAL*)(hash_tbl + (uint64_t)c * hash_table_n);
+            for (uint32_t v = lane; v < hash_table_n / 4; v += 64) {
+              uint64_t q = __hip_atomic_load(&tv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              bool changed = false;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const uint32_t e = (uint32_t)(q >> (16 * k)) & 0xffffu;
+                if (((T - e) & 0xffffu) > window_n) { q = (q & ~(0xffffull << (16 * k))) | ((uint64_t)marker << (16 * k)); changed = true; }
+              }
+              if (changed) tv[v] = q;
+            }
+            next_sweep += kLbSweepPeriod;
+          }
+        }
+        const uint64_t bucket = lv >> (c == 0 ? 0 : 8);
+        uint32_t slot[3], val[3];
+        slot[0] = c * hash_table_n + hash_fn(bucket - 1); slot[1] = c * hash_table_n + hash_fn(bucket); slot[2] = c * hash_table_n + hash_fn(bucket + 1);
+        if constexpr (kLdsTables) { for (int r = 0; r < 3; r++) val[r] = act ? (uint32_t)ltab[slot[r]] : 0u; }
+        else { for (int r = 0; r < 3; r++) val[r] = h_val[r]; }
+        // (u16 entries: positions mod 2^16; an in-tile hit below stores the hit's position the same way)
+        // in-tile hazards: an earlier element of the tile wrote its centre bucket (slot[1]) before we read; each of my three slots needs the
+        // LAST earlier lane whose centre slot equals it.  Eight wave votes give every lane the lanes whose centre slot agrees with a
+        // slot of mine in its low 8 bits (usually nobody); the few candidates are checked newest first.
+        uint32_t jmatch = 0xffffffffu;   // the earlier lane with my own centre slot, if any (then that lane's table update is dead)
+        {
+          uint64_t vote[8];
+#pragma unroll
+          for (int b = 0; b < 8; b++) vote[b] = __ballot(act && ((slot[1] >> b) & 1u));
+          const uint64_t earlier = __ballot(act) & (((uint64_t)1 << lane) - 1);
+          uint64_t cand[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            uint64_t m = earlier;
+#pragma unroll
+            for (int b = 0; b < 8; b++) m &= ((slot[r] >> b) & 1u) ? vote[b] : ~vote[b];
+            cand[r] = act ? m : 0ull;
+          }
+          for (;;) {
+            if (!__any(cand[0] != 0 || cand[1] != 0 || cand[2] != 0)) break;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+              const uint32_t j = cand[r] ? 63u - (uint32_t)__builtin_clzll(cand[r]) : 0u;
+              const uint32_t theirs = (uint32_t)__shfl((int)slot[1], (int)j, 64);   // (every lane takes part in the exchange)
+              if (cand[r]) {
+                if (theirs == slot[r]) { val[r] = (i0 + j) & 0xffffu; cand[r] = 0; if (r == 1) jmatch = j; }
+                else cand[r] &= ~((uint64_t)1 << j);
+              }
+            }
+          }
+        }
+        {
+          // plain stores: of the lanes that share a centre slot only the last may write (lookback.rs:60 in element order)
+          uint64_t mm = __ballot(act && jmatch != 0xffffffffu);
+          bool shadowed = false;
+          while (mm) { const uint32_t k = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1; if ((uint32_t)__builtin_amdgcn_readlane((int)jmatch, (int)k) == lane) shadowed = true; }
+          if (act && !shadowed) { if constexpr (kLdsTables) ltab[slot[1]] = (uint16_t)ie; else hash_tbl[slot[1]] = (uint16_t)ie; }
+        }
+        // the next tile's latents and table entries travel while this step's other stages run
+        h_lv = h_lv2; h_lv2 = tile_latent(i0 + 128);
+        if constexpr (!kLdsTables) {
+          const uint32_t i1 = i0 + 64; const bool a1 = i1 < n && lane < n - i1;
+          const uint64_t b1 = h_lv >> (c == 0 ? 0 : 8);
+          const uint32_t s0 = c * hash_table_n + hash_fn(b1 - 1), s1 = c * hash_table_n + hash_fn(b1), s2 = c * hash_table_n + hash_fn(b1 + 1);
+          h_val[0] = a1 ? (uint32_t)__hip_atomic_load(&hash_tbl[s0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;   // L2-served (this wave's own stores are there)
+          h_val[1] = a1 ? (uint32_t)__hip_atomic_load(&hash_tbl[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+          h_val[2] = a1 ? (uint32_t)__hip_atomic_load(&hash_tbl[s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
+        uint16_t PCO_LDS* qp = q_plb + (step % 3u) * 6 * 64;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const uint32_t lb = (ie - val[r]) & 0xffffu;   // the entry's age (no entry is ever 2^16 positions old: the sweep)
+          const uint32_t pidx = 10 + 3 * c + r;
+          const uint32_t plb = lb <= window_n ? lb : (pidx < ie ? pidx : ie);   // lookback.rs:52-56
+          qp[(3 * c + r) * 64 + lane] = (uint16_t)(act ? plb : 1u);
+        }
+      }
+    } else if (wave == 2) {
+      // ============================================================ C: the decision-independent candidates of tile step - 1
+      if (step >= 1 && step - 1 < n_tiles) {
+        const uint32_t ts = step - 1, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
+        const bool act = lane < tile_n;
+        const uint32_t ie = act ? i0 + lane : i0;
+        const uint16_t PCO_LDS* qp = q_plb + (ts % 3u) * 6 * 64;
+        uint8_t PCO_LDS* ql = q_lz + (ts & 1u) * 12 * 64;
+        const L l = (L)ring[ie & (kRing - 1)];
+        uint32_t lb[12];
+#pragma unroll
+        for (int k = 0; k < 6; k++) lb[k] = (uint32_t)k + 1;   // brute force: 1..6 (clamped to the position on the page's first tile by stage D itself)
+#pragma unroll
+        for (int r = 0; r < 6; r++) lb[6 + r] = (uint32_t)qp[r * 64 + lane];
+        L c_near[12], c_far[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {   // both sources are read for every candidate, unconditionally (a per-lane branch around each read serialises them)
+          const uint32_t b = lb[k] <= ie ? lb[k] : ie;
+          const bool far = b >= kNear;
+          c_near[k] = (L)ring[(ie - b) & (kRing - 1)];
+          c_far[k] = k < 6 ? (L)0 : pre[ie - (far ? b : 0u)];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          const uint32_t b = lb[k] <= ie ? lb[k] : ie;
+          ql[k * 64 + lane] = (uint8_t)lz_of(l, (k >= 6 && b >= kNear) ? c_far[k] : c_near[k]);
+        }
+      }
+    } else if (wave == 3) {
+      // ============================================================ D: the decisions of tile step - 2
+      if (step >= 2 && step - 2 < n_tiles) {
+        const uint32_t ts = step - 2, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
+        const bool act = lane < tile_n;
+        const uint32_t ie = i0 + lane;
+        const uint16_t PCO_LDS* qp = q_plb + (ts % 3u) * 6 * 64;
+        const uint8_t PCO_LDS* ql = q_lz + (ts & 1u) * 12 * 64;
+        uint32_t my_lb = 1;   // lane e keeps the lookback chosen for element e of the tile
+        auto count_of = [&](uint32_t lb) -> uint32_t {   // lookback_counts[lb - 1] as of now (far ones live in HBM; only this wave touches them)
+          if (kCounts >= (1u << 15) || lb - 1 < kCounts) return (uint32_t)lcounts[lb - 1 < kCounts ? lb - 1 : 0u];
+          return __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, kLbScope);
+        };
+        if (ts == 0) {
+          // ---- the page's first tile, element by element: lanes 0..15 = the 16 proposals.  (The brute-force slots fill up over the first 16
+          //      positions and overwrite the "repeating" slots on the way: lookback.rs:129-130.  From the second tile on none of that happens.)
+          //      Every lookback here is at most 64: latents from the ring, counts from LDS. ----
+          for (uint32_t e = 0; e < tile_n; e++) {
+            const uint32_t i = i0 + e;
+            const L l = (L)ring[i & (kRing - 1)];   // uniform
+            if (i <= 16) { const uint32_t new_brute = i < 16 ? i : 16; if (lane == new_brute - 1) proposed = new_brute; }
+            else if (lane == 15) proposed = 16;       // (slot 15 is a hash slot: rewritten below)
+            if (lane >= 10 && lane < 16) proposed = (uint32_t)qp[(lane - 10) * 64 + e];
+            uint32_t key = 0;
+            if (lane < 16) {
+              const uint32_t lb = proposed;
+              const L other = (L)ring[(i - lb) & (kRing - 1)];
+              const uint32_t cnt = (uint32_t)lcounts[lb - 1];
+              const uint32_t goodness = (32u - clz_u32(cnt)) + lz_of(l, other);
+              key = (goodness << 4) | (15u - lane);  // max key = max goodness, first proposal on ties (lookback.rs:88-96)
+            }
+            // arg-max over lanes 0..15 on the DPP network (row 0): after row_shr 1, 2, 4, 8 lane 15 holds the maximum
+            { uint32_t o = dpp0<0x111, 0xf>(key); key = o > key ? o : key; o = dpp0<0x112, 0xf>(key); key = o > key ? o : key;
+              o = dpp0<0x114, 0xf>(key); key = o > key ? o : key; o = dpp0<0x118, 0xf>(key); key = o > key ? o : key; }
+            const uint32_t best_p = 15u - ((uint32_t)__builtin_amdgcn_readlane((int)key, 15) & 15u);
+            const uint32_t new_best = (uint32_t)__builtin_amdgcn_readlane((int)proposed, (int)best_p);
+            if (new_best != best_lookback) repeating_idx++;
+            if (lane == 6 + (repeating_idx & 3u)) proposed = new_best;
+            best_lookback = new_best;
+            if (lane == e) my_lb = new_best;
+            if (lane == 0) lcounts[new_best - 1] = (CountT)(lcounts[new_best - 1] + 1);
+            lb_sync();
+          }
+          // hand the state over to the tile-parallel path
+          ring_lb0 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 6); ring_lb1 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 7);
+          ring_lb2 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 8); ring_lb3 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 9);
+          ring_c0 = uni(count_of(ring_lb0)); ring_c1 = uni(count_of(ring_lb1)); ring_c2 = uni(count_of(ring_lb2)); ring_c3 = uni(count_of(ring_lb3));
+          cnt_best = uni(count_of(best_lookback));
+        } else {
+          // ---- later tiles: one lane per element, all 64 decided together under the guess that every element repeats the lookback of the
+          //      one before it (B).  Under that guess the "repeating" slots never change and only B's count moves, so an element's 16
+          //      candidates and their counts are known without waiting for its predecessors.  The first element that decides otherwise
+          //      ends the round: everything before it, and its own decision, were made on the true state; the state is brought up to
+          //      date and the rest of the tile is decided again.  Exactly choose_lookbacks' sequence (lookback.rs:101-159). ----
+          const uint32_t ie_s = act ? ie : i0;
+          const L l = (L)ring[ie_s & (kRing - 1)];
+          uint32_t s_lb[12], s_lz[12], c_far[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) s_lb[k] = (uint32_t)k + 1;
+#pragma unroll
+          for (int r = 0; r < 6; r++) s_lb[6 + r] = (uint32_t)qp[r * 64 + lane];
+#pragma unroll
+          for (int k = 0; k < 12; k++) s_lz[k] = act ? (uint32_t)ql[k * 64 + lane] : 0u;
+          // the four repeating slots are the one part of the candidate set that depends on the previous tile's decisions
+          uint32_t r_lz0 = act ? lz_of(l, latent_back(ie_s, ring_lb0 <= ie_s ? ring_lb0 : ie_s)) : 0u, r_lz1 = act ? lz_of(l, latent_back(ie_s, ring_lb1 <= ie_s ? ring_lb1 : ie_s)) : 0u;
+          uint32_t r_lz2 = act ? lz_of(l, latent_back(ie_s, ring_lb2 <= ie_s ? ring_lb2 : ie_s)) : 0u, r_lz3 = act ? lz_of(l, latent_back(ie_s, ring_lb3 <= ie_s ? ring_lb3 : ie_s)) : 0u;
+          // counts of far hashed proposals (beyond the LDS counts): from HBM, as of the end of the previous tile
+          {
+            bool far_any = false;
+#pragma unroll
+            for (int r = 0; r < 6; r++) far_any = far_any || (act && s_lb[6 + r] - 1 >= kCounts);
+#pragma unroll
+            for (int r = 0; r < 6; r++) c_far[r] = 0u;
+            if (kCounts < (1u << 15) && __any(far_any)) {
+#pragma unroll
+              for (int r = 0; r < 6; r++) { const uint32_t lb = s_lb[6 + r]; if (act && lb - 1 >= kCounts) c_far[r] = __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, kLbScope); }
+            }
+          }
+          uint32_t e_start = 0;
+          auto add_count = [&](uint32_t lb, uint32_t k) -> uint32_t {   // count `lb` += k for everything that mirrors it; returns the new count
+            if (k == 0) return 0u;
+            uint32_t now;
+            if (kCounts >= (1u << 15) || lb - 1 < kCounts) { const uint32_t idx = lb - 1 < kCounts ? lb - 1 : 0u; now = uni((uint32_t)lcounts[idx]) + k; if (lane == 0) lcounts[idx] = (CountT)now; }
+            else {
+              uint32_t old = 0; if (lane == 0) old = __hip_atomic_fetch_add(&gcounts[lb - 1], k, __ATOMIC_RELAXED, kLbScope);
+              now = uni(old) + k;
+#pragma unroll
+              for (int r = 0; r < 6; r++) c_far[r] += s_lb[6 + r] == lb ? k : 0u;
+            }
+            if (ring_lb0 == lb) ring_c0 = now; if (ring_lb1 == lb) ring_c1 = now; if (ring_lb2 == lb) ring_c2 = now; if (ring_lb3 == lb) ring_c3 = now;
+            return now;
+          };
+          for (;;) {
+#ifdef PCO_LBP_TIMING
+            tm_rounds++;
+#endif
+            if (ts >= kLbAbortFrom) d_rounds++;
+            const uint32_t B = best_lookback;
+            const uint32_t cb = cnt_best + (lane - e_start);   // B's count as this element sees it
+            uint32_t best_g = 0, best = 0;
+            auto consider = [&](uint32_t lb, uint32_t lz, uint32_t cnt) { const uint32_t g = (32u - clz_u32(lb == B ? cb : cnt)) + lz; if (g > best_g) { best_g = g; best = lb; } };
+#pragma unroll
+            for (int k = 0; k < 6; k++) consider(s_lb[k], s_lz[k], (uint32_t)lcounts[k]);
+            consider(ring_lb0, r_lz0, ring_c0); consider(ring_lb1, r_lz1, ring_c1); consider(ring_lb2, r_lz2, ring_c2); consider(ring_lb3, r_lz3, ring_c3);
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+              const uint32_t lb = s_lb[6 + r];
+              const bool near_cnt = kCounts >= (1u << 15) || lb - 1 < kCounts;
+              const uint32_t nearv = (uint32_t)lcounts[near_cnt ? lb - 1 : 0u];
+              consider(lb, s_lz[6 + r], near_cnt ? nearv : c_far[r]);
+            }
+            const uint64_t mism = __ballot(act && lane >= e_start && best != B);
+            const uint32_t e_star = mism ? (uint32_t)__builtin_ctzll(mism) : tile_n;
+            if (lane >= e_start && lane < e_star) my_lb = B;
+            lb_sync();   // (the counts were read by every lane before lane 0 changes them)
+            const uint32_t nb = add_count(B, e_star - e_start);
+            if (nb) cnt_best = nb;
+            if (e_star >= tile_n) break;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)best, (int)e_star);
+            if (lane == e_star) my_lb = c;
+            repeating_idx++;
+            // the slot takes the new lookback BEFORE its count is bumped; add_count then mirrors the bump into the slot's count
+            const uint32_t rs = repeating_idx & 3u;
+            const uint32_t c_lz = act && lane > e_star ? lz_of(l, latent_back(ie, c)) : 0u;   // (only the elements still to be decided; c may reach before the page for earlier ones)
+            if (rs == 0) { ring_lb0 = c; r_lz0 = c_lz; } else if (rs == 1) { ring_lb1 = c; r_lz1 = c_lz; } else if (rs == 2) { ring_lb2 = c; r_lz2 = c_lz; } else { ring_lb3 = c; r_lz3 = c_lz; }
+            cnt_best = add_count(c, 1u);
+            best_lookback = c;
+            e_start = e_star + 1;
+            lb_sync();
+            if (e_start >= tile_n) break;
+          }
+          lb_sync();
+        }
+        q_lb[(ts & 1u) * 64 + lane] = my_lb;
+        if (ts + 1 == kLbAbortAt && d_rounds > (kLbAbortAt - kLbAbortFrom) * kLbAbortRounds && n_tiles > 4 * kLbAbortAt) { if (lane == 0) *abort_flag = 1; }
+      }
+    } else {
+      // ============================================================ A: lookback.rs:166-185 on tile step - 3
+      if (step >= 3 && step - 3 < n_tiles) {
+        const uint32_t ts = step - 3, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
+        const bool act = lane < tile_n;
+        const uint32_t ie = i0 + lane;
+        const uint32_t my_lb = q_lb[(ts & 1u) * 64 + lane];
+        if (act) {
+          const L lv = (L)ring[ie & (kRing - 1)];
+          const L other = latent_back(ie, my_lb);
+          const L d = (L)(lv - other + lmid<L>());
+          out[ie] = d; lbs[ie] = my_lb;
+          mn1 = d < mn1 ? d : mn1; mx1 = d > mx1 ? d : mx1; mn0 = my_lb < mn0 ? my_lb : mn0; mx0 = my_lb > mx0 ? my_lb : mx0;
+        }
+      }
+    }
+#ifdef PCO_LBP_TIMING
+    tm_acc += __builtin_readcyclecounter() - tm0;
+#endif
+    // step barrier: what the stages hand over lives in LDS, so only the LDS queue has to drain -- the global loads a stage sent ahead
+    // (next tile's latents and table entries, far latents) and its stores stay in flight across it (__syncthreads would wait for them all)
+    __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (uni(*abort_flag)) return true;   // (every wave sees the flag after the same barrier; nothing global but the page's own slices was written)
+  }
+#ifdef PCO_LBP_TIMING
+  if (lane == 0) { atomicAdd(&g_lbp_timing[wave], tm_acc); if (wave == 3) { atomicAdd(&g_lbp_timing[5], tm_rounds); atomicAdd(&g_lbp_timing[6], (unsigned long long)n_tiles); atomicAdd(&g_lbp_timing[7], 1ull); } }
+#endif
+  if (wave == 4) {
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+      L o1 = shfl_idx(mn1, (int)(lane ^ dlt)); mn1 = o1 < mn1 ? o1 : mn1;
+      L o2 = shfl_idx(mx1, (int)(lane ^ dlt)); mx1 = o2 > mx1 ? o2 : mx1;
+      uint32_t o3 = __shfl_xor(mn0, dlt, 64); mn0 = o3 < mn0 ? o3 : mn0;
+      uint32_t o4 = __shfl_xor(mx0, dlt, 64); mx0 = o4 > mx0 ? o4 : mx0;
+    }
+    if (lane == 0) {
+      atomicMin((unsigned long long*)&ws.chunks[t].v[1].minv, (unsigned long long)mn1); atomicMax((unsigned long long*)&ws.chunks[t].v[1].maxv, (unsigned long long)mx1);
+      atomicMin((unsigned long long*)&ws.chunks[t].v[0].minv, (unsigned long long)mn0); atomicMax((unsigned long long*)&ws.chunks[t].v[0].maxv, (unsigned long long)mx0);
+    }
+  }
+  return false;
+}
+
+// grid = a pool of page slots (at most as many as keep their tables in the memory-side cache), one workgroup of five waves per slot; a
+// slot takes pages blockIdx.x, blockIdx.x + gridDim.x, ... of the lookback pages (page_ids lists them).  redo[k] = 1: lookback page k
+// was handed back to enc_lookback_kernel.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads) void enc_lookback_pipe_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32, uint32_t* redo) {
+  uint32_t PCO_GLOBAL* base = (uint32_t PCO_GLOBAL*)lb_scratch + (uint64_t)blockIdx.x * scratch_stride_u32;
+  for (uint32_t k = blockIdx.x; k < n_lb_pages; k += gridDim.x) {
+    const uint32_t p = page_ids[k];
+    EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+    if (threadIdx.x == 0) redo[k] = 0;
+    if (uni(pg->flags) & kPageFlagMetaOnly) continue;
+    const uint32_t t = uni(pg->chunk);
+    EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+    if (uni(ch->status) != PCO_GFX_OK || uni(ch->delta_kind) != kDeltaLookback) continue;
+    const uint32_t wlog = uni(ch->window_n_log);
+    uint16_t PCO_GLOBAL* hash_tbl = (uint16_t PCO_GLOBAL*)base; uint32_t PCO_GLOBAL* gcounts = base + (2ull << wlog);   // u16[2][2 << wlog], then u32[1 << wlog]
+    const int bits = dtype_bits(uni(ch->dtype));
+    bool aborted;
+    if (bits == 64) aborted = lookback_page_pipe<uint64_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
+    else if (bits == 32) aborted = lookback_page_pipe<uint32_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
+    else if (bits == 16) aborted = lookback_page_pipe<uint16_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
+    else aborted = lookback_page_pipe<uint8_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
+    if (aborted && threadIdx.x == 0) redo[k] = 1;
+    __syncthreads();   // the next page re-initialises the LDS every wave of this one may still be reading
+  }
+}
+
+}  // namespace pcogfx

@@ -24,6 +24,7 @@
 #include "decode_kernel.hip"
 #include "decode_fast.hip"
 #include "encode_kernels.hip"
+#include "encode_lookback.hip"
 #include "encode_hist_select.hip"
 #include "auto_mode_kernels.hip"
 #include "encode_fast.hip"
@@ -399,6 +400,13 @@ extern "C" int pco_gfx_debug_sel_timing(unsigned long long* out, int reset) {
 extern "C" int pco_gfx_debug_hist_timing(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[16] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(pcogfx::g_hist_timing), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_hist_timing), 128);
+}
+#endif
+
+#ifdef PCO_LBP_TIMING
+extern "C" int pco_gfx_debug_lbp_timing(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(pcogfx::g_lbp_timing), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_lbp_timing), 128);
 }
 #endif
 

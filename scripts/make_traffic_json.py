@@ -7,6 +7,10 @@ import json
 import re
 import sys
 
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import csrc_sha16  # noqa: E402  (the table is only quoted by bench.py for the kernel sources it was measured on)
+
 d, chunks, workload, out_json, out_txt = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
 TY = {"unsigned long": "u64", "unsigned int": "u32", "unsigned short": "u16", "unsigned char": "u8"}
 
@@ -44,7 +48,7 @@ for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, (0, 0))[1])):
     kern[k] = {"fetch_bytes_per_launch": int(2 * f.get(k, (0, 0))[0] * 1000), "write_bytes_per_launch": int(w.get(k, (0, 0))[0] * 1000)}
 json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --chunks {chunks} "
                      "--no-cpu-baseline; counters are kilobytes per dispatch; FETCH_SIZE doubled (gfx950 note, MI355X_MICROARCH.md HBM section)",
-           "chunks": chunks, "workload": workload, "kernels": kern}, open(out_json, "w"), indent=1)
+           "chunks": chunks, "workload": workload, "csrc_sha16": csrc_sha16(), "kernels": kern}, open(out_json, "w"), indent=1)
 with open(out_txt, "w") as o:
     o.write(open(f"{d}/pmc_FETCH_SIZE.txt").read()); o.write(open(f"{d}/pmc_WRITE_SIZE.txt").read())
     o.write("\nper launch, bytes (FETCH_SIZE x 2 x 1000, WRITE_SIZE x 1000):\n")

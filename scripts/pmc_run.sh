@@ -8,7 +8,7 @@ ROOT=$PWD
 mkdir -p $ROOT/gpurun_out/$OUT
 cd /tmp
 rm -rf /tmp/pmc_out
-rocprofv3 --pmc $CTRS -d /tmp/pmc_out -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --chunks $CH --no-cpu-baseline ${BENCH_ARGS} > $ROOT/gpurun_out/$OUT/run.log 2>&1
+rocprofv3 --pmc $CTRS -d /tmp/pmc_out -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --chunks $CH --no-cpu-baseline --no-others --verify-chunks 0 ${BENCH_ARGS} > $ROOT/gpurun_out/$OUT/run.log 2>&1
 DB=$(find /tmp/pmc_out -name "*.db" | head -1)
 python3 $ROOT/scripts/pmc_summary.py "$DB" > $ROOT/gpurun_out/$OUT/pmc.txt
 cat $ROOT/gpurun_out/$OUT/pmc.txt

@@ -52,7 +52,7 @@ def needs_secondary_history(kw):
     return kw.get("delta") == O.TE_DELTA_LOOKBACK and kw.get("secondary_uses_delta") and kw.get("mode") not in (O.MODE_CLASSIC, O.MODE_TRY_DICT)
 
 
-@pytest.mark.parametrize("kind,count", [("dict", 330), ("conv1", 320), ("extra", 200)])
+@pytest.mark.parametrize("kind,count", [("dict", 330), ("conv1", 320), ("extra", 320)])
 def test_gpu_decode_of_generated_streams(L, kind, count):
     """>= 200 valid streams of each kind: GPU decode == the input == the oracle's decode.  Batched 40 files per call (mixed dtypes)."""
     batch = []; refused = 0; compared = 0
