@@ -233,15 +233,18 @@ class Bench:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; reporting n_gpus={self.world}", file=sys.stderr)
         torch.cuda.set_device(local_rank)
         self.device = torch.device("cuda", local_rank)
-        if self.world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # PCO_BENCH_FORCE_DIST=1: go through the process group (RCCL init, barrier, all-reduce, gather-v) at world size 1 too, so that a
+        # single-GPU box exercises the code an 8-GPU run depends on
+        self.use_dist = self.world > 1 or os.environ.get("PCO_BENCH_FORCE_DIST") == "1"
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
         self.L = G.lib()
         self.L.pco_gfx_compact_chunks.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
 
     def sync_all(self):
         self.torch.cuda.synchronize()
-        if self.world > 1:
+        if self.use_dist:
             self.dist.barrier()
 
     def verify_against_oracle(self, kinds, cfg_kw, kind_of, row_of, data, comp, cap_off, n_out, k_verify):
@@ -321,7 +324,7 @@ class Bench:
             payload = torch.zeros(stream_cap, dtype=torch.uint8, device=device)
             d_offs = torch.zeros(nch + 1, dtype=torch.int64, device=device)
             recv = torch.zeros(stream_cap, dtype=torch.uint8, device=device)
-            file_body = torch.zeros(stream_cap * world, dtype=torch.uint8, device=device) if rank == 0 and world > 1 else None
+            file_body = torch.zeros(stream_cap * world, dtype=torch.uint8, device=device) if rank == 0 and self.use_dist else None
         gather_ms = []
         state = {"n_bytes": 0, "offs": None}
 
@@ -332,7 +335,7 @@ class Bench:
                 total = C.c_uint64(0)
                 G.check(L.pco_gfx_compact_chunks(nch, enc_tasks.ctypes.data, d_res.data_ptr(), payload.data_ptr(), stream_cap - 64, 0, d_offs.data_ptr(), C.byref(total), None))
                 state["n_bytes"] = int(total.value)
-                if world > 1:
+                if self.use_dist:
                     totals = S.exchange_totals(state["n_bytes"], device)
                     _, state["offs"] = S.gather_stream(payload, state["n_bytes"], dst=0, out=file_body, totals=totals)
                     torch.cuda.synchronize()
@@ -340,7 +343,7 @@ class Bench:
 
         def decode():
             if gather:   # decoders read the byte ranges the root hands out
-                if world > 1:
+                if self.use_dist:
                     S.scatter_stream(file_body, state["offs"], recv, src=0)
                     base = recv.data_ptr()
                 else:
@@ -378,7 +381,7 @@ class Bench:
         names = C.create_string_buffer(1 << 18); ms = (C.c_float * 65536)()
         nk = L.pco_gfx_profile_end(names, len(names), ms, 65536)
         el = torch.tensor([elapsed, t_enc, t_dec], device=device, dtype=torch.float64)
-        if world > 1:
+        if self.use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed, t_enc, t_dec = (float(x) for x in el.tolist())
         ms_per_step = elapsed * 1e3 / steps
@@ -494,7 +497,7 @@ def main():
         if "cpu_baseline" in head:
             line["cpu_baseline"] = head["cpu_baseline"]
         print(json.dumps(line), flush=True)
-    if B.world > 1:
+    if B.use_dist:
         B.dist.destroy_process_group()
 
 

@@ -253,7 +253,35 @@ size_t pco_page_decompressor_consumed(const PcoGfxPageDecompressor*);
 void pco_page_decompressor_free(PcoGfxPageDecompressor*);
 
 /* ------------------------------------------------------------------------------------------
- * 5. Test hook (NOT part of the drop-in surface; exported so that the GPU tests can check the device's arithmetic operation by
+ * 5. Chunk-sharded files over RCCL / xGMI (one process per GPU).  Chunks are independent (standalone/simple.rs:62-91: header |
+ *    chunk | chunk ... | 0x00), so ranks encode contiguous blocks of chunks with no collective on the data path; assembling ONE
+ *    file is a gather-v of the ranks' compacted chunk bytes (pco_gfx_compact_chunks) to a root, decoding a file that lives on one
+ *    rank the mirror-image scatter.  RCCL is loaded on first use.  All buffers are DEVICE buffers; `stream` as above.
+ *
+ *    Bootstrap like ncclCommInitRank: rank 0 calls pco_gfx_comm_unique_id and hands the 128 bytes to the other ranks by whatever
+ *    channel the host has (MPI, TCP, a file); every rank then calls pco_gfx_comm_init on ITS device.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct PcoGfxComm PcoGfxComm;
+enum PcoError pco_gfx_comm_unique_id(void* id128);
+enum PcoError pco_gfx_comm_init(const void* id128, int n_ranks, int rank, PcoGfxComm** out);
+void pco_gfx_comm_free(PcoGfxComm*);
+int pco_gfx_comm_rank(const PcoGfxComm*);
+int pco_gfx_comm_size(const PcoGfxComm*);
+/* Every rank passes its compacted chunk stream [d_stream, d_stream + n_bytes); on `root` the streams land in rank (= chunk) order
+ * at d_file + file_offset.  offsets (HOST array of n_ranks + 1 entries, filled on EVERY rank) = where each rank's bytes start
+ * relative to file_offset, the total last.  An 8-byte all-gather of the sizes, then one ncclGroup of exact-size ncclSend / ncclRecv.
+ * The call synchronises `stream` for the sizes; the byte transfers are asynchronous on it.  (d_file / file_cap are ignored off the
+ * root; a file_cap that is too small is INVALID_ARGUMENT on the root before anything is posted -- check offsets[n_ranks] on all
+ * ranks alike.) */
+enum PcoError pco_gfx_gather_chunks(PcoGfxComm*, int root, const void* d_stream, uint64_t n_bytes, void* d_file, uint64_t file_cap,
+                                    uint64_t file_offset, uint64_t* offsets, void* stream);
+/* The decode direction: `root` holds the chunk stream at d_file + file_offset; rank r receives bytes [offsets[r], offsets[r + 1])
+ * into d_stream (capacity stream_cap, >= its share + the decoder's 16 bytes of slack).  *n_bytes = this rank's share. */
+enum PcoError pco_gfx_scatter_chunks(PcoGfxComm*, int root, const void* d_file, uint64_t file_offset, const uint64_t* offsets,
+                                     void* d_stream, uint64_t stream_cap, uint64_t* n_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 6. Test hook (NOT part of the drop-in surface; exported so that the GPU tests can check the device's arithmetic operation by
  *    operation against an IEEE reference).  Stage 1 of ModeSpec::Auto detection on floats (mode/float_mult.rs:145-275,
  *    mode/float_quant.rs:73-118) run on a host array taken as the sample, in order.  out[0..66]: s_size, tz5, n_gcd, sim[3],
  *    hist[56], has_euclid, k, n_ints, base_c (lo, hi).  Returns a PcoGfxStatus.

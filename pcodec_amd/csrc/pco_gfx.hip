@@ -353,6 +353,7 @@ enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size
 }  // extern "C"
 
 #include "pco_gfx_encode_api.inc"
+#include "pco_gfx_comm.inc"
 
 #ifdef PCO_WALK_TIMING
 extern "C" int pco_gfx_debug_walk_timing(unsigned long long* out) {

@@ -159,3 +159,55 @@ def split_payload(payload: bytes, sizes: Sequence[int]) -> List[bytes]:
     for s in sizes:
         out.append(payload[pos: pos + int(s)]); pos += int(s)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ the same over the C ABI
+class Comm:
+    """include/pco_gfx.h section 5: the gather-v / scatter of chunk bytes through libpco_gfx.so itself (RCCL called directly, no
+    torch.distributed) -- what a Rust / C host binds.  Rank 0 makes the 128-byte id (Comm.unique_id()) and hands it to the other
+    ranks over its own channel; every rank then builds Comm(id, world, rank) on its device."""
+
+    def __init__(self, ident: bytes, world: int, rank: int):
+        import ctypes as C
+        from . import _lib as G
+        self._G, self._C, self._L = G, C, G.lib()
+        L = self._L
+        L.pco_gfx_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.pco_gfx_comm_free.argtypes = [C.c_void_p]
+        L.pco_gfx_gather_chunks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.pco_gfx_scatter_chunks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        self.world, self.rank = world, rank
+        self._h = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(ident))
+        G.check(L.pco_gfx_comm_init(buf, world, rank, C.byref(self._h)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib as G
+        L = G.lib()
+        L.pco_gfx_comm_unique_id.argtypes = [C.c_void_p]
+        buf = (C.c_ubyte * 128)()
+        G.check(L.pco_gfx_comm_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pco_gfx_comm_free(self._h); self._h = None
+
+    __del__ = close
+
+    def gather(self, stream_ptr: int, n_bytes: int, file_ptr: int = 0, file_cap: int = 0, file_offset: int = 0, root: int = 0, hip_stream=None) -> List[int]:
+        """pco_gfx_gather_chunks on raw device pointers; returns the per-rank byte offsets (total last), on every rank."""
+        C = self._C
+        offs = (C.c_uint64 * (self.world + 1))()
+        self._G.check(self._L.pco_gfx_gather_chunks(self._h, root, stream_ptr, n_bytes, file_ptr, file_cap, file_offset, offs, hip_stream))
+        return [int(x) for x in offs]
+
+    def scatter(self, file_ptr: int, offsets: Sequence[int], recv_ptr: int, recv_cap: int, file_offset: int = 0, root: int = 0, hip_stream=None) -> int:
+        """pco_gfx_scatter_chunks; returns this rank's byte count."""
+        C = self._C
+        offs = (C.c_uint64 * (self.world + 1))(*[int(x) for x in offsets])
+        got = C.c_uint64(0)
+        self._G.check(self._L.pco_gfx_scatter_chunks(self._h, root, file_ptr, file_offset, offs, recv_ptr, recv_cap, C.byref(got), hip_stream))
+        return int(got.value)
