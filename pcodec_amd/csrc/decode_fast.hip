@@ -31,7 +31,17 @@ template <uint32_t KQ> struct WalkCfg {
   static constexpr uint32_t kRetryStatus = KQ == 8 ? 101u : 100u;       // where a task goes whose tables do not fit
   static_assert(kGrpBytes % 16 == 0, "chunk slices must stay 16-byte aligned");
   static_assert(kWalkLdsBytes < 65536, "walk entries hold 16-bit LDS addresses");
+  // Fused walk + expand (dec_walk_kernel<L, 8, true>): once the tables are built the scratch belongs to the hand-over between the walker
+  // wave and the block's two expander waves.
+  static constexpr uint32_t kFuseCtlOff = kWalkTmpOff + 16;              // u32[KQ]: batches of the slot's chunk whose symbols are in HBM (kFuseDone / kFuseDead)
+  static constexpr uint32_t kFuseMomOff = kFuseCtlOff + 32;              // u64[KQ][2][2]: the delta moments of (primary, secondary), orders <= 2
+  static constexpr uint32_t kFuseLdsBytes = kWalkLdsBytes;               // (the block's LDS does not grow: four blocks per CU, as without the expanders)
+  static_assert(KQ != 8 || kFuseMomOff + 256 <= kFuseLdsBytes, "fused hand-over area");
 };
+constexpr uint32_t kFuseDone = 0x7fffffffu, kFuseDead = 0xffffffffu;
+// Three expander waves: with the walker that is four waves per block and, at four blocks per CU (the LDS), four per SIMD -- what the
+// kernel's ~117 VGPRs allow.  (Four expanders would leave room for three blocks only: the walk would take two rounds.)
+constexpr uint32_t kFuseExpWaves = 3, kFuseSlotsPerExp = 3;   // expander e takes slots e, e + 3, e + 6 (< 8)
 constexpr uint32_t kFastMaxBins = 256;
 constexpr uint32_t kStatusRetryLegacy = 100;     // internal: hand the task to the single-kernel decoder
 constexpr uint32_t kStatusRetryK4 = 101;         // internal: tables too big for an 8-chunk wave, try the 4-chunk walker
@@ -45,6 +55,7 @@ struct DecPlan {   // written by dec_walk_kernel, read by dec_expand_kernel
   uint32_t window_n_log, state_n_log;
   uint64_t moments[2][8];
   uint64_t consumed;
+  uint32_t fused, pad;      // 1: the chunk was expanded inside dec_walk_kernel (its result is written there), dec_expand_kernel skips it
 };
 constexpr uint64_t kBinsAreaPerVar = kFastMaxBins * 8 + kFastMaxBins;   // lowers (8 B stride) then offset bits
 constexpr uint64_t kBinsAreaPerTask = 3 * kBinsAreaPerVar;
@@ -140,6 +151,7 @@ struct FrontOut {
   uint32_t status, n;
   uint64_t bitpos;          // first bit of the page body
   uint32_t states[3][4];
+  uint64_t moments[2][2];   // the first two delta moments of (primary, secondary)
 };
 
 // Everything before the page body for one task, executed by the whole wave on behalf of group q.
@@ -157,7 +169,8 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
   out.status = PCO_GFX_OK; out.n = 0; out.bitpos = 0;
   for (int v = 0; v < 3; v++) for (int j = 0; j < 4; j++) out.states[v][j] = 0;
   VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(lds_base() + q * kGrpBytes + kGrpVarOff);
-  auto fail = [&](uint32_t s) { out.status = s; if (lane == 0) { plan->status = s; plan->consumed = mr.bit >> 3; plan->n = 0; } };
+  auto fail = [&](uint32_t s) { out.status = s; if (lane == 0) { plan->status = s; plan->consumed = mr.bit >> 3; plan->n = 0; plan->fused = 0; } };
+  out.moments[0][0] = out.moments[0][1] = out.moments[1][0] = out.moments[1][1] = 0;
   if (dtype_bits(dtype) != (int)LB) { fail(PCO_GFX_INVALID_ARGUMENT); return; }
   if (flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY)) { fail(kStatusRetryLegacy); return; }
   if (flags & PCO_GFX_TASK_HAS_FILE_HEADER) {  // standalone/decompressor.rs:85-137
@@ -281,7 +294,7 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
     const uint32_t dk = uni(vinfo[vi].delta_kind);
     for (uint32_t i = 0; i < nlps[vi]; i++) {
       const L x = (L)mr.read(lbits);
-      if (dk == kDeltaConsecutive) { if (lane == 0 && i < 8) plan->moments[vi == 2 ? 1 : 0][i] = (uint64_t)x; }
+      if (dk == kDeltaConsecutive) { if (lane == 0 && i < 8) plan->moments[vi == 2 ? 1 : 0][i] = (uint64_t)x; if (i < 2) out.moments[vi == 2 ? 1 : 0][i] = (uint64_t)x; }
       else if (vi == 1 && i < n && mr.in_bounds()) { if (lane == 0) dst[i] = from_latent_ordered<L>(x, num_kind); }
     }
     const uint32_t asl = uni(vinfo[vi].ans_size_log);
@@ -293,7 +306,7 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
   if (n_in_body > 0) for (int vi = 0; vi < 3; vi++) if (present[vi] && uni(vinfo[vi].n_bins) == 0) { fail(PCO_GFX_CORRUPTION); return; }
   if (lane == 0) {
     plan->status = PCO_GFX_OK; plan->n = n; plan->mode_kind = mode_kind; plan->mode_k = mode_k; plan->mode_base = (uint64_t)mode_base;
-    plan->num_kind = num_kind; plan->dtype = dtype; plan->window_n_log = wlog; plan->state_n_log = slog; plan->consumed = 0;
+    plan->num_kind = num_kind; plan->dtype = dtype; plan->window_n_log = wlog; plan->state_n_log = slog; plan->consumed = 0; plan->fused = 0;
     for (int vi = 0; vi < 3; vi++) {
       plan->present[vi] = present[vi]; plan->n_bins[vi] = vinfo[vi].n_bins; plan->max_ob[vi] = vinfo[vi].max_ob;
       plan->delta_kind[vi] = vinfo[vi].delta_kind; plan->delta_order[vi] = vinfo[vi].delta_order; plan->nlps[vi] = nlps[vi];
@@ -367,18 +380,31 @@ __device__ __forceinline__ void walk_step(WalkRegs& r, const QuadMasks& m, uint3
 __device__ unsigned long long g_walk_timing[8];
 #define WT_NOW() __builtin_readcyclecounter()
 #endif
-// accept_status: 0 = the first stage (every task), else only the tasks an earlier stage left with that status
-template <class L, uint32_t kWQ>
-__global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
+template <class L>
+__device__ void fused_expander(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, const DecPlan* plans, const uint8_t* bins_area,
+                               const uint8_t* sym_area, uint64_t sym_stride, const uint64_t* offpos_area, uint64_t offpos_stride);
+
+// accept_status: 0 = the first stage (every task), else only the tasks an earlier stage left with that status.
+// kFused (kWQ == 8 only): the block has two more waves that expand the batches of the wave's eight chunks as soon as their symbols are
+// out (fused_expander below) -- the walker is a latency chain that leaves its SIMD nine tenths idle, the expansion is what fills it; the
+// LDS is the walker's, so the expanders work from registers, global memory and the 1.6 KB the table build no longer needs.
+template <class L, uint32_t kWQ, bool kFused = false>
+__global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                                       uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
-                                                      uint32_t accept_status) {
+                                                      uint32_t accept_status, PcoGfxTaskResult* results) {
+  static_assert(!kFused || kWQ == 8, "the fused form is the eight-chunk walker's");
   constexpr uint32_t kGrpBytes = WalkCfg<kWQ>::kGrpBytes;
+  if constexpr (kFused) {
+    if (uni(threadIdx.x >> 6) != 0) { fused_expander<L>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride); return; }
+  }
+  if constexpr (kFused) __builtin_amdgcn_s_setprio(3);   // the walker's chain sets the kernel's duration: it goes first whenever it can issue
   const uint32_t lane = lane_id();
   const uint32_t slot = lane >> 2, j = lane & 3;
   // ---- phase 0: metadata + tables, one task at a time with the whole wave; slot q belongs to lanes 4q..4q+3 ----
   uint32_t my_ti = 0xffffffffu, my_active = 0, my_front_ok = 0, my_n = 0, my_flags = 0;
   uint32_t st0 = 0, st1 = 0, st2 = 0;   // this lane's chain state per variable, as an entry address
   uint64_t my_bitpos = 0, my_len = 0;
+  uint64_t my_mom[2][2] = {{0, 0}, {0, 0}};
   gcptr_u8 my_src = nullptr;
   for (uint32_t q = 0; q < kWQ; q++) {
     const uint32_t bi = blockIdx.x * kWQ + q;
@@ -391,6 +417,7 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
     if (slot == q) {
       my_ti = ti; my_active = fo.status == PCO_GFX_OK ? 1u : 0u; my_front_ok = my_active; my_n = fo.n; my_bitpos = fo.bitpos;
       my_len = task.src_len; my_flags = task.flags; my_src = (gcptr_u8)task.src;
+      my_mom[0][0] = fo.moments[0][0]; my_mom[0][1] = fo.moments[0][1]; my_mom[1][0] = fo.moments[1][0]; my_mom[1][1] = fo.moments[1][1];
       st0 = j == 0 ? fo.states[0][0] : (j == 1 ? fo.states[0][1] : (j == 2 ? fo.states[0][2] : fo.states[0][3]));
       st1 = j == 0 ? fo.states[1][0] : (j == 1 ? fo.states[1][1] : (j == 2 ? fo.states[1][2] : fo.states[1][3]));
       st2 = j == 0 ? fo.states[2][0] : (j == 1 ? fo.states[2][1] : (j == 2 ? fo.states[2][2] : fo.states[2][3]));
@@ -413,6 +440,28 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
     st0 = lds0 + slice + kGrpTblOff + vinfo[0].off_nodes + 4u * st0;
     st1 = lds0 + slice + kGrpTblOff + vinfo[1].off_nodes + 4u * st1;
     st2 = lds0 + slice + kGrpTblOff + vinfo[2].off_nodes + 4u * st2;
+  }
+  bool my_fused = false;
+  if constexpr (kFused) {
+    // which of the wave's chunks the block's expanders take: no lookback (its history needs an LDS area of its own), offsets of at most
+    // 16 bits (a lane's four fields in one 64-bit window), delta orders up to 2 (the moments' LDS).  The others go to dec_expand_kernel.
+    if (my_active && slot < kWQ) {
+      my_fused = vinfo[0].present == 0;
+      for (int v = 1; v < 3; v++) if (vinfo[v].present) {
+        if (vinfo[v].max_ob > 16) my_fused = false;
+        if (vinfo[v].delta_kind == kDeltaConsecutive ? vinfo[v].delta_order > 2 : vinfo[v].delta_kind != kDeltaNone) my_fused = false;
+      }
+    }
+    uint32_t PCO_LDS* ctl = (uint32_t PCO_LDS*)(lds_base() + WalkCfg<kWQ>::kFuseCtlOff);
+    uint64_t PCO_LDS* fmom = (uint64_t PCO_LDS*)(lds_base() + WalkCfg<kWQ>::kFuseMomOff);
+    if (j == 0 && slot < kWQ) {
+      ctl[slot] = my_fused ? 0u : kFuseDead;
+      L PCO_LDS* mp = (L PCO_LDS*)(fmom + slot * 4); L PCO_LDS* ms = (L PCO_LDS*)(fmom + slot * 4 + 2);   // (consecutive_decode indexes them as L)
+      mp[0] = (L)my_mom[0][0]; mp[1] = (L)my_mom[0][1]; ms[0] = (L)my_mom[1][0]; ms[1] = (L)my_mom[1][1];
+      if (my_fused) ((DecPlan PCO_GLOBAL*)plans + my_ti)->fused = 1u;
+    }
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the plans and bins the expanders are about to read have reached L2
+    __syncthreads();
   }
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   QuadMasks qm = {j >= 1 ? ~0u : 0u, j >= 2 ? ~0u : 0u, j >= 3 ? ~0u : 0u, 63u};
@@ -469,6 +518,12 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
       for (int k = 0; k < 7; k++) { const uint32_t qi = 2 * j + 8 * k; if (qi < nq) { win[qi] = lo[k]; win[qi + 1] = hi[k]; } }
     }
     wave_sync_lds();
+    if constexpr (kFused) {
+      // `batch` batches of my chunk are complete: their symbol and section-start stores were issued in earlier rounds, and everything
+      // issued before this round's staging loads has been acknowledged now that those loads are back
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (my_fused && j == 0) __hip_atomic_store((uint32_t*)(lds_base() + WalkCfg<kWQ>::kFuseCtlOff) + slot, batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 #ifdef PCO_WALK_TIMING
     { const unsigned long long t = WT_NOW(); wt_s3 += t - wt_t1; }
 #endif
@@ -478,7 +533,7 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
     // chunk's four lanes touch eight 128-byte lines around it.  The loaded values get their (dummy) use one round later,
     // right here, where this round's staging loads have already been waited for -- VMEM returns in order, so that use
     // never waits.
-    ((uint32_t PCO_LDS*)(lds_base() + WalkCfg<kWQ>::kWalkTmpOff))[lane] = touch_r0 ^ touch_r1;   // (the table-build scratch is idle during the walk)
+    ((uint32_t PCO_LDS*)(lds_base() + WalkCfg<kWQ>::kWalkTmpOff))[kFused ? (lane & 3u) : lane] = touch_r0 ^ touch_r1;   // (the table-build scratch is idle during the walk; the fused form keeps 16 bytes of it for this)
     if (walk) {
       const uint64_t cur = q0 * 8, pred = cur + (cur - touch_prev);
       touch_prev = cur;
@@ -562,6 +617,10 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
 #ifdef PCO_WALK_TIMING
   if (blockIdx.x == 0 && lane == 0 && wt_rounds > 0) { g_walk_timing[0] = wt_stage; g_walk_timing[1] = wt_walk; g_walk_timing[2] = wt_tail; g_walk_timing[3] = wt_rounds; g_walk_timing[4] = wt_start; g_walk_timing[5] = WT_NOW(); g_walk_timing[6] = wt_s1; g_walk_timing[7] = wt_s2 | (wt_s3 << 32); }
 #endif
+  if constexpr (kFused) {
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (my_fused && j == 0) __hip_atomic_store((uint32_t*)(lds_base() + WalkCfg<kWQ>::kFuseCtlOff) + slot, status == PCO_GFX_OK ? kFuseDone : kFuseDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   // ---- page end (page_decompressor.rs:184-188) and stream end ----
   if (my_ti != 0xffffffffu && j == 0 && slot < kWQ) {
     DecPlan PCO_GLOBAL* plan = (DecPlan PCO_GLOBAL*)plans + my_ti;
@@ -582,6 +641,14 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
         plan->consumed = byte;
       }
       plan->status = status;
+      if constexpr (kFused) {
+        // a chunk the block's expanders took is finished when this kernel is: its result is written here (a stream with another chunk
+        // behind this one goes to the single-kernel decoder whole, which then reports it)
+        if (my_fused && status != kStatusRetryLegacy) {
+          PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? my_n : 0; r.consumed = plan->consumed; r.status = status; r.aux = 0;
+          results[my_ti] = r;
+        }
+      }
     }
   }
 }
@@ -704,6 +771,7 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
     const DecPlan PCO_GLOBAL* plan = (const DecPlan PCO_GLOBAL*)plans + ti;
     const uint32_t pstatus = uni(plan->status);
     if (pstatus == kStatusRetryLegacy) continue;   // the single-kernel decoder finishes this task
+    if (uni(plan->fused)) continue;                // expanded inside dec_walk_kernel, result written there
     if (pstatus != PCO_GFX_OK) {
       if (tid == 0) { PcoGfxTaskResult r; r.n_out = 0; r.consumed = plan->consumed; r.status = pstatus; r.aux = 0; results[ti] = r; }
       continue;
@@ -889,6 +957,156 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
       const uint32_t status = turn[1] ? PCO_GFX_CORRUPTION : PCO_GFX_OK;
       PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? n : 0; r.consumed = plan->consumed; r.status = status; r.aux = 0; results[ti] = r;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fused_expander: waves 1..3 of dec_walk_kernel<L, 8, true>.  Wave e takes the chunks of slots e - 1, e + 2, e + 5 (below 8), batch after
+// batch in turn, each as soon as the walker has published it.  What dec_expand_kernel keeps in LDS comes from elsewhere here: the bins'
+// lowers and offset bits are gathered from the bins area (2 KB per variable, L1-resident), a lane cuts its four offsets out of one
+// 64-bit window it loads at its own bit position (offsets of at most 16 bits), the delta moments live in the hand-over area.  The
+// symbols and section starts the walker wrote are read past the L1 (another wave of this CU wrote them since the line was last seen);
+// those of the next batch are requested before the current one is expanded.
+// ---------------------------------------------------------------------------------------------------------
+struct FuseVar { uint32_t n_bins, max_ob, dk, dord, nlps; };
+template <class L> struct FuseSlot {
+  bool live; uint32_t ti, n, n_batches, mode_kind, mode_k, num_kind; L mode_base; bool has_sec;
+  gcptr_u8 src; uint64_t src_len; L PCO_GLOBAL* dst;
+  FuseVar v[2];   // [0] the secondary variable, [1] the primary
+  uint32_t pf_syms[2]; uint64_t pf_start[2];   // batch b's symbol dword of this lane / section start, requested during batch b - 1
+};
+
+template <class LV>
+__device__ __forceinline__ void fused_expand_item(uint32_t syms_dword, gcptr_u8 src, uint64_t src_len, uint64_t start_bit, uint32_t cnt, bool any_ob,
+                                                  const uint64_t PCO_GLOBAL* g_low, const uint8_t PCO_GLOBAL* g_ob, bool single_bin, LV out[4]) {
+  const uint32_t lane = lane_id();
+  // the walker's layout has chain c, block b of a 64-symbol group at dword 4 c + b; this lane wants chain lane % 4 of block lane / 4
+  const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ((lane & 48u) + 4u * (lane & 3u) + ((lane >> 2) & 3u))), (int)syms_dword);
+  const uint32_t syms = single_bin ? 0u : quad_transpose_u8(mine, lane & 3);
+  uint32_t ob[4]; LV low[4]; uint32_t t = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const bool act = 4 * lane + k < cnt;
+    const uint32_t s = act ? (syms >> (8 * k)) & 0xffu : 0u;
+    ob[k] = (uint32_t)g_ob[s]; low[k] = (LV)g_low[s];
+    if (!act) { ob[k] = 0; low[k] = 0; }
+    t += ob[k];
+  }
+  if (!any_ob) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = low[k];
+    return;
+  }
+  const uint32_t incl = wave_incl_scan(t);
+  const uint64_t bit = start_bit + (incl - t);
+  const uint64_t byte = bit >> 3; const uint32_t sh = (uint32_t)(bit & 7);
+  // t <= 64 bits from bit `sh` of the byte: nine bytes at most
+  uint64_t v64 = t ? load_u64_le_safe(src, byte, src_len + 16) >> sh : 0ull;
+  if (sh + t > 64) v64 |= (uint64_t)src[byte + 8 < src_len + 16 ? byte + 8 : 0] << (64 - sh);
+#pragma unroll
+  for (int k = 0; k < 4; k++) { out[k] = (LV)(low[k] + (LV)__builtin_amdgcn_ubfe((uint32_t)v64, 0u, ob[k])); v64 >>= ob[k]; }
+}
+
+template <class L>
+__device__ void fused_expander(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, const DecPlan* plans, const uint8_t* bins_area,
+                               const uint8_t* sym_area, uint64_t sym_stride, const uint64_t* offpos_area, uint64_t offpos_stride) {
+  typedef WalkCfg<8> Cfg;
+  const uint32_t lane = lane_id(), ew = uni(threadIdx.x >> 6) - 1;   // expander 0..3
+  uint32_t PCO_LDS* ctl = (uint32_t PCO_LDS*)(lds_base() + Cfg::kFuseCtlOff);
+  uint64_t PCO_LDS* fmom = (uint64_t PCO_LDS*)(lds_base() + Cfg::kFuseMomOff);
+  __syncthreads();   // the walker has parsed the metadata of all eight chunks, built their tables and said which chunks are ours
+  FuseSlot<L> S[kFuseSlotsPerExp];
+  auto request = [&](FuseSlot<L>& c, uint32_t b) {   // the loads whose addresses do not depend on anything the batch computes
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) {
+      c.pf_syms[sl] = 0; c.pf_start[sl] = 0;
+      if (!c.live || b >= c.n_batches || (sl == 0 && !c.has_sec)) continue;
+      const int v = sl == 1 ? 1 : 2;
+      const uint32_t n_remaining = c.n - b * kBatchN, rem = n_remaining > c.v[sl].nlps ? n_remaining - c.v[sl].nlps : 0, cnt = rem < kBatchN ? rem : kBatchN;
+      if (cnt == 0) continue;
+      const uint8_t PCO_GLOBAL* syms = (const uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)c.ti * 3 + v) * sym_stride + (uint64_t)b * kBatchN;
+      if (c.v[sl].n_bins > 1 && 64 * (lane >> 4) < cnt) c.pf_syms[sl] = __hip_atomic_load((const uint32_t PCO_GLOBAL*)(syms + 4 * lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c.pf_start[sl] = __hip_atomic_load(offpos_area + ((uint64_t)c.ti * 3 + v) * offpos_stride + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto ready = [&](uint32_t slot, uint32_t b, bool& dead) -> bool {
+    const uint32_t w = uni(__hip_atomic_load(ctl + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    dead = w == kFuseDead;
+    return w > b && !dead;
+  };
+#pragma unroll
+  for (int q = 0; q < (int)kFuseSlotsPerExp; q++) {
+    FuseSlot<L>& c = S[q];
+    const uint32_t slot = ew + q * kFuseExpWaves, bi = blockIdx.x * 8 + slot;
+    c.live = slot < 8 && bi < n_ids && uni(__hip_atomic_load(ctl + (slot < 8 ? slot : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != kFuseDead;
+    c.ti = c.live ? (task_ids ? uni(task_ids[bi]) : bi) : 0u;
+    const DecPlan PCO_GLOBAL* plan = (const DecPlan PCO_GLOBAL*)plans + c.ti;
+    const PcoGfxDecodeTask PCO_GLOBAL* task = (const PcoGfxDecodeTask PCO_GLOBAL*)tasks + c.ti;
+    c.n = c.live ? uni(plan->n) : 0u; c.n_batches = (c.n + kBatchN - 1) / kBatchN;
+    c.mode_kind = uni(plan->mode_kind); c.mode_k = uni(plan->mode_k); c.num_kind = uni(plan->num_kind); c.mode_base = (L)uni((uint64_t)plan->mode_base);
+    c.has_sec = c.live && uni(plan->present[2]) != 0;
+    c.src = (gcptr_u8)(uintptr_t)uni((uint64_t)(uintptr_t)task->src); c.src_len = uni((uint64_t)task->src_len); c.dst = (L PCO_GLOBAL*)(uintptr_t)uni((uint64_t)(uintptr_t)task->dst);
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) {
+      const int v = sl == 1 ? 1 : 2;
+      c.v[sl].n_bins = uni(plan->n_bins[v]); c.v[sl].max_ob = uni(plan->max_ob[v]); c.v[sl].dk = uni(plan->delta_kind[v]); c.v[sl].dord = uni(plan->delta_order[v]); c.v[sl].nlps = uni(plan->nlps[v]);
+    }
+    c.pf_syms[0] = c.pf_syms[1] = 0; c.pf_start[0] = c.pf_start[1] = 0;
+  }
+  uint32_t have[kFuseSlotsPerExp]; for (int q = 0; q < (int)kFuseSlotsPerExp; q++) have[q] = 0xffffffffu;   // the batch whose loads are in flight / in registers, per slot
+  for (uint32_t b = 0;; b++) {
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < (int)kFuseSlotsPerExp; q++) {
+      FuseSlot<L>& c = S[q];
+      if (!c.live || b >= c.n_batches) continue;
+      any = true;
+      const uint32_t slot = ew + q * kFuseExpWaves;
+      bool dead = false;
+      while (!ready(slot, b, dead)) { if (dead) break; __builtin_amdgcn_s_sleep(8); }
+      if (dead) { c.live = false; continue; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (have[q] != b) request(c, b);
+      const uint32_t syms_now[2] = {c.pf_syms[0], c.pf_syms[1]}; const uint64_t start_now[2] = {uni(c.pf_start[0]), uni(c.pf_start[1])};
+      // the next batch's symbols and section starts, if the walker is already past it (usually: the expanders trail it)
+      { bool d2 = false; if (b + 1 < c.n_batches && ready(slot, b + 1, d2)) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); request(c, b + 1); have[q] = b + 1; } }
+      const uint32_t j0 = b * kBatchN, n_remaining = c.n - j0, batch_n = n_remaining < kBatchN ? n_remaining : kBatchN;
+      const uint8_t PCO_GLOBAL* bins = (const uint8_t PCO_GLOBAL*)bins_area + (uint64_t)c.ti * kBinsAreaPerTask;
+      L prim[4] = {0, 0, 0, 0}, sec[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int sl = 0; sl < 2; sl++) {
+        if (sl == 0 && !c.has_sec) continue;
+        const int v = sl == 1 ? 1 : 2;
+        const uint32_t rem = n_remaining > c.v[sl].nlps ? n_remaining - c.v[sl].nlps : 0, cnt = rem < kBatchN ? rem : kBatchN;
+        if (cnt == 0) continue;
+        const uint64_t PCO_GLOBAL* g_low = (const uint64_t PCO_GLOBAL*)(bins + (uint64_t)v * kBinsAreaPerVar);
+        const uint8_t PCO_GLOBAL* g_ob = bins + (uint64_t)v * kBinsAreaPerVar + kFastMaxBins * 8;
+        L tmp[4];
+        fused_expand_item<L>(syms_now[sl], c.src, c.src_len, start_now[sl], cnt, c.v[sl].max_ob != 0, g_low, g_ob, c.v[sl].n_bins <= 1, tmp);
+        if (sl == 1) { for (int k = 0; k < 4; k++) prim[k] = tmp[k]; } else { for (int k = 0; k < 4; k++) sec[k] = tmp[k]; }
+      }
+      // delta decode: the chunk's batches come in order, the moments wait in the hand-over area
+      if (c.v[1].dk == kDeltaConsecutive) consecutive_decode<L>(prim, c.v[1].dord, (L PCO_LDS*)(fmom + slot * 4));
+      if (c.has_sec && c.v[0].dk == kDeltaConsecutive) consecutive_decode<L>(sec, c.v[0].dord, (L PCO_LDS*)(fmom + slot * 4 + 2));
+      L outv[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) outv[k] = join_one<L>(c.mode_kind, c.num_kind, c.mode_base, c.mode_k, prim[k], sec[k]);
+      const uint32_t i0 = 4 * lane;
+      L PCO_GLOBAL* o = c.dst + j0 + i0;
+      if (i0 + 4 <= batch_n && (((uintptr_t)o) & 15) == 0) {
+        if constexpr (sizeof(L) == 8) {
+          typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+          u64x2 PCO_GLOBAL* p = (u64x2 PCO_GLOBAL*)o;
+          u64x2 a; a.x = outv[0]; a.y = outv[1]; u64x2 bb; bb.x = outv[2]; bb.y = outv[3];
+          p[0] = a; p[1] = bb;
+        } else if constexpr (sizeof(L) == 4) {
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 a; a.x = outv[0]; a.y = outv[1]; a.z = outv[2]; a.w = outv[3];
+          *(u32x4 PCO_GLOBAL*)o = a;
+        } else { for (int k = 0; k < 4; k++) o[k] = outv[k]; }
+      } else { for (int k = 0; k < 4; k++) if (i0 + k < batch_n) o[k] = outv[k]; }
+    }
+    if (!any) break;
   }
 }
 

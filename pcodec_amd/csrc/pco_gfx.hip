@@ -116,6 +116,10 @@ struct ScopedKernelTimer {
 // ---------------------------------------------------------------------------------------------------------
 static uint32_t g_decode_lds_bytes = 16 * 1024;  // dynamic LDS per wave (fixed area + tANS tables)
 static bool g_decode_fast = std::getenv("PCO_GFX_NO_FAST_DECODE") == nullptr;  // A/B switch for the two-kernel path
+// A/B switch: expand inside the walker's block (dec_walk_kernel<L, 8, true>).  Measured and NOT the default: an expander wave needs ~10 k
+// cycles per batch whatever kernel it runs in, so the expansion wants ~24 waves per CU, and a kernel that also holds the walker (LDS full
+// at four blocks, ~117 VGPRs) has room for 12: 13.7 - 16.5 ms against 6.5 + 6.25 ms for the two kernels back to back.
+static bool g_decode_fused = [] { const char* e = std::getenv("PCO_GFX_DEC_FUSED"); return e && e[0] == '1'; }();
 
 static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results,
                           PcoGfxTaskResult* d_results_user, hipStream_t stream) {
@@ -168,10 +172,12 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     const uint32_t fstride = (uint32_t)(sizeof(DecPlan) / 4);
     if (fast) {  // walk with 8 chunks per wave, then with 4 for the chunks whose tables did not fit, then expand
 #define PCO_FAST_DECODE(L, name)                                                                                                                          \
-      PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8>), dim3((cnt + 7) / 8), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,   \
-                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u);                                               \
-      PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4>), dim3((cnt + 3) / 4), dim3(64), WalkCfg<4>::kWalkLdsBytes, stream,  \
-                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4);                                  \
+      if (g_decode_fused) PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8, true>), dim3((cnt + 7) / 8), dim3(64 * (1 + kFuseExpWaves)), WalkCfg<8>::kFuseLdsBytes, stream,   \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results);                                    \
+      else PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8, false>), dim3((cnt + 7) / 8), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,   \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results);                                    \
+      PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4, false>), dim3((cnt + 3) / 4), dim3(64), WalkCfg<4>::kWalkLdsBytes, stream,  \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4, d_results);                       \
       PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, dec_expand_kernel<L>, dim3(grid), dim3(256), kExpLdsBytes, stream,                        \
                        d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
       if (g == 0) { PCO_FAST_DECODE(uint64_t, "u64") } else if (g == 1) { PCO_FAST_DECODE(uint32_t, "u32") } else if (g == 2) { PCO_FAST_DECODE(uint16_t, "u16") } else { PCO_FAST_DECODE(uint8_t, "u8") }
