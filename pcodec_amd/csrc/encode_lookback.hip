@@ -18,46 +18,42 @@
 // chosen lookbacks, double / triple buffered by tile parity.
 //
 // The last-index tables are what the search's random accesses go to (six reads and two updates per element into 2 x 2^(w+1) entries),
-// and with u32 entries a 2^18-number page owns 640 KB of them: beyond ~256 pages in flight the tables no longer fit the 256 MB memory-side
-// cache and every access is an HBM access -- the kernel then does 7 G elements/s whatever else is done (scripts/lb_scaling.py).  So:
+// and with u32 entries a 2^18-number page owns 640 KB of them.  So:
 //   * entries are u16, the position mod 2^16.  Only entries within window_n <= 2^15 positions matter (lookback.rs:52-56), and a sweep
 //     every 2^14 positions rewrites every entry older than the window to "window_n + 1 positions old", so no entry ever ages past 2^16
 //     and (position - entry) mod 2^16 IS its age.  Tables: 256 KB per page instead of 512;
-//   * a launch keeps at most as many pages in flight as fit the cache (the grid is a pool of page slots, each block takes pages until
-//     none are left);
-//   * pages of at most 8192 numbers (the Auto-delta trial samples: thousands per call) keep their tables in LDS -- a position fits 13
-//     bits, nothing ever goes stale -- and with them every random access of the search.
+//   * a launch keeps two pages per CU in flight (the grid is a pool of page slots, each block takes pages until none are left): beyond
+//     that nothing is gained -- measured, scripts/lb_scaling.py: 256 pages 9.9 ms, 512 pages 17-18 ms, 1024 pages 34-39 ms whatever the
+//     entry width; a CU completes one tile's stage work (~17 k busy wave-cycles) per ~5 k cycles however many pages share it;
+//   * pages of at most 8192 numbers (the Auto-delta trial samples: thousands per call) need no sweep -- a position fits 13 bits.  They
+//     only come here on request (the host's PCO_GFX_LB_PIPE_SMALL): five per CU are no faster than sixteen one-wave pages.
 // Data on which the "repeats its predecessor" guess fails for nearly every element (small random integers: ~49 rounds per tile) makes stage D
 // the whole cost; there one wave per page and sixteen pages per CU (enc_lookback_kernel) is the better shape, so a page that averages more
-// than kLbAbortRounds rounds per tile early on is handed back to that kernel (redo list), which runs after this one.  Small pages go to
-// this kernel only on request (PCO_GFX_LB_PIPE_SMALL=1): with their tables in LDS one page fills a CU, and a degenerate page costs it a
-// twelfth of the throughput sixteen one-wave pages get.
+// than kLbAbortRounds rounds for a tile right after its opening is handed back to that kernel (redo list), which runs after this one.
 #pragma once
 // (included by pco_gfx.hip after encode_kernels.hip, whose workspace types and lookback helpers it uses)
 
 namespace pcogfx {
 
 template <bool kSmall> struct LbPipe {
-  static constexpr bool kLdsTables = kSmall;
   static constexpr uint32_t kWaves = 5, kThreads = 64 * kWaves;
   static constexpr uint32_t kRing = kSmall ? 1024u : 2048u;            // latents of the last kRing positions (u64 each)
   static constexpr uint32_t kNear = kRing - 64 * kWaves;               // lookbacks below this are served from the ring by every stage (they run up to four tiles apart)
   static constexpr uint32_t kCounts = kSmall ? 8192u : 4096u;          // lookback_counts kept in LDS (small pages: all of them, as u16)
   typedef std::conditional_t<kSmall, uint16_t, uint32_t> CountT;
-  static constexpr uint32_t kTableSlots = kSmall ? (1u << 14) : 0u;    // per table: 2 << window_n_log, window_n_log <= 13 for n <= 8192
   static constexpr uint32_t kOffCounts = 0;
   static constexpr uint32_t kOffRing = kOffCounts + kCounts * sizeof(CountT);
   static constexpr uint32_t kOffPlb = kOffRing + kRing * 8;             // u16[3][6][64]
   static constexpr uint32_t kOffLz = kOffPlb + 3 * 6 * 64 * 2;          // u8[2][12][64]
-  static constexpr uint32_t kOffLb = kOffLz + 2 * 12 * 64;              // u32[2][64]
-  static constexpr uint32_t kOffTables = kOffLb + 2 * 64 * 4 + 16;      // (abort flag), then u16[2][kTableSlots] (small pages only)
-  static constexpr uint32_t kLdsBytes = kOffTables + 2 * kTableSlots * 2;
+  static constexpr uint32_t kOffLb = kOffLz + 2 * 12 * 64;              // u32[2][64], then the abort flag
+  static constexpr uint32_t kLdsBytes = kOffLb + 2 * 64 * 4 + 16;       // 37 KB (four pages per CU) / 28.5 KB (five)
 };
 constexpr uint32_t kLbPipeSmallMaxPage = 8192;
 constexpr uint32_t kLbSweepPeriod = 1u << 14;      // positions between two sweeps of the u16 tables (window_n + 1 + period + a tile < 2^16)
-// more than kLbAbortRounds rounds per tile over tiles [kLbAbortFrom, kLbAbortAt) -- past the page's opening, where nothing has a history
-// yet and every element decides differently whatever the data -- sends the page to enc_lookback_kernel
-constexpr uint32_t kLbAbortFrom = 8, kLbAbortAt = 16, kLbAbortRounds = 8;
+// The page's first kLbSeqTiles tiles are decided element by element, sixteen lanes = the sixteen proposals: nothing has a history there
+// and every element decides differently whatever the data, so speculation only costs (all lookbacks are below kNear there: latents from
+// the ring).  A tile among the next kLbAbortWindow that needs more than kLbAbortRounds rounds sends the page to enc_lookback_kernel.
+constexpr uint32_t kLbSeqTiles = 8, kLbAbortWindow = 8, kLbAbortRounds = 24;
 
 #ifdef PCO_LBP_TIMING
 __device__ unsigned long long g_lbp_timing[16];
@@ -67,7 +63,8 @@ template <class L, class Cfg>
 __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, uint16_t PCO_GLOBAL* hash_tbl, uint32_t PCO_GLOBAL* gcounts) {
   typedef typename Cfg::CountT CountT;
   constexpr uint32_t kRing = Cfg::kRing, kNear = Cfg::kNear, kCounts = Cfg::kCounts;
-  constexpr bool kLdsTables = Cfg::kLdsTables;
+  // (tables in LDS were tried for small pages -- u16 entries, 64 KB: one page then fills a CU, and a page on which stage D is the whole cost
+  //  gets a twelfth of the throughput of sixteen one-wave pages: 144 ms instead of 20 for the 8192 trial pages of f64 decimals)
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = uni(tid >> 6);
   const uint32_t wlog = uni(ch->window_n_log), state_n = 1u << uni(ch->state_n_log);
@@ -82,7 +79,6 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
   uint16_t PCO_LDS* q_plb = (uint16_t PCO_LDS*)(smem + Cfg::kOffPlb);
   uint8_t PCO_LDS* q_lz = (uint8_t PCO_LDS*)(smem + Cfg::kOffLz);
   uint32_t PCO_LDS* q_lb = (uint32_t PCO_LDS*)(smem + Cfg::kOffLb);
-  uint16_t PCO_LDS* ltab = (uint16_t PCO_LDS*)(smem + Cfg::kOffTables);
   uint32_t PCO_LDS* abort_flag = q_lb + 2 * 64;   // (one word behind the lookback queue)
   // delta state = the first state_n latents, right aligned (lookback.rs:179-181); state_n == 1 from this encoder
   if (tid == 0) for (uint32_t i = 0; i < state_n && i < 8; i++) pg->moments[i] = i < n ? (uint64_t)pre[i] : 0ull;
@@ -91,11 +87,8 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
   for (uint32_t i = tid; i < state_n; i += Cfg::kThreads) ring[i & (kRing - 1)] = (uint64_t)pre[i];   // the positions before the first tile
   const uint32_t n_counts = window_n < n ? window_n : n;
   for (uint32_t i = tid; i < kCounts; i += Cfg::kThreads) lcounts[i] = (CountT)1;
-  if constexpr (kLdsTables) { for (uint32_t i = tid; i < 2 * hash_table_n; i += Cfg::kThreads) ltab[i] = 0; }
-  else {
-    for (uint32_t i = kCounts + tid; i < n_counts; i += Cfg::kThreads) gcounts[i] = 1;
-    for (uint32_t i = tid; i < hash_table_n / 2; i += Cfg::kThreads) ((uint64_t PCO_GLOBAL*)hash_tbl)[i] = 0ull;   // 2 tables x hash_table_n u16
-  }
+  for (uint32_t i = kCounts + tid; i < n_counts; i += Cfg::kThreads) gcounts[i] = 1;
+  for (uint32_t i = tid; i < hash_table_n / 2; i += Cfg::kThreads) ((uint64_t PCO_GLOBAL*)hash_tbl)[i] = 0ull;   // 2 tables x hash_table_n u16
   __threadfence_block();
   __syncthreads();
   const uint32_t n_tiles = (n - state_n + 63) / 64;
@@ -115,7 +108,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
   L mn1 = (L)~(L)0, mx1 = 0; uint32_t mn0 = 0xffffffffu, mx0 = 0;
   if (wave < 2) {
     h_lv = tile_latent(state_n); h_lv2 = tile_latent(state_n + 64);
-    if constexpr (!kLdsTables) {
+    {
       const uint32_t c = wave;
       const uint64_t bucket = h_lv >> (c == 0 ? 0 : 8);
       const bool a = lane < n - state_n;
@@ -144,7 +137,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
         const bool act = lane < tile_n;
         const uint64_t lv = h_lv;
         if (c == 0 && act) ring[ie & (kRing - 1)] = lv;
-        if constexpr (!kLdsTables) {
+        {
           if (i0 >= next_sweep) {
             // sweep of this wave's table: every entry older than the window becomes "window_n + 1 positions old" (stale either way), so that
             // no entry's age can reach 2^16 before the next sweep.  (The entries prefetched for this tile were read before the sweep: a
@@ -167,8 +160,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
         const uint64_t bucket = lv >> (c == 0 ? 0 : 8);
         uint32_t slot[3], val[3];
         slot[0] = c * hash_table_n + hash_fn(bucket - 1); slot[1] = c * hash_table_n + hash_fn(bucket); slot[2] = c * hash_table_n + hash_fn(bucket + 1);
-        if constexpr (kLdsTables) { for (int r = 0; r < 3; r++) val[r] = act ? (uint32_t)ltab[slot[r]] : 0u; }
-        else { for (int r = 0; r < 3; r++) val[r] = h_val[r]; }
+        for (int r = 0; r < 3; r++) val[r] = h_val[r];
         // (u16 entries: positions mod 2^16; an in-tile hit below stores the hit's position the same way)
         // in-tile hazards: an earlier element of the tile wrote its centre bucket (slot[1]) before we read; each of my three slots needs the
         // LAST earlier lane whose centre slot equals it.  Eight wave votes give every lane the lanes whose centre slot agrees with a
@@ -205,11 +197,11 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
           uint64_t mm = __ballot(act && jmatch != 0xffffffffu);
           bool shadowed = false;
           while (mm) { const uint32_t k = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1; if ((uint32_t)__builtin_amdgcn_readlane((int)jmatch, (int)k) == lane) shadowed = true; }
-          if (act && !shadowed) { if constexpr (kLdsTables) ltab[slot[1]] = (uint16_t)ie; else hash_tbl[slot[1]] = (uint16_t)ie; }
+          if (act && !shadowed) hash_tbl[slot[1]] = (uint16_t)ie;
         }
         // the next tile's latents and table entries travel while this step's other stages run
         h_lv = h_lv2; h_lv2 = tile_latent(i0 + 128);
-        if constexpr (!kLdsTables) {
+        {
           const uint32_t i1 = i0 + 64; const bool a1 = i1 < n && lane < n - i1;
           const uint64_t b1 = h_lv >> (c == 0 ? 0 : 8);
           const uint32_t s0 = c * hash_table_n + hash_fn(b1 - 1), s1 = c * hash_table_n + hash_fn(b1), s2 = c * hash_table_n + hash_fn(b1 + 1);
@@ -267,10 +259,10 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
           if (kCounts >= (1u << 15) || lb - 1 < kCounts) return (uint32_t)lcounts[lb - 1 < kCounts ? lb - 1 : 0u];
           return __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, kLbScope);
         };
-        if (ts == 0) {
-          // ---- the page's first tile, element by element: lanes 0..15 = the 16 proposals.  (The brute-force slots fill up over the first 16
-          //      positions and overwrite the "repeating" slots on the way: lookback.rs:129-130.  From the second tile on none of that happens.)
-          //      Every lookback here is at most 64: latents from the ring, counts from LDS. ----
+        if (ts < kLbSeqTiles) {
+          // ---- the page's first tiles, element by element: lanes 0..15 = the 16 proposals, exactly choose_lookbacks' loop.  (The brute-force
+          //      slots fill up over the first 16 positions and overwrite the "repeating" slots on the way: lookback.rs:129-130.)
+          //      Every lookback here is at most 64 kLbSeqTiles: latents from the ring, counts from LDS. ----
           for (uint32_t e = 0; e < tile_n; e++) {
             const uint32_t i = i0 + e;
             const L l = (L)ring[i & (kRing - 1)];   // uniform
@@ -297,7 +289,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
             if (lane == 0) lcounts[new_best - 1] = (CountT)(lcounts[new_best - 1] + 1);
             lb_sync();
           }
-          // hand the state over to the tile-parallel path
+          // hand the state over to the tile-parallel path (after every sequential tile: the last one's is what counts)
           ring_lb0 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 6); ring_lb1 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 7);
           ring_lb2 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 8); ring_lb3 = (uint32_t)__builtin_amdgcn_readlane((int)proposed, 9);
           ring_c0 = uni(count_of(ring_lb0)); ring_c1 = uni(count_of(ring_lb1)); ring_c2 = uni(count_of(ring_lb2)); ring_c3 = uni(count_of(ring_lb3));
@@ -350,7 +342,8 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
 #ifdef PCO_LBP_TIMING
             tm_rounds++;
 #endif
-            if (ts >= kLbAbortFrom) d_rounds++;
+            d_rounds++;
+            if (d_rounds > kLbAbortRounds && ts < kLbSeqTiles + kLbAbortWindow && n_tiles > 4 * (kLbSeqTiles + kLbAbortWindow)) { if (lane == 0) *abort_flag = 1; break; }
             const uint32_t B = best_lookback;
             const uint32_t cb = cnt_best + (lane - e_start);   // B's count as this element sees it
             uint32_t best_g = 0, best = 0;
@@ -388,7 +381,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
           lb_sync();
         }
         q_lb[(ts & 1u) * 64 + lane] = my_lb;
-        if (ts + 1 == kLbAbortAt && d_rounds > (kLbAbortAt - kLbAbortFrom) * kLbAbortRounds && n_tiles > 4 * kLbAbortAt) { if (lane == 0) *abort_flag = 1; }
+        d_rounds = 0;
       }
     } else {
       // ============================================================ A: lookback.rs:166-185 on tile step - 3
