@@ -23,11 +23,11 @@ constexpr uint32_t kGrpWinOff = 0;
 constexpr uint32_t kGrpVarOff = 448;
 constexpr uint32_t kGrpTblOff = 640;
 template <uint32_t KQ> struct WalkCfg {
-  static constexpr uint32_t kGrpBytes = KQ == 8 ? 4912u : 9952u;
-  static constexpr uint32_t kGrpTblBytes = kGrpBytes - kGrpTblOff;      // 4272 / 9312
+  static constexpr uint32_t kGrpBytes = KQ == 8 ? 4912u : 9904u;   // (x 4 + the 1312 B of scratch = 40928 B: four blocks per CU in either form)
+  static constexpr uint32_t kGrpTblBytes = kGrpBytes - kGrpTblOff;      // 4272 / 9264
   static constexpr uint32_t kWalkTmpOff = KQ * kGrpBytes;                // scratch for the table build (one chunk at a time): u32[264] cumulative weights | u8[256] offset bits
   static constexpr uint32_t kWalkTmpObOff = kWalkTmpOff + 1056;
-  static constexpr uint32_t kWalkLdsBytes = kWalkTmpObOff + 256;         // 40608 / 41120: four waves per CU
+  static constexpr uint32_t kWalkLdsBytes = kWalkTmpObOff + 256;         // 40608 / 40928: four waves per CU
   static constexpr uint32_t kRetryStatus = KQ == 8 ? 101u : 100u;       // where a task goes whose tables do not fit
   static_assert(kGrpBytes % 16 == 0, "chunk slices must stay 16-byte aligned");
   static_assert(kWalkLdsBytes < 65536, "walk entries hold 16-bit LDS addresses");
@@ -664,6 +664,11 @@ constexpr uint32_t kExpTurnOff = kExpMomOff + 128;         // u32 turn (next bat
 constexpr uint32_t kExpWaveOff = kExpTurnOff + 16;         // per wave: dlat u32[256] | scratch u64[256] | parent u32[256]
 constexpr uint32_t kExpWaveBytes = 4096;
 constexpr uint32_t kExpLdsBytes = kExpWaveOff + kExpWaves * kExpWaveBytes;    // 23440
+// the lookback form adds the decoded latents of the chunk's last kExpRing batches (u64[8][256]): a lookback that reaches one of them is
+// served from LDS inside the ordered section, one that reaches further back is a global read that can be sent before the batch's turn
+constexpr uint32_t kExpRing = 8;
+constexpr uint32_t kExpRingOff = kExpLdsBytes;
+constexpr uint32_t kExpLbLdsBytes = kExpRingOff + kExpRing * 256 * 8;          // 39824
 
 // What one lane prefetches of one (batch, variable) item: its symbol dword and 32 bytes of the offsets section.
 struct ExpPre { uint32_t syms; uint32_t sec[8]; };
@@ -760,8 +765,12 @@ __device__ __forceinline__ void expand_item(const ExpPre& pre, uint32_t PCO_LDS*
 // One workgroup of kExpWaves waves per chunk.  Unpacking a batch (symbols -> bins -> offsets) is independent of
 // every other batch and hides its HBM latency behind the other waves; only the delta decode is ordered: wave b % 4
 // enters it when `turn` reaches b, reads the moments the previous batch left in LDS, and passes the turn on.
-template <class L>
-__global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids, uint32_t n_ids,
+#ifndef PCO_EXP_MIN_WAVES
+#define PCO_EXP_MIN_WAVES 1   // waves per SIMD the register allocator must leave room for (k blocks of 256 threads per CU = k)
+#endif
+// kLb: the chunks with a lookback delta (and only those); the plain form leaves them alone.
+template <class L, bool kLb>
+__global__ __launch_bounds__(256, PCO_EXP_MIN_WAVES) void dec_expand_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids, uint32_t n_ids,
                                                          const DecPlan* plans, const uint8_t* bins_area, const uint8_t* sym_area, uint64_t sym_stride,
                                                          const uint64_t* offpos_area, uint64_t offpos_stride) {
   const uint32_t lane = lane_id(), tid = threadIdx.x, wave = tid >> 6;
@@ -772,6 +781,7 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
     const uint32_t pstatus = uni(plan->status);
     if (pstatus == kStatusRetryLegacy) continue;   // the single-kernel decoder finishes this task
     if (uni(plan->fused)) continue;                // expanded inside dec_walk_kernel, result written there
+    if ((uni(plan->delta_kind[1]) == kDeltaLookback) != kLb) continue;   // the other form's
     if (pstatus != PCO_GFX_OK) {
       if (tid == 0) { PcoGfxTaskResult r; r.n_out = 0; r.consumed = plan->consumed; r.status = pstatus; r.aux = 0; results[ti] = r; }
       continue;
@@ -800,6 +810,7 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
     uint32_t PCO_LDS* parent = (uint32_t PCO_LDS*)(wsm + 3072);
     uint32_t PCO_LDS* stg = (uint32_t PCO_LDS*)(wsm + 1024);   // section staging; shares scratch / parent, which only the ordered lookback part uses
     L PCO_LDS* moments0 = (L PCO_LDS*)mom64; L PCO_LDS* moments1 = (L PCO_LDS*)(mom64 + 8);
+    L PCO_LDS* hring = (L PCO_LDS*)(smem + kExpRingOff);   // (kLb) decoded latents of batch b at [(b % kExpRing) * 256, + 256)
     __syncthreads();   // the previous chunk's LDS state is dead
     const uint8_t PCO_GLOBAL* bins = (const uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask;
 #pragma unroll
@@ -883,15 +894,30 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
       }
 #pragma unroll
       for (int sl = 0; sl < 2; sl++) { pre[sl] = nxt[sl]; st_cur[sl] = st_nxt[sl]; st_nxt[sl] = uni(st_raw[sl]); }
+      // (kLb) every element's lookback is known now.  A parent beyond the ring -- more than kExpRing - 1 batches back, or in the page's
+      // stored state -- was written at least two laps of the block's waves ago and acknowledged (each wave drains its stores after it
+      // passes the turn on): those reads go out here, before the batch waits for its turn.
+      L far_val[4] = {0, 0, 0, 0};
+      if constexpr (kLb) {
+        wave_sync_lds();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t i = 4 * lane + k;
+          const uint32_t lb = i < prim_cnt ? dlat[i] : 0u;
+          const int64_t q = (int64_t)(state_n + j0 + i) - (int64_t)lb;
+          const bool far = lb > i && lb <= (1u << window_n_log) && q >= 0 && (q < (int64_t)state_n || batch - (uint32_t)((q - state_n) >> 8) >= kExpRing);
+          if (far) far_val[k] = to_latent_ordered<L>(__hip_atomic_load(&dst[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), num_kind);
+        }
+      }
       // ---- ordered: delta decode, batch after batch ----
       if (ordered) {
         while (__hip_atomic_load((uint32_t*)turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != batch) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (dk[1] == kDeltaConsecutive) consecutive_decode<L>(prim, dord[1], moments0);
         if (present[2] && dk[2] == kDeltaConsecutive) consecutive_decode<L>(sec, dord[2], moments1);
-        if (dk[1] == kDeltaLookback) {
-          // history lives in dst: earlier batches' stores were acknowledged by L2 before their wave passed the turn on
-          // (s_waitcnt vmcnt(0) below), and the loads here are agent-scope atomics, i.e. served by L2
+        if constexpr (kLb) {
+          // F[state_n + k] = delta_k + MID + F[state_n + k - lb_k] (delta/lookback.rs:200-246).  Parents inside the batch: pointer
+          // jumping; in one of the last kExpRing - 1 batches: the ring (no global access inside the ordered section); further back: far_val.
           __builtin_amdgcn_wave_barrier();
           const uint32_t window_n = 1u << window_n_log;
           const uint64_t kbase = (uint64_t)j0;
@@ -901,37 +927,50 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
             uint32_t par = 0xffffffffu;
             if (i < prim_cnt) {
               uint32_t lb = dlat[i];
-              if (lb > window_n) { lb_oob = 1; lb = 1; }
+              if (lb > window_n) { lb_oob = 1; lb = 1; val = (L)(prim[k] + lmid<L>()); }
               if (lb == 0) { }
               else if (lb <= i) par = i - lb;
               else {
-                const int64_t jsrc = (int64_t)(state_n + kbase + i) - (int64_t)lb;
-                if (jsrc >= 0) val = (L)(val + to_latent_ordered<L>(__hip_atomic_load(&dst[jsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), num_kind));
+                const int64_t q = (int64_t)(state_n + kbase + i) - (int64_t)lb;
+                if (q >= 0) {
+                  const bool ring_hit = q >= (int64_t)state_n && batch - (uint32_t)((q - state_n) >> 8) < kExpRing;
+                  if (ring_hit) val = (L)(val + hring[(uint32_t)(q - state_n) & (kExpRing * 256 - 1)]);
+                  else if (dlat[i] <= window_n) val = (L)(val + far_val[k]);
+                  else val = (L)(val + to_latent_ordered<L>(__hip_atomic_load(&dst[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), num_kind));   // (an out-of-window lookback, replaced by 1: the page is corrupt and will say so)
+                }
               }
             }
             scratch[i] = val; parent[i] = par;
           }
           wave_sync_lds();
-          for (int round = 0; round < 8; round++) {
-            L nv[4]; uint32_t np[4];
+          for (int round = 0; round < 8; round++) {   // pointer jumping over the in-batch parents; seasonal data (lookbacks beyond a batch) has none
+            L nv[4]; uint32_t np[4]; bool open = false;
             for (int k = 0; k < 4; k++) {
               const uint32_t i = 4 * lane + k; const uint32_t p = parent[i];
               nv[k] = scratch[i]; np[k] = p;
-              if (p != 0xffffffffu) { nv[k] = (L)(nv[k] + scratch[p]); np[k] = parent[p]; }
+              if (p != 0xffffffffu) { nv[k] = (L)(nv[k] + scratch[p]); np[k] = parent[p]; open = true; }
             }
+            if (!__any(open)) break;   // (nothing was read that a lane is about to overwrite: no lane writes in this round)
             wave_sync_lds();
             for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; scratch[i] = nv[k]; parent[i] = np[k]; }
             wave_sync_lds();
           }
-          for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; if (i < prim_cnt) dst[state_n + kbase + i] = from_latent_ordered<L>(scratch[i], num_kind); }
-          __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          for (int k = 0; k < 4; k++) {
+            const uint32_t i = 4 * lane + k;
+            if (i < prim_cnt) {
+              const L f = scratch[i];
+              hring[(uint32_t)(kbase + i) & (kExpRing * 256 - 1)] = f;
+              dst[state_n + kbase + i] = from_latent_ordered<L>(f, num_kind);
+            }
+          }
           __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) __hip_atomic_store((uint32_t*)turn, batch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (kLb) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // off the chunk's serial chain: this batch's numbers are in L2 before this wave reads or sends anything else
       }
-      if (dk[1] != kDeltaLookback) {
+      if constexpr (!kLb) {
         L outv[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) outv[k] = join_one<L>(mode_kind, num_kind, mode_base, mode_k, prim[k], sec[k]);

@@ -178,7 +178,9 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
                        d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results);                                    \
       PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4, false>), dim3((cnt + 3) / 4), dim3(64), WalkCfg<4>::kWalkLdsBytes, stream,  \
                        d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4, d_results);                       \
-      PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, dec_expand_kernel<L>, dim3(grid), dim3(256), kExpLdsBytes, stream,                        \
+      PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, (dec_expand_kernel<L, false>), dim3(grid), dim3(256), kExpLdsBytes, stream,               \
+                       d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);                                        \
+      PCO_TIMED_LAUNCH("dec_expand_lb_kernel<" name ">", stream, (dec_expand_kernel<L, true>), dim3(grid), dim3(256), kExpLbLdsBytes, stream,           \
                        d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
       if (g == 0) { PCO_FAST_DECODE(uint64_t, "u64") } else if (g == 1) { PCO_FAST_DECODE(uint32_t, "u32") } else if (g == 2) { PCO_FAST_DECODE(uint16_t, "u16") } else { PCO_FAST_DECODE(uint8_t, "u8") }
 #undef PCO_FAST_DECODE
