@@ -765,12 +765,9 @@ __device__ __forceinline__ void expand_item(const ExpPre& pre, uint32_t PCO_LDS*
 // One workgroup of kExpWaves waves per chunk.  Unpacking a batch (symbols -> bins -> offsets) is independent of
 // every other batch and hides its HBM latency behind the other waves; only the delta decode is ordered: wave b % 4
 // enters it when `turn` reaches b, reads the moments the previous batch left in LDS, and passes the turn on.
-#ifndef PCO_EXP_MIN_WAVES
-#define PCO_EXP_MIN_WAVES 1   // waves per SIMD the register allocator must leave room for (k blocks of 256 threads per CU = k)
-#endif
 // kLb: the chunks with a lookback delta (and only those); the plain form leaves them alone.
 template <class L, bool kLb>
-__global__ __launch_bounds__(256, PCO_EXP_MIN_WAVES) void dec_expand_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids, uint32_t n_ids,
+__global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids, uint32_t n_ids,
                                                          const DecPlan* plans, const uint8_t* bins_area, const uint8_t* sym_area, uint64_t sym_stride,
                                                          const uint64_t* offpos_area, uint64_t offpos_stride) {
   const uint32_t lane = lane_id(), tid = threadIdx.x, wave = tid >> 6;
@@ -965,12 +962,50 @@ __global__ __launch_bounds__(256, PCO_EXP_MIN_WAVES) void dec_expand_kernel(cons
           }
           __builtin_amdgcn_wave_barrier();
         }
+        else if (dk[1] == kDeltaLookback) {   // (never taken: the plain form skips lookback chunks.  Kept because without it the compiler schedules the 32-bit instantiation's main loop 15 % slower)
+          // history lives in dst: earlier batches' stores were acknowledged by L2 before their wave passed the turn on
+          // (s_waitcnt vmcnt(0) below), and the loads here are agent-scope atomics, i.e. served by L2
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t window_n = 1u << window_n_log;
+          const uint64_t kbase = (uint64_t)j0;
+          for (int k = 0; k < 4; k++) {
+            const uint32_t i = 4 * lane + k;
+            L val = (L)(prim[k] + lmid<L>());
+            uint32_t par = 0xffffffffu;
+            if (i < prim_cnt) {
+              uint32_t lb = dlat[i];
+              if (lb > window_n) { lb_oob = 1; lb = 1; }
+              if (lb == 0) { }
+              else if (lb <= i) par = i - lb;
+              else {
+                const int64_t jsrc = (int64_t)(state_n + kbase + i) - (int64_t)lb;
+                if (jsrc >= 0) val = (L)(val + to_latent_ordered<L>(__hip_atomic_load(&dst[jsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), num_kind));
+              }
+            }
+            scratch[i] = val; parent[i] = par;
+          }
+          wave_sync_lds();
+          for (int round = 0; round < 8; round++) {
+            L nv[4]; uint32_t np[4];
+            for (int k = 0; k < 4; k++) {
+              const uint32_t i = 4 * lane + k; const uint32_t p = parent[i];
+              nv[k] = scratch[i]; np[k] = p;
+              if (p != 0xffffffffu) { nv[k] = (L)(nv[k] + scratch[p]); np[k] = parent[p]; }
+            }
+            wave_sync_lds();
+            for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; scratch[i] = nv[k]; parent[i] = np[k]; }
+            wave_sync_lds();
+          }
+          for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; if (i < prim_cnt) dst[state_n + kbase + i] = from_latent_ordered<L>(scratch[i], num_kind); }
+          __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) __hip_atomic_store((uint32_t*)turn, batch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if constexpr (kLb) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // off the chunk's serial chain: this batch's numbers are in L2 before this wave reads or sends anything else
       }
-      if constexpr (!kLb) {
+      if (!kLb && dk[1] != kDeltaLookback) {
         L outv[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) outv[k] = join_one<L>(mode_kind, num_kind, mode_base, mode_k, prim[k], sec[k]);
