@@ -164,6 +164,11 @@ typedef struct PcoGfxDecodeTask {
 #define PCO_GFX_TASK_WRAPPED_PAGE 2u
 /* parse + validate a ChunkMeta only; `consumed` = its byte length */
 #define PCO_GFX_TASK_META_ONLY 4u
+/* decode the FIRST chunk of the stream only (standalone/decompressor.rs:233-301, one DecompressorItem at a time): result.aux bit 0 = another
+ * chunk follows, `consumed` = the bytes through this chunk (and the terminator, if it was the last).  A file stores no chunk lengths, so
+ * the chunks of one file decode one after the other; this is the step a caller (or pco_standalone_simple_decompress_into) repeats.  On a
+ * stream without file header, bits 8..15 of `flags` carry the format's major version when it is not the current one. */
+#define PCO_GFX_TASK_ONE_CHUNK 8u
 
 typedef struct PcoGfxTaskResult {
   uint64_t n_out;    /* encode: bytes written; decode: elements written */

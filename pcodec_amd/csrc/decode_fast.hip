@@ -55,7 +55,7 @@ struct DecPlan {   // written by dec_walk_kernel, read by dec_expand_kernel
   uint32_t window_n_log, state_n_log;
   uint64_t moments[2][8];
   uint64_t consumed;
-  uint32_t fused, pad;      // 1: the chunk was expanded inside dec_walk_kernel (its result is written there), dec_expand_kernel skips it
+  uint32_t fused, more;     // fused = 1: the chunk was expanded inside dec_walk_kernel (its result is written there), dec_expand_kernel skips it; more = 1: PCO_GFX_TASK_ONE_CHUNK and another chunk follows
 };
 constexpr uint64_t kBinsAreaPerVar = kFastMaxBins * 8 + kFastMaxBins;   // lowers (8 B stride) then offset bits
 constexpr uint64_t kBinsAreaPerTask = 3 * kBinsAreaPerVar;
@@ -169,7 +169,7 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
   out.status = PCO_GFX_OK; out.n = 0; out.bitpos = 0;
   for (int v = 0; v < 3; v++) for (int j = 0; j < 4; j++) out.states[v][j] = 0;
   VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(lds_base() + q * kGrpBytes + kGrpVarOff);
-  auto fail = [&](uint32_t s) { out.status = s; if (lane == 0) { plan->status = s; plan->consumed = mr.bit >> 3; plan->n = 0; plan->fused = 0; } };
+  auto fail = [&](uint32_t s) { out.status = s; if (lane == 0) { plan->status = s; plan->consumed = mr.bit >> 3; plan->n = 0; plan->fused = 0; plan->more = 0; } };
   out.moments[0][0] = out.moments[0][1] = out.moments[1][0] = out.moments[1][1] = 0;
   if (dtype_bits(dtype) != (int)LB) { fail(PCO_GFX_INVALID_ARGUMENT); return; }
   if (flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY)) { fail(kStatusRetryLegacy); return; }
@@ -193,6 +193,7 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
     }
     if (status) { fail(status); return; }
   } else if (src_len == 0) { fail(kStatusRetryLegacy); return; }  // empty stream: zero chunks
+  else if ((flags & PCO_GFX_TASK_ONE_CHUNK) && ((flags >> 8) & 0xffu) != 0) format_major = (flags >> 8) & 0xffu;   // the caller read the file's header itself
   // chunk preamble (standalone/decompressor.rs:190-231)
   const uint32_t tb = (uint32_t)mr.read(8);
   if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
@@ -306,7 +307,7 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
   if (n_in_body > 0) for (int vi = 0; vi < 3; vi++) if (present[vi] && uni(vinfo[vi].n_bins) == 0) { fail(PCO_GFX_CORRUPTION); return; }
   if (lane == 0) {
     plan->status = PCO_GFX_OK; plan->n = n; plan->mode_kind = mode_kind; plan->mode_k = mode_k; plan->mode_base = (uint64_t)mode_base;
-    plan->num_kind = num_kind; plan->dtype = dtype; plan->window_n_log = wlog; plan->state_n_log = slog; plan->consumed = 0; plan->fused = 0;
+    plan->num_kind = num_kind; plan->dtype = dtype; plan->window_n_log = wlog; plan->state_n_log = slog; plan->consumed = 0; plan->fused = 0; plan->more = 0;
     for (int vi = 0; vi < 3; vi++) {
       plan->present[vi] = present[vi]; plan->n_bins[vi] = vinfo[vi].n_bins; plan->max_ob[vi] = vinfo[vi].max_ob;
       plan->delta_kind[vi] = vinfo[vi].delta_kind; plan->delta_order[vi] = vinfo[vi].delta_order; plan->nlps[vi] = nlps[vi];
@@ -633,7 +634,11 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
       }
       if (status == PCO_GFX_OK) {
         uint64_t byte = bit >> 3;
-        if (my_flags & PCO_GFX_TASK_HAS_FILE_HEADER) {
+        if (my_flags & PCO_GFX_TASK_ONE_CHUNK) {   // this chunk only: say whether another follows (the caller comes back for it)
+          if (byte < my_len && my_src[byte] != 0) plan->more = 1u;
+          else if (byte < my_len) byte += 1;     // the terminator
+          else if (my_flags & PCO_GFX_TASK_HAS_FILE_HEADER) status = PCO_GFX_INSUFFICIENT_DATA;
+        } else if (my_flags & PCO_GFX_TASK_HAS_FILE_HEADER) {
           if (byte >= my_len) status = PCO_GFX_INSUFFICIENT_DATA;
           else if (my_src[byte] != 0) status = kStatusRetryLegacy;  // another chunk follows: general path
           else byte += 1;
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
         // a chunk the block's expanders took is finished when this kernel is: its result is written here (a stream with another chunk
         // behind this one goes to the single-kernel decoder whole, which then reports it)
         if (my_fused && status != kStatusRetryLegacy) {
-          PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? my_n : 0; r.consumed = plan->consumed; r.status = status; r.aux = 0;
+          PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? my_n : 0; r.consumed = plan->consumed; r.status = status; r.aux = plan->more;
           results[my_ti] = r;
         }
       }
@@ -1029,7 +1034,7 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
     __syncthreads();
     if (tid == 0) {
       const uint32_t status = turn[1] ? PCO_GFX_CORRUPTION : PCO_GFX_OK;
-      PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? n : 0; r.consumed = plan->consumed; r.status = status; r.aux = 0; results[ti] = r;
+      PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? n : 0; r.consumed = plan->consumed; r.status = status; r.aux = plan->more; results[ti] = r;
     }
   }
 }

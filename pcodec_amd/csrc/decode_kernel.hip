@@ -872,6 +872,8 @@ __global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const
         }
       }
     }
+    if (!status && !(flags & PCO_GFX_TASK_HAS_FILE_HEADER) && (flags & PCO_GFX_TASK_ONE_CHUNK) && ((flags >> 8) & 0xffu) != 0) format_major = (flags >> 8) & 0xffu;
+    uint32_t more = 0;
     while (!status) {
       // chunk preamble (standalone/decompressor.rs:190-231)
       if (!(flags & PCO_GFX_TASK_HAS_FILE_HEADER) && (mr.bit >> 3) >= src_len) break;
@@ -887,9 +889,16 @@ __global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const
       status = uni(status);
       if (!status) n_out += n;
       wave_sync_lds();
+      if (!status && (flags & PCO_GFX_TASK_ONE_CHUNK)) {   // this chunk only: say whether another follows, take the terminator if not
+        const uint64_t byte = mr.bit >> 3;
+        if (byte < src_len && uni((uint32_t)src[byte]) != 0) more = 1;
+        else if (byte < src_len) mr.bit += 8;
+        else if (flags & PCO_GFX_TASK_HAS_FILE_HEADER) status = PCO_GFX_INSUFFICIENT_DATA;
+        break;
+      }
     }
     if (lane == 0) {
-      PcoGfxTaskResult r; r.n_out = n_out; r.consumed = mr.bit >> 3; r.status = status; r.aux = 0;
+      PcoGfxTaskResult r; r.n_out = n_out; r.consumed = mr.bit >> 3; r.status = status; r.aux = more;
       results[ti] = r;
     }
   }

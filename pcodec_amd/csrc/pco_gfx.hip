@@ -330,6 +330,33 @@ enum PcoError pco_gfx_compact_chunks(size_t n_tasks, const PcoGfxEncodeTask* tas
   } catch (const HostError& e) { return fail_with(e, PcoCompressionError); }
 }
 
+// standalone/decompressor.rs:85-137 on the host: where the first chunk starts and which format version the file declares.  Anything out
+// of the ordinary (old layouts without a version byte, a foreign uniform type, padding that is not zero, truncation) returns false and the
+// device's own parser reports it.
+static bool parse_standalone_header_host(const uint8_t* p, size_t len, unsigned char dtype, size_t& off, uint32_t& fmt_major) {
+  if (len < 6 || p[0] != 'p' || p[1] != 'c' || p[2] != 'o' || p[3] != '!') return false;
+  const uint32_t sv = p[4];
+  if (sv < 2 || sv > 3) return false;
+  size_t pos = 5;
+  if (sv >= 3) { const uint32_t uniform = p[pos++]; if (uniform != 0 && uniform != dtype) return false; }
+  if (pos + 9 > len) return false;
+  uint64_t bits = 0; for (int i = 0; i < 9 && i < 8; i++) bits |= (uint64_t)p[pos + i] << (8 * i);
+  const uint32_t power = 1 + (uint32_t)(bits & 63u);
+  const uint32_t vbits = kBitsVarintPower + power, vbytes = (vbits + 7) / 8;
+  if (vbits & 7) {   // the padding up to the byte boundary must be zero
+    const uint32_t last = p[pos + vbytes - 1];
+    if ((last >> (vbits & 7)) != 0) return false;
+  }
+  pos += vbytes;
+  if (pos >= len) return false;
+  fmt_major = p[pos++];
+  if (fmt_major > 4) return false;
+  if (fmt_major >= 4) pos++;
+  if (pos > len) return false;
+  off = pos;
+  return true;
+}
+
 enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size_t compressed_len, unsigned char dtype,
                                                     void* dst, size_t dst_cap, size_t* n_written) {
   clear_error();
@@ -340,20 +367,39 @@ enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size
     Workspace& ws = workspace();
     WorkspaceUse use(ws, 0);   // (ordered behind an asynchronous batched call of this thread that may still be running on another stream)
     uint8_t* d_in = (uint8_t*)ws.io_in.ensure(compressed_len + 64);
-    const size_t out_bytes = dst_cap * (size_t)(bits / 8);
+    const size_t esz = (size_t)(bits / 8), out_bytes = dst_cap * esz;
     uint8_t* d_out = (uint8_t*)ws.io_out.ensure(out_bytes + 64);
     PCO_HIP_CHECK(hipMemsetAsync(d_in + compressed_len, 0, 64, 0));
     if (compressed_len) PCO_HIP_CHECK(hipMemcpyAsync(d_in, compressed, compressed_len, hipMemcpyHostToDevice, 0));
-    PcoGfxDecodeTask task{d_in, compressed_len, d_out, dst_cap, dtype, PCO_GFX_TASK_HAS_FILE_HEADER};
-    PcoGfxTaskResult res{};
-    launch_decode(1, &task, &res, nullptr, 0);
-    if (res.status != PCO_GFX_OK) {
-      // a too-small dst is PcoDecompressionError, like pco_c/src/lib.rs:110-112
-      set_error((int)res.status, "decompression failed");
-      return PcoDecompressionError;
+    // A file stores no chunk lengths: chunk k + 1 starts where chunk k's bit stream ends, so the chunks of one file decode one after the
+    // other whatever does the decoding (standalone/decompressor.rs:233-301).  Each goes through the two-kernel path on its own (one
+    // PCO_GFX_TASK_ONE_CHUNK task per chunk, ~4 ms of tANS chain latency each); handing the whole file to the single-kernel decoder, one
+    // wave walking and expanding chunk after chunk, cost 14 ms per 2^18-number chunk.
+    size_t off = 0, done = 0; uint32_t fmt_major = 4;
+    const bool by_chunk = g_decode_fast && parse_standalone_header_host((const uint8_t*)compressed, compressed_len, dtype, off, fmt_major);
+    if (!by_chunk) {
+      PcoGfxDecodeTask task{d_in, compressed_len, d_out, dst_cap, dtype, PCO_GFX_TASK_HAS_FILE_HEADER};
+      PcoGfxTaskResult res{};
+      launch_decode(1, &task, &res, nullptr, 0);
+      if (res.status != PCO_GFX_OK) {
+        // a too-small dst is PcoDecompressionError, like pco_c/src/lib.rs:110-112
+        set_error((int)res.status, "decompression failed");
+        return PcoDecompressionError;
+      }
+      done = res.n_out;
+    } else {
+      for (;;) {
+        if (off >= compressed_len) { set_error(PCO_GFX_INSUFFICIENT_DATA, "decompression failed: the file ends without its terminator"); return PcoDecompressionError; }
+        PcoGfxDecodeTask task{d_in + off, compressed_len - off, d_out + done * esz, dst_cap - done, dtype, PCO_GFX_TASK_ONE_CHUNK | (fmt_major << 8)};
+        PcoGfxTaskResult res{};
+        launch_decode(1, &task, &res, nullptr, 0);
+        if (res.status != PCO_GFX_OK) { set_error((int)res.status, "decompression failed"); return PcoDecompressionError; }
+        done += res.n_out; off += res.consumed;
+        if (!(res.aux & 1u) || res.consumed == 0) break;
+      }
     }
-    if (res.n_out) PCO_HIP_CHECK(hipMemcpy(dst, d_out, res.n_out * (size_t)(bits / 8), hipMemcpyDeviceToHost));
-    if (n_written) *n_written = res.n_out;
+    if (done) PCO_HIP_CHECK(hipMemcpy(dst, d_out, done * esz, hipMemcpyDeviceToHost));
+    if (n_written) *n_written = done;
     return PcoSuccess;
   } catch (const HostError& e) { return fail_with(e, PcoDecompressionError); }
 }
