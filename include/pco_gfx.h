@@ -107,7 +107,7 @@ enum PcoGfxStatus {
   PCO_GFX_CORRUPTION = 1,
   PCO_GFX_INSUFFICIENT_DATA = 2,
   PCO_GFX_INVALID_ARGUMENT = 3,
-  PCO_GFX_UNSUPPORTED = 4,   /* feature outside the hot-path scope (Dict / Conv1 encode) */
+  PCO_GFX_UNSUPPORTED = 4,   /* feature outside the hot-path scope (Dict / Conv1 encode; lookback with a delta'd secondary variable in an ASYNCHRONOUS decode call) */
   PCO_GFX_DEVICE_ERROR = 5,  /* no GPU / HIP failure: the product has no CPU fallback */
 };
 int pco_gfx_last_status(void);

@@ -45,6 +45,7 @@ constexpr uint32_t kFuseExpWaves = 3, kFuseSlotsPerExp = 3;   // expander e take
 constexpr uint32_t kFastMaxBins = 256;
 constexpr uint32_t kStatusRetryLegacy = 100;     // internal: hand the task to the single-kernel decoder
 constexpr uint32_t kStatusRetryK4 = 101;         // internal: tables too big for an 8-chunk wave, try the 4-chunk walker
+constexpr uint32_t kStatusNeedHist = 102;        // internal: lookback with a delta'd secondary variable -- the task comes again with scratch for that history
 
 struct DecPlan {   // written by dec_walk_kernel, read by dec_expand_kernel
   uint32_t status, n;

@@ -299,6 +299,7 @@ struct PageParams {
   uint64_t mode_base;
   uint64_t dict_byte; uint32_t dict_n;     // Dict mode: the dictionary's first byte in src and its length (metadata/mode.rs:138-165)
   uint32_t conv_order, conv_quant;         // Conv1 delta (metadata/delta_encoding.rs): weights and bias live in LDS (kLdsConvOff)
+  void PCO_GLOBAL* sec_hist;               // lookback with a delta'd SECONDARY variable: n latents of scratch for its history (else null)
 };
 // Conv1 parameters in LDS, in the lookback path's "parent" area (the two deltas exclude each other): i64 bias | i64 weights[32]
 constexpr uint32_t kLdsConvOff = kLdsParentOff;
@@ -378,9 +379,10 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
       const L x = (L)mr.read(lbits);
       if (dk[vi] == kDeltaConsecutive) { if (lane == 0) { if (vi == 2) moments1[i] = x; else moments0[i] = x; } }
       else if (dk[vi] == kDeltaConv1) { if (lane == 0 && i < 32) ((uint32_t PCO_LDS*)(smem + kLdsScratchOff))[i] = (uint32_t)x; }
-      else if (vi == 1 && i < n && mr.in_bounds()) {  // lookback state = the first state_n latents (classic mode only)
+      else if (vi == 1 && i < n && mr.in_bounds()) {  // lookback state = the first state_n latents
         if (lane == 0) dst[i] = raw_hist ? x : from_latent_ordered<L>(x, num_kind);
       }
+      else if (vi == 2 && dk[2] == kDeltaLookback && i < n && mr.in_bounds()) { if (lane == 0) ((L PCO_GLOBAL*)pp.sec_hist)[i] = x; }
     }
     uint32_t mine = 0;
     for (uint32_t j = 0; j < 4; j++) { const uint32_t s = (uint32_t)mr.read(asl[vi]); if (lane == j) mine = s; }
@@ -482,12 +484,48 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
         const uint32_t i = 4 * lane + k;
         if (i < prim_cnt) dst[state_n + kbase + i] = raw_hist ? scratch[i] : from_latent_ordered<L>(scratch[i], num_kind);
       }
+      if (dk[2] == kDeltaLookback) {
+        // the secondary variable follows the same lookbacks (delta/mod.rs:125-159: both variables are decoded against the one delta
+        // variable); its history lives in the task's scratch
+        L PCO_GLOBAL* sh = (L PCO_GLOBAL*)pp.sec_hist;
+        wave_sync_lds();
+        for (int k = 0; k < 4; k++) {
+          const uint32_t i = 4 * lane + k;
+          L val = (L)(sec[k] + lmid<L>());
+          uint32_t par = 0xffffffffu;
+          if (i < prim_cnt) {
+            uint32_t lb = dlat[i];
+            if (lb > window_n) lb = 1;   // (already flagged)
+            if (lb == 0) { }
+            else if (lb <= i) par = i - lb;
+            else {
+              const int64_t jsrc = (int64_t)(state_n + kbase + i) - (int64_t)lb;
+              if (jsrc >= 0) val = (L)(val + __hip_atomic_load(&sh[jsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+          }
+          scratch[i] = val; parent[i] = par;
+        }
+        wave_sync_lds();
+        for (int round = 0; round < 8; round++) {
+          L nv[4]; uint32_t np[4];
+          for (int k = 0; k < 4; k++) {
+            const uint32_t i = 4 * lane + k; const uint32_t p = parent[i];
+            nv[k] = scratch[i]; np[k] = p;
+            if (p != 0xffffffffu) { nv[k] = (L)(nv[k] + scratch[p]); np[k] = parent[p]; }
+          }
+          wave_sync_lds();
+          for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; scratch[i] = nv[k]; parent[i] = np[k]; }
+          wave_sync_lds();
+        }
+        for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; if (i < prim_cnt) sh[state_n + kbase + i] = scratch[i]; }
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
     } else {
       // join + coalesced store: 4 contiguous numbers per lane
-      if (raw_hist) {  // second pass: the primary latents are what the first pass left in dst
+      if (raw_hist) {  // second pass: the primary latents are what the first pass left in dst (the secondary's, if delta'd too, in its scratch)
         for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; prim[k] = i < batch_n ? __hip_atomic_load(&dst[j0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (L)0; }
+        if (dk[2] == kDeltaLookback) { for (int k = 0; k < 4; k++) { const uint32_t i = 4 * lane + k; sec[k] = i < batch_n ? __hip_atomic_load((L PCO_GLOBAL*)pp.sec_hist + j0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (L)0; } }
       }
       L outv[4];
 #pragma unroll
@@ -660,7 +698,7 @@ __device__ __noinline__ void decode_page_body_dict(gcptr_u8 src, uint64_t src_le
 template <class L>
 __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaReader& mr, uint32_t lds_table_budget,
                                          gptr_u8 tbl_ws, uint32_t format_major, uint32_t dtype, uint32_t n, L PCO_GLOBAL* dst, uint32_t& status,
-                                         bool meta_only) {
+                                         bool meta_only, void PCO_GLOBAL* sec_hist = nullptr, uint32_t need_hist_status = PCO_GFX_UNSUPPORTED) {
   const uint32_t lane = lane_id();
   const uint32_t num_kind = dtype_kind(dtype);
   constexpr uint32_t LB = LBits<L>::v;
@@ -767,7 +805,9 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
       if (lw < 1 || lw > (1u << wlog)) bad = 1;
     }
     if (uni(wave_or_u32(bad))) { status = PCO_GFX_CORRUPTION; return; }
-    if (sec_uses_delta && present[2]) { status = PCO_GFX_UNSUPPORTED; return; }  // (no encoder writes it; the history of a second variable would need its own buffer)
+    // a delta'd secondary variable has a history of its own, which needs n latents of scratch: a task that came without is handed back
+    // (synchronous calls come again with the scratch; no encoder writes this combination, wrapped/chunk_compressor.rs:343,384)
+    if (sec_uses_delta && present[2] && !meta_only && sec_hist == nullptr) { status = need_hist_status; return; }
   }
   // mode validity for the number type (data_types/unsigned.rs:65-71, float.rs:377-390)
   {
@@ -801,7 +841,7 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
   // (the only kind an encoder writes, mode/dict.rs:12-33) always does; a padded one on an 8- / 16-bit type is refused.
   if (dict && dkind == kDeltaLookback && LB < 32 && dict_n > (1u << LB)) { status = PCO_GFX_UNSUPPORTED; return; }
   if (meta_only) return;
-  PageParams pp{mode_kind, mode_k, num_kind, n, (uint64_t)mode_base, dict_byte, dict_n, dorder, conv_quant};
+  PageParams pp{mode_kind, mode_k, num_kind, n, (uint64_t)mode_base, dict_byte, dict_n, dorder, conv_quant, sec_hist};
   if (dict) {
     if (lds_tables) decode_page_body_dict<L, true>(src, src_len, mr, tbl_lds, pp, dst, status);
     else decode_page_body_dict<L, false>(src, src_len, mr, tbl_ws, pp, dst, status);
@@ -818,7 +858,8 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
 template <class L>
 __global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids,
                                                         uint32_t n_ids, uint32_t lds_table_budget, uint8_t* tbl_ws_base,
-                                                        const uint32_t* only_if_status, uint32_t status_stride_u32, uint32_t status_value) {
+                                                        const uint32_t* only_if_status, uint32_t status_stride_u32, uint32_t status_value,
+                                                        uint8_t* hist_base, const uint64_t* hist_off, uint32_t need_hist_status) {
   const uint32_t lane = lane_id();
   for (uint32_t bi = blockIdx.x; bi < n_ids; bi += gridDim.x) {
     const uint32_t ti = task_ids ? task_ids[bi] : bi;
@@ -842,7 +883,8 @@ __global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const
       if (!meta_only && (dst_cap == 0 || dst_cap > kMaxEntries)) status = PCO_GFX_INVALID_ARGUMENT;
       if (!status) {
         gptr_u8 tbl_ws = tbl_ws_base ? (gptr_u8)tbl_ws_base + (uint64_t)blockIdx.x * kTblWsBytes : (gptr_u8) nullptr;
-        decode_chunk<L>(src, src_len, mr, lds_table_budget, tbl_ws, format_major, dtype, n, (L PCO_GLOBAL*)task.dst, status, meta_only);
+        decode_chunk<L>(src, src_len, mr, lds_table_budget, tbl_ws, format_major, dtype, n, (L PCO_GLOBAL*)task.dst, status, meta_only,
+                        hist_base ? (void PCO_GLOBAL*)(hist_base + hist_off[bi]) : (void PCO_GLOBAL*)nullptr, need_hist_status);
         status = uni(status);
         if (!status && !meta_only) n_out = n;
       }
@@ -885,7 +927,8 @@ __global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const
       if (!mr.in_bounds()) { status = PCO_GFX_INSUFFICIENT_DATA; break; }
       if (n_out + n > dst_cap) { status = PCO_GFX_INVALID_ARGUMENT; break; }
       gptr_u8 tbl_ws = tbl_ws_base ? (gptr_u8)tbl_ws_base + (uint64_t)blockIdx.x * kTblWsBytes : (gptr_u8) nullptr;
-      decode_chunk<L>(src, src_len, mr, lds_table_budget, tbl_ws, format_major, dtype, n, (L PCO_GLOBAL*)task.dst + n_out, status, false);
+      decode_chunk<L>(src, src_len, mr, lds_table_budget, tbl_ws, format_major, dtype, n, (L PCO_GLOBAL*)task.dst + n_out, status, false,
+                      hist_base ? (void PCO_GLOBAL*)((L PCO_GLOBAL*)(hist_base + hist_off[bi]) + n_out) : (void PCO_GLOBAL*)nullptr, need_hist_status);
       status = uni(status);
       if (!status) n_out += n;
       wave_sync_lds();

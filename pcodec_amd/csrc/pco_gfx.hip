@@ -163,6 +163,7 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     d_sym = (uint8_t*)ws.dec_sym.ensure(n_tasks * 3 * sym_stride + 64);
     d_offpos = (uint64_t*)ws.dec_offpos.ensure(n_tasks * 3 * offpos_stride * 8);
   }
+  const uint32_t need_hist = results ? kStatusNeedHist : (uint32_t)PCO_GFX_UNSUPPORTED;   // (only a synchronous call can come back with the scratch)
   for (int g = 0; g < 4; g++) {
     if (ids[g].empty()) continue;
     const uint32_t cnt = (uint32_t)ids[g].size();
@@ -185,15 +186,45 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
       if (g == 0) { PCO_FAST_DECODE(uint64_t, "u64") } else if (g == 1) { PCO_FAST_DECODE(uint32_t, "u32") } else if (g == 2) { PCO_FAST_DECODE(uint16_t, "u16") } else { PCO_FAST_DECODE(uint8_t, "u8") }
 #undef PCO_FAST_DECODE
     }
-    if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
-    else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
-    else if (g == 2) PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
-    else PCO_TIMED_LAUNCH("pco_decode_kernel<u8>", stream, pco_decode_kernel<uint8_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy);
+    if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist);
+    else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist);
+    else if (g == 2) PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist);
+    else PCO_TIMED_LAUNCH("pco_decode_kernel<u8>", stream, pco_decode_kernel<uint8_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist);
     PCO_HIP_CHECK(hipGetLastError());
   }
   if (results) {
     PCO_HIP_CHECK(hipMemcpyAsync(results, d_results, n_tasks * sizeof(PcoGfxTaskResult), hipMemcpyDeviceToHost, stream));
     PCO_HIP_CHECK(hipStreamSynchronize(stream));
+    // Tasks handed back for want of scratch (a lookback delta whose secondary variable is delta'd too: its history needs dst_cap latents):
+    // once more through the single-kernel decoder, with the scratch.  The format allows the combination; no encoder writes it.
+    std::vector<uint32_t> again[4]; size_t n_again = 0;
+    for (size_t i = 0; i < n_tasks; i++) if (results[i].status == kStatusNeedHist) {
+      const int b = dtype_bits(tasks[i].dtype);
+      again[b == 64 ? 0 : (b == 32 ? 1 : (b == 16 ? 2 : 3))].push_back((uint32_t)i); n_again++;
+    }
+    if (n_again) {
+      std::vector<uint32_t> flat_ids; std::vector<uint64_t> offs; uint64_t hist_bytes = 0;
+      size_t goff[4];
+      for (int g = 0; g < 4; g++) { goff[g] = flat_ids.size(); for (uint32_t i : again[g]) { flat_ids.push_back(i); offs.push_back(hist_bytes); hist_bytes += ((tasks[i].dst_cap * (uint64_t)(dtype_bits(tasks[i].dtype) / 8)) + 255) & ~(uint64_t)255; } }
+      uint8_t* d_hist = (uint8_t*)ws.dec_hist.ensure(hist_bytes + n_again * 12 + 256);
+      uint64_t* d_hoff = (uint64_t*)(d_hist + ((hist_bytes + 15) & ~(uint64_t)15));
+      uint32_t* d_again = (uint32_t*)(d_hoff + n_again);
+      PCO_HIP_CHECK(hipMemcpyAsync(d_hoff, offs.data(), n_again * 8, hipMemcpyHostToDevice, stream));
+      PCO_HIP_CHECK(hipMemcpyAsync(d_again, flat_ids.data(), n_again * 4, hipMemcpyHostToDevice, stream));
+      uint8_t* tbl2 = (uint8_t*)ws.tbl_ws.ensure(std::max<size_t>(max_grid, std::min<size_t>(n_again, 16384)) * kTblWsBytes);
+      for (int g = 0; g < 4; g++) {
+        if (again[g].empty()) continue;
+        const uint32_t cnt = (uint32_t)again[g].size(), grid = (uint32_t)std::min<size_t>(cnt, 16384);
+        const uint32_t* idp = d_again + goff[g]; const uint64_t* hop = d_hoff + goff[g];
+        if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED);
+        else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED);
+        else if (g == 2) PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED);
+        else PCO_TIMED_LAUNCH("pco_decode_kernel<u8>", stream, pco_decode_kernel<uint8_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED);
+      }
+      PCO_HIP_CHECK(hipGetLastError());
+      PCO_HIP_CHECK(hipMemcpyAsync(results, d_results, n_tasks * sizeof(PcoGfxTaskResult), hipMemcpyDeviceToHost, stream));
+      PCO_HIP_CHECK(hipStreamSynchronize(stream));
+    }
   }
 }
 
