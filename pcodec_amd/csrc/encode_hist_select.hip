@@ -23,63 +23,49 @@
 
 namespace pcogfx {
 
-constexpr uint32_t kSelT = 1024;
-constexpr uint32_t kSelSegs = 128, kSelSubLog = 6, kSelSample = 2048, kSelSortCap = 8192, kSelBigCap = 256, kSelWaveSortCap = 512;
+constexpr uint32_t kSelT = 1024;     // threads of enc_hist_small_kernel (block_radix_sort_inplace's array order is built on 16 waves)
+constexpr uint32_t kSelThr = 512;    // threads of enc_hist_select_kernel: two blocks per CU, one streaming while the other sorts / scans / queries
+constexpr uint32_t kSelSegs = 128, kSelSubLog = 6, kSelSample = 2048, kSelRegionBytes = 32768, kSelBigCap = 256;
 static_assert(kSelSegs << kSelSubLog == kSelBuckets, "segments x sub-buckets");
-static_assert(kSelSortCap == kSmallHistCap, "what enc_hist_small_kernel takes is what enc_hist_select_kernel leaves");
-static_assert(kSelWaveSortCap * (kSelT / 64) == kSelSortCap, "the block sort area is also the waves' private sort areas");
-constexpr uint32_t kSelLdsP = kHistLdsCounts;                                   // u32[8192 + 8] bucket counts, then exclusive prefix
+constexpr uint32_t kSelLdsP = 0;                                                // u32[8192 + 8] bucket counts, then exclusive prefix (hist_emit's scratch at the end)
 constexpr uint32_t kSelLdsNeed = kSelLdsP + (kSelBuckets + 8) * 4;              // u32[256] bitmap of the buckets to gather
-constexpr uint32_t kSelLdsSlot = kSelLdsNeed + kSelBuckets / 8;                 // u16[8192] bucket -> position in the list
-constexpr uint32_t kSelLdsNlK = kSelLdsSlot + kSelBuckets * 2;                  // u32[1600] marked buckets, ascending
-constexpr uint32_t kSelLdsNlOc = kSelLdsNlK + kSelMaxNeeded * 4;                // u32[1601 + 1] first subset index of each one's window
-constexpr uint32_t kSelLdsCur = kSelLdsNlOc + (kSelMaxNeeded + 2) * 4;          // u32[1600] fill cursors of the windows
-constexpr uint32_t kSelLdsSegLo = kSelLdsCur + kSelMaxNeeded * 4;               // u64[128] segment lower bounds
-constexpr uint32_t kSelLdsSegPar = kSelLdsSegLo + kSelSegs * 8;                 // u32[128] segment scaling: multiplier | pre-shift << 24
-constexpr uint32_t kSelLdsLut = kSelLdsSegPar + kSelSegs * 4;                   // u16[256 + 8] value cell -> first | last << 8 segment it meets
+constexpr uint32_t kSelLdsWpre = kSelLdsNeed + kSelBuckets / 8;                 // u16[256 + 8] marked buckets in the bitmap words before this one
+constexpr uint32_t kSelLdsNlOc = kSelLdsWpre + (256 + 8) * 2;                   // u32[1600 + 2] first subset index of each window (the gather pass's fill cursors: see (F))
+constexpr uint32_t kSelLdsSeg = (kSelLdsNlOc + (kSelMaxNeeded + 2) * 4 + 15) & ~15u;   // {lower bound, scaling}[128], 16 bytes each for 64-bit latents
+constexpr uint32_t kSelLdsLut = kSelLdsSeg + kSelSegs * 16;                     // u16[256 + 8] value cell -> first | last << 8 segment it meets
 constexpr uint32_t kSelLdsBig = kSelLdsLut + (256 + 8) * 2;                     // u32[256 + 4] windows the block orders in LDS; counters
-constexpr uint32_t kSelLdsSort = (kSelLdsBig + (kSelBigCap + 4) * 4 + 15) & ~15u;   // u64[8192] sample / block sort area / 16 x u64[512] wave sort areas
-constexpr uint32_t kSelLdsBytes = kSelLdsSort + kSelSortCap * 8;
-static_assert(kSelLdsBytes <= 160 * 1024, "one block per CU");
+constexpr uint32_t kSelLdsRec = (kSelLdsBig + (kSelBigCap + 4) * 4 + 15) & ~15u;   // 32 KB: the sample, then the waves' private sort areas / the block sort area, then (its first
+                                                                                    // 12 KB, laid out like enc_hist_kernel's) the rank records and the block-scan scratch
+constexpr uint32_t kSelLdsBytes = kSelLdsRec + kSelRegionBytes;
+static_assert(kHistLdsCounts <= kSelRegionBytes && 2 * kSelLdsBytes <= 160 * 1024, "two blocks per CU");
 
-// ascending bitonic sort of one latent per lane
-template <class L> __device__ __forceinline__ L wave_sort64(L x) {
+// One compare-exchange stage of the bitonic network over the 64 lanes: partner = lane ^ J inside sorted runs of K
+template <uint32_t K, uint32_t J, class L> __device__ __forceinline__ L bitonic_stage(L x) {
   const uint32_t lane = lane_id();
-#pragma unroll
-  for (uint32_t k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      const L o = shfl_idx(x, (int)(lane ^ j));
-      const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-      const L mn = x < o ? x : o, mx = x < o ? o : x;
-      x = keep_min ? mn : mx;
-    }
-  }
-  return x;
+  const L o = xor_lane<J>(x);
+  const bool keep_min = ((lane & J) == 0) == ((lane & K) == 0);
+  const L mn = x < o ? x : o, mx = x < o ? o : x;
+  return keep_min ? mn : mx;
 }
-// the same for kN independent sets at once: the kN exchanges of a stage are issued together (a lone sort is a chain of 21
-// dependent cross-lane reads, some 100 cycles each)
-template <class L, uint32_t kN> __device__ __forceinline__ void wave_sort64_multi(L (&x)[kN]) {
-  const uint32_t lane = lane_id();
+template <uint32_t K, uint32_t J, class L, uint32_t kN> __device__ __forceinline__ void bitonic_merge(L (&x)[kN]) {
 #pragma unroll
-  for (uint32_t k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      L o[kN];
-#pragma unroll
-      for (uint32_t g = 0; g < kN; g++) o[g] = shfl_idx(x[g], (int)(lane ^ j));
-      const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-#pragma unroll
-      for (uint32_t g = 0; g < kN; g++) { const L mn = x[g] < o[g] ? x[g] : o[g], mx = x[g] < o[g] ? o[g] : x[g]; x[g] = keep_min ? mn : mx; }
-    }
-  }
+  for (uint32_t g = 0; g < kN; g++) x[g] = bitonic_stage<K, J>(x[g]);
+  if constexpr (J > 1) bitonic_merge<K, J / 2>(x);
 }
+template <uint32_t K, class L, uint32_t kN> __device__ __forceinline__ void bitonic_level(L (&x)[kN]) {
+  bitonic_merge<K, K / 2>(x);
+  if constexpr (K < 64) bitonic_level<K * 2>(x);
+}
+// ascending bitonic sort of one latent per lane, kN independent sets at once (the kN exchanges of a stage are issued together);
+// the exchanges run on DPP / permlane swaps (xor_lane), not through the LDS crossbar
+template <class L, uint32_t kN> __device__ __forceinline__ void wave_sort64_multi(L (&x)[kN]) { bitonic_level<2>(x); }
+template <class L> __device__ __forceinline__ L wave_sort64(L x) { L a[1] = {x}; wave_sort64_multi<L, 1>(a); return a[0]; }
 // ascending bitonic sort of a[0 .. n) in LDS by the whole block, n a power of two (every thread of the block calls this)
 template <class L> __device__ __forceinline__ void block_sort_lds(L PCO_LDS* a, uint32_t n) {
   const uint32_t tid = threadIdx.x;
   for (uint32_t k = 2; k <= n; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = tid; i < (n >> 1); i += kSelT) {
+      for (uint32_t i = tid; i < (n >> 1); i += kSelThr) {
         const uint32_t l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l | j;
         const L x = a[l], y = a[r];
         const bool asc = (l & k) == 0;
@@ -178,7 +164,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   if (n_lat == 0) return;
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   if ((uint64_t)(L)(maxv - minv) < kWideHistRange) return;   // the LDS-counting kernels own it
-  if (n_lat <= kSelSortCap) return;                            // enc_hist_small_kernel orders the whole variable in LDS
+  if (n_lat <= kSmallHistCap) return;                            // enc_hist_small_kernel orders the whole variable in LDS
   const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
   const uint32_t n_all = (uint32_t)ch->n, skip = ev->lat_start, plow = ch->page_low, pr = ch->page_r;
   const bool single_page = ch->n_pages == 1;
@@ -191,26 +177,28 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   };
   auto stored = [&](uint32_t i) { return skip == 0 || (single_page ? i >= skip : (uint64_t)i - (exact_paging ? exact_start(i) : page_start_of(i, plow, pr)) >= skip); };
   uint8_t PCO_LDS* smem = enc_lds_base();
-  L PCO_LDS* rv = (L PCO_LDS*)(smem + kHistLdsRecV);
-  L PCO_LDS* rnext = (L PCO_LDS*)(smem + kHistLdsRecV + 2048);
-  L PCO_LDS* rpred = (L PCO_LDS*)(smem + kHistLdsRecV + 4096);
-  L PCO_LDS* rsucc = (L PCO_LDS*)(smem + kHistLdsRecV + 6144);
-  uint32_t PCO_LDS* rst = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 8192);
-  uint32_t PCO_LDS* ren = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 9216);
-  uint32_t PCO_LDS* scan = (uint32_t PCO_LDS*)(smem + kHistLdsRecV + 10240);   // u32[512]
+  L PCO_LDS* rv = (L PCO_LDS*)(smem + kSelLdsRec);
+  L PCO_LDS* rnext = (L PCO_LDS*)(smem + kSelLdsRec + 2048);
+  L PCO_LDS* rpred = (L PCO_LDS*)(smem + kSelLdsRec + 4096);
+  L PCO_LDS* rsucc = (L PCO_LDS*)(smem + kSelLdsRec + 6144);
+  uint32_t PCO_LDS* rst = (uint32_t PCO_LDS*)(smem + kSelLdsRec + 8192);
+  uint32_t PCO_LDS* ren = (uint32_t PCO_LDS*)(smem + kSelLdsRec + 9216);
+  uint32_t PCO_LDS* scan = (uint32_t PCO_LDS*)(smem + kSelLdsRec + 10240);   // u32[512]
   uint32_t PCO_LDS* P = (uint32_t PCO_LDS*)(smem + kSelLdsP);
   uint32_t PCO_LDS* need = (uint32_t PCO_LDS*)(smem + kSelLdsNeed);
-  uint16_t PCO_LDS* slot_of = (uint16_t PCO_LDS*)(smem + kSelLdsSlot);
-  uint32_t PCO_LDS* nl_k = (uint32_t PCO_LDS*)(smem + kSelLdsNlK);
+  uint16_t PCO_LDS* wpre = (uint16_t PCO_LDS*)(smem + kSelLdsWpre);
   uint32_t PCO_LDS* nl_oc = (uint32_t PCO_LDS*)(smem + kSelLdsNlOc);
-  uint32_t PCO_LDS* cur = (uint32_t PCO_LDS*)(smem + kSelLdsCur);
-  L PCO_LDS* seg_lo = (L PCO_LDS*)(smem + kSelLdsSegLo);
-  uint32_t PCO_LDS* seg_par = (uint32_t PCO_LDS*)(smem + kSelLdsSegPar);
+  // window (list position) of a marked bucket: its rank among the set bits of the bitmap
+  auto slot_of = [&](uint32_t k) { return (uint32_t)wpre[k >> 5] + (uint32_t)__popc(need[k >> 5] & ((1u << (k & 31)) - 1u)); };
+  struct alignas(sizeof(L) == 8 ? 16 : 8) SegRec { L lo; uint32_t par; };   // lower bound | scaling (multiplier | pre-shift << 24): one LDS read
+  SegRec PCO_LDS* seg = (SegRec PCO_LDS*)(smem + kSelLdsSeg);
   uint16_t PCO_LDS* lut = (uint16_t PCO_LDS*)(smem + kSelLdsLut);
   uint16_t PCO_GLOBAL* ids = clat_ptr(ws, t, var);   // bucket of every latent, written by the count pass for the gather pass (the compact-latent area is idle for wide ranges)
   uint32_t PCO_LDS* big = (uint32_t PCO_LDS*)(smem + kSelLdsBig);   // [0, kSelBigCap): slots; [kSelBigCap]: count; [+1]: fail flag; [+2]: n_seg
-  L PCO_LDS* srt = (L PCO_LDS*)(smem + kSelLdsSort);
+  L PCO_LDS* srt = (L PCO_LDS*)(smem + kSelLdsRec);
   constexpr uint32_t NB = kSelBuckets;
+  constexpr uint32_t kBlockSortCap = kSelRegionBytes / (sizeof(L) < 4 ? 4 : sizeof(L)), kWaveSortCap = kBlockSortCap / (kSelThr / 64);   // 4096 (8192) and 512 (1024) latents of 8 (<= 4) bytes
+  static_assert(kSelSample * sizeof(L) <= kSelRegionBytes, "the sample is sorted in the sort area");
   const uint32_t B = 1u << bins_log;
   const uint64_t n64 = n_lat;
   auto c_count = [&](uint32_t b) { return (uint32_t)((((uint64_t)b + 1) * n64 + B - 1) >> bins_log); };
@@ -220,15 +208,14 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   __syncthreads();
   // ---- (A) sample: 2048 evenly spaced positions (positions that are not stored hold defined junk or, for lookback, possibly
   //      nothing at all: clamping into [min, max] makes any value a harmless boundary candidate), sorted by the block ----
-  for (uint32_t k = tid; k < kSelSample; k += kSelT) {
+  for (uint32_t k = tid; k < kSelSample; k += kSelThr) {
     const uint32_t i = (uint32_t)(((uint64_t)k * n_all) / kSelSample);
     L x = lat[i];
     x = x < minv ? minv : (x > maxv ? maxv : x);
     srt[k] = x;
   }
-  for (uint32_t i = tid; i < NB + 8; i += kSelT) P[i] = 0;
-  for (uint32_t i = tid; i < NB / 32; i += kSelT) need[i] = 0;
-  for (uint32_t i = tid; i < NB / 2; i += kSelT) ((uint32_t PCO_LDS*)slot_of)[i] = 0xffffffffu;   // bucket -> window: 0xffff = not gathered
+  for (uint32_t i = tid; i < NB + 8; i += kSelThr) P[i] = 0;
+  for (uint32_t i = tid; i < NB / 32; i += kSelThr) need[i] = 0;
   if (tid < 4) big[kSelBigCap + tid] = 0;
   __syncthreads();
   block_sort_lds<L>(srt, kSelSample);
@@ -236,21 +223,43 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   // ---- (B) segments: lower bounds at sample quantiles -- every 19th sample in the interior, and geometrically closer (8, 4, 2, 1
   //      samples from either end) in the tails, where a power law would otherwise pile a whole segment's population into its
   //      first bucket.  Two equal neighbouring quantiles are a heavy value, which gets a segment of its own, [v, v + 1) ----
-  if (tid == 0) {
+  const uint32_t range_bl = bitlen<L>((L)(maxv - minv));
+  const uint32_t cell_sh = range_bl > 8 ? range_bl - 8 : 0u;   // value cells: the top 8 bits of x - min
+  if (tid == 0) {   // (par holds 1 for the bounds of a heavy value's segment until the scaling is written below)
     uint32_t ns = 0; L last_q = minv;
-    seg_lo[ns++] = minv;
+    seg[ns].lo = minv; seg[ns++].par = 0;
     auto cand = [&](uint32_t idx) {
       const L q = srt[idx];
-      if (q == last_q) { if (seg_lo[ns - 1] == q && q < maxv && ns < kSelSegs) seg_lo[ns++] = (L)(q + 1); }
-      else if (q > seg_lo[ns - 1] && ns < kSelSegs) seg_lo[ns++] = q;
+      if (q == last_q) { if (seg[ns - 1].lo == q && q < maxv && ns < kSelSegs) { seg[ns - 1].par = 1; seg[ns].lo = (L)(q + 1); seg[ns++].par = 1; } }
+      else if (q > seg[ns - 1].lo && ns < kSelSegs) { seg[ns].lo = q; seg[ns++].par = 0; }
       last_q = q;
     };
     cand(1); cand(2); cand(4); cand(8);
     for (uint32_t idx = 19; idx + 8 < kSelSample; idx += 19) cand(idx);
     cand(kSelSample - 8); cand(kSelSample - 4); cand(kSelSample - 2); cand(kSelSample - 1);
-    for (uint32_t j = 0; j < ns; j++) {
-      const L last = j + 1 < ns ? (L)(seg_lo[j + 1] - 1) : maxv;     // last value of the segment
-      const L w1 = (L)(last - seg_lo[j]);                              // width - 1
+    big[kSelBigCap + 2] = ns;
+  }
+  __syncthreads();
+  const uint32_t n_seg = uni(big[kSelBigCap + 2]);
+  // A bound that is alone in its value cell moves down to the cell's first value (any monotone map will do): the cell then lies in ONE
+  // segment and its latents need no search in the count pass.  On smooth data that is nearly every cell; where the data is dense
+  // (several bounds in a cell) and around heavy values the bounds stay where the sample put them.
+  {
+    L lo = (L)0;
+    if (tid < n_seg) {
+      lo = seg[tid].lo;
+      if (tid >= 1 && seg[tid].par == 0) {
+        const uint32_t c = (uint32_t)((L)(lo - minv) >> cell_sh), pc = (uint32_t)((L)(seg[tid - 1].lo - minv) >> cell_sh);
+        const uint32_t nc = tid + 1 < n_seg ? (uint32_t)((L)(seg[tid + 1].lo - minv) >> cell_sh) : 0xffffffffu;
+        if (pc != c && nc != c) lo = (L)(minv + ((L)c << cell_sh));
+      }
+    }
+    __syncthreads();
+    if (tid < n_seg) seg[tid].lo = lo;
+    __syncthreads();
+    if (tid < n_seg) {
+      const L last = tid + 1 < n_seg ? (L)(seg[tid + 1].lo - 1) : maxv;     // last value of the segment
+      const L w1 = (L)(last - lo);                                             // width - 1
       // sub-bucket = ((x - lo) >> pre) * m >> 16, monotone and < 64: segments of at most 64 values get one bucket per value
       // (pre 0, m 65536: "exact"), the others spread their (pre-shifted, < 2^16) width over all 64 sub-buckets
       uint32_t pre = 0, m = 65536;
@@ -260,18 +269,14 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
         const uint32_t vmax = (uint32_t)(w1 >> pre);
         m = (uint32_t)(((uint64_t)1 << (16 + kSelSubLog)) / ((uint64_t)vmax + 1));
       }
-      seg_par[j] = m | (pre << 24);
+      seg[tid].par = m | (pre << 24);
     }
-    big[kSelBigCap + 2] = ns;
   }
   __syncthreads();
-  const uint32_t n_seg = uni(big[kSelBigCap + 2]);
   // value cells (the top 8 bits of x - min) -> the segments a cell meets: most cells meet one or two, and the search below
   // only walks the segments of the latent's cell
-  const uint32_t range_bl = bitlen<L>((L)(maxv - minv));
-  const uint32_t cell_sh = range_bl > 8 ? range_bl - 8 : 0u;
   if (tid < 256) {
-    auto seg_of = [&](L x) { uint32_t lo = 0, hi = n_seg; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_lo[mid] <= x) lo = mid; else hi = mid; } return lo; };
+    auto seg_of = [&](L x) { uint32_t lo = 0, hi = n_seg; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg[mid].lo <= x) lo = mid; else hi = mid; } return lo; };
     const L c0 = (L)(minv + ((L)tid << cell_sh));
     L c1 = (L)(c0 + (L)(((L)1 << cell_sh) - 1));
     const bool in = (uint64_t)tid <= ((uint64_t)(L)(maxv - minv) >> cell_sh);
@@ -284,15 +289,15 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
     uint32_t j = e & 0xffu, jn = e >> 8;
     while (__any(j < jn)) {   // last segment of [j, jn] whose lower bound is <= x
       const uint32_t mid = (j + jn + 1) >> 1;
-      const bool ge = seg_lo[mid] <= x;
+      const bool ge = seg[mid].lo <= x;
       j = ge ? mid : j; jn = ge ? jn : mid - 1;
     }
-    const uint32_t par = seg_par[j];
-    const uint32_t v = (uint32_t)((L)(x - seg_lo[j]) >> (par >> 24));
+    const L rlo = seg[j].lo; const uint32_t par = seg[j].par;
+    const uint32_t v = (uint32_t)((L)(x - rlo) >> (par >> 24));
     return (j << kSelSubLog) + ((v * (par & 0x1ffffu)) >> 16);
   };
-  auto bucket_exact = [&](uint32_t k) { return seg_par[k >> kSelSubLog] == 65536u; };
-  auto bucket_value = [&](uint32_t k) { return (L)(seg_lo[k >> kSelSubLog] + (L)(k & ((1u << kSelSubLog) - 1))); };   // of an exact bucket
+  auto bucket_exact = [&](uint32_t k) { return seg[k >> kSelSubLog].par == 65536u; };
+  auto bucket_value = [&](uint32_t k) { return (L)(seg[k >> kSelSubLog].lo + (L)(k & ((1u << kSelSubLog) - 1))); };   // of an exact bucket
   // ---- (C) count; the bucket of every latent is kept (u16) for the gather pass.  A thread owns kE consecutive latents per
   //      round, fetched with 16-byte loads (64 bytes in flight per thread: dword loads left the block at a third of what HBM gives
   //      one CU); every stage of the kE searches is issued together ----
@@ -303,16 +308,16 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
     uint32_t base = 0;
     VecL nxt;   // the next round's latents are fetched before this round's are worked on (the block's waves run in step: without it
                 // they all wait for HBM together, then all compute together)
-    if (kE * kSelT <= n_all) {
+    if (kE * kSelThr <= n_all) {
 #pragma unroll
       for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + tid * kE))[q];
     }
-    for (; base + kE * kSelT <= n_all; base += kE * kSelT) {
+    for (; base + kE * kSelThr <= n_all; base += kE * kSelThr) {
       VecL d = nxt; uint32_t j[kE], jn[kE];
       const uint32_t i0 = base + tid * kE;
-      if (base + 2 * kE * kSelT <= n_all) {
+      if (base + 2 * kE * kSelThr <= n_all) {
 #pragma unroll
-        for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + i0 + kE * kSelT))[q];
+        for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + i0 + kE * kSelThr))[q];
       }
 #pragma unroll
       for (uint32_t k = 0; k < kE; k++) {
@@ -328,15 +333,15 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
 #pragma unroll
         for (uint32_t k = 0; k < kE; k++) {
           const uint32_t mid = (j[k] + jn[k] + 1) >> 1;
-          const bool ge = seg_lo[mid] <= d.x[k];
+          const bool ge = seg[mid].lo <= d.x[k];
           j[k] = ge ? mid : j[k]; jn[k] = ge ? jn[k] : mid - 1;
         }
       }
       uint32_t bb[kE];
 #pragma unroll
       for (uint32_t k = 0; k < kE; k++) {
-        const uint32_t par = seg_par[j[k]];
-        const uint32_t v = (uint32_t)((L)(d.x[k] - seg_lo[j[k]]) >> (par >> 24));
+        const L rlo = seg[j[k]].lo; const uint32_t par = seg[j[k]].par;
+        const uint32_t v = (uint32_t)((L)(d.x[k] - rlo) >> (par >> 24));
         const uint32_t b = (j[k] << kSelSubLog) + ((v * (par & 0x1ffffu)) >> 16);
         const bool on = stored(i0 + k);
         bb[k] = on ? b : 0xffffu;
@@ -348,7 +353,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
         ((u32x4 PCO_GLOBAL*)(ids + i0))[q] = w;
       }
     }
-    for (uint32_t i0 = base; i0 < n_all; i0 += kSelT) {   // (whole waves run bucket_of: its search loop votes)
+    for (uint32_t i0 = base; i0 < n_all; i0 += kSelThr) {   // (whole waves run bucket_of: its search loop votes)
       const uint32_t i = i0 + tid;
       const bool on = i < n_all && stored(i);
       L xv = i < n_all ? lat[i] : minv; xv = xv < minv ? minv : (xv > maxv ? maxv : xv);
@@ -362,7 +367,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   SEL_STAMP(1);
   // ---- (D) exclusive prefix over the buckets ----
   {
-    constexpr uint32_t PER = NB / kSelT;
+    constexpr uint32_t PER = NB / kSelThr;
     uint32_t s0 = 0;
     for (uint32_t k = 0; k < PER; k++) s0 += P[tid * PER + k];
     const uint32_t incl = wave_incl_scan(s0);
@@ -371,7 +376,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
     uint32_t wbase = 0; for (uint32_t w = 0; w < wave; w++) wbase += scan[w];
     uint32_t run = wbase + incl - s0;
     for (uint32_t k = 0; k < PER; k++) { const uint32_t c = P[tid * PER + k]; P[tid * PER + k] = run; run += c; }
-    if (tid == kSelT - 1) P[NB] = run;   // == n_lat
+    if (tid == kSelThr - 1) P[NB] = run;   // == n_lat
   }
   __syncthreads();
   auto bucket_of_rank = [&](uint32_t r) {   // the (non-empty) bucket holding rank r: last k with P[k] <= r
@@ -409,9 +414,11 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
     uint32_t slot = b_nb + i_nb - nb_here, off = b_el + i_el - el_here;
     for (uint32_t w = word; w; w &= w - 1) {
       const uint32_t k = tid * 32 + (uint32_t)__builtin_ctz(w);
-      if (slot < kSelMaxNeeded) { nl_k[slot] = k; nl_oc[slot] = off; cur[slot] = 0; slot_of[k] = (uint16_t)slot; }
+      if (slot < kSelMaxNeeded) nl_oc[slot + 1] = off;   // window `slot` starts at off: entry slot + 1 is its fill cursor in (G), which leaves it at the window's end = the next one's start
       slot++; off += P[k + 1] - P[k];
     }
+    if (tid < NB / 32) wpre[tid] = (uint16_t)(b_nb + i_nb - nb_here);
+    if (tid == 0) nl_oc[0] = 0;
     n_need = scan[0] + scan[1] + scan[2] + scan[3]; n_sub = scan[16] + scan[17] + scan[18] + scan[19];   // (the bitmap's 256 words live in waves 0..3)
   }
   __syncthreads();
@@ -420,7 +427,6 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
     __syncthreads();
     return;
   }
-  if (tid == 0) nl_oc[n_need] = n_sub;
   L PCO_GLOBAL* S = sort_ptr<L>(ws, t, 1);
   SEL_STAMP(2);
   // ---- (G) gather: every latent of a marked bucket goes into its bucket's window, in any order.  Same thread-to-latent mapping
@@ -430,32 +436,34 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
     uint32_t base = 0;
     union IdV { u32x4 v[kE / 8]; uint16_t k[kE]; };
     VecL nxt; IdV nid;
-    if (kE * kSelT <= n_all) {
+    if (kE * kSelThr <= n_all) {
 #pragma unroll
       for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + tid * kE))[q];
 #pragma unroll
       for (uint32_t q = 0; q < kE / 8; q++) nid.v[q] = ((const u32x4 PCO_GLOBAL*)(ids + tid * kE))[q];
     }
-    for (; base + kE * kSelT <= n_all; base += kE * kSelT) {
+    for (; base + kE * kSelThr <= n_all; base += kE * kSelThr) {
       VecL d = nxt; IdV id = nid; uint32_t sl[kE], at[kE];
       const uint32_t i0 = base + tid * kE;
-      if (base + 2 * kE * kSelT <= n_all) {
+      if (base + 2 * kE * kSelThr <= n_all) {
 #pragma unroll
-        for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + i0 + kE * kSelT))[q];
+        for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + i0 + kE * kSelThr))[q];
 #pragma unroll
-        for (uint32_t q = 0; q < kE / 8; q++) nid.v[q] = ((const u32x4 PCO_GLOBAL*)(ids + i0 + kE * kSelT))[q];
+        for (uint32_t q = 0; q < kE / 8; q++) nid.v[q] = ((const u32x4 PCO_GLOBAL*)(ids + i0 + kE * kSelThr))[q];
       }
 #pragma unroll
-      for (uint32_t k = 0; k < kE; k++) sl[k] = id.k[k] == 0xffffu ? 0xffffu : (uint32_t)slot_of[id.k[k]];
+      for (uint32_t k = 0; k < kE; k++) {   // (an id of 0xffff: not stored)
+        const uint32_t kk = id.k[k], wi = (kk & (kSelBuckets - 1)) >> 5, wd = need[wi];
+        sl[k] = kk != 0xffffu && ((wd >> (kk & 31)) & 1u) ? (uint32_t)wpre[wi] + (uint32_t)__popc(wd & ((1u << (kk & 31)) - 1u)) : 0xffffu;
+      }
 #pragma unroll
-      for (uint32_t k = 0; k < kE; k++) at[k] = sl[k] != 0xffffu ? nl_oc[sl[k]] + atomicAdd((uint32_t*)&cur[sl[k]], 1u) : 0u;
+      for (uint32_t k = 0; k < kE; k++) at[k] = sl[k] != 0xffffu ? atomicAdd((uint32_t*)&nl_oc[sl[k] + 1], 1u) : 0u;
 #pragma unroll
       for (uint32_t k = 0; k < kE; k++) if (sl[k] != 0xffffu) S[at[k]] = d.x[k];
     }
-    for (uint32_t i = base + tid; i < n_all; i += kSelT) {
+    for (uint32_t i = base + tid; i < n_all; i += kSelThr) {
       const uint32_t k = ids[i];
-      const uint32_t sl = k == 0xffffu ? 0xffffu : (uint32_t)slot_of[k];
-      if (sl != 0xffffu) S[nl_oc[sl] + atomicAdd((uint32_t*)&cur[sl], 1u)] = lat[i];
+      if (k != 0xffffu && ((need[k >> 5] >> (k & 31)) & 1u)) S[atomicAdd((uint32_t*)&nl_oc[slot_of(k) + 1], 1u)] = lat[i];
     }
   }
   __threadfence_block();
@@ -464,8 +472,8 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   // ---- (H) order every window: one value -> nothing to do; up to 64 latents -> one wave, in registers; up to 8192 -> the
   //      block, in LDS; more -> the fallback kernel ----
   {
-    L PCO_LDS* wsrt = srt + wave * kSelWaveSortCap;   // this wave's private sort area
-    constexpr uint32_t kWaves = kSelT / 64, kGrp = 4;
+    L PCO_LDS* wsrt = srt + wave * kWaveSortCap;   // this wave's private sort area
+    constexpr uint32_t kWaves = kSelThr / 64, kGrp = 4;
     uint32_t noc[kGrp], nlen[kGrp]; L nfirst[kGrp];
     auto fetch = [&](uint32_t s0) {   // the first 64 latents of four windows
 #pragma unroll
@@ -486,7 +494,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
 #pragma unroll
       for (uint32_t g = 0; g < kGrp; g++) {
         L mx = lane < len[g] ? first[g] : (L)0, mn = lane < len[g] ? first[g] : (L)~(L)0;
-        for (int d = 32; d >= 1; d >>= 1) { const L o1 = shfl_idx(mn, (int)(lane ^ d)), o2 = shfl_idx(mx, (int)(lane ^ d)); mn = o1 < mn ? o1 : mn; mx = o2 > mx ? o2 : mx; }
+        mn = wave_butterfly(mn, [](L p, L q) { return p < q ? p : q; }); mx = wave_butterfly(mx, [](L p, L q) { return p > q ? p : q; });
         small_multi[g] = len[g] > 1 && len[g] <= 64 && mn != mx;   // (wave-uniform)
         key[g] = lane < len[g] ? first[g] : mx;
       }
@@ -500,11 +508,11 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
         const uint32_t n_w = len[g];
         if (n_w <= 64) continue;
         L mn = first[g], mx = first[g];
-        if (n_w <= kSelWaveSortCap) wsrt[lane] = first[g];
-        for (uint32_t i = 64 + lane; i < n_w; i += 64) { const L x = S[oc[g] + i]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; if (n_w <= kSelWaveSortCap) wsrt[i] = x; }
-        for (int d = 32; d >= 1; d >>= 1) { const L o1 = shfl_idx(mn, (int)(lane ^ d)), o2 = shfl_idx(mx, (int)(lane ^ d)); mn = o1 < mn ? o1 : mn; mx = o2 > mx ? o2 : mx; }
+        if (n_w <= kWaveSortCap) wsrt[lane] = first[g];
+        for (uint32_t i = 64 + lane; i < n_w; i += 64) { const L x = S[oc[g] + i]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; if (n_w <= kWaveSortCap) wsrt[i] = x; }
+        mn = wave_butterfly(mn, [](L p, L q) { return p < q ? p : q; }); mx = wave_butterfly(mx, [](L p, L q) { return p > q ? p : q; });
         if (mn == mx) continue;   // one value: in order as it is
-        if (n_w <= kSelWaveSortCap) {
+        if (n_w <= kWaveSortCap) {
           uint32_t p2 = 128; while (p2 < n_w) p2 <<= 1;
           for (uint32_t i = n_w + lane; i < p2; i += 64) wsrt[i] = mx;
           enc_wave_sync();
@@ -512,7 +520,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
           for (uint32_t i = lane; i < n_w; i += 64) S[oc[g] + i] = wsrt[i];
           enc_wave_sync();
         } else if (lane == 0) {
-          if (n_w > kSelSortCap) big[kSelBigCap + 1] = 1;
+          if (n_w > kBlockSortCap) big[kSelBigCap + 1] = 1;
           else { const uint32_t at = atomicAdd((uint32_t*)&big[kSelBigCap], 1u); if (at < kSelBigCap) big[at] = s0 + g; else big[kSelBigCap + 1] = 1; }
         }
       }
@@ -530,10 +538,10 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   for (uint32_t bi = 0; bi < n_big; bi++) {
     const uint32_t s = big[bi], oc = nl_oc[s], len = nl_oc[s + 1] - oc;
     uint32_t p2 = 128; while (p2 < len) p2 <<= 1;
-    for (uint32_t i = tid; i < p2; i += kSelT) srt[i] = i < len ? S[oc + i] : maxv;
+    for (uint32_t i = tid; i < p2; i += kSelThr) srt[i] = i < len ? S[oc + i] : maxv;
     __syncthreads();
     block_sort_lds<L>(srt, p2);
-    for (uint32_t i = tid; i < len; i += kSelT) S[oc + i] = srt[i];
+    for (uint32_t i = tid; i < len; i += kSelThr) S[oc + i] = srt[i];
     __syncthreads();
   }
   __threadfence_block();
@@ -543,12 +551,12 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   auto value_at = [&](uint32_t r) {
     const uint32_t k = bucket_of_rank(r);
     if (bucket_exact(k)) return bucket_value(k);
-    return S[nl_oc[slot_of[k]] + (r - P[k])];
+    return S[nl_oc[slot_of(k)] + (r - P[k])];
   };
   auto lookup = [&](uint32_t r, L& value, uint32_t& st, uint32_t& en) {
     const uint32_t k = bucket_of_rank(r);
     if (bucket_exact(k)) { value = bucket_value(k); st = P[k]; en = P[k + 1]; return; }
-    const uint32_t oc = nl_oc[slot_of[k]];
+    const uint32_t oc = nl_oc[slot_of(k)];
     const uint32_t at = oc + (r - P[k]), wend = oc + (P[k + 1] - P[k]);
     value = S[at];
     uint32_t lo = oc, hi = at;   // first index with S[idx] >= value
@@ -568,7 +576,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   }
   __syncthreads();
   SEL_STAMP(6);
-  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts),
+  hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 1u, (uint32_t PCO_LDS*)(smem + kSelLdsP),
                ws.walk != nullptr ? (uint8_t PCO_GLOBAL*)ws.walk + ((uint64_t)t * 3 + var) * kWalkRecBytes : (uint8_t PCO_GLOBAL*)nullptr);
   __syncthreads();
   SEL_STAMP(7);
@@ -578,7 +586,7 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
 }
 
 // grid = chunks, 1024 threads: every wide-range variable of the chunk
-__global__ __launch_bounds__(kSelT) void enc_hist_select_kernel(EncWorkspace ws, uint32_t n_tasks) {
+__global__ __launch_bounds__(kSelThr, 4) void enc_hist_select_kernel(EncWorkspace ws, uint32_t n_tasks) {
   const uint32_t t = blockIdx.x;
   if (t >= n_tasks) return;
   const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(kSelT) void enc_hist_select_kernel(EncWorkspace ws,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// enc_hist_small_kernel: variables of at most kSelSortCap latents whose value range is beyond enc_hist_kernel's counters (>= 4096) (the 6.6 k-latent samples of the Auto-delta trials,
+// enc_hist_small_kernel: variables of at most kSmallHistCap latents whose value range is beyond enc_hist_kernel's counters (>= 4096) (the 6.6 k-latent samples of the Auto-delta trials,
 // short chunks).  The whole variable is ordered in LDS: keys are x - min, 32 bits wide whenever the range allows, sorted in
 // place by block_radix_sort_inplace, and the <= 256 rank queries read the sorted array directly.  LDS = the record area +
 // n keys (launcher: small_lds_bytes), so two to four blocks share a CU and hide each other's barriers and loads.
@@ -681,7 +689,7 @@ __device__ void small_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   EncVar PCO_GLOBAL* ev = &ch->v[var];
   const uint32_t n_lat = ev->n_lat;
-  if (n_lat == 0 || n_lat > kSelSortCap) return;
+  if (n_lat == 0 || n_lat > kSmallHistCap) return;
   const L minv = (L)ev->minv, maxv = (L)ev->maxv;
   const uint64_t range = (uint64_t)(L)(maxv - minv);
   if (range < kDirectHistRange) return;   // enc_hist_kernel's value-space counting owns it

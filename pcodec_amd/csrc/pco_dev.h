@@ -183,6 +183,27 @@ template <class T> __device__ __forceinline__ T wave_last(T v) {
   else return (T)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
 }
 template <class T> __device__ __forceinline__ T wave_sum(T v) { return wave_last(wave_incl_scan(v)); }
+// The value of lane (lane ^ J), J a power of two, on the VALU's own cross-lane paths (DPP inside a row of 16 lanes, gfx950's
+// v_permlane16_swap / v_permlane32_swap across rows): a butterfly through __shfl_xor is a ds_bpermute per step, i.e. LDS-pipe
+// traffic, and the kernels that sort in registers are LDS-bound as it is.
+template <uint32_t J> __device__ __forceinline__ uint32_t xor_lane32(uint32_t v) {
+  static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "a power of two below 64");
+  if constexpr (J == 1) return dpp0<0xB1, 0xf>(v);                               // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return dpp0<0x4E, 0xf>(v);                          // quad_perm [2,3,0,1]
+  else if constexpr (J == 4) return dpp0<0x1B, 0xf>(dpp0<0x141, 0xf>(v));        // row_half_mirror (lane ^ 7), then quad_perm [3,2,1,0] (lane ^ 3)
+  else if constexpr (J == 8) return dpp0<0x128, 0xf>(v);                         // row_ror:8
+  else if constexpr (J == 16) {   // vdst' = {d0, s0, d2, s2}, vsrc' = {d1, s1, d3, s3} (rows of 16 lanes)
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (threadIdx.x & 16u) ? (uint32_t)r[0] : (uint32_t)r[1];
+  } else {                        // vdst' = {d_lo, s_lo}, vsrc' = {d_hi, s_hi} (halves of 32 lanes)
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (threadIdx.x & 32u) ? (uint32_t)r[0] : (uint32_t)r[1];
+  }
+}
+template <uint32_t J, class T> __device__ __forceinline__ T xor_lane(T v) {
+  if constexpr (sizeof(T) == 8) return (T)(((uint64_t)xor_lane32<J>((uint32_t)((uint64_t)v >> 32)) << 32) | xor_lane32<J>((uint32_t)v));
+  else return (T)xor_lane32<J>((uint32_t)v);
+}
 // ---- quad (4 consecutive lanes) helpers ----
 template <int CTRL> __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
 // 4x4 byte transpose across the four lanes of a quad: lane j ends up with byte j of every lane's dword
@@ -202,16 +223,13 @@ __device__ __forceinline__ void quad_transpose_u16(uint32_t& a, uint32_t& b, uin
   a = __builtin_amdgcn_perm(x1, x0, sel); b = __builtin_amdgcn_perm(x3, x2, sel);
 }
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(v, d, 64); v = v > o ? v : o; }
+template <class T, class F> __device__ __forceinline__ T wave_butterfly(T v, F f) {   // every lane ends up with f over the whole wave
+  v = f(v, xor_lane<32>(v)); v = f(v, xor_lane<16>(v)); v = f(v, xor_lane<8>(v));
+  v = f(v, xor_lane<4>(v)); v = f(v, xor_lane<2>(v)); v = f(v, xor_lane<1>(v));
   return v;
 }
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, 64);
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return wave_butterfly(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) { return wave_butterfly(v, [](uint32_t a, uint32_t b) { return a | b; }); }
 
 // ---- explicit global address space (pointers loaded from task structs are generic/flat otherwise;
 //      flat loads would also tick lgkmcnt and serialise against the LDS traffic of the walkers) ----

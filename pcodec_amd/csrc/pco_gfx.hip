@@ -482,6 +482,38 @@ extern "C" int pco_gfx_debug_sel_timing(unsigned long long* out, int reset) {
 }
 #endif
 
+#ifdef PCO_OCCUPANCY_PROBE
+namespace pcogfx {
+__global__ void xor_lane_check_kernel(uint32_t* bad) {
+  const uint32_t lane = threadIdx.x & 63u; const uint32_t v = 0x9e3779b9u * (threadIdx.x + 1u); const uint64_t w = ((uint64_t)v << 32) | (v ^ 0x5555u);
+  uint32_t n = 0;
+  n += xor_lane<1>(v) != (uint32_t)__shfl((int)v, (int)(lane ^ 1), 64); n += xor_lane<2>(v) != (uint32_t)__shfl((int)v, (int)(lane ^ 2), 64);
+  n += xor_lane<4>(v) != (uint32_t)__shfl((int)v, (int)(lane ^ 4), 64); n += xor_lane<8>(v) != (uint32_t)__shfl((int)v, (int)(lane ^ 8), 64);
+  n += xor_lane<16>(v) != (uint32_t)__shfl((int)v, (int)(lane ^ 16), 64); n += xor_lane<32>(v) != (uint32_t)__shfl((int)v, (int)(lane ^ 32), 64);
+  n += xor_lane<16>(w) != shfl_idx(w, (int)(lane ^ 16)); n += xor_lane<4>(w) != shfl_idx(w, (int)(lane ^ 4));
+  uint64_t key = (uint64_t)(v >> 7) * 2654435761ull; const uint64_t sorted = wave_sort64<uint64_t>(key);
+  const uint64_t prev = shfl_idx(sorted, (int)(lane == 0 ? 0 : lane - 1)); n += sorted < prev;
+  if (n) atomicAdd(bad, n);
+}
+}
+extern "C" int pco_gfx_debug_xor_lane_check(unsigned* bad_out) {
+  uint32_t* d = nullptr; if (hipMalloc(&d, 4) != hipSuccess) return -1;
+  (void)hipMemset(d, 0, 4);
+  hipLaunchKernelGGL(pcogfx::xor_lane_check_kernel, dim3(4), dim3(256), 0, 0, d);
+  const int rc = (int)hipMemcpy(bad_out, d, 4, hipMemcpyDeviceToHost); (void)hipFree(d); return rc;
+}
+// resident blocks per CU of the kernels whose design counts on a number (scripts/occupancy.py, variant build only)
+extern "C" int pco_gfx_debug_occupancy(int which, int* blocks) {
+  using namespace pcogfx;
+  hipError_t e = hipErrorInvalidValue;
+  if (which == 0) { (void)hipFuncSetAttribute((const void*)enc_hist_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSelLdsBytes); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, enc_hist_select_kernel, (int)kSelThr, kSelLdsBytes); }
+  else if (which == 1) { (void)hipFuncSetAttribute((const void*)enc_hist_wide_kernel<kMidHistRange>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds_bytes(kMidHistRange)); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, enc_hist_wide_kernel<kMidHistRange>, 1024, hist_lds_bytes(kMidHistRange)); }
+  else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, enc_walk_kernel<8>, 64, EwCfg<8>::kLdsBytes);
+  else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, enc_pack_kernel, 64, 6144);
+  return (int)e;
+}
+#endif
+
 #ifdef PCO_HIST_TIMING
 extern "C" int pco_gfx_debug_hist_timing(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[16] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(pcogfx::g_hist_timing), z, sizeof(z)); }
