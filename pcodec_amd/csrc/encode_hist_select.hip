@@ -60,6 +60,62 @@ template <uint32_t K, class L, uint32_t kN> __device__ __forceinline__ void bito
 // the exchanges run on DPP / permlane swaps (xor_lane), not through the LDS crossbar
 template <class L, uint32_t kN> __device__ __forceinline__ void wave_sort64_multi(L (&x)[kN]) { bitonic_level<2>(x); }
 template <class L> __device__ __forceinline__ L wave_sort64(L x) { L a[1] = {x}; wave_sort64_multi<L, 1>(a); return a[0]; }
+// Ascending bitonic sort of the 2048-latent sample by the 512 threads of the block, four keys per thread, element i = wave * 256 +
+// r * 64 + lane: the exchanges at distance < 64 run on the lanes (xor_lane), those at distance 64 / 128 between a thread's own keys,
+// and only the six at distance >= 256 cross the waves through `ex` (L[2048]), where the sorted sample is left.
+template <uint32_t J, class L> __device__ __forceinline__ void sample_lane_stage(L (&key)[4], uint32_t ibase, uint32_t k) {
+#pragma unroll
+  for (uint32_t r = 0; r < 4; r++) {
+    const uint32_t i = ibase + r * 64;
+    const L o = xor_lane<J>(key[r]);
+    const bool keep_min = ((i & J) == 0) == ((i & k) == 0);
+    const L mn = key[r] < o ? key[r] : o, mx = key[r] < o ? o : key[r];
+    key[r] = keep_min ? mn : mx;
+  }
+}
+template <class L> __device__ __forceinline__ void block_sort_sample(L (&key)[4], L PCO_LDS* ex) {
+  static_assert(kSelSample == 2048 && kSelThr == 512, "four keys per thread");
+  const uint32_t ibase = (threadIdx.x >> 6) * 256 + (threadIdx.x & 63);
+#pragma unroll
+  for (uint32_t k = 2; k <= kSelSample; k <<= 1) {
+#pragma unroll
+    for (uint32_t j = k >> 1; j >= 256; j >>= 1) {   // across waves
+#pragma unroll
+      for (uint32_t r = 0; r < 4; r++) ex[ibase + r * 64] = key[r];
+      __syncthreads();
+#pragma unroll
+      for (uint32_t r = 0; r < 4; r++) {
+        const uint32_t i = ibase + r * 64;
+        const L o = ex[i ^ j];
+        const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+        const L mn = key[r] < o ? key[r] : o, mx = key[r] < o ? o : key[r];
+        key[r] = keep_min ? mn : mx;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (uint32_t jr = 2; jr >= 1; jr >>= 1) {       // between the thread's own keys (distance 128, 64)
+      if (k < 128 * jr) continue;
+#pragma unroll
+      for (uint32_t r = 0; r < 4; r++) {
+        if (r & jr) continue;
+        const bool asc = ((ibase + r * 64) & k) == 0;
+        const L a = key[r], b = key[r | jr];
+        const L mn = a < b ? a : b, mx = a < b ? b : a;
+        key[r] = asc ? mn : mx; key[r | jr] = asc ? mx : mn;
+      }
+    }
+    if (k >= 64) sample_lane_stage<32>(key, ibase, k);
+    if (k >= 32) sample_lane_stage<16>(key, ibase, k);
+    if (k >= 16) sample_lane_stage<8>(key, ibase, k);
+    if (k >= 8) sample_lane_stage<4>(key, ibase, k);
+    if (k >= 4) sample_lane_stage<2>(key, ibase, k);
+    sample_lane_stage<1>(key, ibase, k);
+  }
+#pragma unroll
+  for (uint32_t r = 0; r < 4; r++) ex[ibase + r * 64] = key[r];
+  __syncthreads();
+}
 // ascending bitonic sort of a[0 .. n) in LDS by the whole block, n a power of two (every thread of the block calls this)
 template <class L> __device__ __forceinline__ void block_sort_lds(L PCO_LDS* a, uint32_t n) {
   const uint32_t tid = threadIdx.x;
@@ -155,7 +211,7 @@ template <class L> __device__ __forceinline__ void wave_sort_lds(L PCO_LDS* a, u
 }
 
 template <class L>
-__device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log) {
+__device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log) {
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   EncVar PCO_GLOBAL* ev = &ch->v[var];
   const PlanRef plan = plan_ref(ws, t, var);
@@ -208,17 +264,17 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
   __syncthreads();
   // ---- (A) sample: 2048 evenly spaced positions (positions that are not stored hold defined junk or, for lookback, possibly
   //      nothing at all: clamping into [min, max] makes any value a harmless boundary candidate), sorted by the block ----
-  for (uint32_t k = tid; k < kSelSample; k += kSelThr) {
-    const uint32_t i = (uint32_t)(((uint64_t)k * n_all) / kSelSample);
-    L x = lat[i];
-    x = x < minv ? minv : (x > maxv ? maxv : x);
-    srt[k] = x;
+  L skey[4];
+#pragma unroll
+  for (uint32_t r = 0; r < 4; r++) {
+    const uint32_t k = wave * 256 + r * 64 + lane;
+    const L x = lat[(uint32_t)(((uint64_t)k * n_all) / kSelSample)];
+    skey[r] = x < minv ? minv : (x > maxv ? maxv : x);
   }
   for (uint32_t i = tid; i < NB + 8; i += kSelThr) P[i] = 0;
   for (uint32_t i = tid; i < NB / 32; i += kSelThr) need[i] = 0;
   if (tid < 4) big[kSelBigCap + tid] = 0;
-  __syncthreads();
-  block_sort_lds<L>(srt, kSelSample);
+  block_sort_sample<L>(skey, srt);
   SEL_STAMP(0);
   // ---- (B) segments: lower bounds at sample quantiles -- every 19th sample in the interior, and geometrically closer (8, 4, 2, 1
   //      samples from either end) in the tails, where a power law would otherwise pile a whole segment's population into its
@@ -337,16 +393,22 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
           j[k] = ge ? mid : j[k]; jn[k] = ge ? jn[k] : mid - 1;
         }
       }
-      uint32_t bb[kE];
+      // (staged: all segment records, then all buckets, then the stored-or-not flags, then the counter bumps -- one loop over the
+      //  latents made every LDS round trip wait for the one before it)
+      L rlo[kE]; uint32_t par[kE], bb[kE];
+#pragma unroll
+      for (uint32_t k = 0; k < kE; k++) { rlo[k] = seg[j[k]].lo; par[k] = seg[j[k]].par; }
 #pragma unroll
       for (uint32_t k = 0; k < kE; k++) {
-        const L rlo = seg[j[k]].lo; const uint32_t par = seg[j[k]].par;
-        const uint32_t v = (uint32_t)((L)(d.x[k] - rlo) >> (par >> 24));
-        const uint32_t b = (j[k] << kSelSubLog) + ((v * (par & 0x1ffffu)) >> 16);
-        const bool on = stored(i0 + k);
-        bb[k] = on ? b : 0xffffu;
-        if (on) atomicAdd((uint32_t*)&P[b], 1u);
+        const uint32_t v = (uint32_t)((L)(d.x[k] - rlo[k]) >> (par[k] >> 24));
+        bb[k] = (j[k] << kSelSubLog) + ((v * (par[k] & 0x1ffffu)) >> 16);
       }
+      if (skip != 0) {   // (block-uniform)
+#pragma unroll
+        for (uint32_t k = 0; k < kE; k++) bb[k] = stored(i0 + k) ? bb[k] : 0xffffu;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kE; k++) if (bb[k] != 0xffffu) atomicAdd((uint32_t*)&P[bb[k]], 1u);
 #pragma unroll
       for (uint32_t q = 0; q < kE / 8; q++) {   // eight u16 ids per 16-byte store
         u32x4 w; w.x = bb[8 * q] | (bb[8 * q + 1] << 16); w.y = bb[8 * q + 2] | (bb[8 * q + 3] << 16); w.z = bb[8 * q + 4] | (bb[8 * q + 5] << 16); w.w = bb[8 * q + 6] | (bb[8 * q + 7] << 16);
@@ -452,9 +514,16 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
         for (uint32_t q = 0; q < kE / 8; q++) nid.v[q] = ((const u32x4 PCO_GLOBAL*)(ids + i0 + kE * kSelThr))[q];
       }
 #pragma unroll
-      for (uint32_t k = 0; k < kE; k++) {   // (an id of 0xffff: not stored)
-        const uint32_t kk = id.k[k], wi = (kk & (kSelBuckets - 1)) >> 5, wd = need[wi];
-        sl[k] = kk != 0xffffu && ((wd >> (kk & 31)) & 1u) ? (uint32_t)wpre[wi] + (uint32_t)__popc(wd & ((1u << (kk & 31)) - 1u)) : 0xffffu;
+      for (uint32_t k = 0; k < kE; k++) at[k] = ((uint32_t)id.k[k] & (kSelBuckets - 1)) >> 5;   // bitmap word (an id of 0xffff -- not stored -- reads the last one)
+      uint32_t wd[kE];
+#pragma unroll
+      for (uint32_t k = 0; k < kE; k++) { wd[k] = need[at[k]]; sl[k] = wpre[at[k]]; }   // unconditional reads, all in flight together
+#pragma unroll
+      for (uint32_t k = 0; k < kE; k++) {
+        const uint32_t kk = id.k[k];
+        const uint32_t hit = (uint32_t)(kk != 0xffffu) & (wd[k] >> (kk & 31)) & 1u;   // (bitwise: no short-circuit branch per latent)
+        const uint32_t slot = sl[k] + (uint32_t)__popc(wd[k] & ((1u << (kk & 31)) - 1u));
+        sl[k] = hit ? slot : 0xffffu;
       }
 #pragma unroll
       for (uint32_t k = 0; k < kE; k++) at[k] = sl[k] != 0xffffu ? atomicAdd((uint32_t*)&nl_oc[sl[k] + 1], 1u) : 0u;
@@ -493,10 +562,8 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
       L key[kGrp]; bool small_multi[kGrp];
 #pragma unroll
       for (uint32_t g = 0; g < kGrp; g++) {
-        L mx = lane < len[g] ? first[g] : (L)0, mn = lane < len[g] ? first[g] : (L)~(L)0;
-        mn = wave_butterfly(mn, [](L p, L q) { return p < q ? p : q; }); mx = wave_butterfly(mx, [](L p, L q) { return p > q ? p : q; });
-        small_multi[g] = len[g] > 1 && len[g] <= 64 && mn != mx;   // (wave-uniform)
-        key[g] = lane < len[g] ? first[g] : mx;
+        small_multi[g] = len[g] > 1 && len[g] <= 64;   // (wave-uniform)
+        key[g] = lane < len[g] ? first[g] : (L)~(L)0;
       }
       if (small_multi[0] || small_multi[1] || small_multi[2] || small_multi[3]) {
         wave_sort64_multi<L, kGrp>(key);
@@ -585,22 +652,20 @@ __device__ void select_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uin
 #endif
 }
 
-// grid = chunks, 1024 threads: every wide-range variable of the chunk
+// grid = chunks, 512 threads: every wide-range variable of the chunks whose latents are L (one instantiation per latent width, launched
+// for the widths the call holds: as one kernel over all four the variable bodies were out-of-line calls with the workspace on the stack
+// and their callee-saved registers spilled around the streaming loops).  The delta latent variable (lookbacks < 2^15) never has a wide range.
+template <class L>
 __global__ __launch_bounds__(kSelThr, 4) void enc_hist_select_kernel(EncWorkspace ws, uint32_t n_tasks) {
   const uint32_t t = blockIdx.x;
   if (t >= n_tasks) return;
   const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
   if (uni(ch->status) != PCO_GFX_OK || uni(ch->big) != 0) return;   // (more than 256 bins: the sort kernel)
-  const int bits = dtype_bits(uni(ch->dtype));
+  if ((uint32_t)dtype_bits(uni(ch->dtype)) != LBits<L>::v) return;
   const uint32_t ubl = uni(ch->unopt_bins_log);
-  for (uint32_t var = 0; var < 3; var++) {
+  for (uint32_t var = 1; var < 3; var++) {
     if (!uni(ch->v[var].present)) continue;
-    const uint32_t bl = var == 2 ? (ubl < 6 ? ubl : 6) : ubl;
-    if (var == 0) select_var<uint32_t>(ws, t, var, bl);
-    else if (bits == 64) select_var<uint64_t>(ws, t, var, bl);
-    else if (bits == 32) select_var<uint32_t>(ws, t, var, bl);
-    else if (bits == 16) select_var<uint16_t>(ws, t, var, bl);
-    else select_var<uint8_t>(ws, t, var, bl);
+    select_var<L>(ws, t, var, var == 2 ? (ubl < 6 ? ubl : 6) : ubl);
   }
 }
 

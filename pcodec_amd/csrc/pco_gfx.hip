@@ -506,7 +506,7 @@ extern "C" int pco_gfx_debug_xor_lane_check(unsigned* bad_out) {
 extern "C" int pco_gfx_debug_occupancy(int which, int* blocks) {
   using namespace pcogfx;
   hipError_t e = hipErrorInvalidValue;
-  if (which == 0) { (void)hipFuncSetAttribute((const void*)enc_hist_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSelLdsBytes); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, enc_hist_select_kernel, (int)kSelThr, kSelLdsBytes); }
+  if (which == 0) { (void)hipFuncSetAttribute((const void*)enc_hist_select_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSelLdsBytes); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, enc_hist_select_kernel<uint32_t>, (int)kSelThr, kSelLdsBytes); }
   else if (which == 1) { (void)hipFuncSetAttribute((const void*)enc_hist_wide_kernel<kMidHistRange>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds_bytes(kMidHistRange)); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, enc_hist_wide_kernel<kMidHistRange>, 1024, hist_lds_bytes(kMidHistRange)); }
   else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, enc_walk_kernel<8>, 64, EwCfg<8>::kLdsBytes);
   else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, enc_pack_kernel, 64, 6144);
