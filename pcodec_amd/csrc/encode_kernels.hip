@@ -409,11 +409,10 @@ __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const Pco
       for (uint32_t k = 0; k < kSplitE; k++) if (e0 + k < n) { c1[e0 + k] = w1[k]; if (has_sec) c2[e0 + k] = w2[k]; }
     }
     // range of the tile, on the 32-bit relative values (a tile that does not fit contributes nothing: its chunk is redone)
-#pragma unroll
-    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
-      const uint32_t o1 = __shfl_xor(rmin1, dlt, 64), o2 = __shfl_xor(rmax1, dlt, 64);
-      rmin1 = o1 < rmin1 ? o1 : rmin1; rmax1 = o2 > rmax1 ? o2 : rmax1;
-      if (has_sec) { const uint32_t o3 = __shfl_xor(rmin2, dlt, 64), o4 = __shfl_xor(rmax2, dlt, 64); rmin2 = o3 < rmin2 ? o3 : rmin2; rmax2 = o4 > rmax2 ? o4 : rmax2; }
+    {
+      auto umin = [](uint32_t p, uint32_t q) { return p < q ? p : q; }; auto umax = [](uint32_t p, uint32_t q) { return p > q ? p : q; };
+      rmin1 = wave_butterfly(rmin1, umin); rmax1 = wave_butterfly(rmax1, umax);
+      if (has_sec) { rmin2 = wave_butterfly(rmin2, umin); rmax2 = wave_butterfly(rmax2, umax); }
     }
     const uint32_t wbad = __any(bad != 0) ? 1u : 0u;
     uint32_t PCO_LDS* red32 = (uint32_t PCO_LDS*)(smem + kSplitLdsRed);
@@ -1737,7 +1736,7 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
       if (cost < bc) { bc = cost; bjv = (uint32_t)j; }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
+    for (int d = 32; d >= 1; d >>= 1) {   // (through ds_bpermute: as DPP / permlane exchanges this chain of six dependent steps was 8 % slower -- one wave per SIMD, nothing to overlap)
       const float oc = __shfl_xor(bc, d, 64); const uint32_t oj = __shfl_xor(bjv, d, 64);
       const bool take = oj != 0xffffffffu && (bjv == 0xffffffffu || oc < bc || (oc == bc && oj > bjv));
       if (take) { bc = oc; bjv = oj; }
