@@ -78,8 +78,14 @@ __device__ __forceinline__ void dissect_batch_t(const uint8_t PCO_LDS* vt, const
   const uint8_t PCO_LDS* lut = vt + 2048 + 256;
   uint64_t x[4]; uint32_t sym[4] = {0, 0, 0, 0};
   if (kFull) {
+    if constexpr (sizeof(LV) == 2) {   // four 16-bit latents: one 8-byte load (2-byte aligned: a page may start at an odd index)
+      typedef uint64_t __attribute__((aligned(2))) u64_align2;
+      const uint64_t w = *(const u64_align2 PCO_GLOBAL*)(lat + 4 * lane);
+      x[0] = w & 0xffffu; x[1] = (w >> 16) & 0xffffu; x[2] = (w >> 32) & 0xffffu; x[3] = w >> 48;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = (uint64_t)lat[4 * lane + k];
+      for (int k = 0; k < 4; k++) x[k] = (uint64_t)lat[4 * lane + k];
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 4; k++) x[k] = 4 * lane + k < cnt ? (uint64_t)lat[4 * lane + k] : minv;
@@ -121,8 +127,10 @@ __device__ __forceinline__ void dissect_batch(const uint8_t PCO_LDS* vt, const L
   }
 }
 
+constexpr uint32_t kDisRuns = 4;   // runs per dissect block: the tables (bin lowers from the plan, the value -> bin table) are built once per block
 template <class L>
-__device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run, EncPage PCO_GLOBAL* pg, EncChunk PCO_GLOBAL* ch) {
+__device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run0, EncPage PCO_GLOBAL* pg, EncChunk PCO_GLOBAL* ch) {
+  const uint32_t run = run0;   // (first run of the block: the one that decides whether the block has anything to do)
   const uint32_t t = uni(pg->chunk);
   const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
   const uint64_t pstart = uni((uint64_t)pg->start);
@@ -164,8 +172,8 @@ __device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncF
   }
   __syncthreads();
   const uint32_t wave = threadIdx.x >> 6;
-  for (uint32_t bb = wave; bb < kRunBatches; bb += 4) {
-    const uint32_t batch = run * kRunBatches + bb;
+  for (uint32_t bb = wave; bb < kDisRuns * kRunBatches; bb += 4) {
+    const uint32_t batch = run0 * kRunBatches + bb;
     const uint32_t base = batch * kBatchN;
 #pragma unroll
     for (int v = 0; v < 3; v++) {
@@ -184,9 +192,10 @@ __device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncF
   }
 }
 
-// grid pages * runs_per_page, 256 threads
+// grid pages * ceil(runs_per_page / kDisRuns), 256 threads
 __global__ __launch_bounds__(256) void enc_dissect_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
-  const uint32_t p = blockIdx.x / fx.runs_per_page, run = blockIdx.x % fx.runs_per_page;
+  const uint32_t bpp = (fx.runs_per_page + kDisRuns - 1) / kDisRuns;
+  const uint32_t p = blockIdx.x / bpp, run = (blockIdx.x % bpp) * kDisRuns;
   if (p >= n_pages) return;
   EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + uni(pg->chunk);
@@ -530,8 +539,13 @@ __device__ __forceinline__ void pack_load(PackItem& it, const LV PCO_GLOBAL* lat
     if (!single_bin) it.syms = *(const u32_unaligned PCO_GLOBAL*)(sym + 4 * lane);
     if (needs_ans) { const uint64_t w = *(const u64_align2 PCO_GLOBAL*)(answ + 4 * lane); it.a = (uint32_t)w; it.b = (uint32_t)(w >> 32); }
     if (has_offsets) {
+      if constexpr (sizeof(LV) == 2) {
+        const uint64_t w = *(const u64_align2 PCO_GLOBAL*)(lat + 4 * lane);
+        it.x[0] = w & 0xffffu; it.x[1] = (w >> 16) & 0xffffu; it.x[2] = (w >> 32) & 0xffffu; it.x[3] = w >> 48;
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; k++) it.x[k] = (uint64_t)lat[4 * lane + k];
+        for (int k = 0; k < 4; k++) it.x[k] = (uint64_t)lat[4 * lane + k];
+      }
     }
     return;
   }

@@ -411,8 +411,8 @@ __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const Pco
     // range of the tile, on the 32-bit relative values (a tile that does not fit contributes nothing: its chunk is redone)
     {
       auto umin = [](uint32_t p, uint32_t q) { return p < q ? p : q; }; auto umax = [](uint32_t p, uint32_t q) { return p > q ? p : q; };
-      rmin1 = wave_butterfly(rmin1, umin); rmax1 = wave_butterfly(rmax1, umax);
-      if (has_sec) { rmin2 = wave_butterfly(rmin2, umin); rmax2 = wave_butterfly(rmax2, umax); }
+      rmin1 = wave_reduce_u32(rmin1, umin); rmax1 = wave_reduce_u32(rmax1, umax);
+      if (has_sec) { rmin2 = wave_reduce_u32(rmin2, umin); rmax2 = wave_reduce_u32(rmax2, umax); }
     }
     const uint32_t wbad = __any(bad != 0) ? 1u : 0u;
     uint32_t PCO_LDS* red32 = (uint32_t PCO_LDS*)(smem + kSplitLdsRed);
@@ -1735,11 +1735,14 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
       const float cost = __fadd_rn(best[j], bin_cost_dev<L>(meta, lows[j], upper, cci - cc[j], total_log2));
       if (cost < bc) { bc = cost; bjv = (uint32_t)j; }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {   // (through ds_bpermute: as DPP / permlane exchanges this chain of six dependent steps was 8 % slower -- one wave per SIMD, nothing to overlap)
-      const float oc = __shfl_xor(bc, d, 64); const uint32_t oj = __shfl_xor(bjv, d, 64);
-      const bool take = oj != 0xffffffffu && (bjv == 0xffffffffu || oc < bc || (oc == bc && oj > bjv));
-      if (take) { bc = oc; bjv = oj; }
+    {   // argmin over the wave, ties -> largest j: the smallest cost by a DPP reduction over the floats' order-preserving bit patterns
+        // (lanes without a candidate hold FLT_MAX; costs are positive, never NaN), then the largest j among the lanes that hold it
+      const uint32_t fb = __float_as_uint(bc);
+      const uint32_t cbits = fb ^ (((uint32_t)((int32_t)fb >> 31)) | 0x80000000u);
+      const uint32_t cmin = wave_reduce_u32(cbits, [](uint32_t p, uint32_t q) { return p < q ? p : q; });
+      const uint32_t jc = bjv != 0xffffffffu && cbits == cmin ? bjv + 1u : 0u;
+      const uint32_t jmax = wave_reduce_u32(jc, [](uint32_t p, uint32_t q) { return p > q ? p : q; });
+      bc = __uint_as_float(cmin ^ ((cmin >> 31) - 1u | 0x80000000u)); bjv = jmax - 1u;   // (jmax == 0: no lane had a candidate -- bjv = 0xffffffff as before)
     }
     if (NW > 1) {   // across the block's waves (only those that had a j to look at)
       const uint32_t n_act = (i >> 6) + 1 < NW ? (i >> 6) + 1 : NW;

@@ -223,13 +223,21 @@ __device__ __forceinline__ void quad_transpose_u16(uint32_t& a, uint32_t& b, uin
   a = __builtin_amdgcn_perm(x1, x0, sel); b = __builtin_amdgcn_perm(x3, x2, sel);
 }
 
+// f over the whole wave, wave-uniform, for an idempotent f (min / max / or): the scan's DPP steps with lanes that have no source keeping
+// their own value, the total read from lane 63.  Eight dependent VALU steps where a ds_bpermute butterfly is six LDS round trips.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_self(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false); }
+template <class F> __device__ __forceinline__ uint32_t wave_reduce_u32(uint32_t v, F f) {
+  v = f(v, dpp_self<0x111, 0xf>(v)); v = f(v, dpp_self<0x112, 0xf>(v)); v = f(v, dpp_self<0x114, 0xf>(v)); v = f(v, dpp_self<0x118, 0xf>(v));
+  v = f(v, dpp_self<0x142, 0xa>(v)); v = f(v, dpp_self<0x143, 0xc>(v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 template <class T, class F> __device__ __forceinline__ T wave_butterfly(T v, F f) {   // every lane ends up with f over the whole wave
   v = f(v, xor_lane<32>(v)); v = f(v, xor_lane<16>(v)); v = f(v, xor_lane<8>(v));
   v = f(v, xor_lane<4>(v)); v = f(v, xor_lane<2>(v)); v = f(v, xor_lane<1>(v));
   return v;
 }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return wave_butterfly(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) { return wave_butterfly(v, [](uint32_t a, uint32_t b) { return a | b; }); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return wave_reduce_u32(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) { return wave_reduce_u32(v, [](uint32_t a, uint32_t b) { return a | b; }); }
 
 // ---- explicit global address space (pointers loaded from task structs are generic/flat otherwise;
 //      flat loads would also tick lgkmcnt and serialise against the LDS traffic of the walkers) ----
