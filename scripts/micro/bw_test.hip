@@ -40,6 +40,38 @@ __global__ __launch_bounds__(256) void read16(const u64x2* __restrict__ s, u64* 
   for (int k = 0; k < 8; k++) { u64x2 v = s[base + k * 256]; acc += v.x ^ v.y; }
   if (acc == 0x1234567) d[0] = acc;
 }
+// read patterns (sum, never stored): R x 16 B per thread, lane-strided (coalesced) or thread-contiguous
+template <int R> __global__ __launch_bounds__(256) void read_strided(const u64x2* __restrict__ s, u64* __restrict__ d, size_t n2) {
+  size_t base = (size_t)blockIdx.x * (256 * R) + threadIdx.x; u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < R; k++) { u64x2 v = s[base + k * 256]; acc += v.x ^ v.y; }
+  if (acc == 0x1234567) d[0] = acc;
+}
+template <int R> __global__ __launch_bounds__(256) void read_contig(const u64x2* __restrict__ s, u64* __restrict__ d, size_t n2) {
+  size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * R; u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < R; k++) { u64x2 v = s[base + k]; acc += v.x ^ v.y; }
+  if (acc == 0x1234567) d[0] = acc;
+}
+// write patterns: R x 16 B per thread
+template <int R> __global__ __launch_bounds__(256) void write_strided(u64x2* __restrict__ d, size_t n2) {
+  size_t base = (size_t)blockIdx.x * (256 * R) + threadIdx.x; u64x2 v; v.x = base; v.y = 1;
+#pragma unroll
+  for (int k = 0; k < R; k++) d[base + k * 256] = v;
+}
+template <int R> __global__ __launch_bounds__(256) void write_contig(u64x2* __restrict__ d, size_t n2) {
+  size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * R; u64x2 v; v.x = base; v.y = 1;
+#pragma unroll
+  for (int k = 0; k < R; k++) d[base + k] = v;
+}
+// the split kernel's shape: 64 B read per thread (contiguous or strided), 16 B written per thread
+template <bool kContig> __global__ __launch_bounds__(256) void split_like(const u64x2* __restrict__ s, u64x2* __restrict__ d, size_t n2) {
+  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; u64x2 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = kContig ? s[t * 4 + k] : s[(size_t)blockIdx.x * 1024 + k * 256 + threadIdx.x];
+  u64x2 o; o.x = v[0].x + v[1].y + v[2].x; o.y = v[3].y ^ v[0].y;
+  d[t] = o;
+}
 int main() {
   size_t n = (size_t)1 << 30;  // 8 GiB in, 8 GiB out
   u64 *s, *d; hipMalloc(&s, n * 8); hipMalloc(&d, n * 8);
@@ -58,6 +90,16 @@ int main() {
   run("copy16x8", [&] { copy16<8><<<n / 2 / 2048, 256>>>((u64x2*)s, (u64x2*)d, n / 2); }, 16.0 * n);
   run("copy64c", [&] { copy64c<<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, n / 2); }, 16.0 * n);
   run("read16x8", [&] { read16<<<n / 2 / 2048, 256>>>((u64x2*)s, d, n / 2); }, 8.0 * n);
+  run("read16s x1", [&] { read_strided<1><<<n / 2 / 256, 256>>>((u64x2*)s, d, n / 2); }, 8.0 * n);
+  run("read16s x4", [&] { read_strided<4><<<n / 2 / 1024, 256>>>((u64x2*)s, d, n / 2); }, 8.0 * n);
+  run("read16c x2", [&] { read_contig<2><<<n / 2 / 512, 256>>>((u64x2*)s, d, n / 2); }, 8.0 * n);
+  run("read16c x4", [&] { read_contig<4><<<n / 2 / 1024, 256>>>((u64x2*)s, d, n / 2); }, 8.0 * n);
+  run("write16s x1", [&] { write_strided<1><<<n / 2 / 256, 256>>>((u64x2*)d, n / 2); }, 8.0 * n);
+  run("write16s x2", [&] { write_strided<2><<<n / 2 / 512, 256>>>((u64x2*)d, n / 2); }, 8.0 * n);
+  run("write16c x2", [&] { write_contig<2><<<n / 2 / 512, 256>>>((u64x2*)d, n / 2); }, 8.0 * n);
+  run("write16c x4", [&] { write_contig<4><<<n / 2 / 1024, 256>>>((u64x2*)d, n / 2); }, 8.0 * n);
+  run("split contig", [&] { split_like<true><<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
+  run("split strided", [&] { split_like<false><<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
   run("memset", [&] { hipMemsetAsync(d, 0, n * 8); }, 8.0 * n);
   run("memcpyD2D", [&] { hipMemcpyAsync(d, s, n * 8, hipMemcpyDeviceToDevice); }, 16.0 * n);
   return 0;
