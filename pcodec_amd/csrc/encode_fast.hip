@@ -606,12 +606,16 @@ __device__ __forceinline__ void pack_item_t(PackSink& sink, const uint8_t PCO_LD
     }
     const uint32_t incl = wave_incl_scan(t);
     uint32_t rel = incl - t;
-    if (max_ob <= 16) {  // the lane's four fields fit one 64-bit word: one put
+    // the widest offset of THIS batch decides how many puts it takes (a variable with a few far outliers has a large max_ob and narrow
+    // offsets in nearly every batch)
+    const uint32_t o01 = ob[0] > ob[1] ? ob[0] : ob[1], o23 = ob[2] > ob[3] ? ob[2] : ob[3];
+    const uint32_t bmax = max_ob <= 16 ? max_ob : wave_max_u32(o01 > o23 ? o01 : o23);
+    if (bmax <= 16) {  // the lane's four fields fit one 64-bit word: one put
       uint64_t acc = 0; uint32_t sh = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) { acc |= (uint64_t)__builtin_amdgcn_ubfe((uint32_t)x[k], 0u, ob[k]) << sh; sh += ob[k]; }
       sink.put(rel, acc, t);
-    } else if (max_ob <= 32) {  // two fields per 64-bit word: two puts
+    } else if (bmax <= 32) {  // two fields per 64-bit word: two puts
 #pragma unroll
       for (int k = 0; k < 4; k += 2) {
         const uint64_t lo = x[k] & (((uint64_t)1 << ob[k]) - 1), hi = x[k + 1] & (((uint64_t)1 << ob[k + 1]) - 1);
