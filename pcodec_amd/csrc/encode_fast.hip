@@ -28,8 +28,9 @@ struct EncFast {
   uint32_t* bat;        // [page][3][bat_stride][2]: offset bits, tANS bits of the batch
   uint64_t* run_start;  // [page][run_stride] first bit of the run, relative to the page task's dst
   uint32_t* fstate;     // [page][3][4] final tANS states
+  uint16_t* vlut;       // [task][slot][kDirectHistRange] value -> bin | offset bits << 8 of the variables enc_walkd_kernel takes (enc_vlut_kernel)
   uint32_t bat_stride, run_stride;
-  uint32_t runs_per_page, pad;   // 1-D grids of dissect / pack: block = page * runs_per_page + run
+  uint32_t runs_per_page, fused; // 1-D grids of dissect / pack: block = page * runs_per_page + run.  fused: which variables enc_walkd_kernel takes (wd_takes)
   uint64_t stride;               // elements per (task, slot) in sym / answ: n_stride + 16 per page, so that the 16-latent
                                  // blocks of neighbouring pages never overlap (see fast_at)
 };
@@ -44,7 +45,7 @@ __device__ __forceinline__ uint16_t PCO_GLOBAL* fansw_ptr(const EncWorkspace& ws
 }
 
 // The page's view of one variable (as in page_task)
-struct PageVar { uint32_t present, n_bins, asl, max_ob, needs_ans, trivial, skip, n_lat, compact; uint64_t minv, rel; };   // rel: what the compact (16-bit) latents are relative to
+struct PageVar { uint32_t present, n_bins, asl, max_ob, needs_ans, trivial, skip, n_lat, compact; uint64_t minv, rel, range; };   // rel: what the compact (16-bit) latents are relative to
 __device__ __forceinline__ PageVar page_var(const EncChunk PCO_GLOBAL* ch, uint32_t v, uint32_t page_n) {
   PageVar r;
   r.present = uni(ch->v[v].present); r.n_bins = uni(ch->v[v].n_bins); r.asl = uni(ch->v[v].ans_size_log); r.max_ob = uni(ch->v[v].max_ob);
@@ -54,9 +55,30 @@ __device__ __forceinline__ PageVar page_var(const EncChunk PCO_GLOBAL* ch, uint3
   r.n_lat = page_n - r.skip;
   r.compact = uni(ch->v[v].hist_path) == 0 ? 1u : 0u;   // histogram by LDS counting: compact latents exist (clat_ptr)
   r.minv = uni((uint64_t)ch->v[v].minv);
+  r.range = uni((uint64_t)ch->v[v].maxv) - r.minv;
   // compact latents: the histogram's copy relative to the minimum, or -- when the split speculated on 16-bit latents and held -- the split's own, relative to c16_ref
   r.rel = v != 0 && uni(ch->c16_ok) == 1 ? uni(ch->c16_ref[v == 2 ? 1 : 0]) : r.minv;
   return r;
+}
+
+// Q (page, variable) items per wave: 8 (slot 4608 B: any table of the fast path) or 16 (slot 2304 B, all 64 lanes busy).
+// The walk is latency-bound, so what matters is that every item is resident at once: with more than 8192 items the launch
+// first walks the items whose tables fit the small slots 16 per wave, then the rest 8 per wave (never worse than two rounds
+// of 8 per wave).  Slot: next states u16[T] | info u64[n_bins] (see ew_step) | ... | symbols u8[2][256] of the current / next batch.
+template <uint32_t Q> struct EwCfg {
+  static constexpr uint32_t kSlotBytes = Q == 16 ? 2304u : 4608u;
+  static constexpr uint32_t kSymOff = kSlotBytes - 512;
+  static constexpr uint32_t kLdsBytes = Q * kSlotBytes;   // 36864
+};
+__device__ __forceinline__ uint32_t ew_info_off(uint32_t asl) { return ((2u << asl) + 7u) & ~7u; }
+__device__ __forceinline__ bool ew_fits16(uint32_t asl, uint32_t n_bins) { return ew_info_off(asl) + 8u * n_bins <= EwCfg<16>::kSymOff; }
+// Does enc_walkd_kernel (walk + dissect in one block, below) take this page variable?  fused = 0: no; 1: every variable with 16-bit
+// latents; 2: only those whose tables do not fit the 16-per-wave slots of enc_walk_kernel<16> (launches of more than 8192 items)
+__device__ __forceinline__ bool wd_takes(uint32_t fused, const PageVar& pv) {
+  return fused != 0 && pv.present && pv.n_bins > 1 && pv.n_lat > 0 && pv.compact && pv.range < kDirectHistRange && (fused == 1 || !ew_fits16(pv.asl, pv.n_bins));
+}
+__device__ __forceinline__ uint16_t PCO_GLOBAL* vlut_ptr(const EncWorkspace& ws, const EncFast& fx, uint32_t task, uint32_t var) {
+  return (uint16_t PCO_GLOBAL*)fx.vlut + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * kDirectHistRange;
 }
 
 // =========================================================================================================
@@ -138,7 +160,11 @@ __device__ __forceinline__ void dissect_block(const EncWorkspace& ws, const EncF
   PageVar pv[3];
   bool any = false;
 #pragma unroll
-  for (int v = 0; v < 3; v++) { pv[v] = page_var(ch, v, page_n); if (pv[v].present && pv[v].n_bins > 1 && (uint64_t)run * kRunBatches * kBatchN < pv[v].n_lat) any = true; }
+  for (int v = 0; v < 3; v++) {
+    pv[v] = page_var(ch, v, page_n);
+    if (wd_takes(fx.fused, pv[v])) pv[v].present = 0;   // (enc_walkd_kernel finds this variable's symbols itself)
+    if (pv[v].present && pv[v].n_bins > 1 && (uint64_t)run * kRunBatches * kBatchN < pv[v].n_lat) any = true;
+  }
   if (!any) return;
   bool use_lut[3]; uint64_t rel0[3];   // rel0: what the element values are relative to (the minimum for compact latents, else 0)
 #pragma unroll
@@ -210,18 +236,6 @@ __global__ __launch_bounds__(256) void enc_dissect_kernel(EncWorkspace ws, EncFa
 // =========================================================================================================
 // reverse tANS walk
 // =========================================================================================================
-// Q (page, variable) items per wave: 8 (slot 4608 B: any table of the fast path) or 16 (slot 2304 B, all 64 lanes busy).
-// The walk is latency-bound, so what matters is that every item is resident at once: with more than 8192 items the launch
-// first walks the items whose tables fit the small slots 16 per wave, then the rest 8 per wave (never worse than two rounds
-// of 8 per wave).  Slot: next states u16[T] | info u64[n_bins] (see ew_step) | ... | symbols u8[2][256] of the current / next batch.
-template <uint32_t Q> struct EwCfg {
-  static constexpr uint32_t kSlotBytes = Q == 16 ? 2304u : 4608u;
-  static constexpr uint32_t kSymOff = kSlotBytes - 512;
-  static constexpr uint32_t kLdsBytes = Q * kSlotBytes;   // 36864
-};
-__device__ __forceinline__ uint32_t ew_info_off(uint32_t asl) { return ((2u << asl) + 7u) & ~7u; }
-__device__ __forceinline__ bool ew_fits16(uint32_t asl, uint32_t n_bins) { return ew_info_off(asl) + 8u * n_bins <= EwCfg<16>::kSymOff; }
-
 // one reverse step of one chain (ans/encoding.rs:65-87).  info = D | row << 32 with D = ((min_renorm_bits + 1) << 16) - cutoff,
 // so that bits = min_renorm_bits + (state >= cutoff) = (state + D) >> 16 (states are below 2^13), and row = the LDS address
 // of the symbol's next-state row.  The dependent stretch is v_add, v_lshrrev, v_lshrrev, v_lshl_add -> ds_read_u16; the value
@@ -263,6 +277,7 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
       if (pv.present && lane < 4 && stage != 2) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
       continue;
     }
+    if (wd_takes(fx.fused, pv)) continue;                                        // enc_walkd_kernel's item
     if (stage != 0 && ew_fits16(pv.asl, pv.n_bins) != (stage == 1)) continue;   // the other stage's item
     const uint32_t kEwInfoOff = ew_info_off(pv.asl);
     const PlanRef plan = plan_ref(ws, t, v);
@@ -385,6 +400,243 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
     enc_wave_sync();
   }
   if (my_n_lat > 0 && slot < kEwQ) fx.fstate[((uint64_t)my_p * 3 + my_v) * 4 + j] = state;
+}
+
+// =========================================================================================================
+// walk + dissect in one block
+// =========================================================================================================
+// The symbols of a variable whose latents are 16-bit and span fewer than 4096 values need not pass through HBM on their way to the
+// walk.  enc_vlut_kernel writes the variable's value -> (bin | offset bits << 8) table once (<= 8 KB, L2-resident); the second wave
+// of the walker's block gathers from it, one batch ahead of the walk: it leaves the symbols in the LDS buffer the walker reads and
+// (for enc_pack_kernel) in the symbol scratch, and adds up the batch's offset bits.  16 items per block, 4.5 KB of LDS each
+// (enc_walk_kernel<8>'s slot): two blocks per CU, one wave per SIMD -- the walker's chain of dependent steps shares its issue slots
+// with nobody, and the gathers run on the texture path the walker does not use.
+constexpr uint32_t kWdQ = 16, kWdSlot = EwCfg<8>::kSlotBytes, kWdSymOff = EwCfg<8>::kSymOff, kWdLdsBytes = kWdQ * kWdSlot;
+static_assert(2 * kWdLdsBytes <= 160 * 1024, "two blocks per CU");
+
+// grid = chunks * 3, 256 threads: the table of one variable (each thread 16 consecutive values: one search, then a walk over the sorted lowers)
+__global__ __launch_bounds__(256) void enc_vlut_kernel(EncWorkspace ws, EncFast fx, uint32_t n_tasks) {
+  const uint32_t t = blockIdx.x / 3, v = blockIdx.x % 3;
+  if (t >= n_tasks) return;
+  const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (uni(ch->status) != PCO_GFX_OK || uni(ch->fast_ok) == 0) return;
+  const PageVar pv = page_var(ch, v, 0xffffffffu);
+  PageVar any = pv; any.n_lat = 1;   // (the page length does not matter here)
+  if (!wd_takes(fx.fused, any)) return;
+  __shared__ uint64_t low[256]; __shared__ uint8_t obs[256];
+  const PlanRef plan = plan_ref(ws, t, v);
+  const uint32_t b = threadIdx.x;
+  low[b] = b < pv.n_bins ? (uint64_t)plan.blower()[b] - pv.minv : ~0ull;   // relative to the minimum: table slot = value - min
+  obs[b] = b < pv.n_bins ? plan.bob()[b] : 0;
+  __syncthreads();
+  uint16_t PCO_GLOBAL* lut = vlut_ptr(ws, fx, t, v);
+  const uint32_t m0 = (uint32_t)(pv.minv - pv.rel);   // the minimum as a 16-bit latent
+  const uint32_t u0 = threadIdx.x * (kDirectHistRange / 256);
+  if (u0 > pv.range) return;
+  uint32_t sym = 0;
+  { uint32_t lo = 0, hi = pv.n_bins; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (low[mid] <= u0) lo = mid; else hi = mid; } sym = lo; }
+  for (uint32_t k = 0; k < kDirectHistRange / 256; k++) {
+    const uint64_t x = (uint64_t)u0 + k;
+    while (sym + 1 < pv.n_bins && low[sym + 1] <= x) sym++;
+    lut[(m0 + u0 + k) & (kDirectHistRange - 1)] = (uint16_t)(sym | ((uint32_t)obs[sym] << 8));   // slot = the 16-bit latent mod 4096
+  }
+}
+
+// the block's barrier of the walk loop: LDS traffic only is waited for -- the walker's stores and the gathering wave's loads stay in flight across it
+// (__syncthreads drains vmcnt: every batch would wait for HBM)
+__device__ __forceinline__ void wd_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(128) void enc_walkd_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t n_items = n_pages * ws.n_slots;
+  typedef uint64_t __attribute__((aligned(2))) u64_align2;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+  // ---- phase 0: the items' tables (wave 0: next states + info, as enc_walk_kernel).  A walker lane keeps the item of its quad
+  //      (slot = lane >> 2), a gathering lane the item lane & 15 (handed round with v_readlane) ----
+  const uint32_t my_q = wave == 0 ? lane >> 2 : lane & 15u;
+  uint32_t my_n_lat = 0, my_T = 0, my_p = 0, my_v = 0, my_task = 0, my_info_off = 0, my_m0 = 0;
+  uint64_t my_at = 0, my_clat = 0;
+  for (uint32_t q = 0; q < kWdQ; q++) {
+    const uint32_t item = blockIdx.x * kWdQ + q;
+    if (item >= n_items) break;
+    const uint32_t p = item / ws.n_slots, sl = item % ws.n_slots;
+    const uint32_t v = ws.slot_of_var[0] == sl ? 0u : (ws.slot_of_var[1] == sl ? 1u : 2u);
+    EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+    const uint32_t t = uni(pg->chunk);
+    EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+    if (!page_is_fast(ch, pg)) continue;
+    const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
+    const PageVar pv = page_var(ch, v, page_n);
+    if (!wd_takes(fx.fused, pv)) continue;
+    const uint32_t info_off = ew_info_off(pv.asl);
+    if (wave == 0) {
+      const PlanRef plan = plan_ref(ws, t, v);
+      uint8_t PCO_LDS* slot = smem + q * kWdSlot;
+      const uint32_t T = 1u << pv.asl;
+      for (uint32_t i = lane; i < T; i += 64) ((uint16_t PCO_LDS*)slot)[i] = plan.next_states()[i];
+      for (uint32_t b = lane; b < pv.n_bins; b += 64) {
+        const uint32_t si = plan.syminfo()[b];   // cutoff(14) | min_renorm_bits(4) << 14 | (row + 8192)(14) << 18
+        const uint32_t cutoff = si & 0x3fffu, minb = (si >> 14) & 15u, row = (si >> 18) - 8192u;
+        const uint32_t row_addr = lds0 + q * kWdSlot + 2u * row;
+        ((uint64_t PCO_LDS*)(slot + info_off))[b] = (uint64_t)(((minb + 1u) << 16) - cutoff) | ((uint64_t)row_addr << 32);
+      }
+    }
+    if (my_q == q) {
+      my_n_lat = pv.n_lat; my_T = 1u << pv.asl; my_p = p; my_v = v; my_task = t; my_info_off = info_off; my_m0 = (uint32_t)(pv.minv - pv.rel);
+      my_at = fast_at(pg, pv.skip); my_clat = uni((uint64_t)pg->start) + pv.skip;
+    }
+  }
+  const uint32_t my_nb = (my_n_lat + kBatchN - 1) / kBatchN;
+  const uint32_t max_nb = wave_max_u32(my_nb);   // (the same in both waves: each holds every item of the block)
+  if (max_nb == 0) return;
+  wd_barrier();
+  if (wave == 1) {
+    // ================= the gathering wave: batch nb - 1 - it of every item, for it = 0 .. max_nb - 1, each one barrier ahead of the walk =================
+    // What depends on the item alone stays in the lane that holds the item (lane & 15): the batch's address, its length; the wave takes the
+    // items in turn and fetches the two or three scalars it needs with v_readlane.  A lane without an item points at the start of the
+    // table area: its loads are issued like everybody's and never used.
+    const bool mine = my_n_lat != 0;
+    const uint64_t my_clat_p = mine ? (uint64_t)(uintptr_t)(clat_ptr(ws, my_task, my_v) + my_clat) : (uint64_t)(uintptr_t)fx.vlut;
+    uint8_t PCO_GLOBAL* my_gsym = mine ? fsym_ptr(ws, fx, my_task, my_v) + my_at : (uint8_t PCO_GLOBAL*)nullptr;
+    uint32_t PCO_GLOBAL* my_gbat = (uint32_t PCO_GLOBAL*)fx.bat + (mine ? (uint64_t)(my_p * 3 + my_v) * fx.bat_stride * 2 : 0ull);
+    const uint32_t my_lut_off = mine ? (my_task * ws.n_slots + ws.slot_of_var[my_v]) * kDirectHistRange : 0u;   // (u16 elements)
+    auto bcast = [](uint32_t x, uint32_t q) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)q); };
+    auto bcast64 = [&](uint64_t x, uint32_t q) { return ((uint64_t)bcast((uint32_t)(x >> 32), q) << 32) | bcast((uint32_t)x, q); };
+    auto batch_of = [&](uint32_t it) { return it < my_nb ? my_nb - 1 - it : 0u; };   // (no batch at this step: batch 0 is read, and never used)
+    // (branch-free on purpose: with a branch per item the compiler waited for every load where it was issued -- sixteen HBM round trips
+    //  per batch.  The 8 bytes of a page's last, partial batch may run into the scratch behind the page: those latents count for nothing)
+    auto load_batches = [&](uint32_t it, uint64_t (&w)[kWdQ]) {   // the 4 latents a lane owns of every item's batch: 16 loads in flight
+      const uint64_t my_src = my_clat_p + 2ull * batch_of(it) * kBatchN;
+#pragma unroll
+      for (uint32_t q = 0; q < kWdQ; q++) w[q] = *(const u64_align2 PCO_GLOBAL*)((const uint16_t PCO_GLOBAL*)(uintptr_t)bcast64(my_src, q) + 4 * lane);
+    };
+    auto gather = [&](const uint64_t (&w)[kWdQ], uint32_t (&e)[kWdQ][4]) {   // (branch-free, as the loads)
+#pragma unroll
+      for (uint32_t q = 0; q < kWdQ; q++) {
+        const uint16_t PCO_GLOBAL* lut = (const uint16_t PCO_GLOBAL*)fx.vlut + bcast(my_lut_off, q);   // (uniform base + 32-bit lane offset)
+        const uint32_t lo = (uint32_t)w[q], hi = (uint32_t)(w[q] >> 32);
+        // the table is indexed by the 16-bit latent mod 4096 (a window of fewer than 4096 consecutive values: no two share a slot; nothing
+        // reads beyond the table whatever the scratch holds)
+        e[q][0] = lut[lo & (kDirectHistRange - 1)]; e[q][1] = lut[(lo >> 16) & (kDirectHistRange - 1)];
+        e[q][2] = lut[hi & (kDirectHistRange - 1)]; e[q][3] = lut[(hi >> 16) & (kDirectHistRange - 1)];
+      }
+    };
+    // software pipeline: at step `it` the table entries of step it + 1 are gathered (from latents loaded during step it - 1) and the
+    // latents of step it + 2 requested, in that order -- loads return in order, so nothing below waits for HBM -- while the entries gathered
+    // during step it - 1 are turned into symbols
+    uint64_t wnxt[kWdQ]; uint32_t e[kWdQ][4], enxt[kWdQ][4];
+    load_batches(0, wnxt);
+    gather(wnxt, enxt);
+    if (1 < max_nb) load_batches(1, wnxt);
+    for (uint32_t it = 0; it <= max_nb; it++) {   // it == max_nb: nothing left to find, only the barrier
+      if (it < max_nb) {
+#pragma unroll
+        for (uint32_t q = 0; q < kWdQ; q++) { e[q][0] = enxt[q][0]; e[q][1] = enxt[q][1]; e[q][2] = enxt[q][2]; e[q][3] = enxt[q][3]; }
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < max_nb) gather(wnxt, enxt);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 2 < max_nb) load_batches(it + 2, wnxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool my_on = it < my_nb;
+        const uint32_t my_hb = batch_of(it), my_base = my_hb * kBatchN;
+        const uint32_t my_cnt = my_on ? (my_n_lat - my_base < kBatchN ? my_n_lat - my_base : kBatchN) : 0u;
+        const uint32_t my_buf = lds0 + my_q * kWdSlot + kWdSymOff + (my_hb & 1) * 256;   // this step's symbol buffer of the lane's item
+        uint32_t my_total = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < kWdQ; q++) {
+          const uint32_t cnt = bcast(my_cnt, q);
+          if (cnt == 0) continue;
+          if (cnt < kBatchN) {   // (the page's last batch: a latent beyond it is bin 0 with no bits)
+#pragma unroll
+            for (int k = 0; k < 4; k++) e[q][k] = 4 * lane + k < cnt ? e[q][k] : 0u;
+          }
+          const uint32_t e01 = e[q][0] | (e[q][1] << 16), e23 = e[q][2] | (e[q][3] << 16);
+          const uint32_t packed = __builtin_amdgcn_perm(e23, e01, 0x06040200u);               // the four bin bytes
+          const uint32_t obs4 = __builtin_amdgcn_perm(e23, e01, 0x07050301u);                 // the four offset-bit counts (<= 64 each)
+          const uint32_t total = wave_sum(__builtin_amdgcn_sad_u8(obs4, 0u, 0u));
+          my_total = (lane & 15u) == q ? total : my_total;
+          *(uint32_t PCO_LDS*)(uintptr_t)(bcast(my_buf, q) + 4 * lane) = quad_transpose_u8(packed, lane & 3);
+        }
+        // the symbols go on to enc_pack_kernel's scratch from the LDS buffers: a lane copies a quarter (64 bytes) of its own item's batch,
+        // whole 16-latent blocks as enc_dissect_kernel writes them; lanes 0..15 leave the batch's offset-bit total
+        if (my_on) {
+          const uint32_t quarter = lane >> 4, blocks = (my_cnt + 15u) >> 4;
+#pragma unroll
+          for (uint32_t r = 0; r < 4; r++) {
+            if (quarter * 4 + r < blocks) *(u32x4_unaligned PCO_GLOBAL*)(my_gsym + my_base + 64 * quarter + 16 * r) = *(const u32x4 PCO_LDS*)(uintptr_t)(my_buf + 64 * quarter + 16 * r);
+          }
+          if (lane < 16) my_gbat[(uint64_t)my_hb * 2] = my_total;
+        }
+      }
+      wd_barrier();
+    }
+    return;
+  }
+  // ================= the walker wave (enc_walk_kernel's walk, its symbols already in LDS) =================
+  const uint32_t j = lane & 3;
+  const uint32_t slice = lds0 + my_q * kWdSlot;
+  const uint32_t info_addr = slice + my_info_off, symbuf = slice + kWdSymOff;
+  uint16_t PCO_GLOBAL* gans = fansw_ptr(ws, fx, my_task, my_v) + my_at;
+  uint32_t PCO_GLOBAL* gbat = (uint32_t PCO_GLOBAL*)fx.bat + ((uint64_t)my_p * 3 + my_v) * fx.bat_stride * 2;
+  uint32_t state = my_T;
+  wd_barrier();   // (the gathering wave's it = 0)
+  for (uint32_t it = 0; it < max_nb; it++) {
+    if (it < my_nb) {
+      const uint32_t b = my_nb - 1 - it, base = b * kBatchN, cnt = my_n_lat - base < kBatchN ? my_n_lat - base : kBatchN;
+      const uint32_t buf = symbuf + (b & 1) * 256;
+      uint32_t bits_acc = 0;
+      if (cnt < kBatchN) {   // the last (partial) batch: per-step predicates
+        const uint32_t steps = (cnt + 3) >> 2;
+        for (uint32_t blk = (steps + 3) >> 2; blk-- > 0;) {
+          const uint32_t sd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * blk + 4 * j);
+          uint64_t out = 0;
+#pragma unroll
+          for (int k = 3; k >= 0; k--) {
+            const uint32_t g = 4 * blk + k;
+            if (4 * g + j < cnt) {
+              const uint64_t info = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> (8 * k)) & 0xffu));
+              out |= (uint64_t)ew_step(state, bits_acc, info) << (16 * k);
+            }
+          }
+          *(u64_align2 PCO_GLOBAL*)(gans + base + 16 * blk + 4 * j) = out;
+        }
+      } else {               // a full batch, software-pipelined as in enc_walk_kernel
+        uint16_t PCO_GLOBAL* ga = gans + (uint64_t)b * kBatchN + 4 * j;
+        uint32_t sd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * 15 + 4 * j);
+        uint32_t nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * 14 + 4 * j);
+        uint64_t i0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (sd & 0xffu));
+        uint64_t i1 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> 8) & 0xffu));
+        uint64_t i2 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> 16) & 0xffu));
+        uint64_t i3 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (sd >> 24));
+        for (uint32_t blk = 16; blk-- > 0;) {
+          const uint32_t nnblk = blk > 1 ? blk - 2 : 0;
+          const uint32_t o3 = ew_step(state, bits_acc, i3);
+          const uint64_t n3 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd >> 24));
+          __builtin_amdgcn_sched_barrier(0);
+          const uint32_t o2 = ew_step(state, bits_acc, i2);
+          const uint64_t n2 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((nsd >> 16) & 0xffu));
+          const uint32_t o23 = o2 | (o3 << 16);
+          __builtin_amdgcn_sched_barrier(0);
+          const uint32_t o1 = ew_step(state, bits_acc, i1);
+          const uint64_t n1 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((nsd >> 8) & 0xffu));
+          __builtin_amdgcn_sched_barrier(0);
+          const uint32_t o0 = ew_step(state, bits_acc, i0);
+          const uint64_t n0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd & 0xffu));
+          nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * nnblk + 4 * j);
+          *(u64_align2 PCO_GLOBAL*)(ga + 16 * blk) = (uint64_t)(o0 | (o1 << 16)) | ((uint64_t)o23 << 32);
+          __builtin_amdgcn_sched_barrier(0);
+          i0 = n0; i1 = n1; i2 = n2; i3 = n3;
+        }
+      }
+      bits_acc += quad_dpp<0xB1>(bits_acc); bits_acc += quad_dpp<0x4E>(bits_acc);
+      if (j == 0) gbat[(uint64_t)b * 2 + 1] = bits_acc;
+    }
+    wd_barrier();
+  }
+  if (my_n_lat > 0) fx.fstate[((uint64_t)my_p * 3 + my_v) * 4 + j] = state;
 }
 
 // =========================================================================================================

@@ -73,12 +73,12 @@ struct Workspace {
   DevBuf compact_tasks;                   // pco_gfx_compact_chunks
   DevBuf enc_state;                       // encode: per chunk plans etc. (see encode_kernels.hip)
   DevBuf enc_lat, enc_sort, enc_ans, enc_small, enc_lb, enc_walk;
-  DevBuf enc_sym, enc_answ, enc_bat, enc_run, enc_fstate;   // encode fast path (encode_fast.hip)
+  DevBuf enc_sym, enc_answ, enc_bat, enc_run, enc_fstate, enc_vlut;   // encode fast path (encode_fast.hip)
   DevBuf auto_idx, auto_samp, auto_tasks, auto_sum, auto_log2;  // Auto spec resolution
   HostBuf h_samp, h_sum;                             // ... and its read-backs
   void release_all() {
     tasks.release(); results.release(); tbl_ws.release(); dec_plans.release(); dec_bins.release(); dec_sym.release(); dec_offpos.release(); dec_hist.release(); io_in.release(); io_out.release(); compact_tasks.release();
-    enc_state.release(); enc_lat.release(); enc_sort.release(); enc_ans.release(); enc_small.release(); enc_lb.release(); enc_walk.release(); enc_sym.release(); enc_answ.release(); enc_bat.release(); enc_run.release(); enc_fstate.release(); auto_idx.release(); auto_samp.release(); auto_tasks.release(); auto_sum.release(); auto_log2.release(); h_samp.release(); h_sum.release();
+    enc_state.release(); enc_lat.release(); enc_sort.release(); enc_ans.release(); enc_small.release(); enc_lb.release(); enc_walk.release(); enc_sym.release(); enc_answ.release(); enc_bat.release(); enc_run.release(); enc_fstate.release(); enc_vlut.release(); auto_idx.release(); auto_samp.release(); auto_tasks.release(); auto_sum.release(); auto_log2.release(); h_samp.release(); h_sum.release();
   }
 };
 Workspace& workspace();
