@@ -72,11 +72,13 @@ template <uint32_t Q> struct EwCfg {
 };
 __device__ __forceinline__ uint32_t ew_info_off(uint32_t asl) { return ((2u << asl) + 7u) & ~7u; }
 __device__ __forceinline__ bool ew_fits16(uint32_t asl, uint32_t n_bins) { return ew_info_off(asl) + 8u * n_bins <= EwCfg<16>::kSymOff; }
-// Does enc_walkd_kernel (walk + dissect in one block, below) take this page variable?  fused = 0: no; 1: every variable with 16-bit
-// latents; 2: only those whose tables do not fit the 16-per-wave slots of enc_walk_kernel<16> (launches of more than 8192 items)
-__device__ __forceinline__ bool wd_takes(uint32_t fused, const PageVar& pv) {
-  return fused != 0 && pv.present && pv.n_bins > 1 && pv.n_lat > 0 && pv.compact && pv.range < kDirectHistRange && (fused == 1 || !ew_fits16(pv.asl, pv.n_bins));
+// enc_walkd_kernel (below) walks a page variable when fused != 0 and, in a launch of more than 8192 items (fused == 2), its tables do not fit
+// the 16-per-wave slots of enc_walk_kernel<16>; it also FINDS the symbols of the variables it walks whose latents are 16-bit and span fewer
+// than 4096 values (wd_takes: enc_dissect_kernel leaves those alone).
+__device__ __forceinline__ bool wd_walks(uint32_t fused, const PageVar& pv) {
+  return fused != 0 && pv.present && pv.n_bins > 1 && pv.n_lat > 0 && (fused == 1 || !ew_fits16(pv.asl, pv.n_bins));
 }
+__device__ __forceinline__ bool wd_takes(uint32_t fused, const PageVar& pv) { return wd_walks(fused, pv) && pv.compact && pv.range < kDirectHistRange; }
 __device__ __forceinline__ uint16_t PCO_GLOBAL* vlut_ptr(const EncWorkspace& ws, const EncFast& fx, uint32_t task, uint32_t var) {
   return (uint16_t PCO_GLOBAL*)fx.vlut + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * kDirectHistRange;
 }
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
       if (pv.present && lane < 4 && stage != 2) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
       continue;
     }
-    if (wd_takes(fx.fused, pv)) continue;                                        // enc_walkd_kernel's item
+    if (wd_walks(fx.fused, pv)) continue;                                        // enc_walkd_kernel's item
     if (stage != 0 && ew_fits16(pv.asl, pv.n_bins) != (stage == 1)) continue;   // the other stage's item
     const uint32_t kEwInfoOff = ew_info_off(pv.asl);
     const PlanRef plan = plan_ref(ws, t, v);
@@ -402,6 +404,9 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
   if (my_n_lat > 0 && slot < kEwQ) fx.fstate[((uint64_t)my_p * 3 + my_v) * 4 + j] = state;
 }
 
+#ifndef PCO_WD_HELPERS
+#define PCO_WD_HELPERS 1
+#endif
 // =========================================================================================================
 // walk + dissect in one block
 // =========================================================================================================
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
 // (for enc_pack_kernel) in the symbol scratch, and adds up the batch's offset bits.  16 items per block, 4.5 KB of LDS each
 // (enc_walk_kernel<8>'s slot): two blocks per CU, one wave per SIMD -- the walker's chain of dependent steps shares its issue slots
 // with nobody, and the gathers run on the texture path the walker does not use.
+constexpr uint32_t kWdHelpers = PCO_WD_HELPERS, kWdH = 16 / kWdHelpers;   // gathering waves per block, items per gathering wave
 constexpr uint32_t kWdQ = 16, kWdSlot = EwCfg<8>::kSlotBytes, kWdSymOff = EwCfg<8>::kSymOff, kWdLdsBytes = kWdQ * kWdSlot;
 static_assert(2 * kWdLdsBytes <= 160 * 1024, "two blocks per CU");
 
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(256) void enc_vlut_kernel(EncWorkspace ws, EncFast 
 // (__syncthreads drains vmcnt: every batch would wait for HBM)
 __device__ __forceinline__ void wd_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(128) void enc_walkd_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+__global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   uint8_t PCO_LDS* smem = enc_lds_base();
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -456,9 +462,10 @@ __global__ __launch_bounds__(128) void enc_walkd_kernel(EncWorkspace ws, EncFast
   typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
   // ---- phase 0: the items' tables (wave 0: next states + info, as enc_walk_kernel).  A walker lane keeps the item of its quad
   //      (slot = lane >> 2), a gathering lane the item lane & 15 (handed round with v_readlane) ----
-  const uint32_t my_q = wave == 0 ? lane >> 2 : lane & 15u;
-  uint32_t my_n_lat = 0, my_T = 0, my_p = 0, my_v = 0, my_task = 0, my_info_off = 0, my_m0 = 0;
+  const uint32_t my_q = wave == 0 ? lane >> 2 : (wave - 1) * kWdH + (lane & (kWdH - 1));   // (gathering wave w takes the items (w - 1) * kWdH ..)
+  uint32_t my_n_lat = 0, my_T = 0, my_p = 0, my_v = 0, my_task = 0, my_info_off = 0, my_m0 = 0, my_finds = 0;   // (a gathering lane's n_lat is 0 for an item it has nothing to find for)
   uint64_t my_at = 0, my_clat = 0;
+  uint32_t max_nb = 0;   // batches of the block's longest item: what every wave's loop runs to (uniform)
   for (uint32_t q = 0; q < kWdQ; q++) {
     const uint32_t item = blockIdx.x * kWdQ + q;
     if (item >= n_items) break;
@@ -470,8 +477,13 @@ __global__ __launch_bounds__(128) void enc_walkd_kernel(EncWorkspace ws, EncFast
     if (!page_is_fast(ch, pg)) continue;
     const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
     const PageVar pv = page_var(ch, v, page_n);
-    if (!wd_takes(fx.fused, pv)) continue;
+    if (!wd_walks(fx.fused, pv)) {   // (with every walked item here -- fused == 1 -- nobody else writes the states of the variables that need no walk)
+      if (fx.fused == 1 && pv.present && (pv.n_bins <= 1 || pv.n_lat == 0) && wave == 0 && lane < 4) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
+      continue;
+    }
+    const bool finds = wd_takes(fx.fused, pv);   // its symbols come from the gathering wave; else from enc_dissect_kernel, staged by the walker itself
     const uint32_t info_off = ew_info_off(pv.asl);
+    { const uint32_t nbq = (pv.n_lat + kBatchN - 1) / kBatchN; max_nb = nbq > max_nb ? nbq : max_nb; }
     if (wave == 0) {
       const PlanRef plan = plan_ref(ws, t, v);
       uint8_t PCO_LDS* slot = smem + q * kWdSlot;
@@ -485,15 +497,16 @@ __global__ __launch_bounds__(128) void enc_walkd_kernel(EncWorkspace ws, EncFast
       }
     }
     if (my_q == q) {
-      my_n_lat = pv.n_lat; my_T = 1u << pv.asl; my_p = p; my_v = v; my_task = t; my_info_off = info_off; my_m0 = (uint32_t)(pv.minv - pv.rel);
+      my_finds = finds ? 1u : 0u;
+      my_n_lat = wave == 0 || finds ? pv.n_lat : 0u; my_T = 1u << pv.asl; my_p = p; my_v = v; my_task = t; my_info_off = info_off; my_m0 = (uint32_t)(pv.minv - pv.rel);
       my_at = fast_at(pg, pv.skip); my_clat = uni((uint64_t)pg->start) + pv.skip;
     }
   }
   const uint32_t my_nb = (my_n_lat + kBatchN - 1) / kBatchN;
-  const uint32_t max_nb = wave_max_u32(my_nb);   // (the same in both waves: each holds every item of the block)
   if (max_nb == 0) return;
   wd_barrier();
-  if (wave == 1) {
+  if (wave != 0) {
+    const uint32_t q0 = (wave - 1) * kWdH;   // this wave's first item
     // ================= the gathering wave: batch nb - 1 - it of every item, for it = 0 .. max_nb - 1, each one barrier ahead of the walk =================
     // What depends on the item alone stays in the lane that holds the item (lane & 15): the batch's address, its length; the wave takes the
     // items in turn and fetches the two or three scalars it needs with v_readlane.  A lane without an item points at the start of the
@@ -508,14 +521,14 @@ __global__ __launch_bounds__(128) void enc_walkd_kernel(EncWorkspace ws, EncFast
     auto batch_of = [&](uint32_t it) { return it < my_nb ? my_nb - 1 - it : 0u; };   // (no batch at this step: batch 0 is read, and never used)
     // (branch-free on purpose: with a branch per item the compiler waited for every load where it was issued -- sixteen HBM round trips
     //  per batch.  The 8 bytes of a page's last, partial batch may run into the scratch behind the page: those latents count for nothing)
-    auto load_batches = [&](uint32_t it, uint64_t (&w)[kWdQ]) {   // the 4 latents a lane owns of every item's batch: 16 loads in flight
+    auto load_batches = [&](uint32_t it, uint64_t (&w)[kWdH]) {   // the 4 latents a lane owns of every item's batch: 16 loads in flight
       const uint64_t my_src = my_clat_p + 2ull * batch_of(it) * kBatchN;
 #pragma unroll
-      for (uint32_t q = 0; q < kWdQ; q++) w[q] = *(const u64_align2 PCO_GLOBAL*)((const uint16_t PCO_GLOBAL*)(uintptr_t)bcast64(my_src, q) + 4 * lane);
+      for (uint32_t q = 0; q < kWdH; q++) w[q] = *(const u64_align2 PCO_GLOBAL*)((const uint16_t PCO_GLOBAL*)(uintptr_t)bcast64(my_src, q) + 4 * lane);
     };
-    auto gather = [&](const uint64_t (&w)[kWdQ], uint32_t (&e)[kWdQ][4]) {   // (branch-free, as the loads)
+    auto gather = [&](const uint64_t (&w)[kWdH], uint32_t (&e)[kWdH][4]) {   // (branch-free, as the loads)
 #pragma unroll
-      for (uint32_t q = 0; q < kWdQ; q++) {
+      for (uint32_t q = 0; q < kWdH; q++) {
         const uint16_t PCO_GLOBAL* lut = (const uint16_t PCO_GLOBAL*)fx.vlut + bcast(my_lut_off, q);   // (uniform base + 32-bit lane offset)
         const uint32_t lo = (uint32_t)w[q], hi = (uint32_t)(w[q] >> 32);
         // the table is indexed by the 16-bit latent mod 4096 (a window of fewer than 4096 consecutive values: no two share a slot; nothing
@@ -527,14 +540,14 @@ __global__ __launch_bounds__(128) void enc_walkd_kernel(EncWorkspace ws, EncFast
     // software pipeline: at step `it` the table entries of step it + 1 are gathered (from latents loaded during step it - 1) and the
     // latents of step it + 2 requested, in that order -- loads return in order, so nothing below waits for HBM -- while the entries gathered
     // during step it - 1 are turned into symbols
-    uint64_t wnxt[kWdQ]; uint32_t e[kWdQ][4], enxt[kWdQ][4];
+    uint64_t wnxt[kWdH]; uint32_t e[kWdH][4], enxt[kWdH][4];
     load_batches(0, wnxt);
     gather(wnxt, enxt);
     if (1 < max_nb) load_batches(1, wnxt);
     for (uint32_t it = 0; it <= max_nb; it++) {   // it == max_nb: nothing left to find, only the barrier
       if (it < max_nb) {
 #pragma unroll
-        for (uint32_t q = 0; q < kWdQ; q++) { e[q][0] = enxt[q][0]; e[q][1] = enxt[q][1]; e[q][2] = enxt[q][2]; e[q][3] = enxt[q][3]; }
+        for (uint32_t q = 0; q < kWdH; q++) { e[q][0] = enxt[q][0]; e[q][1] = enxt[q][1]; e[q][2] = enxt[q][2]; e[q][3] = enxt[q][3]; }
         __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < max_nb) gather(wnxt, enxt);
         __builtin_amdgcn_sched_barrier(0);
@@ -546,7 +559,7 @@ __global__ __launch_bounds__(128) void enc_walkd_kernel(EncWorkspace ws, EncFast
         const uint32_t my_buf = lds0 + my_q * kWdSlot + kWdSymOff + (my_hb & 1) * 256;   // this step's symbol buffer of the lane's item
         uint32_t my_total = 0;
 #pragma unroll
-        for (uint32_t q = 0; q < kWdQ; q++) {
+        for (uint32_t q = 0; q < kWdH; q++) {
           const uint32_t cnt = bcast(my_cnt, q);
           if (cnt == 0) continue;
           if (cnt < kBatchN) {   // (the page's last batch: a latent beyond it is bin 0 with no bits)
@@ -557,18 +570,20 @@ __global__ __launch_bounds__(128) void enc_walkd_kernel(EncWorkspace ws, EncFast
           const uint32_t packed = __builtin_amdgcn_perm(e23, e01, 0x06040200u);               // the four bin bytes
           const uint32_t obs4 = __builtin_amdgcn_perm(e23, e01, 0x07050301u);                 // the four offset-bit counts (<= 64 each)
           const uint32_t total = wave_sum(__builtin_amdgcn_sad_u8(obs4, 0u, 0u));
-          my_total = (lane & 15u) == q ? total : my_total;
+          my_total = (lane & (kWdH - 1)) == q ? total : my_total;
           *(uint32_t PCO_LDS*)(uintptr_t)(bcast(my_buf, q) + 4 * lane) = quad_transpose_u8(packed, lane & 3);
         }
         // the symbols go on to enc_pack_kernel's scratch from the LDS buffers: a lane copies a quarter (64 bytes) of its own item's batch,
         // whole 16-latent blocks as enc_dissect_kernel writes them; lanes 0..15 leave the batch's offset-bit total
         if (my_on) {
-          const uint32_t quarter = lane >> 4, blocks = (my_cnt + 15u) >> 4;
+          constexpr uint32_t kParts = 64 / kWdH, kPer = 16 / kParts;   // lanes per item, 16-byte blocks per lane
+          const uint32_t part = lane / kWdH, blocks = (my_cnt + 15u) >> 4;
 #pragma unroll
-          for (uint32_t r = 0; r < 4; r++) {
-            if (quarter * 4 + r < blocks) *(u32x4_unaligned PCO_GLOBAL*)(my_gsym + my_base + 64 * quarter + 16 * r) = *(const u32x4 PCO_LDS*)(uintptr_t)(my_buf + 64 * quarter + 16 * r);
+          for (uint32_t r = 0; r < kPer; r++) {
+            const uint32_t blk = part * kPer + r;
+            if (blk < blocks) *(u32x4_unaligned PCO_GLOBAL*)(my_gsym + my_base + 16 * blk) = *(const u32x4 PCO_LDS*)(uintptr_t)(my_buf + 16 * blk);
           }
-          if (lane < 16) my_gbat[(uint64_t)my_hb * 2] = my_total;
+          if (lane < kWdH) my_gbat[(uint64_t)my_hb * 2] = my_total;
         }
       }
       wd_barrier();
@@ -582,8 +597,25 @@ __global__ __launch_bounds__(128) void enc_walkd_kernel(EncWorkspace ws, EncFast
   uint16_t PCO_GLOBAL* gans = fansw_ptr(ws, fx, my_task, my_v) + my_at;
   uint32_t PCO_GLOBAL* gbat = (uint32_t PCO_GLOBAL*)fx.bat + ((uint64_t)my_p * 3 + my_v) * fx.bat_stride * 2;
   uint32_t state = my_T;
+  // an item whose symbols enc_dissect_kernel wrote: the walker's quad stages them itself, a batch ahead, as enc_walk_kernel does
+  const bool stages = my_n_lat != 0 && my_finds == 0;
+  const uint8_t PCO_GLOBAL* gsym = (const uint8_t PCO_GLOBAL*)fsym_ptr(ws, fx, my_task, my_v) + my_at;
+  u32x4 pre[4];
+  auto fetch_syms = [&](uint32_t b) {   // whole 16-latent blocks of batch b
+    const uint32_t cnt = my_n_lat - b * kBatchN < kBatchN ? my_n_lat - b * kBatchN : kBatchN, blocks_bytes = (cnt + 15u) & ~15u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { pre[k] = u32x4{0, 0, 0, 0}; if (64 * j + 16 * k < blocks_bytes) pre[k] = *(const u32x4_unaligned PCO_GLOBAL*)(gsym + (uint64_t)b * kBatchN + 64 * j + 16 * k); }
+  };
+  if (stages) fetch_syms(my_nb - 1);
   wd_barrier();   // (the gathering wave's it = 0)
   for (uint32_t it = 0; it < max_nb; it++) {
+    if (stages && it < my_nb) {
+      const uint32_t b = my_nb - 1 - it;
+#pragma unroll
+      for (int k = 0; k < 4; k++) *(u32x4 PCO_LDS*)(uintptr_t)(symbuf + (b & 1) * 256 + 64 * j + 16 * k) = pre[k];
+      if (b > 0) fetch_syms(b - 1);
+    }
+    enc_wave_sync();
     if (it < my_nb) {
       const uint32_t b = my_nb - 1 - it, base = b * kBatchN, cnt = my_n_lat - base < kBatchN ? my_n_lat - base : kBatchN;
       const uint32_t buf = symbuf + (b & 1) * 256;
