@@ -79,6 +79,9 @@ __device__ __forceinline__ bool wd_walks(uint32_t fused, const PageVar& pv) {
   return fused != 0 && pv.present && pv.n_bins > 1 && pv.n_lat > 0 && (fused == 1 || !ew_fits16(pv.asl, pv.n_bins));
 }
 __device__ __forceinline__ bool wd_takes(uint32_t fused, const PageVar& pv) { return wd_walks(fused, pv) && pv.compact && pv.range < kDirectHistRange; }
+// Where a table's window of used slots starts is rotated from table to table: the tables sit 8 KB apart and a narrow variable uses a
+// quarter of its table or less -- at the same offset in every table of similar chunks, i.e. in the same few L2 sets.
+__device__ __forceinline__ uint32_t vlut_rot(uint32_t table_index) { return (table_index * 1600u) & (kDirectHistRange - 1) & ~31u; }
 __device__ __forceinline__ uint16_t PCO_GLOBAL* vlut_ptr(const EncWorkspace& ws, const EncFast& fx, uint32_t task, uint32_t var) {
   return (uint16_t PCO_GLOBAL*)fx.vlut + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * kDirectHistRange;
 }
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(256) void enc_vlut_kernel(EncWorkspace ws, EncFast 
   obs[b] = b < pv.n_bins ? plan.bob()[b] : 0;
   __syncthreads();
   uint16_t PCO_GLOBAL* lut = vlut_ptr(ws, fx, t, v);
-  const uint32_t m0 = (uint32_t)(pv.minv - pv.rel);   // the minimum as a 16-bit latent
+  const uint32_t m0 = (uint32_t)(pv.minv - pv.rel) + vlut_rot(t * ws.n_slots + ws.slot_of_var[v]);   // the minimum as a 16-bit latent, plus the table's rotation
   const uint32_t u0 = threadIdx.x * (kDirectHistRange / 256);
   if (u0 > pv.range) return;
   uint32_t sym = 0;
@@ -516,6 +519,7 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
     uint8_t PCO_GLOBAL* my_gsym = mine ? fsym_ptr(ws, fx, my_task, my_v) + my_at : (uint8_t PCO_GLOBAL*)nullptr;
     uint32_t PCO_GLOBAL* my_gbat = (uint32_t PCO_GLOBAL*)fx.bat + (mine ? (uint64_t)(my_p * 3 + my_v) * fx.bat_stride * 2 : 0ull);
     const uint32_t my_lut_off = mine ? (my_task * ws.n_slots + ws.slot_of_var[my_v]) * kDirectHistRange : 0u;   // (u16 elements)
+    const uint32_t my_rot2 = vlut_rot(my_lut_off / kDirectHistRange) * 0x10001u;                                     // the table's rotation, for both 16-bit halves of a dword (no carry: latents < 2^15)
     auto bcast = [](uint32_t x, uint32_t q) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)q); };
     auto bcast64 = [&](uint64_t x, uint32_t q) { return ((uint64_t)bcast((uint32_t)(x >> 32), q) << 32) | bcast((uint32_t)x, q); };
     auto batch_of = [&](uint32_t it) { return it < my_nb ? my_nb - 1 - it : 0u; };   // (no batch at this step: batch 0 is read, and never used)
@@ -524,13 +528,14 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
     auto load_batches = [&](uint32_t it, uint64_t (&w)[kWdH]) {   // the 4 latents a lane owns of every item's batch: 16 loads in flight
       const uint64_t my_src = my_clat_p + 2ull * batch_of(it) * kBatchN;
 #pragma unroll
-      for (uint32_t q = 0; q < kWdH; q++) w[q] = *(const u64_align2 PCO_GLOBAL*)((const uint16_t PCO_GLOBAL*)(uintptr_t)bcast64(my_src, q) + 4 * lane);
+      for (uint32_t q = 0; q < kWdH; q++) w[q] = __builtin_nontemporal_load((const u64_align2 PCO_GLOBAL*)((const uint16_t PCO_GLOBAL*)(uintptr_t)bcast64(my_src, q) + 4 * lane));   // (streamed once: must not push the tables out of L2)
     };
     auto gather = [&](const uint64_t (&w)[kWdH], uint32_t (&e)[kWdH][4]) {   // (branch-free, as the loads)
 #pragma unroll
       for (uint32_t q = 0; q < kWdH; q++) {
         const uint16_t PCO_GLOBAL* lut = (const uint16_t PCO_GLOBAL*)fx.vlut + bcast(my_lut_off, q);   // (uniform base + 32-bit lane offset)
-        const uint32_t lo = (uint32_t)w[q], hi = (uint32_t)(w[q] >> 32);
+        const uint32_t rot2 = bcast(my_rot2, q);
+        const uint32_t lo = (uint32_t)w[q] + rot2, hi = (uint32_t)(w[q] >> 32) + rot2;
         // the table is indexed by the 16-bit latent mod 4096 (a window of fewer than 4096 consecutive values: no two share a slot; nothing
         // reads beyond the table whatever the scratch holds)
         e[q][0] = lut[lo & (kDirectHistRange - 1)]; e[q][1] = lut[(lo >> 16) & (kDirectHistRange - 1)];

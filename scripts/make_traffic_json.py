@@ -27,6 +27,8 @@ def label(name):
         return "enc_walk_kernel"
     if name.startswith("enc_split_kernel"):
         return {"<true, false>": "enc_split_kernel<c16>", "<false, true>": "enc_split_kernel(redo)"}.get(name[len("enc_split_kernel"):], "enc_split_kernel")
+    if name.startswith("enc_hist_select_kernel"):
+        return "enc_hist_select_kernel"
     m = re.match(r"enc_hist_wide_kernel<(\d+)u>", name)
     if m:
         return f"enc_hist_wide_kernel<{m.group(1)}>"
@@ -38,7 +40,8 @@ def parse(path):
     for line in open(path):
         m = re.match(r"^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.e+]+)\s+\(", line)
         if m and not line.startswith("kernel"):
-            rows[label(m.group(1))] = (float(m.group(4)), float(m.group(3)))
+            k = label(m.group(1)); old = rows.get(k, (0.0, 0.0))   # (instantiations that share a launch label add up)
+            rows[k] = (old[0] + float(m.group(4)), old[1] + float(m.group(3)))
     return rows
 
 
