@@ -821,3 +821,31 @@ def test_levels_nine_to_twelve_full_size(L, level):
         got = U.gpu_simple_compress(nums, G.make_config(level=level, **kw))
         assert got == want, (level, nums.dtype, nums.size, kw)
         assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums), (level, nums.dtype, nums.size, kw)
+
+
+def test_walk_arrangements_of_small_and_large_launches(L):
+    """encode_fast.hip's two walk arrangements: up to 8192 (page, variable) items every walk goes through enc_walkd_kernel (narrow
+    16-bit variables looked up by the block's gathering wave, the rest staged from enc_dissect_kernel's symbols); beyond that the
+    variables with small tANS tables go 16 per wave through enc_walk_kernel<16>.  Both launch sizes, chunk lengths around the batch
+    size (a page's last batch is partial; one-number chunks), narrow / wide / constant / two-variable chunks side by side: every chunk
+    equals the oracle's bytes."""
+    rng = np.random.default_rng(77)
+
+    def make(i):
+        n = int([1, 2, 255, 256, 257, 300, 511, 513, 1000, 1537][i % 10])
+        kind = i % 7
+        if kind == 0: return (np.uint64(1 << 40) + np.uint64(1000) * np.arange(n, dtype=np.uint64) + rng.integers(0, 512, n).astype(np.uint64))   # narrow after delta 1
+        if kind == 1: return rng.integers(0, 1 << 62, n, dtype=np.uint64)                                                                      # wide
+        if kind == 2: return np.full(n, 12345, np.uint64)                                                                                        # constant
+        if kind == 3: return (rng.integers(0, 3000, n) + (1 << 20)).astype(np.uint64)                                                            # narrow, many bins
+        if kind == 4: return (rng.integers(0, 40, n) * 7 + 3).astype(np.uint64)                                                                  # few values
+        if kind == 5: return np.cumsum(rng.integers(-5, 6, n)).astype(np.int64).view(np.uint64)                                                  # random walk
+        return (rng.integers(0, 5000, n) + (1 << 33)).astype(np.uint64)                                                                          # range just above 4096
+    for count, kw in ((300, dict(mode=1, delta=2, delta_order=1)), (9100, dict(mode=1, delta=2, delta_order=1)), (9100, dict(mode=4, mode_u64=7, delta=1))):
+        arrays = [make(i) for i in range(count)]
+        chunks, back = U.gpu_batched(arrays, G.make_config(**kw))
+        for i in range(count):
+            assert U.bits_equal(back[i], arrays[i]), (count, kw, i)
+        for i in list(range(0, count, max(1, count // 140))) + list(range(min(count, 70))):   # the oracle on a spread of them (every kind and length)
+            want = O.simple_compress(arrays[i], O.make_config(**kw))
+            assert chunks[i] == U.chunk_of_file(want, len(chunks[i])), (count, kw, i, arrays[i].size)
