@@ -23,17 +23,20 @@
 
 namespace pcogfx {
 
+#ifndef PCO_SEL_CELL_LOG
+#define PCO_SEL_CELL_LOG 11
+#endif
 constexpr uint32_t kSelT = 1024;     // threads of enc_hist_small_kernel (block_radix_sort_inplace's array order is built on 16 waves)
 constexpr uint32_t kSelThr = 512;    // threads of enc_hist_select_kernel: two blocks per CU, one streaming while the other sorts / scans / queries
-constexpr uint32_t kSelSegs = 128, kSelSubLog = 6, kSelSample = 2048, kSelRegionBytes = 32768, kSelBigCap = 256;
+constexpr uint32_t kSelSegs = 128, kSelSubLog = 6, kSelSample = 2048, kSelRegionBytes = 32768, kSelBigCap = 256, kSelCellLog = PCO_SEL_CELL_LOG, kSelCells = 1u << kSelCellLog;
 static_assert(kSelSegs << kSelSubLog == kSelBuckets, "segments x sub-buckets");
 constexpr uint32_t kSelLdsP = 0;                                                // u32[8192 + 8] bucket counts, then exclusive prefix (hist_emit's scratch at the end)
 constexpr uint32_t kSelLdsNeed = kSelLdsP + (kSelBuckets + 8) * 4;              // u32[256] bitmap of the buckets to gather
 constexpr uint32_t kSelLdsWpre = kSelLdsNeed + kSelBuckets / 8;                 // u16[256 + 8] marked buckets in the bitmap words before this one
 constexpr uint32_t kSelLdsNlOc = kSelLdsWpre + (256 + 8) * 2;                   // u32[1600 + 2] first subset index of each window (the gather pass's fill cursors: see (F))
 constexpr uint32_t kSelLdsSeg = (kSelLdsNlOc + (kSelMaxNeeded + 2) * 4 + 15) & ~15u;   // {lower bound, scaling}[128], 16 bytes each for 64-bit latents
-constexpr uint32_t kSelLdsLut = kSelLdsSeg + kSelSegs * 16;                     // u16[256 + 8] value cell -> first | last << 8 segment it meets
-constexpr uint32_t kSelLdsBig = kSelLdsLut + (256 + 8) * 2;                     // u32[256 + 4] windows the block orders in LDS; counters
+constexpr uint32_t kSelLdsLut = kSelLdsSeg + kSelSegs * 16;                     // u16[2048 + 8] value cell -> first | last << 8 segment it meets
+constexpr uint32_t kSelLdsBig = kSelLdsLut + (kSelCells + 8) * 2;                     // u32[256 + 4] windows the block orders in LDS; counters
 constexpr uint32_t kSelLdsRec = (kSelLdsBig + (kSelBigCap + 4) * 4 + 15) & ~15u;   // 32 KB: the sample, then the waves' private sort areas / the block sort area, then (its first
                                                                                     // 12 KB, laid out like enc_hist_kernel's) the rank records and the block-scan scratch
 constexpr uint32_t kSelLdsBytes = kSelLdsRec + kSelRegionBytes;
@@ -280,7 +283,7 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
   //      samples from either end) in the tails, where a power law would otherwise pile a whole segment's population into its
   //      first bucket.  Two equal neighbouring quantiles are a heavy value, which gets a segment of its own, [v, v + 1) ----
   const uint32_t range_bl = bitlen<L>((L)(maxv - minv));
-  const uint32_t cell_sh = range_bl > 8 ? range_bl - 8 : 0u;   // value cells: the top 8 bits of x - min
+  const uint32_t cell_sh = range_bl > kSelCellLog ? range_bl - kSelCellLog : 0u;   // value cells: the top 11 bits of x - min
   if (tid == 0) {   // (par holds 1 for the bounds of a heavy value's segment until the scaling is written below)
     uint32_t ns = 0; L last_q = minv;
     seg[ns].lo = minv; seg[ns++].par = 0;
@@ -329,15 +332,16 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
     }
   }
   __syncthreads();
-  // value cells (the top 8 bits of x - min) -> the segments a cell meets: most cells meet one or two, and the search below
-  // only walks the segments of the latent's cell
-  if (tid < 256) {
+  // value cells (the top 11 bits of x - min) -> the segments a cell meets: most cells meet one (the bounds were moved to cell starts
+  // above), and the search below only walks the segments of the latent's cell.  (256 cells left skewed data -- a power law, the delta of
+  // anything -- with most of its segments in one or two cells and up to seven search steps per latent.)
+  for (uint32_t cell = tid; cell < kSelCells; cell += kSelThr) {
     auto seg_of = [&](L x) { uint32_t lo = 0, hi = n_seg; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg[mid].lo <= x) lo = mid; else hi = mid; } return lo; };
-    const L c0 = (L)(minv + ((L)tid << cell_sh));
+    const L c0 = (L)(minv + ((L)cell << cell_sh));
     L c1 = (L)(c0 + (L)(((L)1 << cell_sh) - 1));
-    const bool in = (uint64_t)tid <= ((uint64_t)(L)(maxv - minv) >> cell_sh);
+    const bool in = (uint64_t)cell <= ((uint64_t)(L)(maxv - minv) >> cell_sh);
     if (c1 > maxv || c1 < c0) c1 = maxv;
-    lut[tid] = in ? (uint16_t)(seg_of(c0) | (seg_of(c1) << 8)) : (uint16_t)0;
+    lut[cell] = in ? (uint16_t)(seg_of(c0) | (seg_of(c1) << 8)) : (uint16_t)0;
   }
   __syncthreads();
   auto bucket_of = [&](L x) {   // monotone in x
