@@ -75,10 +75,12 @@ __device__ __forceinline__ bool ew_fits16(uint32_t asl, uint32_t n_bins) { retur
 // enc_walkd_kernel (below) walks a page variable when fused != 0 and, in a launch of more than 8192 items (fused == 2), its tables do not fit
 // the 16-per-wave slots of enc_walk_kernel<16>; it also FINDS the symbols of the variables it walks whose latents are 16-bit and span fewer
 // than 4096 values (wd_takes: enc_dissect_kernel leaves those alone).
+constexpr uint32_t kFusedLookups = 0x100u;   // EncFast::fused flag: the value -> bin tables exist (the host allocates them unless they would dwarf the input)
 __device__ __forceinline__ bool wd_walks(uint32_t fused, const PageVar& pv) {
-  return fused != 0 && pv.present && pv.n_bins > 1 && pv.n_lat > 0 && (fused == 1 || !ew_fits16(pv.asl, pv.n_bins));
+  const uint32_t mode = fused & 0xffu;
+  return mode != 0 && pv.present && pv.n_bins > 1 && pv.n_lat > 0 && (mode == 1 || !ew_fits16(pv.asl, pv.n_bins));
 }
-__device__ __forceinline__ bool wd_takes(uint32_t fused, const PageVar& pv) { return wd_walks(fused, pv) && pv.compact && pv.range < kDirectHistRange; }
+__device__ __forceinline__ bool wd_takes(uint32_t fused, const PageVar& pv) { return (fused & kFusedLookups) != 0 && wd_walks(fused, pv) && pv.compact && pv.range < kDirectHistRange; }
 // Where a table's window of used slots starts is rotated from table to table: the tables sit 8 KB apart and a narrow variable uses a
 // quarter of its table or less -- at the same offset in every table of similar chunks, i.e. in the same few L2 sets.
 __device__ __forceinline__ uint32_t vlut_rot(uint32_t table_index) { return (table_index * 1600u) & (kDirectHistRange - 1) & ~31u; }
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
     const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
     const PageVar pv = page_var(ch, v, page_n);
     if (!wd_walks(fx.fused, pv)) {   // (with every walked item here -- fused == 1 -- nobody else writes the states of the variables that need no walk)
-      if (fx.fused == 1 && pv.present && (pv.n_bins <= 1 || pv.n_lat == 0) && wave == 0 && lane < 4) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
+      if ((fx.fused & 0xffu) == 1 && pv.present && (pv.n_bins <= 1 || pv.n_lat == 0) && wave == 0 && lane < 4) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
       continue;
     }
     const bool finds = wd_takes(fx.fused, pv);   // its symbols come from the gathering wave; else from enc_dissect_kernel, staged by the walker itself
@@ -546,11 +548,14 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
     // latents of step it + 2 requested, in that order -- loads return in order, so nothing below waits for HBM -- while the entries gathered
     // during step it - 1 are turned into symbols
     uint64_t wnxt[kWdH]; uint32_t e[kWdH][4], enxt[kWdH][4];
-    load_batches(0, wnxt);
-    gather(wnxt, enxt);
-    if (1 < max_nb) load_batches(1, wnxt);
+    const bool lookups = (fx.fused & kFusedLookups) != 0;   // (no tables in this call: the wave only keeps the walker's barriers company)
+    if (lookups) {
+      load_batches(0, wnxt);
+      gather(wnxt, enxt);
+      if (1 < max_nb) load_batches(1, wnxt);
+    }
     for (uint32_t it = 0; it <= max_nb; it++) {   // it == max_nb: nothing left to find, only the barrier
-      if (it < max_nb) {
+      if (it < max_nb && lookups) {
 #pragma unroll
         for (uint32_t q = 0; q < kWdH; q++) { e[q][0] = enxt[q][0]; e[q][1] = enxt[q][1]; e[q][2] = enxt[q][2]; e[q][3] = enxt[q][3]; }
         __builtin_amdgcn_sched_barrier(0);

@@ -72,6 +72,40 @@ template <bool kContig> __global__ __launch_bounds__(256) void split_like(const 
   u64x2 o; o.x = v[0].x + v[1].y + v[2].x; o.y = v[3].y ^ v[0].y;
   d[t] = o;
 }
+// split_like with the real kernel's per-block extras, one at a time: kMeta = a chain of three dependent loads before the data loads (page ->
+// chunk -> task); kHalo = neighbour exchange through LDS + barrier; kRed = block reduction through LDS + barrier + two global atomics
+struct Meta { unsigned next; unsigned pad[15]; };
+template <bool kMeta, bool kHalo, bool kRed> __global__ __launch_bounds__(256) void split_real(const u64x2* __restrict__ s, u64x2* __restrict__ d, const Meta* __restrict__ m, u64* __restrict__ mm, size_t n2) {
+  __shared__ u64 halo[257]; __shared__ u64 red[8];
+  size_t blk = blockIdx.x;
+  if (kMeta) { unsigned a = m[blockIdx.x & 8191].next; unsigned b = m[8192 + (a & 8191)].next; unsigned c = m[16384 + (b & 8191)].next; blk += c; }   // (c == 0)
+  size_t t = blk * 256 + threadIdx.x; u64x2 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = s[t * 4 + k];
+  u64 prev = 0;
+  if (kHalo) { halo[threadIdx.x + 1] = v[3].y; __syncthreads(); prev = halo[threadIdx.x]; }
+  u64x2 o; o.x = (v[0].x - prev) + v[1].y + v[2].x; o.y = v[3].y ^ v[0].y;
+  d[t] = o;
+  if (kRed) {
+    u64 mn = o.x < o.y ? o.x : o.y, mx = o.x < o.y ? o.y : o.x;
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) { u64 a = __shfl_xor(mn, dlt, 64), b = __shfl_xor(mx, dlt, 64); mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mn; red[4 + (threadIdx.x >> 6)] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; } atomicMin(&mm[(blockIdx.x >> 7) * 2], mn); atomicMax(&mm[(blockIdx.x >> 7) * 2 + 1], mx); }
+  }
+}
+// does the block's LDS allocation (not its use) or its register count set the rate at which blocks are dispatched?
+template <int kRegs> __global__ __launch_bounds__(256) void split_lds(const u64x2* __restrict__ s, u64x2* __restrict__ d, size_t n2) {
+  extern __shared__ u64 dyn[];
+  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; u64x2 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = s[t * 4 + k];
+  if (threadIdx.x == 0) dyn[0] = v[0].x;
+  u64 extra = 0;
+  if constexpr (kRegs > 0) { u64 r[kRegs > 0 ? kRegs : 1]; for (int k = 0; k < kRegs; k++) r[k] = v[k & 3].x * (k + 3); asm volatile("" ::: "memory"); for (int k = 0; k < kRegs; k++) { asm volatile("v_mov_b32 %0, %0" : "+v"(*(unsigned*)&r[k])); extra ^= r[k]; } }
+  u64x2 o; o.x = v[0].x + v[1].y + v[2].x + (extra & 1); o.y = v[3].y ^ v[0].y;
+  d[t] = o;
+}
 int main() {
   size_t n = (size_t)1 << 30;  // 8 GiB in, 8 GiB out
   u64 *s, *d; hipMalloc(&s, n * 8); hipMalloc(&d, n * 8);
@@ -100,6 +134,17 @@ int main() {
   run("write16c x4", [&] { write_contig<4><<<n / 2 / 1024, 256>>>((u64x2*)d, n / 2); }, 8.0 * n);
   run("split contig", [&] { split_like<true><<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
   run("split strided", [&] { split_like<false><<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
+  Meta* meta; hipMalloc(&meta, 3 * 8192 * sizeof(Meta)); hipMemset(meta, 0, 3 * 8192 * sizeof(Meta));
+  u64* mm; hipMalloc(&mm, 16 * 65536); hipMemset(mm, 0, 16 * 65536);
+  run("split meta", [&] { split_real<true, false, false><<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, meta, mm, n / 2); }, 10.0 * n);
+  run("split halo", [&] { split_real<false, true, false><<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, meta, mm, n / 2); }, 10.0 * n);
+  run("split red", [&] { split_real<false, false, true><<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, meta, mm, n / 2); }, 10.0 * n);
+  run("split all3", [&] { split_real<true, true, true><<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, meta, mm, n / 2); }, 10.0 * n);
+  run("split lds0", [&] { split_lds<0><<<n / 2 / 1024, 256, 64>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
+  run("split lds14k", [&] { split_lds<0><<<n / 2 / 1024, 256, 14520>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
+  run("split lds30k", [&] { split_lds<0><<<n / 2 / 1024, 256, 30000>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
+  run("split regs24", [&] { split_lds<24><<<n / 2 / 1024, 256, 64>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
+  run("split r24+l14", [&] { split_lds<24><<<n / 2 / 1024, 256, 14520>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
   run("memset", [&] { hipMemsetAsync(d, 0, n * 8); }, 8.0 * n);
   run("memcpyD2D", [&] { hipMemcpyAsync(d, s, n * 8, hipMemcpyDeviceToDevice); }, 16.0 * n);
   return 0;

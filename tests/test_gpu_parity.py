@@ -849,3 +849,17 @@ def test_walk_arrangements_of_small_and_large_launches(L):
         for i in list(range(0, count, max(1, count // 140))) + list(range(min(count, 70))):   # the oracle on a spread of them (every kind and length)
             want = O.simple_compress(arrays[i], O.make_config(**kw))
             assert chunks[i] == U.chunk_of_file(want, len(chunks[i])), (count, kw, i, arrays[i].size)
+
+
+def test_many_short_chunks_keep_the_dissect_kernel(L):
+    """The value -> bin tables of enc_walkd_kernel are 8 KB per (chunk, variable): a call whose chunks are much shorter than that does not
+    allocate them (the symbols come from enc_dissect_kernel, the walk from the same kernel) -- same bytes either way."""
+    rng = np.random.default_rng(78)
+    arrays = [(np.uint64(1 << 30) + np.cumsum(rng.integers(0, 9, int(rng.integers(1, 700)))).astype(np.uint64)) for _ in range(7000)]   # 7000 x <= 5.6 KB against 56 MB of tables
+    kw = dict(mode=1, delta=2, delta_order=1)
+    chunks, back = U.gpu_batched(arrays, G.make_config(**kw))
+    for i in range(len(arrays)):
+        assert U.bits_equal(back[i], arrays[i]), i
+    for i in range(0, len(arrays), 50):
+        want = O.simple_compress(arrays[i], O.make_config(**kw))
+        assert chunks[i] == U.chunk_of_file(want, len(chunks[i])), (i, arrays[i].size)
