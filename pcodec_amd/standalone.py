@@ -90,7 +90,9 @@ def simple_decompress(data):
         code = L.pco_standalone_simple_decompress_into(buf.ctypes.data_as(C.c_void_p), len(buf), dt,
                                                        out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
         if code != G.PcoSuccess and L.pco_gfx_last_status() == G.ST_INVALID_ARGUMENT and cap < (1 << 34):
-            cap *= 4  # n_hint is only a hint (standalone/decompressor.rs:265-277)
+            # n_hint is only a hint (standalone/decompressor.rs:265-277) -- but an honest writer puts the exact count there: a file that
+            # outgrew the defensive first allocation is given what its header says next (one more pass, not up to four), else four times the room
+            cap = min(int(n_hint), plausible) if cap < int(n_hint) <= plausible else cap * 4
             continue
         G.check(code)
         return out[: n.value].copy()
