@@ -17,14 +17,22 @@ TY = {"unsigned long": "u64", "unsigned int": "u32", "unsigned short": "u16", "u
 
 def label(name):
     name = name.strip()
-    m = re.match(r"dec_walk_kernel<(.*), (\d)u>", name)
+    # (pmc_summary.py cuts the names at 34 characters: "dec_walk_kernel<unsigned long, 8u," / "dec_expand_kernel<unsigned long, f")
+    m = re.match(r"dec_walk_kernel<([^,>]*), (\d)u", name)
     if m:
         return ("dec_walk_kernel" if m.group(2) == "8" else "dec_walk4_kernel") + f"<{TY.get(m.group(1), m.group(1))}>"
-    m = re.match(r"(dec_expand_kernel|pco_decode_kernel)<(.*)>", name)
+    m = re.match(r"dec_expand_kernel<([^,>]*)(, (t|f))?", name)
     if m:
-        return f"{m.group(1)}<{TY.get(m.group(2), m.group(2))}>"
+        return ("dec_expand_lb_kernel" if m.group(3) == "t" else "dec_expand_kernel") + f"<{TY.get(m.group(1), m.group(1))}>"
+    m = re.match(r"pco_decode_kernel<([^,>]*)>?", name)
+    if m:
+        return f"pco_decode_kernel<{TY.get(m.group(1), m.group(1))}>"
     if name.startswith("enc_walk_kernel"):
-        return "enc_walk_kernel"
+        return "enc_walk16_kernel" if name.startswith("enc_walk_kernel<16") else "enc_walk_kernel"
+    if name.startswith("enc_lookback_pipe_kernel"):
+        return "enc_lookback_pipe_kernel<small>" if name.startswith("enc_lookback_pipe_kernel<LbPipe<t") else "enc_lookback_pipe_kernel"
+    if name.startswith("enc_lookback_kernel"):
+        return "enc_lookback_kernel<small>" if name.startswith("enc_lookback_kernel<LbCfg<256") else "enc_lookback_kernel"
     if name.startswith("enc_split_kernel"):
         return {"<true, false>": "enc_split_kernel<c16>", "<false, true>": "enc_split_kernel(redo)"}.get(name[len("enc_split_kernel"):], "enc_split_kernel")
     if name.startswith("enc_hist_select_kernel"):
