@@ -1728,6 +1728,41 @@ __device__ void train_var(const EncWorkspace& ws, uint32_t t, uint32_t var) {
   const float total_log2 = log2_approx_dev((float)total_count);
   const float meta = (float)(est + LBits<L>::v + offset_bits_bits(LBits<L>::v));
   // ---- DP (bin_optimization.rs:104-178): best[i+1] = min_j best[j] + cost(j..i); ties -> largest j ----
+  if constexpr (NW == 1 && CAP == 256) {
+    // One wave, at most 256 bins: lane t OWNS the candidates j = t, t + 64, t + 128, t + 192 -- their lower bound, cumulative count and
+    // best[j] live in its registers (best[j] arrives when step j - 1 ends: every lane knows the step's minimum, the owner keeps it), so a
+    // step reads nothing from LDS but its own upper bound and count, which were fetched during the step before, and waits for no store.
+    L low_j[4]; uint32_t cc_j[4]; float best_j[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) { const uint32_t j = tid + 64 * q; low_j[q] = j < nb ? lows[j] : (L)0; cc_j[q] = j < nb ? cc[j] : 0u; best_j[q] = 0.0f; }   // (best[0] = 0; the others are filled in below)
+    L upper = ups[0]; uint32_t cci = cc[1];
+    for (uint32_t i = 0; i < nb; i++) {
+      const L upper_i = upper; const uint32_t cci_i = cci;
+      if (i + 1 < nb) { upper = ups[i + 1]; cci = cc[i + 2]; }
+      float bc = 3.402823466e+38f; uint32_t bjv = 0xffffffffu;
+      const uint32_t nq = (i >> 6) + 1;   // (uniform) slots that hold a candidate j <= i in some lane
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        if (q >= nq) break;
+        const uint32_t j = tid + 64 * q;
+        const float cost = __fadd_rn(best_j[q], bin_cost_dev<L>(meta, low_j[q], upper_i, cci_i - cc_j[q], total_log2));
+        const bool take = j <= i && cost <= bc;   // (j ascends with q: on equal cost the larger j wins, as the reference's descending scan with '<' keeps it)
+        bc = take ? cost : bc; bjv = take ? j : bjv;
+      }
+      {
+        const uint32_t fb = __float_as_uint(bc);
+        const uint32_t cbits = fb ^ (((uint32_t)((int32_t)fb >> 31)) | 0x80000000u);
+        const uint32_t cmin = wave_reduce_u32(cbits, [](uint32_t p, uint32_t q) { return p < q ? p : q; });
+        const uint32_t jc = bjv != 0xffffffffu && cbits == cmin ? bjv + 1u : 0u;
+        const uint32_t jmax = wave_reduce_u32(jc, [](uint32_t p, uint32_t q) { return p > q ? p : q; });
+        bc = __uint_as_float(cmin ^ ((cmin >> 31) - 1u | 0x80000000u)); bjv = jmax - 1u;
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) best_j[q] = tid + 64 * q == i + 1 ? bc : best_j[q];
+      if (lane == 0) { best[i + 1] = bc; bj[i] = (uint16_t)bjv; }   // (for the rewind below, which a wave sync precedes)
+    }
+    enc_wave_sync();
+  } else
   for (uint32_t i = 0; i < nb; i++) {
     const L upper = ups[i]; const uint32_t cci = cc[i + 1];
     float bc = 3.402823466e+38f; uint32_t bjv = 0xffffffffu;
