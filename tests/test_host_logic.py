@@ -114,3 +114,41 @@ extern "C" int cmp64(int n, int* f) {{ return run<uint64_t, double>(n, f); }}
         found = C.c_int(0)
         assert fn(1200, C.byref(found)) == 0
         assert found.value >= min_found, found.value   # the generator really produces float-mult bids
+
+
+def test_traffic_tables_are_only_quoted_for_the_build_and_the_kernels_they_were_measured_on(tmp_path, monkeypatch):
+    """bench.load_traffic (the `roofline.traffic` of the bench line): a committed PMC table is used only if its csrc_sha16 is the running
+    sources' and it lists every kernel that ran; scripts/make_traffic_json.py maps rocprofv3's (truncated) kernel names to the launch labels."""
+    root = os.path.join(HERE, "..")
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "scripts"))
+    import importlib
+    import json
+    bench = importlib.import_module("bench")
+    prof = tmp_path / "profiles"; prof.mkdir()
+    sha = bench.csrc_sha16()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_sha16", lambda: sha)
+    table = {"chunks": 100, "workload": "c2", "csrc_sha16": sha, "kernels": {"enc_pack_kernel": {"fetch_bytes_per_launch": 1000, "write_bytes_per_launch": 500},
+                                                                               "dec_walk_kernel<u64>": {"fetch_bytes_per_launch": 300, "write_bytes_per_launch": 0}}}
+    (prof / "r09_traffic_c2.json").write_text(json.dumps(table))
+    tab, src = bench.load_traffic("c2", 200, ["enc_pack_kernel", "dec_walk_kernel<u64>"])
+    assert src == "r09_traffic_c2.json" and tab["enc_pack_kernel"] == 3000 and tab["dec_walk_kernel<u64>"] == 600   # scaled by the chunk count
+    tab, src = bench.load_traffic("c2", 200, ["enc_pack_kernel", "enc_walkd_kernel"])
+    assert tab is None and "enc_walkd_kernel" in src
+    table["csrc_sha16"] = "0" * 16
+    (prof / "r09_traffic_c2.json").write_text(json.dumps(table))
+    tab, src = bench.load_traffic("c2", 200, ["enc_pack_kernel"])
+    assert tab is None and "other kernel sources" in src
+    tab, src = bench.load_traffic("c9", 200, ["enc_pack_kernel"])
+    assert tab is None
+    # the label mapping (names as pmc_summary.py prints them: cut at 34 characters)
+    src_text = open(os.path.join(root, "scripts", "make_traffic_json.py")).read()
+    ns = {"re": __import__("re")}
+    exec(src_text[src_text.index("TY = {"):src_text.index("def parse(")], ns)
+    label = ns["label"]
+    assert label("dec_walk_kernel<unsigned long, 8u,") == "dec_walk_kernel<u64>" and label("dec_walk_kernel<unsigned int, 4u, ") == "dec_walk4_kernel<u32>"
+    assert label("dec_expand_kernel<unsigned long, f") == "dec_expand_kernel<u64>" and label("dec_expand_kernel<unsigned long, t") == "dec_expand_lb_kernel<u64>"
+    assert label("enc_walk_kernel<16u>") == "enc_walk16_kernel" and label("enc_walk_kernel<8u>") == "enc_walk_kernel" and label("enc_walkd_kernel") == "enc_walkd_kernel"
+    assert label("enc_lookback_kernel<LbCfg<256u, 25") == "enc_lookback_kernel<small>" and label("enc_lookback_kernel<LbCfg<1024u, 1") == "enc_lookback_kernel"
+    assert label("enc_lookback_pipe_kernel<LbPipe<fa") == "enc_lookback_pipe_kernel" and label("enc_hist_select_kernel<unsigned in") == "enc_hist_select_kernel"
+    assert label("enc_split_kernel<true, false>") == "enc_split_kernel<c16>" and label("pco_decode_kernel<unsigned long>") == "pco_decode_kernel<u64>"
