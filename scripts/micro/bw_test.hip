@@ -106,6 +106,15 @@ template <int kRegs> __global__ __launch_bounds__(256) void split_lds(const u64x
   u64x2 o; o.x = v[0].x + v[1].y + v[2].x + (extra & 1); o.y = v[3].y ^ v[0].y;
   d[t] = o;
 }
+// does the size of the kernel-argument segment matter (the product's kernels take a 150-byte workspace struct by value)?
+struct BigArgs { u64 p[20]; };
+__global__ __launch_bounds__(256) void split_bigargs(const u64x2* __restrict__ s, u64x2* __restrict__ d, BigArgs a, size_t n2) {
+  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; u64x2 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = s[t * 4 + k];
+  u64x2 o; o.x = v[0].x + v[1].y + v[2].x + a.p[blockIdx.x & 15]; o.y = v[3].y ^ v[0].y;
+  d[t] = o;
+}
 int main() {
   size_t n = (size_t)1 << 30;  // 8 GiB in, 8 GiB out
   u64 *s, *d; hipMalloc(&s, n * 8); hipMalloc(&d, n * 8);
@@ -145,6 +154,7 @@ int main() {
   run("split lds30k", [&] { split_lds<0><<<n / 2 / 1024, 256, 30000>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
   run("split regs24", [&] { split_lds<24><<<n / 2 / 1024, 256, 64>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
   run("split r24+l14", [&] { split_lds<24><<<n / 2 / 1024, 256, 14520>>>((u64x2*)s, (u64x2*)d, n / 2); }, 10.0 * n);
+  { BigArgs a{}; run("split bigargs", [&] { split_bigargs<<<n / 2 / 1024, 256>>>((u64x2*)s, (u64x2*)d, a, n / 2); }, 10.0 * n); }
   run("memset", [&] { hipMemsetAsync(d, 0, n * 8); }, 8.0 * n);
   run("memcpyD2D", [&] { hipMemcpyAsync(d, s, n * 8, hipMemcpyDeviceToDevice); }, 16.0 * n);
   return 0;
