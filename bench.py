@@ -9,7 +9,14 @@ produced (ONE call).  Default workload = BASELINE.json configs[1]: u64, classic 
 chunks of a noisy linear ramp.  value = uncompressed GB/s over encode+decode, 2*bytes/(t_enc+t_dec), aggregated over all
 ranks (chunks are independent: each rank owns a contiguous block of chunks, weak scaling, no collective on the data
 path).  `--gather` adds the file-assembly path of BASELINE configs[4]: device-side compaction of the rank's chunks,
-gather-v of the exact byte ranges to rank 0 over RCCL, and for the decode direction the scatter of the byte ranges back.
+gather-v of the exact byte ranges to rank 0 over RCCL, and for the decode direction the scatter of the byte ranges back --
+through the library's own C ABI (pco_gfx_gather_chunks / pco_gfx_scatter_chunks, what INTEGRATION.md's Rust shim binds;
+`--gather-carrier torch` for the torch.distributed carrier).  The default invocation times that leg too (workload `c5gather`).
+
+Output: ONE JSON line on stdout, kept compact and FLAT where it matters (the driver's record keeps scalars two levels deep
+and a ~10 KB tail): roofline.frac_encode / frac_decode / frac_step, roofline.traffic_over_algorithmic_*, roofline.ms.<kernel>,
+and per extra workload config.<name>_value / _encode_GBps / _decode_GBps / _frac_step / ...  The full nested record (per-kernel
+times and direction rooflines of every workload) goes to stderr as one line prefixed "BENCH_FULL " and to bench_full.json.
 
 With --gpus N > 1 and no torch.distributed environment the script launches the N ranks itself
 (torch.distributed.run, one rank per GPU, RCCL); under an external launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
@@ -239,8 +246,20 @@ class Bench:
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+        self.comm = None
         self.L = G.lib()
         self.L.pco_gfx_compact_chunks.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def c_abi_comm(self):
+        """The library's own communicator (include/pco_gfx.h section 5): rank 0 makes the 128-byte id, the process group (the host's
+        channel here) carries it to the others; at world size 1 nothing else is needed -- RCCL still runs (ncclCommInitRank, the size
+        all-gather)."""
+        if self.comm is None:
+            ident = [self.S.Comm.unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                self.dist.broadcast_object_list(ident, src=0)
+            self.comm = self.S.Comm(ident[0], self.world, self.rank)
+        return self.comm
 
     def sync_all(self):
         self.torch.cuda.synchronize()
@@ -281,7 +300,7 @@ class Bench:
             checked += len(idx)
         return checked
 
-    def run(self, workload, chunks, steps, warmup, gather, verify_chunks, with_cpu, cpu_seconds=14.0):
+    def run(self, workload, chunks, steps, warmup, gather, verify_chunks, with_cpu, cpu_seconds=14.0, carrier="cabi"):
         """One workload: data generation, warm-up (round-trip assertion + oracle spot check), K timed steps.  Returns rank 0's record."""
         torch, dist, G, S, L = self.torch, self.dist, self.G, self.S, self.L
         world, rank, device = self.world, self.rank, self.device
@@ -324,7 +343,11 @@ class Bench:
             payload = torch.zeros(stream_cap, dtype=torch.uint8, device=device)
             d_offs = torch.zeros(nch + 1, dtype=torch.int64, device=device)
             recv = torch.zeros(stream_cap, dtype=torch.uint8, device=device)
-            file_body = torch.zeros(stream_cap * world, dtype=torch.uint8, device=device) if rank == 0 and self.use_dist else None
+            use_cabi = carrier == "cabi"
+            moves = use_cabi or self.use_dist      # the torch carrier needs a process group; the C-ABI one brings its own communicator
+            file_cap = stream_cap * world
+            file_body = torch.zeros(file_cap if rank == 0 else 16, dtype=torch.uint8, device=device) if moves else None
+            comm = self.c_abi_comm() if use_cabi else None
         gather_ms = []
         state = {"n_bytes": 0, "offs": None}
 
@@ -335,7 +358,10 @@ class Bench:
                 total = C.c_uint64(0)
                 G.check(L.pco_gfx_compact_chunks(nch, enc_tasks.ctypes.data, d_res.data_ptr(), payload.data_ptr(), stream_cap - 64, 0, d_offs.data_ptr(), C.byref(total), None))
                 state["n_bytes"] = int(total.value)
-                if self.use_dist:
+                if use_cabi:
+                    state["offs"] = comm.gather(payload.data_ptr(), state["n_bytes"], file_body.data_ptr(), file_cap, 0, root=0)
+                    torch.cuda.synchronize()
+                elif self.use_dist:
                     totals = S.exchange_totals(state["n_bytes"], device)
                     _, state["offs"] = S.gather_stream(payload, state["n_bytes"], dst=0, out=file_body, totals=totals)
                     torch.cuda.synchronize()
@@ -343,7 +369,10 @@ class Bench:
 
         def decode():
             if gather:   # decoders read the byte ranges the root hands out
-                if self.use_dist:
+                if use_cabi:
+                    comm.scatter(file_body.data_ptr(), state["offs"], recv.data_ptr(), stream_cap - 16, 0, root=0)
+                    base = recv.data_ptr()
+                elif self.use_dist:
                     S.scatter_stream(file_body, state["offs"], recv, src=0)
                     base = recv.data_ptr()
                 else:
@@ -428,7 +457,7 @@ class Bench:
                 "config": {"workload": desc, "chunks_per_gpu": nch, "chunk_n": N18, "compression_level": 8,
                            "mode_spec": MODE_NAMES[cfg_kw.get("mode", 0)] + (f"({cfg_kw['mode_f64']})" if "mode_f64" in cfg_kw else ""),
                            "delta_spec": DELTA_NAMES[cfg_kw.get("delta", 0)] + (f"({cfg_kw['delta_order']})" if "delta_order" in cfg_kw else ""),
-                           "parallelism": f"chunk-sharded x{world}, contiguous chunk blocks" + (", device compaction + RCCL gather-v / scatter of the chunk bytes" if gather else ", no data-path collective"),
+                           "parallelism": f"chunk-sharded x{world}, contiguous chunk blocks" + ((f", device compaction + RCCL gather-v / scatter of the chunk bytes ({'C ABI pco_gfx_gather_chunks / _scatter_chunks' if carrier == 'cabi' else 'torch.distributed carrier'})" if gather else ", no data-path collective")),
                            "compressed_bytes_per_chunk": comp_bytes // nch,
                            "encode_GBps": round(total_bytes * steps / t_enc / 1e9, 2),
                            "decode_GBps": round(total_bytes * steps / t_dec / 1e9, 2),

@@ -274,14 +274,18 @@ int pco_gfx_comm_rank(const PcoGfxComm*);
 int pco_gfx_comm_size(const PcoGfxComm*);
 /* Every rank passes its compacted chunk stream [d_stream, d_stream + n_bytes); on `root` the streams land in rank (= chunk) order
  * at d_file + file_offset.  offsets (HOST array of n_ranks + 1 entries, filled on EVERY rank) = where each rank's bytes start
- * relative to file_offset, the total last.  An 8-byte all-gather of the sizes, then one ncclGroup of exact-size ncclSend / ncclRecv.
- * The call synchronises `stream` for the sizes; the byte transfers are asynchronous on it.  (d_file / file_cap are ignored off the
- * root; a file_cap that is too small is INVALID_ARGUMENT on the root before anything is posted -- check offsets[n_ranks] on all
- * ranks alike.) */
+ * relative to file_offset, the total last.  A 16-byte all-gather (every rank's size + the root's room), then one ncclGroup of
+ * exact-size ncclSend / ncclRecv.  The call synchronises `stream` for the sizes; the byte transfers are asynchronous on it.
+ * d_file / file_cap are ignored off the root.  Failure is COLLECTIVE: a root whose buffer is missing or too small for the gathered
+ * bytes makes EVERY rank return INVALID_ARGUMENT (offsets filled) before any send or receive is posted -- nobody is left waiting.
+ * The call makes the communicator's device current. */
 enum PcoError pco_gfx_gather_chunks(PcoGfxComm*, int root, const void* d_stream, uint64_t n_bytes, void* d_file, uint64_t file_cap,
                                     uint64_t file_offset, uint64_t* offsets, void* stream);
 /* The decode direction: `root` holds the chunk stream at d_file + file_offset; rank r receives bytes [offsets[r], offsets[r + 1])
- * into d_stream (capacity stream_cap, >= its share + the decoder's 16 bytes of slack).  *n_bytes = this rank's share. */
+ * into d_stream (capacity stream_cap, >= its share + the decoder's 16 bytes of slack).  *n_bytes = this rank's share.  Every rank
+ * passes the SAME offsets table (the one pco_gfx_gather_chunks filled, or the root's, broadcast by the host).  Collective failure as
+ * above: one rank whose buffer is too small (or a root without a file buffer, or tables that disagree on the total) makes every
+ * rank return INVALID_ARGUMENT after a 16-byte all-gather and before any transfer. */
 enum PcoError pco_gfx_scatter_chunks(PcoGfxComm*, int root, const void* d_file, uint64_t file_offset, const uint64_t* offsets,
                                      void* d_stream, uint64_t stream_cap, uint64_t* n_bytes, void* stream);
 

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
         uint64_t byte = bit >> 3;
         if (my_flags & PCO_GFX_TASK_ONE_CHUNK) {   // this chunk only: say whether another follows (the caller comes back for it)
           if (byte < my_len && my_src[byte] != 0) plan->more = 1u;
-          else if (byte < my_len) byte += 1;     // the terminator
+          else if (byte < my_len) { byte += 1; plan->more = 2u; }     // the terminator (aux bit 1: it was there and is consumed)
           else if (my_flags & PCO_GFX_TASK_HAS_FILE_HEADER) status = PCO_GFX_INSUFFICIENT_DATA;
         } else if (my_flags & PCO_GFX_TASK_HAS_FILE_HEADER) {
           if (byte >= my_len) status = PCO_GFX_INSUFFICIENT_DATA;

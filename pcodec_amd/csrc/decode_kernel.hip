@@ -935,7 +935,7 @@ __global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const
       if (!status && (flags & PCO_GFX_TASK_ONE_CHUNK)) {   // this chunk only: say whether another follows, take the terminator if not
         const uint64_t byte = mr.bit >> 3;
         if (byte < src_len && uni((uint32_t)src[byte]) != 0) more = 1;
-        else if (byte < src_len) mr.bit += 8;
+        else if (byte < src_len) { mr.bit += 8; more = 2; }   // aux bit 1: the terminator was there and is consumed
         else if (flags & PCO_GFX_TASK_HAS_FILE_HEADER) status = PCO_GFX_INSUFFICIENT_DATA;
         break;
       }

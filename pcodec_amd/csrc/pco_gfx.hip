@@ -421,12 +421,17 @@ enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size
     } else {
       for (;;) {
         if (off >= compressed_len) { set_error(PCO_GFX_INSUFFICIENT_DATA, "decompression failed: the file ends without its terminator"); return PcoDecompressionError; }
-        PcoGfxDecodeTask task{d_in + off, compressed_len - off, d_out + done * esz, dst_cap - done, dtype, PCO_GFX_TASK_ONE_CHUNK | (fmt_major << 8)};
+        // (a chunk holds at most 2^24 numbers: the scratch launch_decode sizes from dst_cap stays a chunk's, whatever the caller's buffer)
+        PcoGfxDecodeTask task{d_in + off, compressed_len - off, d_out + done * esz, std::min<size_t>(dst_cap - done, kMaxEntries), dtype, PCO_GFX_TASK_ONE_CHUNK | (fmt_major << 8)};
         PcoGfxTaskResult res{};
         launch_decode(1, &task, &res, nullptr, 0);
         if (res.status != PCO_GFX_OK) { set_error((int)res.status, "decompression failed"); return PcoDecompressionError; }
         done += res.n_out; off += res.consumed;
-        if (!(res.aux & 1u) || res.consumed == 0) break;
+        if (res.aux & 1u) { if (res.consumed == 0) break; continue; }   // another chunk follows
+        // the last chunk: the file must still hold its terminator byte (standalone/decompressor.rs:190-200: chunk_preamble fails with
+        // InsufficientData on a file that ends right behind a chunk); the kernels report it consumed through aux bit 1
+        if (!(res.aux & 2u)) { set_error(PCO_GFX_INSUFFICIENT_DATA, "decompression failed: the file ends without its terminator"); return PcoDecompressionError; }
+        break;
       }
     }
     if (done) PCO_HIP_CHECK(hipMemcpy(dst, d_out, done * esz, hipMemcpyDeviceToHost));

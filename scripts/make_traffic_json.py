@@ -1,8 +1,12 @@
 """profiles/<tag>_traffic.json from the two PMC passes of scripts/profile_round.sh (pmc_FETCH_SIZE.txt, pmc_WRITE_SIZE.txt).
 
 usage: make_traffic_json.py <dir with the pmc_*.txt> <chunks> <workload> <out.json> <out.txt>
-Counters are kilobytes per dispatch; FETCH_SIZE is doubled (gfx950 note, MI355X_MICROARCH.md HBM section).  Kernel names are
-mapped to the names bench.py reports (the library's launch-timer labels)."""
+Counters are kilobytes per dispatch.  The guide's gfx950 correction (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half the
+bytes of a WIDE COALESCED STREAMING read) is calibrated for that access pattern only, so the table keeps the raw counter
+(`fetch_raw_bytes_per_launch`) next to the figure bench.py quotes (`fetch_bytes_per_launch`): doubled for the kernels whose reads are
+16-byte-per-lane streams, RAW for the kernels whose reads are scattered narrow accesses (NARROW below: the lookback search's 2-byte
+table probes), where doubling is uncalibrated and would overstate the traffic.  Kernel names are mapped to the names bench.py reports
+(the library's launch-timer labels)."""
 import json
 import re
 import sys
@@ -12,6 +16,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from bench import csrc_sha16  # noqa: E402  (the table is only quoted by bench.py for the kernel sources it was measured on)
 
 d, chunks, workload, out_json, out_txt = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+# kernels whose fetches are dominated by scattered 2- / 4-byte table probes: FETCH_SIZE is quoted raw for them
+NARROW = ("enc_lookback_pipe_kernel", "enc_lookback_kernel")
 TY = {"unsigned long": "u64", "unsigned int": "u32", "unsigned short": "u16", "unsigned char": "u8"}
 
 
@@ -56,12 +62,15 @@ def parse(path):
 f, w = parse(f"{d}/pmc_FETCH_SIZE.txt"), parse(f"{d}/pmc_WRITE_SIZE.txt")
 kern = {}
 for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, (0, 0))[1])):
-    kern[k] = {"fetch_bytes_per_launch": int(2 * f.get(k, (0, 0))[0] * 1000), "write_bytes_per_launch": int(w.get(k, (0, 0))[0] * 1000)}
+    raw = int(f.get(k, (0, 0))[0] * 1000); streaming = not k.startswith(NARROW)
+    kern[k] = {"fetch_raw_bytes_per_launch": raw, "fetch_bytes_per_launch": 2 * raw if streaming else raw, "fetch_doubled": streaming,
+               "write_bytes_per_launch": int(w.get(k, (0, 0))[0] * 1000)}
 json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --chunks {chunks} "
-                     "--no-cpu-baseline; counters are kilobytes per dispatch; FETCH_SIZE doubled (gfx950 note, MI355X_MICROARCH.md HBM section)",
+                     "--no-cpu-baseline; counters are kilobytes per dispatch; FETCH_SIZE doubled (gfx950 note, MI355X_MICROARCH.md HBM section) for the "
+                     "streaming kernels only (fetch_doubled), raw for scattered narrow reads; fetch_raw_bytes_per_launch is the counter as reported",
            "chunks": chunks, "workload": workload, "csrc_sha16": csrc_sha16(), "kernels": kern}, open(out_json, "w"), indent=1)
 with open(out_txt, "w") as o:
     o.write(open(f"{d}/pmc_FETCH_SIZE.txt").read()); o.write(open(f"{d}/pmc_WRITE_SIZE.txt").read())
-    o.write("\nper launch, bytes (FETCH_SIZE x 2 x 1000, WRITE_SIZE x 1000):\n")
+    o.write("\nper launch, bytes (FETCH_SIZE x 1000 raw; x 2 where the reads are wide coalesced streams; WRITE_SIZE x 1000):\n")
     for k, v in kern.items():
-        o.write(f"{k.ljust(34)} fetch {v['fetch_bytes_per_launch'] / 1e9:8.3f} GB  write {v['write_bytes_per_launch'] / 1e9:8.3f} GB\n")
+        o.write(f"{k.ljust(34)} fetch raw {v['fetch_raw_bytes_per_launch'] / 1e9:8.3f} GB  quoted {v['fetch_bytes_per_launch'] / 1e9:8.3f} GB ({'x2' if v['fetch_doubled'] else 'raw'})  write {v['write_bytes_per_launch'] / 1e9:8.3f} GB\n")

@@ -567,10 +567,19 @@ def test_unsupported_requests_fail_loudly(L):
 def test_truncation_and_corruption_are_reported(L):
     nums = np.array([0] * 50 + [1000] * 50, np.uint32)
     enc = O.simple_compress(nums, O.make_config(mode=1, delta=1))
-    for i in range(len(enc) - 1):  # tests/stability.rs:8-34
+    for i in range(len(enc)):  # tests/stability.rs:8-34 -- every strict prefix, the one that only lost the terminator byte included
         with pytest.raises(G.PcoGfxError) as ei:
             U.gpu_simple_decompress(enc[:i], np.uint32, 128)
         assert ei.value.status == G.ST_INSUFFICIENT_DATA, i
+    # a file of several chunks that ends right behind its last chunk (standalone/decompressor.rs:190-200: chunk_preamble wants a byte)
+    two = U.synth("c2", (1 << 18) + 700)
+    enc2 = O.simple_compress(two, O.make_config(mode=1, delta=2, delta_order=1))
+    assert enc2[-1] == 0
+    assert U.bits_equal(U.gpu_simple_decompress(enc2, np.uint64, two.size), two)
+    for cut in (1, 2):
+        with pytest.raises(G.PcoGfxError) as ei:
+            U.gpu_simple_decompress(enc2[:-cut], np.uint64, two.size)
+        assert ei.value.status == G.ST_INSUFFICIENT_DATA, cut
     big = O.simple_compress(U.synth("c2", 5000), O.make_config(mode=1, delta=2, delta_order=1))
     rng = np.random.default_rng(1)
     for _ in range(200):  # tests/corruption.rs: never crash / hang; error or garbage, like the reference

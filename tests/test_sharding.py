@@ -166,9 +166,9 @@ def _comm_api(L):
     L.pco_gfx_compact_chunks.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
 
 
-def _rank_round_trip(L, comm, rank, world, chunks_of_rank, cfg_kw):
-    """One rank's part of the C-ABI file assembly: encode my block of chunks, compact, pco_gfx_gather_chunks to rank 0,
-    pco_gfx_scatter_chunks back, decode.  Returns (file body on rank 0 else None, my decoded arrays)."""
+def _rank_round_trip(L, comm, rank, world, chunks_of_rank, cfg_kw, root=0):
+    """One rank's part of the C-ABI file assembly: encode my block of chunks, compact, pco_gfx_gather_chunks to `root`,
+    pco_gfx_scatter_chunks back, decode.  Returns (file body on the root else None, my decoded arrays)."""
     import torch
     from pcodec_amd import _lib as G
     arrays = chunks_of_rank
@@ -189,13 +189,13 @@ def _rank_round_trip(L, comm, rank, world, chunks_of_rank, cfg_kw):
     G.check(L.pco_gfx_compact_chunks(k, tasks, d_res.data_ptr(), payload.data_ptr(), stream_cap - 64, 0, d_offs.data_ptr(), C.byref(total), None))
     offsets = (C.c_uint64 * (world + 1))()
     file_cap = 1 << 26
-    file_body = torch.zeros(file_cap if rank == 0 else 16, dtype=torch.uint8, device="cuda")
-    G.check(L.pco_gfx_gather_chunks(comm, 0, payload.data_ptr(), total.value, file_body.data_ptr(), file_cap, 0, offsets, None))
+    file_body = torch.zeros(file_cap if rank == root else 16, dtype=torch.uint8, device="cuda")
+    G.check(L.pco_gfx_gather_chunks(comm, root, payload.data_ptr(), total.value, file_body.data_ptr(), file_cap, 0, offsets, None))
     torch.cuda.synchronize()
     assert offsets[rank + 1] - offsets[rank] == total.value
     recv = torch.zeros(stream_cap, dtype=torch.uint8, device="cuda")
     got = C.c_uint64(0)
-    G.check(L.pco_gfx_scatter_chunks(comm, 0, file_body.data_ptr(), 0, offsets, recv.data_ptr(), stream_cap - 16, C.byref(got), None))
+    G.check(L.pco_gfx_scatter_chunks(comm, root, file_body.data_ptr(), 0, offsets, recv.data_ptr(), stream_cap - 16, C.byref(got), None))
     torch.cuda.synchronize()
     assert got.value == total.value and torch.equal(recv[: got.value], payload[: got.value])
     sizes = np.array([res[i].n_out for i in range(k)], dtype=np.uint64)
@@ -206,7 +206,7 @@ def _rank_round_trip(L, comm, rank, world, chunks_of_rank, cfg_kw):
     if k:
         G.check(L.pco_gfx_decompress_chunks(k, dtasks, dres, None, None))
     back = [outs[i][: arrays[i].nbytes].cpu().numpy().view(arrays[i].dtype) for i in range(k)]
-    body = bytes(file_body[: offsets[world]].cpu().numpy()) if rank == 0 else None
+    body = bytes(file_body[: offsets[world]].cpu().numpy()) if rank == root else None
     return body, back
 
 
@@ -255,10 +255,20 @@ def _header_len(f):
     return 6 + (6 + power + 7) // 8 + 2
 
 
-def _c_abi_rank_main(rank, world, id_path, out_path):
+def _block_of(n_chunks, rank, world, empty_rank):
+    """Contiguous chunk blocks as pcodec_amd.sharding deals them, with one rank (optionally) owning nothing: the ranks left share the chunks."""
+    from pcodec_amd.sharding import shard_range
+    if empty_rank is None:
+        return shard_range(n_chunks, rank, world)
+    if rank == empty_rank:
+        return 0, 0
+    return shard_range(n_chunks, rank - (1 if rank > empty_rank else 0), world - 1)
+
+
+def _c_abi_rank_main(rank, world, id_path, out_path, root=0, one_device=False, empty_rank=None, failure=None):
     import torch
     from pcodec_amd import _lib as G
-    torch.cuda.set_device(rank)
+    torch.cuda.set_device(0 if one_device else rank)
     L = G.lib(); _comm_api(L)
     ident = (C.c_ubyte * 128)()
     if rank == 0:
@@ -276,16 +286,111 @@ def _c_abi_rank_main(rank, world, id_path, out_path):
     comm = C.c_void_p()
     G.check(L.pco_gfx_comm_init(ident, world, rank, C.byref(comm)))
     arrays = _sharded_inputs(11)
-    from pcodec_amd.sharding import shard_range
-    c0, c1 = shard_range(len(arrays), rank, world)
+    c0, c1 = _block_of(len(arrays), rank, world, empty_rank)
     kw = dict(mode=1, delta=2, delta_order=1)
-    body, back = _rank_round_trip(L, comm, rank, world, arrays[c0:c1], kw)
-    ok = all(np.array_equal(a, b) for a, b in zip(arrays[c0:c1], back))
+    if failure is not None:
+        ok = _collective_failures(L, comm, rank, world, root)
+        body = None
+    else:
+        body, back = _rank_round_trip(L, comm, rank, world, arrays[c0:c1], kw, root=root)
+        ok = all(np.array_equal(a, b) for a, b in zip(arrays[c0:c1], back))
     L.pco_gfx_comm_free(comm)
     with open(f"{out_path}.{rank}", "wb") as f:
         f.write(b"OK" if ok else b"NO")
         if body is not None:
             f.write(body)
+
+
+def _collective_failures(L, comm, rank, world, root):
+    """A rank that cannot take part must make EVERY rank return INVALID_ARGUMENT -- before anything is posted, so nobody hangs
+    (the calls below would block for ever otherwise) -- and the communicator must still work afterwards."""
+    import torch
+    from pcodec_amd import _lib as G
+    mine = 1000 + 100 * rank
+    payload = torch.full((mine + 64,), rank + 1, dtype=torch.uint8, device="cuda")
+    offsets = (C.c_uint64 * (world + 1))()
+    small = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    # 1. the root's file buffer is too small
+    rc = L.pco_gfx_gather_chunks(comm, root, payload.data_ptr(), mine, small.data_ptr(), 64, 0, offsets, None)
+    ok = rc != 0 and L.pco_gfx_last_status() == G.ST_INVALID_ARGUMENT and offsets[world] == sum(1000 + 100 * r for r in range(world))
+    # 2. the root passes no buffer at all
+    rc = L.pco_gfx_gather_chunks(comm, root, payload.data_ptr(), mine, None if rank == root else small.data_ptr(), 1 << 20, 0, offsets, None)
+    ok = ok and rc != 0 and L.pco_gfx_last_status() == G.ST_INVALID_ARGUMENT
+    # 3. a good gather, then a scatter in which ONE non-root rank has too little room
+    big = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    G.check(L.pco_gfx_gather_chunks(comm, root, payload.data_ptr(), mine, big.data_ptr(), 1 << 16, 0, offsets, None))
+    torch.cuda.synchronize()
+    if rank == root:
+        want = b"".join(bytes([r + 1]) * (1000 + 100 * r) for r in range(world))
+        ok = ok and bytes(big[: offsets[world]].cpu().numpy()) == want
+    victim = (root + 1) % world
+    recv = torch.zeros(1 << 14, dtype=torch.uint8, device="cuda")
+    got = C.c_uint64(0)
+    rc = L.pco_gfx_scatter_chunks(comm, root, big.data_ptr(), 0, offsets, recv.data_ptr(), 10 if rank == victim else 1 << 14, C.byref(got), None)
+    ok = ok and rc != 0 and L.pco_gfx_last_status() == G.ST_INVALID_ARGUMENT
+    # 4. and the communicator still works
+    G.check(L.pco_gfx_scatter_chunks(comm, root, big.data_ptr(), 0, offsets, recv.data_ptr(), 1 << 14, C.byref(got), None))
+    torch.cuda.synchronize()
+    ok = ok and got.value == mine and bool((recv[:mine] == rank + 1).all())
+    return bool(ok)
+
+
+def _fake_rccl_lib():
+    """tests/fake_rccl.so: the loopback transport (tests/fake_rccl.cpp); built by __graft_entry__.build(), or here when it is missing."""
+    import subprocess
+    so, src = os.path.join(HERE, "fake_rccl.so"), os.path.join(HERE, "fake_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so])
+    return so
+
+
+def _run_ranks(tmp_path, world, extra, env_extra=None):
+    import subprocess
+    idp, outp = str(tmp_path / "id"), str(tmp_path / "out")
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(env_extra or {})
+    procs = [subprocess.Popen([sys.executable, "-c", f"import sys; sys.path.insert(0, {HERE!r}); sys.path.insert(0, {os.path.join(HERE, '..')!r}); import test_sharding as T; T._c_abi_rank_main({r}, {world}, {idp!r}, {outp!r}, {extra})"], env=env) for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [open(f"{outp}.{r}", "rb").read() for r in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,root,empty_rank", [(2, 0, None), (2, 1, None), (3, 2, 1), (3, 0, 0), (4, 1, 3)])
+def test_c_abi_gather_scatter_of_several_ranks_on_one_device(tmp_path, world, root, empty_rank):
+    """pco_gfx_gather_chunks / pco_gfx_scatter_chunks with rank != root, a root that is not rank 0 and a rank that owns no bytes, executed
+    by `world` PROCESSES on ONE device: RCCL itself refuses duplicate devices, so the nine nccl* calls are served by the loopback
+    transport of tests/fake_rccl.cpp (PCO_GFX_RCCL_LIB); everything above them -- the size exchange, the offset arithmetic, which rank
+    posts what -- is the product's code, and the assembled body must be the oracle's chunks in chunk order."""
+    import oracle_lib as O
+    from pcodec_amd import _lib as G
+    if G.lib().pco_gfx_device_count() < 1:
+        pytest.skip("needs a HIP device")
+    outs = _run_ranks(tmp_path, world, f"root={root}, one_device=True, empty_rank={empty_rank}",
+                      {"PCO_GFX_RCCL_LIB": _fake_rccl_lib(), "PCO_FAKE_RCCL_DIR": str(tmp_path)})
+    kw = dict(mode=1, delta=2, delta_order=1)
+    want = b"".join(U_chunk(O, a, kw) for a in _sharded_inputs(11))
+    assert all(o[:2] == b"OK" for o in outs)
+    assert outs[root][2:] == want
+    assert all(len(o) == 2 for r, o in enumerate(outs) if r != root)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 1)])
+def test_c_abi_gather_scatter_fail_collectively(tmp_path, world, root):
+    """A root without room / without a buffer, a receiver without room: every rank returns INVALID_ARGUMENT, nobody blocks in a send
+    or receive whose partner threw, and the communicator is still usable (the advisor's round-3 finding on pco_gfx_comm.inc)."""
+    from pcodec_amd import _lib as G
+    if G.lib().pco_gfx_device_count() < 1:
+        pytest.skip("needs a HIP device")
+    outs = _run_ranks(tmp_path, world, f"root={root}, one_device=True, failure=True",
+                      {"PCO_GFX_RCCL_LIB": _fake_rccl_lib(), "PCO_FAKE_RCCL_DIR": str(tmp_path)})
+    assert all(o[:2] == b"OK" for o in outs), outs
 
 
 @pytest.mark.gpu
