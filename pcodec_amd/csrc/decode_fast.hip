@@ -31,17 +31,18 @@ template <uint32_t KQ> struct WalkCfg {
   static constexpr uint32_t kRetryStatus = KQ == 8 ? 101u : 100u;       // where a task goes whose tables do not fit
   static_assert(kGrpBytes % 16 == 0, "chunk slices must stay 16-byte aligned");
   static_assert(kWalkLdsBytes < 65536, "walk entries hold 16-bit LDS addresses");
-  // Fused walk + expand (dec_walk_kernel<L, 8, true>): once the tables are built the scratch belongs to the hand-over between the walker
-  // wave and the block's two expander waves.
-  static constexpr uint32_t kFuseCtlOff = kWalkTmpOff + 16;              // u32[KQ]: batches of the slot's chunk whose symbols are in HBM (kFuseDone / kFuseDead)
-  static constexpr uint32_t kFuseMomOff = kFuseCtlOff + 32;              // u64[KQ][2][2]: the delta moments of (primary, secondary), orders <= 2
-  static constexpr uint32_t kFuseLdsBytes = kWalkLdsBytes;               // (the block's LDS does not grow: four blocks per CU, as without the expanders)
-  static_assert(KQ != 8 || kFuseMomOff + 256 <= kFuseLdsBytes, "fused hand-over area");
 };
-constexpr uint32_t kFuseDone = 0x7fffffffu, kFuseDead = 0xffffffffu;
-// Three expander waves: with the walker that is four waves per block and, at four blocks per CU (the LDS), four per SIMD -- what the
-// kernel's ~117 VGPRs allow.  (Four expanders would leave room for three blocks only: the walk would take two rounds.)
-constexpr uint32_t kFuseExpWaves = 3, kFuseSlotsPerExp = 3;   // expander e takes slots e, e + 3, e + 6 (< 8)
+// Trailing expanders (decode_trail.hip): dec_walk_kernel<L, 8, true> publishes, per chunk slot, how many batches of the chunk are complete
+// in global memory -- progress[block * 8 + slot] = 1 + batches once the metadata is parsed, kTrailDead for a chunk the expanders must
+// leave alone -- and a second kernel on a second stream expands them while the walk is still going on.
+constexpr uint32_t kTrailDead = 0xffffffffu;
+constexpr uint32_t kTrailProgressStride = 32;   // words per walker block: its eight progress words have a 128-byte line to themselves (the expanders of other blocks poll theirs)
+#ifdef PCO_TRAIL_NODEFER
+constexpr bool kTrailDefer = false;
+#else
+constexpr bool kTrailDefer = true;    // the walker's agent-scope stores go out one round late (see dec_walk_body)
+#endif
+constexpr uint32_t kTrailMaxBins = 64;        // a variable's bins live in the registers of one wave, a bin per lane
 constexpr uint32_t kFastMaxBins = 256;
 constexpr uint32_t kStatusRetryLegacy = 100;     // internal: hand the task to the single-kernel decoder
 constexpr uint32_t kStatusRetryK4 = 101;         // internal: tables too big for an 8-chunk wave, try the 4-chunk walker
@@ -56,7 +57,7 @@ struct DecPlan {   // written by dec_walk_kernel, read by dec_expand_kernel
   uint32_t window_n_log, state_n_log;
   uint64_t moments[2][8];
   uint64_t consumed;
-  uint32_t fused, more;     // fused = 1: the chunk was expanded inside dec_walk_kernel (its result is written there), dec_expand_kernel skips it; more = 1: PCO_GFX_TASK_ONE_CHUNK and another chunk follows
+  uint32_t fused, more;     // fused = 1: the chunk is expanded by dec_trail_kernel while the walk runs (its result is written by the walker), dec_expand_kernel skips it; more: PCO_GFX_TASK_ONE_CHUNK, bit 0 = another chunk follows, bit 1 = the terminator was consumed
 };
 constexpr uint64_t kBinsAreaPerVar = kFastMaxBins * 8 + kFastMaxBins;   // lowers (8 B stride) then offset bits
 constexpr uint64_t kBinsAreaPerTask = 3 * kBinsAreaPerVar;
@@ -70,7 +71,7 @@ __device__ __forceinline__ uint32_t make_wentry(uint32_t next_base, uint32_t sym
 // Build one variable's walk table for chunk slot `q`: u32 entries and per-bin offset bits in LDS; lowers / offset bits
 // go to the global bins area for dec_expand_kernel.  All 64 lanes cooperate.  (ans/spec.rs:37-59, ans/decoding.rs:27-47)
 template <class LV, uint32_t KQ>
-__device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader& mr, uint8_t PCO_GLOBAL* bins_out, uint32_t& status) {
+__device__ __forceinline__ bool fast_build_var_impl(uint32_t q, uint32_t vi, MetaReader& mr, uint8_t PCO_GLOBAL* bins_out, uint32_t& status) {
   constexpr uint32_t kGrpBytes = WalkCfg<KQ>::kGrpBytes, kWalkTmpOff = WalkCfg<KQ>::kWalkTmpOff;
   const uint32_t lane = lane_id();
   uint8_t PCO_LDS* grp = lds_base() + q * kGrpBytes;
@@ -148,6 +149,11 @@ __device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader&
   return true;
 }
 
+// (out of line for the ordinary walkers; the walker that shares its SIMD with the trailing expanders inlines it -- a called function
+//  keeps its own register budget, and that kernel's is capped)
+template <class LV, uint32_t KQ>
+__device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader& mr, uint8_t PCO_GLOBAL* bins_out, uint32_t& status) { return fast_build_var_impl<LV, KQ>(q, vi, mr, bins_out, status); }
+
 struct FrontOut {
   uint32_t status, n;
   uint64_t bitpos;          // first bit of the page body
@@ -156,8 +162,8 @@ struct FrontOut {
 };
 
 // Everything before the page body for one task, executed by the whole wave on behalf of group q.
-template <class L, uint32_t KQ>
-__device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q, DecPlan PCO_GLOBAL* plan, uint8_t PCO_GLOBAL* bins_out, FrontOut& out) {
+template <class L, uint32_t KQ, bool kInline>
+__device__ __forceinline__ void fast_front_impl(const PcoGfxDecodeTask& task, uint32_t q, DecPlan PCO_GLOBAL* plan, uint8_t PCO_GLOBAL* bins_out, FrontOut& out) {
   constexpr uint32_t kGrpBytes = WalkCfg<KQ>::kGrpBytes, kGrpTblBytes = WalkCfg<KQ>::kGrpTblBytes;
   const uint32_t lane = lane_id();
   gcptr_u8 src = (gcptr_u8)task.src;
@@ -256,7 +262,9 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
   for (int vi = 0; vi < 3; vi++) {
     if (!present[vi]) continue;
     mr.bit += kBitsAnsSizeLog + kBitsNBins;
-    const bool ok = vi == 0 ? fast_build_var<uint32_t, KQ>(q, vi, mr, bins_out, status) : fast_build_var<L, KQ>(q, vi, mr, bins_out, status);
+    bool ok;
+    if constexpr (kInline) ok = vi == 0 ? fast_build_var_impl<uint32_t, KQ>(q, vi, mr, bins_out, status) : fast_build_var_impl<L, KQ>(q, vi, mr, bins_out, status);
+    else ok = vi == 0 ? fast_build_var<uint32_t, KQ>(q, vi, mr, bins_out, status) : fast_build_var<L, KQ>(q, vi, mr, bins_out, status);
     if (!ok) { fail(status); return; }
   }
   if (!mr.drain_empty_byte()) { if (mr.in_bounds()) { fail(PCO_GFX_CORRUPTION); return; } }
@@ -317,6 +325,9 @@ __device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q
   out.n = n; out.bitpos = mr.bit;
 }
 
+template <class L, uint32_t KQ>
+__device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q, DecPlan PCO_GLOBAL* plan, uint8_t PCO_GLOBAL* bins_out, FrontOut& out) { fast_front_impl<L, KQ, false>(task, q, plan, bins_out, out); }
+
 // ---------------------------------------------------------------------------------------------------------
 // dec_walk_kernel: kWQ chunks per wave, four lanes per chunk (lane 4c+j walks tANS chain j of chunk slot c).
 //
@@ -353,6 +364,21 @@ __device__ __forceinline__ void walk_window(WalkRegs& r, uint32_t tot) {
   r.d0 = w[0]; r.d1 = w[1]; r.d2 = w[2];
 }
 
+// sixteen symbol bytes of one lane: one 16-byte store, or -- when a kernel on another XCD reads them while this one runs -- two
+// agent-scope 8-byte stores (written through, see decode_trail.hip)
+template <bool kAgent>
+__device__ __forceinline__ void store_syms(uint8_t PCO_GLOBAL* p, uint32_t __attribute__((ext_vector_type(4))) acc) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef PCO_TRAIL_PLAINST
+  if constexpr (false) {
+#else
+  if constexpr (kAgent) {
+#endif
+    __hip_atomic_store((uint64_t*)p, (uint64_t)acc.x | ((uint64_t)acc.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((uint64_t*)p + 1, (uint64_t)acc.z | ((uint64_t)acc.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else *(u32x4 PCO_GLOBAL*)p = acc;
+}
+
 struct QuadMasks { uint32_t m1, m2, m3, c63; };   // all-ones where chain j >= 1, 2, 3; 63
 
 template <int K, bool kTail>
@@ -382,24 +408,20 @@ __device__ __forceinline__ void walk_step(WalkRegs& r, const QuadMasks& m, uint3
 __device__ unsigned long long g_walk_timing[8];
 #define WT_NOW() __builtin_readcyclecounter()
 #endif
-template <class L>
-__device__ void fused_expander(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, const DecPlan* plans, const uint8_t* bins_area,
-                               const uint8_t* sym_area, uint64_t sym_stride, const uint64_t* offpos_area, uint64_t offpos_stride);
-
 // accept_status: 0 = the first stage (every task), else only the tasks an earlier stage left with that status.
-// kFused (kWQ == 8 only): the block has two more waves that expand the batches of the wave's eight chunks as soon as their symbols are
-// out (fused_expander below) -- the walker is a latency chain that leaves its SIMD nine tenths idle, the expansion is what fills it; the
-// LDS is the walker's, so the expanders work from registers, global memory and the 1.6 KB the table build no longer needs.
-template <class L, uint32_t kWQ, bool kFused = false>
-__global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
-                                                      uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
-                                                      uint32_t accept_status, PcoGfxTaskResult* results) {
-  static_assert(!kFused || kWQ == 8, "the fused form is the eight-chunk walker's");
+// kTrail (kWQ == 8, first stage only): the chunks the trailing expanders can take (no lookback, at most 64 bins per variable, delta
+// orders up to 2 on the primary variable only) are marked DecPlan::fused and their progress is published batch by batch (decode_trail.hip);
+// everything the expanders read -- symbols, section starts, progress -- leaves through agent-scope stores, the plans and bins through
+// one agent-scope release after the table build.
+template <class L, uint32_t kWQ, bool kTrail>
+__device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
+                                              uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
+                                              uint32_t accept_status, PcoGfxTaskResult* results, uint32_t* progress) {
+  static_assert(!kTrail || kWQ == 8, "the trailing expanders follow the eight-chunk walker");
   constexpr uint32_t kGrpBytes = WalkCfg<kWQ>::kGrpBytes;
-  if constexpr (kFused) {
-    if (uni(threadIdx.x >> 6) != 0) { fused_expander<L>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride); return; }
-  }
-  if constexpr (kFused) __builtin_amdgcn_s_setprio(3);   // the walker's chain sets the kernel's duration: it goes first whenever it can issue
+#ifndef PCO_TRAIL_NOPRIO
+  if constexpr (kTrail) __builtin_amdgcn_s_setprio(3);   // the walker's chain sets the duration of the decode: it goes first whenever it can issue
+#endif
   const uint32_t lane = lane_id();
   const uint32_t slot = lane >> 2, j = lane & 3;
   // ---- phase 0: metadata + tables, one task at a time with the whole wave; slot q belongs to lanes 4q..4q+3 ----
@@ -415,7 +437,8 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
     if (accept_status != 0 && uni(((const DecPlan PCO_GLOBAL*)plans + ti)->status) != accept_status) continue;   // an earlier stage dealt with this task
     const PcoGfxDecodeTask task = tasks[ti];
     FrontOut fo;
-    fast_front<L, kWQ>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);
+    if constexpr (kTrail) fast_front_impl<L, kWQ, true>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);
+    else fast_front<L, kWQ>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);
     if (slot == q) {
       my_ti = ti; my_active = fo.status == PCO_GFX_OK ? 1u : 0u; my_front_ok = my_active; my_n = fo.n; my_bitpos = fo.bitpos;
       my_len = task.src_len; my_flags = task.flags; my_src = (gcptr_u8)task.src;
@@ -444,30 +467,36 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
     st2 = lds0 + slice + kGrpTblOff + vinfo[2].off_nodes + 4u * st2;
   }
   bool my_fused = false;
-  if constexpr (kFused) {
-    // which of the wave's chunks the block's expanders take: no lookback (its history needs an LDS area of its own), offsets of at most
-    // 16 bits (a lane's four fields in one 64-bit window), delta orders up to 2 (the moments' LDS).  The others go to dec_expand_kernel.
+  uint32_t PCO_GLOBAL* my_progress = nullptr;
+  if constexpr (kTrail) {
+    // which of the wave's chunks the trailing expanders take: ONE latent variable (classic mode, no lookback -- the state of eight chunks
+    // per SIMD has to fit the registers this kernel leaves), bins that fit one wave's registers, delta orders up to 2 (moments in
+    // registers).  The others go to dec_expand_kernel.
     if (my_active && slot < kWQ) {
-      my_fused = vinfo[0].present == 0;
-      for (int v = 1; v < 3; v++) if (vinfo[v].present) {
-        if (vinfo[v].max_ob > 16) my_fused = false;
-        if (vinfo[v].delta_kind == kDeltaConsecutive ? vinfo[v].delta_order > 2 : vinfo[v].delta_kind != kDeltaNone) my_fused = false;
-      }
+      my_fused = vinfo[0].present == 0 && vinfo[2].present == 0 && vinfo[1].n_bins <= kTrailMaxBins;
+      if (vinfo[1].delta_kind == kDeltaConsecutive ? vinfo[1].delta_order > 2 : vinfo[1].delta_kind != kDeltaNone) my_fused = false;
     }
-    uint32_t PCO_LDS* ctl = (uint32_t PCO_LDS*)(lds_base() + WalkCfg<kWQ>::kFuseCtlOff);
-    uint64_t PCO_LDS* fmom = (uint64_t PCO_LDS*)(lds_base() + WalkCfg<kWQ>::kFuseMomOff);
-    if (j == 0 && slot < kWQ) {
-      ctl[slot] = my_fused ? 0u : kFuseDead;
-      L PCO_LDS* mp = (L PCO_LDS*)(fmom + slot * 4); L PCO_LDS* ms = (L PCO_LDS*)(fmom + slot * 4 + 2);   // (consecutive_decode indexes them as L)
-      mp[0] = (L)my_mom[0][0]; mp[1] = (L)my_mom[0][1]; ms[0] = (L)my_mom[1][0]; ms[1] = (L)my_mom[1][1];
-      if (my_fused) ((DecPlan PCO_GLOBAL*)plans + my_ti)->fused = 1u;
-    }
-    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the plans and bins the expanders are about to read have reached L2
-    __syncthreads();
+    if (slot < kWQ) my_progress = (uint32_t PCO_GLOBAL*)progress + (uint64_t)blockIdx.x * kTrailProgressStride + slot;
+    if (j == 0 && my_fused) ((DecPlan PCO_GLOBAL*)plans + my_ti)->fused = 1u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // plans and bins (plain stores of the table build) are visible to every XCD from here on
+    if (j == 0 && slot < kWQ) __hip_atomic_store((uint32_t*)my_progress, my_fused ? 1u : kTrailDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   QuadMasks qm = {j >= 1 ? ~0u : 0u, j >= 2 ? ~0u : 0u, j >= 3 ? ~0u : 0u, 63u};
   asm volatile("" : "+v"(qm.m1), "+v"(qm.m2), "+v"(qm.m3), "+v"(qm.c63));   // opaque, so that they stay VGPR operands of v_and_b32_dpp
+  // kTrail: the agent-scope stores (written through: their acknowledgement takes microseconds) of a round are issued at the NEXT round's
+  // staging point and have that whole round to complete -- issued where the symbols are produced, the last of them would be waited for
+  // together with the next round's staging loads, on the chain (10.3 ms per launch instead of 6.5).
+  u32x4 d_acc[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  uint32_t d_ngrp = 0, issued_batches = 0; uint8_t PCO_GLOBAL* d_sym_out = nullptr;
+  uint64_t d_off_val = 0; uint64_t* d_off_ptr = nullptr;
+  auto flush_deferred = [&]() {
+#pragma unroll
+    for (int g = 0; g < 4; g++) if ((uint32_t)g < d_ngrp) store_syms<true>(d_sym_out + 64 * g, d_acc[g]);
+    d_ngrp = 0;
+    if (d_off_ptr) __hip_atomic_store(d_off_ptr, d_off_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    d_off_ptr = nullptr;
+  };
 #ifdef PCO_WALK_TIMING
   unsigned long long wt_stage = 0, wt_walk = 0, wt_tail = 0, wt_rounds = 0, wt_t0 = WT_NOW(), wt_start = wt_t0, wt_s1 = 0, wt_s2 = 0, wt_s3 = 0, wt_t1 = wt_t0;
 #endif
@@ -520,11 +549,16 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
       for (int k = 0; k < 7; k++) { const uint32_t qi = 2 * j + 8 * k; if (qi < nq) { win[qi] = lo[k]; win[qi + 1] = hi[k]; } }
     }
     wave_sync_lds();
-    if constexpr (kFused) {
-      // `batch` batches of my chunk are complete: their symbol and section-start stores were issued in earlier rounds, and everything
-      // issued before this round's staging loads has been acknowledged now that those loads are back
+    if constexpr (kTrail) {
+      // everything issued before this round's staging loads is acknowledged (the wave has just waited for those loads): the stores of the
+      // round before last, issued at the last staging point, are out -- `issued_batches` batches of my chunk can be published; then the
+      // last round's stores go out
+#ifndef PCO_TRAIL_NOWAIT
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (my_fused && j == 0) __hip_atomic_store((uint32_t*)(lds_base() + WalkCfg<kWQ>::kFuseCtlOff) + slot, batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+      if (my_fused && j == 0 && status == PCO_GFX_OK) __hip_atomic_store((uint32_t*)my_progress, 1u + issued_batches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (kTrailDefer) { flush_deferred(); issued_batches = batch; }
+      else issued_batches = batch;   // (stores issued where they are produced: everything through the last round is out)
     }
 #ifdef PCO_WALK_TIMING
     { const unsigned long long t = WT_NOW(); wt_s3 += t - wt_t1; }
@@ -535,7 +569,7 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
     // chunk's four lanes touch eight 128-byte lines around it.  The loaded values get their (dummy) use one round later,
     // right here, where this round's staging loads have already been waited for -- VMEM returns in order, so that use
     // never waits.
-    ((uint32_t PCO_LDS*)(lds_base() + WalkCfg<kWQ>::kWalkTmpOff))[kFused ? (lane & 3u) : lane] = touch_r0 ^ touch_r1;   // (the table-build scratch is idle during the walk; the fused form keeps 16 bytes of it for this)
+    ((uint32_t PCO_LDS*)(lds_base() + WalkCfg<kWQ>::kWalkTmpOff))[lane] = touch_r0 ^ touch_r1;   // (the table-build scratch is idle during the walk)
     if (walk) {
       const uint64_t cur = q0 * 8, pred = cur + (cur - touch_prev);
       touch_prev = cur;
@@ -553,8 +587,10 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
     if (walk) {
       r.e = *(const uint32_t PCO_LDS*)(uintptr_t)r.saddr;
       walk_window(r, 0u);
+      if constexpr (kTrail && kTrailDefer) d_sym_out = sym_out;
       if (__all(!walk || cnt == kBatchN)) {   // (lanes outside `walk` are masked off here anyway)
-        for (uint32_t grp = 0; grp < 4; grp++) {
+#pragma unroll
+        for (uint32_t grp = 0; grp < 4; grp++) {   // (unrolled: the trailing form keeps the four groups in registers until the next round)
           u32x4 acc;
 #pragma unroll
           for (int b = 0; b < 4; b++) {
@@ -564,11 +600,15 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
             walk_step<3, false>(r, qm, tbl_addr, true);
             acc[b] = r.symacc;
           }
-          *(u32x4 PCO_GLOBAL*)(sym_out + 64 * grp) = acc;
+          if constexpr (kTrail && kTrailDefer) d_acc[grp] = acc; else store_syms<kTrail>(sym_out + 64 * grp, acc);
         }
+        if constexpr (kTrail && kTrailDefer) d_ngrp = 4;
       } else {
         const uint32_t steps = (cnt + 3) >> 2;
-        for (uint32_t grp = 0; grp * 16 < steps; grp++) {
+        if constexpr (kTrail && kTrailDefer) d_ngrp = (steps + 15) >> 4;
+#pragma unroll
+        for (uint32_t grp = 0; grp < 4; grp++) {
+          if (grp * 16 >= steps) break;
           u32x4 acc = {0u, 0u, 0u, 0u};
 #pragma unroll
           for (int b = 0; b < 4; b++) {
@@ -582,7 +622,7 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
               acc[b] = r.symacc;
             }
           }
-          *(u32x4 PCO_GLOBAL*)(sym_out + 64 * grp) = acc;
+          if constexpr (kTrail && kTrailDefer) d_acc[grp] = acc; else store_syms<kTrail>(sym_out + 64 * grp, acc);
         }
       }
       if (cur_v == 0) st0 = r.saddr; else if (cur_v == 1) st1 = r.saddr; else st2 = r.saddr;
@@ -598,7 +638,12 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
       const uint64_t ans_end = walk ? (q0 << 6) + (r.bitaddr - 8u * win_addr) : my_bitpos;
       uint64_t ob_total = 0;
       if (cnt > 0) ob_total = walk ? (uint64_t)obq : (nb == 1 ? (uint64_t)cnt * *(const uint8_t PCO_LDS*)(uintptr_t)obs_addr : 0ull);
-      if (cnt > 0 && j == 0) offpos_area[((uint64_t)my_ti * 3 + cur_v) * offpos_stride + batch] = ans_end;
+      if (cnt > 0 && j == 0) {
+        uint64_t* op = offpos_area + ((uint64_t)my_ti * 3 + cur_v) * offpos_stride + batch;
+        if constexpr (kTrail && kTrailDefer) { d_off_ptr = op; d_off_val = ans_end; }
+        else if constexpr (kTrail) __hip_atomic_store(op, ans_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *op = ans_end;
+      }
       my_bitpos = ans_end + ob_total;
       if (my_bitpos > my_len * 8) { status = PCO_GFX_INSUFFICIENT_DATA; my_active = 0; }
       uint32_t nv = cur_v + 1;
@@ -619,9 +664,10 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
 #ifdef PCO_WALK_TIMING
   if (blockIdx.x == 0 && lane == 0 && wt_rounds > 0) { g_walk_timing[0] = wt_stage; g_walk_timing[1] = wt_walk; g_walk_timing[2] = wt_tail; g_walk_timing[3] = wt_rounds; g_walk_timing[4] = wt_start; g_walk_timing[5] = WT_NOW(); g_walk_timing[6] = wt_s1; g_walk_timing[7] = wt_s2 | (wt_s3 << 32); }
 #endif
-  if constexpr (kFused) {
+  if constexpr (kTrail) {
+    flush_deferred();
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (my_fused && j == 0) __hip_atomic_store((uint32_t*)(lds_base() + WalkCfg<kWQ>::kFuseCtlOff) + slot, status == PCO_GFX_OK ? kFuseDone : kFuseDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (my_fused && j == 0) __hip_atomic_store((uint32_t*)my_progress, status == PCO_GFX_OK ? 1u + batch : kTrailDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- page end (page_decompressor.rs:184-188) and stream end ----
   if (my_ti != 0xffffffffu && j == 0 && slot < kWQ) {
@@ -647,9 +693,9 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
         plan->consumed = byte;
       }
       plan->status = status;
-      if constexpr (kFused) {
-        // a chunk the block's expanders took is finished when this kernel is: its result is written here (a stream with another chunk
-        // behind this one goes to the single-kernel decoder whole, which then reports it)
+      if constexpr (kTrail) {
+        // a chunk the trailing expanders took is finished when they are (the host joins the two streams): its result is written here (a
+        // stream with another chunk behind this one goes to the single-kernel decoder whole, which then reports it)
         if (my_fused && status != kStatusRetryLegacy) {
           PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? my_n : 0; r.consumed = plan->consumed; r.status = status; r.aux = plan->more;
           results[my_ti] = r;
@@ -657,6 +703,24 @@ __global__ __launch_bounds__(kFused ? 64 * (1 + kFuseExpWaves) : 64) void dec_wa
       }
     }
   }
+}
+
+template <class L, uint32_t kWQ>
+__global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
+                                                      uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
+                                                      uint32_t accept_status, PcoGfxTaskResult* results) {
+  dec_walk_body<L, kWQ, false>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, accept_status, results, nullptr);
+}
+// The walker that publishes its progress to the trailing expanders: at most 128 VGPRs (four waves per SIMD's worth -- what the ordinary
+// walker takes), so that two expander waves of up to 192 fit beside it on every SIMD.  Tighter caps do not pay: at 80 or 96 the per-round
+// code (the staging loads' fourteen 64-bit pieces) spills, and a scratch reload on the chain costs more than anything the cap buys
+// (10.8 ms per launch against 7.2).
+#define PCO_TRAIL_WALK_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+template <class L>
+__global__ __launch_bounds__(64) PCO_TRAIL_WALK_ATTR void dec_walk_trail_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
+                                                      uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
+                                                      PcoGfxTaskResult* results, uint32_t* progress) {
+  dec_walk_body<L, 8, true>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, 0u, results, progress);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -729,8 +793,12 @@ __device__ __forceinline__ void expand_item(const ExpPre& pre, uint32_t PCO_LDS*
   for (int k = 0; k < 4; k++) {
     const bool act = 4 * lane + k < cnt;
     const uint32_t s = (syms >> (8 * k)) & 0xffu;
+#ifdef PCO_EXP_NOLOOKUP   // (ablation builds only: no LDS bin lookups)
+    ob[k] = act ? 8u + (s & 1u) : 0u; low[k] = (LV)s;
+#else
     ob[k] = act ? (uint32_t)obs[s] : 0u;
     low[k] = act ? (LV)lowers[s] : (LV)0;
+#endif
     t += ob[k];
   }
   const uint32_t incl = wave_incl_scan(t);
@@ -914,7 +982,9 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
       }
       // ---- ordered: delta decode, batch after batch ----
       if (ordered) {
+#ifndef PCO_EXP_NOTURN   // (ablation builds only: timing without the batch-to-batch chain; the output is garbage)
         while (__hip_atomic_load((uint32_t*)turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != batch) __builtin_amdgcn_s_sleep(1);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (dk[1] == kDeltaConsecutive) consecutive_decode<L>(prim, dord[1], moments0);
         if (present[2] && dk[2] == kDeltaConsecutive) consecutive_decode<L>(sec, dord[2], moments1);
@@ -1017,6 +1087,9 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
         for (int k = 0; k < 4; k++) outv[k] = join_one<L>(mode_kind, num_kind, mode_base, mode_k, prim[k], sec[k]);
         const uint32_t i0 = 4 * lane;
         L PCO_GLOBAL* o = dst + j0 + i0;
+#ifdef PCO_EXP_NOSTORE   // (ablation builds only: the kernel without its output stream)
+        if ((outv[0] ^ outv[1] ^ outv[2] ^ outv[3]) == (L)0x9e3779b97f4a7c15ull)
+#endif
         if (i0 + 4 <= batch_n && (((uintptr_t)o) & 15) == 0) {
           if constexpr (sizeof(L) == 8) {
             typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -1037,156 +1110,6 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
       const uint32_t status = turn[1] ? PCO_GFX_CORRUPTION : PCO_GFX_OK;
       PcoGfxTaskResult r; r.n_out = status == PCO_GFX_OK ? n : 0; r.consumed = plan->consumed; r.status = status; r.aux = plan->more; results[ti] = r;
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// fused_expander: waves 1..3 of dec_walk_kernel<L, 8, true>.  Wave e takes the chunks of slots e - 1, e + 2, e + 5 (below 8), batch after
-// batch in turn, each as soon as the walker has published it.  What dec_expand_kernel keeps in LDS comes from elsewhere here: the bins'
-// lowers and offset bits are gathered from the bins area (2 KB per variable, L1-resident), a lane cuts its four offsets out of one
-// 64-bit window it loads at its own bit position (offsets of at most 16 bits), the delta moments live in the hand-over area.  The
-// symbols and section starts the walker wrote are read past the L1 (another wave of this CU wrote them since the line was last seen);
-// those of the next batch are requested before the current one is expanded.
-// ---------------------------------------------------------------------------------------------------------
-struct FuseVar { uint32_t n_bins, max_ob, dk, dord, nlps; };
-template <class L> struct FuseSlot {
-  bool live; uint32_t ti, n, n_batches, mode_kind, mode_k, num_kind; L mode_base; bool has_sec;
-  gcptr_u8 src; uint64_t src_len; L PCO_GLOBAL* dst;
-  FuseVar v[2];   // [0] the secondary variable, [1] the primary
-  uint32_t pf_syms[2]; uint64_t pf_start[2];   // batch b's symbol dword of this lane / section start, requested during batch b - 1
-};
-
-template <class LV>
-__device__ __forceinline__ void fused_expand_item(uint32_t syms_dword, gcptr_u8 src, uint64_t src_len, uint64_t start_bit, uint32_t cnt, bool any_ob,
-                                                  const uint64_t PCO_GLOBAL* g_low, const uint8_t PCO_GLOBAL* g_ob, bool single_bin, LV out[4]) {
-  const uint32_t lane = lane_id();
-  // the walker's layout has chain c, block b of a 64-symbol group at dword 4 c + b; this lane wants chain lane % 4 of block lane / 4
-  const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ((lane & 48u) + 4u * (lane & 3u) + ((lane >> 2) & 3u))), (int)syms_dword);
-  const uint32_t syms = single_bin ? 0u : quad_transpose_u8(mine, lane & 3);
-  uint32_t ob[4]; LV low[4]; uint32_t t = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const bool act = 4 * lane + k < cnt;
-    const uint32_t s = act ? (syms >> (8 * k)) & 0xffu : 0u;
-    ob[k] = (uint32_t)g_ob[s]; low[k] = (LV)g_low[s];
-    if (!act) { ob[k] = 0; low[k] = 0; }
-    t += ob[k];
-  }
-  if (!any_ob) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) out[k] = low[k];
-    return;
-  }
-  const uint32_t incl = wave_incl_scan(t);
-  const uint64_t bit = start_bit + (incl - t);
-  const uint64_t byte = bit >> 3; const uint32_t sh = (uint32_t)(bit & 7);
-  // t <= 64 bits from bit `sh` of the byte: nine bytes at most
-  uint64_t v64 = t ? load_u64_le_safe(src, byte, src_len + 16) >> sh : 0ull;
-  if (sh + t > 64) v64 |= (uint64_t)src[byte + 8 < src_len + 16 ? byte + 8 : 0] << (64 - sh);
-#pragma unroll
-  for (int k = 0; k < 4; k++) { out[k] = (LV)(low[k] + (LV)__builtin_amdgcn_ubfe((uint32_t)v64, 0u, ob[k])); v64 >>= ob[k]; }
-}
-
-template <class L>
-__device__ void fused_expander(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, const DecPlan* plans, const uint8_t* bins_area,
-                               const uint8_t* sym_area, uint64_t sym_stride, const uint64_t* offpos_area, uint64_t offpos_stride) {
-  typedef WalkCfg<8> Cfg;
-  const uint32_t lane = lane_id(), ew = uni(threadIdx.x >> 6) - 1;   // expander 0..3
-  uint32_t PCO_LDS* ctl = (uint32_t PCO_LDS*)(lds_base() + Cfg::kFuseCtlOff);
-  uint64_t PCO_LDS* fmom = (uint64_t PCO_LDS*)(lds_base() + Cfg::kFuseMomOff);
-  __syncthreads();   // the walker has parsed the metadata of all eight chunks, built their tables and said which chunks are ours
-  FuseSlot<L> S[kFuseSlotsPerExp];
-  auto request = [&](FuseSlot<L>& c, uint32_t b) {   // the loads whose addresses do not depend on anything the batch computes
-#pragma unroll
-    for (int sl = 0; sl < 2; sl++) {
-      c.pf_syms[sl] = 0; c.pf_start[sl] = 0;
-      if (!c.live || b >= c.n_batches || (sl == 0 && !c.has_sec)) continue;
-      const int v = sl == 1 ? 1 : 2;
-      const uint32_t n_remaining = c.n - b * kBatchN, rem = n_remaining > c.v[sl].nlps ? n_remaining - c.v[sl].nlps : 0, cnt = rem < kBatchN ? rem : kBatchN;
-      if (cnt == 0) continue;
-      const uint8_t PCO_GLOBAL* syms = (const uint8_t PCO_GLOBAL*)sym_area + ((uint64_t)c.ti * 3 + v) * sym_stride + (uint64_t)b * kBatchN;
-      if (c.v[sl].n_bins > 1 && 64 * (lane >> 4) < cnt) c.pf_syms[sl] = __hip_atomic_load((const uint32_t PCO_GLOBAL*)(syms + 4 * lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      c.pf_start[sl] = __hip_atomic_load(offpos_area + ((uint64_t)c.ti * 3 + v) * offpos_stride + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-  auto ready = [&](uint32_t slot, uint32_t b, bool& dead) -> bool {
-    const uint32_t w = uni(__hip_atomic_load(ctl + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    dead = w == kFuseDead;
-    return w > b && !dead;
-  };
-#pragma unroll
-  for (int q = 0; q < (int)kFuseSlotsPerExp; q++) {
-    FuseSlot<L>& c = S[q];
-    const uint32_t slot = ew + q * kFuseExpWaves, bi = blockIdx.x * 8 + slot;
-    c.live = slot < 8 && bi < n_ids && uni(__hip_atomic_load(ctl + (slot < 8 ? slot : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != kFuseDead;
-    c.ti = c.live ? (task_ids ? uni(task_ids[bi]) : bi) : 0u;
-    const DecPlan PCO_GLOBAL* plan = (const DecPlan PCO_GLOBAL*)plans + c.ti;
-    const PcoGfxDecodeTask PCO_GLOBAL* task = (const PcoGfxDecodeTask PCO_GLOBAL*)tasks + c.ti;
-    c.n = c.live ? uni(plan->n) : 0u; c.n_batches = (c.n + kBatchN - 1) / kBatchN;
-    c.mode_kind = uni(plan->mode_kind); c.mode_k = uni(plan->mode_k); c.num_kind = uni(plan->num_kind); c.mode_base = (L)uni((uint64_t)plan->mode_base);
-    c.has_sec = c.live && uni(plan->present[2]) != 0;
-    c.src = (gcptr_u8)(uintptr_t)uni((uint64_t)(uintptr_t)task->src); c.src_len = uni((uint64_t)task->src_len); c.dst = (L PCO_GLOBAL*)(uintptr_t)uni((uint64_t)(uintptr_t)task->dst);
-#pragma unroll
-    for (int sl = 0; sl < 2; sl++) {
-      const int v = sl == 1 ? 1 : 2;
-      c.v[sl].n_bins = uni(plan->n_bins[v]); c.v[sl].max_ob = uni(plan->max_ob[v]); c.v[sl].dk = uni(plan->delta_kind[v]); c.v[sl].dord = uni(plan->delta_order[v]); c.v[sl].nlps = uni(plan->nlps[v]);
-    }
-    c.pf_syms[0] = c.pf_syms[1] = 0; c.pf_start[0] = c.pf_start[1] = 0;
-  }
-  uint32_t have[kFuseSlotsPerExp]; for (int q = 0; q < (int)kFuseSlotsPerExp; q++) have[q] = 0xffffffffu;   // the batch whose loads are in flight / in registers, per slot
-  for (uint32_t b = 0;; b++) {
-    bool any = false;
-#pragma unroll
-    for (int q = 0; q < (int)kFuseSlotsPerExp; q++) {
-      FuseSlot<L>& c = S[q];
-      if (!c.live || b >= c.n_batches) continue;
-      any = true;
-      const uint32_t slot = ew + q * kFuseExpWaves;
-      bool dead = false;
-      while (!ready(slot, b, dead)) { if (dead) break; __builtin_amdgcn_s_sleep(8); }
-      if (dead) { c.live = false; continue; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      if (have[q] != b) request(c, b);
-      const uint32_t syms_now[2] = {c.pf_syms[0], c.pf_syms[1]}; const uint64_t start_now[2] = {uni(c.pf_start[0]), uni(c.pf_start[1])};
-      // the next batch's symbols and section starts, if the walker is already past it (usually: the expanders trail it)
-      { bool d2 = false; if (b + 1 < c.n_batches && ready(slot, b + 1, d2)) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); request(c, b + 1); have[q] = b + 1; } }
-      const uint32_t j0 = b * kBatchN, n_remaining = c.n - j0, batch_n = n_remaining < kBatchN ? n_remaining : kBatchN;
-      const uint8_t PCO_GLOBAL* bins = (const uint8_t PCO_GLOBAL*)bins_area + (uint64_t)c.ti * kBinsAreaPerTask;
-      L prim[4] = {0, 0, 0, 0}, sec[4] = {0, 0, 0, 0};
-#pragma unroll
-      for (int sl = 0; sl < 2; sl++) {
-        if (sl == 0 && !c.has_sec) continue;
-        const int v = sl == 1 ? 1 : 2;
-        const uint32_t rem = n_remaining > c.v[sl].nlps ? n_remaining - c.v[sl].nlps : 0, cnt = rem < kBatchN ? rem : kBatchN;
-        if (cnt == 0) continue;
-        const uint64_t PCO_GLOBAL* g_low = (const uint64_t PCO_GLOBAL*)(bins + (uint64_t)v * kBinsAreaPerVar);
-        const uint8_t PCO_GLOBAL* g_ob = bins + (uint64_t)v * kBinsAreaPerVar + kFastMaxBins * 8;
-        L tmp[4];
-        fused_expand_item<L>(syms_now[sl], c.src, c.src_len, start_now[sl], cnt, c.v[sl].max_ob != 0, g_low, g_ob, c.v[sl].n_bins <= 1, tmp);
-        if (sl == 1) { for (int k = 0; k < 4; k++) prim[k] = tmp[k]; } else { for (int k = 0; k < 4; k++) sec[k] = tmp[k]; }
-      }
-      // delta decode: the chunk's batches come in order, the moments wait in the hand-over area
-      if (c.v[1].dk == kDeltaConsecutive) consecutive_decode<L>(prim, c.v[1].dord, (L PCO_LDS*)(fmom + slot * 4));
-      if (c.has_sec && c.v[0].dk == kDeltaConsecutive) consecutive_decode<L>(sec, c.v[0].dord, (L PCO_LDS*)(fmom + slot * 4 + 2));
-      L outv[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) outv[k] = join_one<L>(c.mode_kind, c.num_kind, c.mode_base, c.mode_k, prim[k], sec[k]);
-      const uint32_t i0 = 4 * lane;
-      L PCO_GLOBAL* o = c.dst + j0 + i0;
-      if (i0 + 4 <= batch_n && (((uintptr_t)o) & 15) == 0) {
-        if constexpr (sizeof(L) == 8) {
-          typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-          u64x2 PCO_GLOBAL* p = (u64x2 PCO_GLOBAL*)o;
-          u64x2 a; a.x = outv[0]; a.y = outv[1]; u64x2 bb; bb.x = outv[2]; bb.y = outv[3];
-          p[0] = a; p[1] = bb;
-        } else if constexpr (sizeof(L) == 4) {
-          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-          u32x4 a; a.x = outv[0]; a.y = outv[1]; a.z = outv[2]; a.w = outv[3];
-          *(u32x4 PCO_GLOBAL*)o = a;
-        } else { for (int k = 0; k < 4; k++) o[k] = outv[k]; }
-      } else { for (int k = 0; k < 4; k++) if (i0 + k < batch_n) o[k] = outv[k]; }
-    }
-    if (!any) break;
   }
 }
 

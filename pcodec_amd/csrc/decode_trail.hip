@@ -1,0 +1,346 @@
+// decode_trail.hip -- the expanders that run UNDER the tANS walk.
+//
+// dec_walk_kernel is a latency chain: one wave per SIMD, the LDS full of tANS tables, 6.5 ms per launch whatever the launch holds, the
+// SIMDs nine tenths idle.  dec_expand_kernel then streamed for another 6 ms.  Two kernels from two streams do share the CUs
+// (scripts/micro/overlap_test.hip: a 6.6 ms LDS chase and a 6.1 ms streaming kernel finish together after 6.9 ms), so the expansion of
+// the common chunks now runs on a second stream WHILE the walk goes on, in a kernel that needs no LDS at all:
+//   * grid = one block of two waves per walker block (persistent: at most four blocks per CU, later walker blocks in later rounds); wave v
+//     follows chunk slots 4v .. 4v + 3 of its walker block, batch after batch, as the walker publishes them (progress words in global
+//     memory, 1 + completed batches; scripts/micro/handoff_test.hip is the hand-over on its own);
+//   * it takes the chunks of ONE latent variable (classic mode without lookback -- the walker marks them): the state of eight chunks per
+//     SIMD has to fit the registers the walker leaves, and a second variable per chunk does not;
+//   * a variable's bins (at most 64) live in registers, a bin per lane: bin lookup = ds_bpermute (the LDS crossbar, no LDS memory);
+//   * a lane cuts its offsets out of a 16-byte window it loads at its own bit position (one window for offsets of up to 16 bits, one
+//     per number beyond that);
+//   * the delta moments are wave-uniform registers (one wave owns a chunk from its first batch to its last: no turn-taking);
+//   * what the walker wrote is read with agent-scope loads (the two kernels may sit on different XCDs, whose L2s are not coherent with
+//     one another for plain accesses); the numbers leave through plain 16-byte stores.
+// A wave stays one batch behind the walker where it can, so that the symbols and section starts of the batch it expands were requested
+// an iteration earlier; the four chunks of a wave are expanded in lockstep (their windows in flight together).  Every wait is bounded: a
+// wave that sees no progress for about a second gives its chunk back (DecPlan::fused = 0) and dec_expand_kernel expands it afterwards.
+// Reference semantics: page_latent_decompressor.rs:15-44,89-213, delta/consecutive.rs:35-50, mode/*.rs (as dec_expand_kernel).
+#include "decode_fast.hip"
+
+namespace pcogfx {
+
+constexpr uint32_t kTrailWaves = 4;            // per walker block
+constexpr uint32_t kTrailSlotsPerWave = 2;     // wave v: chunk slots 2 v, 2 v + 1
+constexpr uint32_t kTrailSpinLimit = 1u << 18; // polls (~3.4 us apart) without progress before a wave gives up
+// DecPlan as 64 words (the expanders fetch it with one request, a word per lane)
+constexpr uint32_t kPlanN = 1, kPlanModeKind = 2, kPlanModeK = 3, kPlanModeBase = 4, kPlanNumKind = 6, kPlanPresent = 8, kPlanNBins = 11, kPlanMaxOb = 14,
+                   kPlanDeltaKind = 17, kPlanDeltaOrder = 20, kPlanNlps = 23, kPlanMoments = 28, kPlanFused = 62;
+static_assert(sizeof(DecPlan) == 256 && offsetof(DecPlan, n) == 4 * kPlanN && offsetof(DecPlan, mode_base) == 4 * kPlanModeBase && offsetof(DecPlan, num_kind) == 4 * kPlanNumKind &&
+              offsetof(DecPlan, present) == 4 * kPlanPresent && offsetof(DecPlan, n_bins) == 4 * kPlanNBins && offsetof(DecPlan, max_ob) == 4 * kPlanMaxOb &&
+              offsetof(DecPlan, delta_kind) == 4 * kPlanDeltaKind && offsetof(DecPlan, delta_order) == 4 * kPlanDeltaOrder && offsetof(DecPlan, nlps) == 4 * kPlanNlps &&
+              offsetof(DecPlan, moments) == 4 * kPlanMoments && offsetof(DecPlan, fused) == 4 * kPlanFused, "DecPlan word layout");
+
+#ifdef PCO_TRAIL_PLAINLD   // (measurement builds only: what the agent scope of the loads costs)
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+__device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) { return *(const volatile uint64_t*)p; }
+#else
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+__device__ __forceinline__ uint32_t bperm(uint32_t byte_index, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)byte_index, (int)v); }
+template <class T> __device__ __forceinline__ T bperm_t(uint32_t byte_index, T v) {
+  if constexpr (sizeof(T) == 8) return (T)(((uint64_t)bperm(byte_index, (uint32_t)((uint64_t)v >> 32)) << 32) | bperm(byte_index, (uint32_t)v));
+  else return (T)bperm(byte_index, (uint32_t)v);
+}
+
+template <class L> struct TrailChunk {
+  bool live, have;                     // have: pf_* hold batch `next`
+  uint32_t ti, n, n_batches, next;
+  uint32_t num_kind, n_bins, max_ob, dord, nlps;
+  gcptr_u8 src; uint64_t src_len; L PCO_GLOBAL* dst;
+  L tbl_low; uint32_t tbl_ob;          // lane b: lower and offset bits of bin b
+  L mom[2];                            // delta moments (wave-uniform)
+  const uint8_t* syms; const uint64_t* starts;   // the walker's output: symbols (256 per batch), section start per batch
+  uint32_t pf_syms, pf_start;          // requested for batch `next` (a section starts less than 2^32 bits into its chunk)
+  uint32_t start_live;                 // the section start of the batch between its stages A and B (pf_start is requested anew in between)
+};
+// what stage A of a batch leaves for stage B (kept small: both chunks' worth are live across the section loads).  syms: the lane's four bin
+// symbols; obs: their offset-bit counts, a byte each; excl: bits of the section before this lane's first field; s*: the section itself for
+// offsets of up to 16 bits, lane l of s_j holding its dword 64 j + l (counted from the dword the section starts in) -- fetched with one to
+// three coalesced requests and handed to the lanes that need a dword through the crossbar.  (A lane loading the 12 bytes at its own bit
+// position is one instruction and 64 addresses: the address unit took ~700 cycles over each, more than a CU has per batch.)  The lowers are
+// looked up in stage B rather than carried.
+struct TrailItem { uint32_t syms, obs, excl, s0, s1, s2; };
+
+typedef uint32_t trail_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t trail_u32x3 __attribute__((ext_vector_type(3)));
+typedef trail_u32x3 __attribute__((aligned(1))) trail_u32x3_unaligned;
+// the 96 bits from byte (bit >> 3) on; a read at any byte <= src_len stays inside the buffer's 16 bytes of slack
+__device__ __forceinline__ trail_u32x3 trail_window(gcptr_u8 src, uint64_t src_len, uint64_t bit) {
+  uint64_t byte = bit >> 3; if (byte > src_len) byte = src_len;
+  return *(const trail_u32x3_unaligned PCO_GLOBAL*)(src + byte);
+}
+
+template <class L> __device__ __forceinline__ uint32_t trail_cnt(const TrailChunk<L>& c, uint32_t batch) {
+  const uint32_t n_remaining = c.n - batch * kBatchN;
+  const uint32_t rem = n_remaining > c.nlps ? n_remaining - c.nlps : 0;
+  return rem < kBatchN ? rem : kBatchN;
+}
+
+// Request the walker's output for batch b of the chunk (addresses that depend on nothing the batch computes).  Unconditional, into
+// registers nothing else writes: a register that is zeroed first and loaded under a condition makes the compiler wait, at the zeroing, for
+// every load but the last few -- statically, whatever is really in flight (the section loads just issued, in this loop).  A batch without
+// latents of its own (the tail of a delta'd chunk) reads its slot's stale bytes; every use is masked by the latent count.
+template <class L> __device__ __forceinline__ void trail_request(TrailChunk<L>& c, uint32_t b) {
+  c.pf_syms = ld_agent((const uint32_t*)(c.syms + (uint64_t)b * kBatchN) + lane_id());
+  c.pf_start = ld_agent((const uint32_t*)(c.starts + b));
+  c.have = true;
+}
+
+// Stage A: symbols -> offset-bit counts (register table), their prefix over the wave, the window load issued.
+template <class L> __device__ __forceinline__ void trail_stage_a(const TrailChunk<L>& c, uint32_t cnt, TrailItem& it) {
+  const uint32_t lane = lane_id();
+  // the walker's layout has chain c, block b of a 64-symbol group at dword 4 c + b; this lane wants chain lane % 4 of block lane / 4
+  const uint32_t mine = bperm(4u * ((lane & 48u) + 4u * (lane & 3u) + ((lane >> 2) & 3u)), c.pf_syms);
+  it.syms = c.n_bins <= 1 ? 0u : quad_transpose_u8(mine, lane & 3);
+  uint32_t t = 0; it.obs = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t looked = bperm(4u * ((it.syms >> (8 * k)) & 63u), c.tbl_ob);   // (by every lane: a lane that sat out would read as zero for the lanes that index it)
+    const uint32_t o = 4 * lane + k < cnt ? looked : 0u;
+    it.obs |= o << (8 * k); t += o;
+  }
+  it.excl = c.max_ob == 0 ? 0u : wave_incl_scan(t) - t;
+}
+
+// The section of a batch (offsets of up to 16 bits: at most 4096 bits + the dwords a lane's 64-bit window may reach into), requested as soon
+// as its start is known: dword 64 j + lane of the section, counted from the dword it starts in.  Reads are clamped to the buffer's 16 bytes of slack.
+template <class L> __device__ __forceinline__ void trail_section(const TrailChunk<L>& c, uint32_t cnt, TrailItem& it) {
+  const uint32_t lane = lane_id();
+  const uint32_t d0 = c.start_live >> 5, nd = c.max_ob <= 16 ? (((c.start_live & 31u) + cnt * c.max_ob + 31u) >> 5) + 2u : 0u;   // (uniform)
+  const uint32_t last = (uint32_t)((c.src_len + 12) >> 2);
+  auto dword = [&](uint32_t i) -> uint32_t { const uint32_t dw = d0 + i < last ? d0 + i : last; return load_u32_le(c.src + 4ull * dw); };
+  it.s0 = dword(lane);
+  if (nd > 64) it.s1 = dword(64 + lane);
+  if (nd > 128) it.s2 = dword(128 + lane);
+}
+
+// Stage B: the lowers (register table), the offsets cut from the window, their sum.
+template <class L> __device__ __forceinline__ void trail_stage_b(const TrailChunk<L>& c, uint32_t cnt, const TrailItem& it, L out[4]) {
+  const uint32_t lane = lane_id();
+  L low[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const L lo = bperm_t<L>(4u * ((it.syms >> (8 * k)) & 63u), c.tbl_low); low[k] = 4 * lane + k < cnt ? lo : (L)0; }
+  if (c.max_ob == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = low[k];
+    return;
+  }
+  uint64_t bit = (uint64_t)c.start_live + it.excl;
+  if (c.max_ob <= 16) {
+    // the lane's four fields span at most 64 bits from bit `rel` of the fetched section: dwords di, di + 1, di + 2 come out of the lanes that hold them
+    const uint32_t rel = (c.start_live & 31u) + it.excl, di = rel >> 5, sh = rel & 31u;
+    const uint32_t nd = (((c.start_live & 31u) + cnt * c.max_ob + 31u) >> 5) + 2u;   // (uniform, as in trail_section)
+    uint32_t w0, w1, w2;
+    if (nd <= 64) { w0 = bperm(4u * di, it.s0); w1 = bperm(4u * di + 4u, it.s0); w2 = bperm(4u * di + 8u, it.s0); }   // (indices past lane 63 wrap: only bits no field uses come from there)
+    else {
+      auto fetch = [&](uint32_t i) -> uint32_t {
+        const uint32_t a = bperm(4u * (i & 63u), it.s0), b = bperm(4u * (i & 63u), it.s1), cc = bperm(4u * (i & 63u), it.s2);
+        return i < 64 ? a : (i < 128 ? b : cc);
+      };
+      w0 = fetch(di); w1 = fetch(di + 1); w2 = fetch(di + 2);
+    }
+    uint64_t v64 = ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t o = (it.obs >> (8 * k)) & 0xffu;
+      out[k] = (L)(low[k] + (L)__builtin_amdgcn_ubfe((uint32_t)v64, 0u, o));
+      v64 >>= o;
+    }
+    return;
+  }
+  // wider offsets: a window per number, all four requested together (their latency is paid here: the chunks that need this are the ones
+  // with near-incompressible offsets, whose walk is short of work anyway)
+  trail_u32x3 w[4]; uint32_t shk[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { w[k] = trail_window(c.src, c.src_len, bit); shk[k] = (uint32_t)(bit & 7); bit += (it.obs >> (8 * k)) & 0xffu; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t o = (it.obs >> (8 * k)) & 0xffu;
+    const uint64_t v64 = ((uint64_t)__builtin_amdgcn_alignbit(w[k].z, w[k].y, shk[k]) << 32) | __builtin_amdgcn_alignbit(w[k].y, w[k].x, shk[k]);
+    const uint64_t val = o >= 64 ? v64 : (v64 & (((uint64_t)1 << o) - 1));
+    out[k] = (L)(low[k] + (L)val);
+  }
+}
+
+// consecutive_decode (decode_kernel.hip) with the moments in registers
+template <class L> __device__ __forceinline__ void trail_delta(L x[4], uint32_t order, L mom[2]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) x[k] = (L)(x[k] + lmid<L>());
+#pragma unroll
+  for (int m = 1; m >= 0; m--) {
+    if ((uint32_t)m >= order) continue;
+    const L e1 = x[0], e2 = (L)(e1 + x[1]), e3 = (L)(e2 + x[2]), t = (L)(e3 + x[3]);
+    const L incl = wave_incl_scan(t);
+    const L base = (L)(mom[m] + (L)(incl - t));
+    x[0] = base; x[1] = (L)(base + e1); x[2] = (L)(base + e2); x[3] = (L)(base + e3);
+    mom[m] = (L)(mom[m] + wave_last(incl));
+  }
+}
+
+#ifdef PCO_TRAIL_TIMING
+__device__ unsigned long long g_trail_timing[8];   // block 0, wave 0: iterations, poll, stage A, requests, stage B (s_memtime units), idle polls
+#define TT_NOW() __builtin_readcyclecounter()
+#define TT_ADD(i, t0) do { const unsigned long long _n = TT_NOW(); tt[i] += _n - (t0); (t0) = _n; } while (0)
+#else
+#define TT_ADD(i, t0) do { } while (0)
+#endif
+template <class L>
+__global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_eu(5, 5))) void dec_trail_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
+                                                                     const uint8_t* bins_area, const uint8_t* sym_area, uint64_t sym_stride,
+                                                                     const uint64_t* offpos_area, uint64_t offpos_stride, const uint32_t* progress,
+                                                                     uint32_t n_walk_blocks) {
+  const uint32_t lane = lane_id(), wave = uni(threadIdx.x >> 6);
+  for (uint32_t wb = blockIdx.x; wb < n_walk_blocks; wb += gridDim.x) {
+    TrailChunk<L> S[kTrailSlotsPerWave];
+    const uint32_t* pline = progress + (uint64_t)wb * kTrailProgressStride + (lane & 7u);
+    // ---- the chunks' constants, once their walker has parsed the metadata (it publishes all eight slots together) ----
+    uint32_t pv = 0;
+    {
+      uint32_t tries = 0;
+      for (;;) {
+        pv = ld_agent(pline);
+        bool all = true;
+#pragma unroll
+        for (int q = 0; q < (int)kTrailSlotsPerWave; q++) if (wb * 8 + wave * kTrailSlotsPerWave + q < n_ids && (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)(wave * kTrailSlotsPerWave + q)) == 0) all = false;
+        if (all || ++tries > kTrailSpinLimit) break;
+        __builtin_amdgcn_s_sleep(64);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < (int)kTrailSlotsPerWave; q++) {
+      TrailChunk<L>& c = S[q];
+      const uint32_t slot = wave * kTrailSlotsPerWave + q, bi = wb * 8 + slot;
+      c.live = bi < n_ids; c.have = false; c.next = 0;
+      const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)slot);
+      if (p0 == 0 || p0 == kTrailDead) c.live = false;   // (0: never started within the time limit -- the walker still owns the chunk, DecPlan::fused is not set)
+      c.ti = c.live ? (task_ids ? uni(task_ids[bi]) : bi) : 0u;
+      // the plan is 64 words: lane i fetches word i (one request), the fields come out of the lanes
+      const uint32_t pw = ld_agent((const uint32_t*)(plans + c.ti) + lane);
+      auto word = [&](uint32_t i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)pw, (int)i); };
+      auto word64 = [&](uint32_t i) -> uint64_t { return (uint64_t)word(i) | ((uint64_t)word(i + 1) << 32); };
+      if (c.live && word(kPlanFused) == 0) c.live = false;
+      // (the walker never marks a chunk this kernel cannot take; belt and braces)
+      if (c.live && (word(kPlanModeKind) != kClassic || word(kPlanPresent) != 0 || word(kPlanPresent + 2) != 0 || word(kPlanNBins + 1) > kTrailMaxBins)) c.live = false;
+      const PcoGfxDecodeTask* task = tasks + c.ti;
+      c.n = c.live ? word(kPlanN) : 0u; c.n_batches = (c.n + kBatchN - 1) / kBatchN;
+      c.num_kind = word(kPlanNumKind);
+      c.src = (gcptr_u8)(uintptr_t)uni((uint64_t)(uintptr_t)task->src); c.src_len = uni((uint64_t)task->src_len); c.dst = (L PCO_GLOBAL*)(uintptr_t)uni((uint64_t)(uintptr_t)task->dst);
+      c.n_bins = word(kPlanNBins + 1); c.max_ob = word(kPlanMaxOb + 1); c.nlps = word(kPlanNlps + 1);
+      c.dord = word(kPlanDeltaKind + 1) == kDeltaConsecutive ? word(kPlanDeltaOrder + 1) : 0u;
+      if (c.dord > 2) c.live = false;
+      c.mom[0] = (L)word64(kPlanMoments); c.mom[1] = (L)word64(kPlanMoments + 2);
+      c.syms = sym_area + ((uint64_t)c.ti * 3 + 1) * sym_stride; c.starts = offpos_area + ((uint64_t)c.ti * 3 + 1) * offpos_stride;
+      c.tbl_low = 0; c.tbl_ob = 0; c.pf_syms = 0; c.pf_start = 0; c.start_live = 0;
+      if (c.live && lane < c.n_bins) {
+        const uint8_t* bins = bins_area + (uint64_t)c.ti * kBinsAreaPerTask + kBinsAreaPerVar;   // the primary variable's area
+        c.tbl_low = (L)ld_agent((const uint64_t*)bins + lane);
+        c.tbl_ob = (ld_agent((const uint32_t*)(bins + kFastMaxBins * 8) + (lane >> 2)) >> (8 * (lane & 3))) & 0xffu;
+      }
+    }
+    // ---- batch after batch, the wave's chunks in lockstep ----
+    uint32_t idle = 0;
+#ifdef PCO_TRAIL_TIMING
+    unsigned long long tt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tt0 = TT_NOW();
+#endif
+    for (;;) {
+      bool any_live = false, did = false;
+      uint32_t ready[kTrailSlotsPerWave];
+#pragma unroll
+      for (int q = 0; q < (int)kTrailSlotsPerWave; q++) {
+        TrailChunk<L>& c = S[q];
+        ready[q] = 0;
+        if (!c.live) continue;
+        if (c.next >= c.n_batches) { c.live = false; continue; }
+        any_live = true;
+        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)(wave * kTrailSlotsPerWave + q));
+        if (p == kTrailDead) { c.live = false; continue; }   // the walker met an error: it reports it, nothing more to expand
+        const uint32_t done = p - 1;                          // batches whose symbols and section starts are out
+        if (done <= c.next) continue;
+        if (!c.have) trail_request(c, c.next);
+        // stay one batch behind the walker unless it has finished the chunk: the requests of the batch after this one can then go out
+        // under this one's windows, and have the rest of the iteration to come back
+        if (done < c.n_batches && done < c.next + 2) continue;
+        ready[q] = done;
+      }
+      if (!any_live) break;
+      TT_ADD(1, tt0);
+      TrailItem it[kTrailSlotsPerWave];
+      uint32_t cnts[kTrailSlotsPerWave];
+#pragma unroll
+      for (int q = 0; q < (int)kTrailSlotsPerWave; q++) it[q].s1 = it[q].s2 = 0;   // (before anything of this iteration is in flight)
+#pragma unroll
+      for (int q = 0; q < (int)kTrailSlotsPerWave; q++) {
+        TrailChunk<L>& c = S[q];
+        if (!ready[q]) continue;
+        did = true;
+        cnts[q] = trail_cnt(c, c.next);
+        c.start_live = uni(c.pf_start);
+        trail_section(c, cnts[q], it[q]);      // (first: it only waits for the section start; the symbol work below runs under it)
+        trail_stage_a(c, cnts[q], it[q]);
+      }
+      TT_ADD(2, tt0);
+      // behind the windows (loads return in order: a request issued before them would be waited for with them): the requests for the
+      // batches after these, and the progress words for the next iteration -- trips to another XCD's memory side, microseconds long
+#pragma unroll
+      for (int q = 0; q < (int)kTrailSlotsPerWave; q++) {
+        TrailChunk<L>& c = S[q];
+        if (!ready[q]) continue;
+        c.have = false;
+        if (c.next + 1 < c.n_batches && ready[q] > c.next + 1) trail_request(c, c.next + 1);
+      }
+      const uint32_t pv_next = ld_agent(pline);
+      TT_ADD(3, tt0);
+#pragma unroll
+      for (int q = 0; q < (int)kTrailSlotsPerWave; q++) {
+        TrailChunk<L>& c = S[q];
+        if (!ready[q]) continue;
+        const uint32_t b = c.next;
+        L prim[4];
+        trail_stage_b(c, cnts[q], it[q], prim);
+        if (c.dord) trail_delta<L>(prim, c.dord, c.mom);
+        L outv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) outv[k] = from_latent_ordered<L>(prim[k], c.num_kind);   // classic join (mode/classic.rs:14-24)
+        const uint32_t j0 = b * kBatchN, n_remaining = c.n - j0, batch_n = n_remaining < kBatchN ? n_remaining : kBatchN;
+        const uint32_t i0 = 4 * lane;
+        L PCO_GLOBAL* o = c.dst + j0 + i0;
+        if (i0 + 4 <= batch_n && (((uintptr_t)o) & 15) == 0) {
+          if constexpr (sizeof(L) == 8) {
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            u64x2 PCO_GLOBAL* p2 = (u64x2 PCO_GLOBAL*)o;
+            u64x2 a; a.x = outv[0]; a.y = outv[1]; u64x2 bb; bb.x = outv[2]; bb.y = outv[3];
+            p2[0] = a; p2[1] = bb;
+          } else if constexpr (sizeof(L) == 4) {
+            trail_u32x4 a; a.x = outv[0]; a.y = outv[1]; a.z = outv[2]; a.w = outv[3];
+            *(trail_u32x4 PCO_GLOBAL*)o = a;
+          } else { for (int k = 0; k < 4; k++) o[k] = outv[k]; }
+        } else { for (int k = 0; k < 4; k++) if (i0 + k < batch_n) o[k] = outv[k]; }
+        c.next = b + 1;
+      }
+      TT_ADD(4, tt0);
+#ifdef PCO_TRAIL_TIMING
+      tt[0]++; if (!did) tt[5]++;
+#endif
+      if (did) { idle = 0; pv = pv_next; continue; }
+      __builtin_amdgcn_s_sleep(127);
+      pv = ld_agent(pline);
+      if (++idle > kTrailSpinLimit) {
+        // no progress for about a second: the walker is not running beside us (or is stuck).  Give the chunks back: dec_expand_kernel
+        // expands a chunk whose plan says fused = 0 from its first batch, after both kernels have ended.
+#pragma unroll
+        for (int q = 0; q < (int)kTrailSlotsPerWave; q++) if (S[q].live && lane == 0) __hip_atomic_store(&plans[S[q].ti].fused, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+#ifdef PCO_TRAIL_TIMING
+    if (blockIdx.x == 0 && wave == 0 && lane == 0) for (int i = 0; i < 8; i++) g_trail_timing[i] = tt[i];
+#endif
+  }
+}
+
+}  // namespace pcogfx

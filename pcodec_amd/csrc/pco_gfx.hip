@@ -22,7 +22,7 @@
 
 #include "pco_auto_host.inc"
 #include "decode_kernel.hip"
-#include "decode_fast.hip"
+#include "decode_trail.hip"   // (includes decode_fast.hip, which includes decode_kernel.hip)
 #include "encode_kernels.hip"
 #include "encode_lookback.hip"
 #include "encode_hist_select.hip"
@@ -116,10 +116,19 @@ struct ScopedKernelTimer {
 // ---------------------------------------------------------------------------------------------------------
 static uint32_t g_decode_lds_bytes = 16 * 1024;  // dynamic LDS per wave (fixed area + tANS tables)
 static bool g_decode_fast = std::getenv("PCO_GFX_NO_FAST_DECODE") == nullptr;  // A/B switch for the two-kernel path
-// A/B switch: expand inside the walker's block (dec_walk_kernel<L, 8, true>).  Measured and NOT the default: an expander wave needs ~10 k
-// cycles per batch whatever kernel it runs in, so the expansion wants ~24 waves per CU, and a kernel that also holds the walker (LDS full
-// at four blocks, ~117 VGPRs) has room for 12: 13.7 - 16.5 ms against 6.5 + 6.25 ms for the two kernels back to back.
-static bool g_decode_fused = [] { const char* e = std::getenv("PCO_GFX_DEC_FUSED"); return e && e[0] == '1'; }();
+// The expanders of the common chunks run on a second stream UNDER the walk (decode_trail.hip); PCO_GFX_DEC_TRAIL=0 keeps the two kernels
+// back to back (A/B switch).
+static bool g_decode_trail = [] { const char* e = std::getenv("PCO_GFX_DEC_TRAIL"); return !(e && e[0] == '0'); }();
+// measurement switches: 's' = the expanders on the walker's own stream (after it, nothing overlaps), 'n' = no expanders at all (the output is garbage)
+static char g_trail_debug = [] { const char* e = std::getenv("PCO_GFX_TRAIL_DEBUG"); return e ? e[0] : '\0'; }();
+
+// the workspace's second stream and the two events that fork it off the caller's stream and join it again
+static void ensure_side_stream(Workspace& ws) {
+  if (!ws.side_stream) PCO_HIP_CHECK(hipStreamCreateWithFlags(&ws.side_stream, hipStreamNonBlocking));
+  if (!ws.fork_event) PCO_HIP_CHECK(hipEventCreateWithFlags(&ws.fork_event, hipEventDisableTiming));
+  if (!ws.join_event) PCO_HIP_CHECK(hipEventCreateWithFlags(&ws.join_event, hipEventDisableTiming));
+  if (!ws.n_cus) { hipDeviceProp_t prop; PCO_HIP_CHECK(hipGetDeviceProperties(&prop, ws.device)); ws.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+}
 
 static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results,
                           PcoGfxTaskResult* d_results_user, hipStream_t stream) {
@@ -171,13 +180,32 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     const uint32_t* idp = mixed ? d_ids + id_off[g] : nullptr;
     const uint32_t* filt = fast ? (const uint32_t*)d_plans : nullptr;
     const uint32_t fstride = (uint32_t)(sizeof(DecPlan) / 4);
-    if (fast) {  // walk with 8 chunks per wave, then with 4 for the chunks whose tables did not fit, then expand
+    if (fast) {  // walk with 8 chunks per wave (the common chunks expanded on the side stream meanwhile), then with 4 for the chunks whose tables did not fit, then expand the rest
+      const uint32_t n_wb = (cnt + 7) / 8;
+      uint32_t* d_progress = nullptr;
+      if (g_decode_trail) {
+        ensure_side_stream(ws);
+        d_progress = (uint32_t*)ws.dec_progress.ensure((size_t)n_wb * kTrailProgressStride * sizeof(uint32_t));
+        PCO_HIP_CHECK(hipMemsetAsync(d_progress, 0, (size_t)n_wb * kTrailProgressStride * sizeof(uint32_t), stream));
+      }
+      // (persistent expander grid: at most four blocks of four waves per CU, so that every walker block finds its wave slot, registers and LDS
+      //  whatever the order in which the two kernels' blocks arrive)
+      const uint32_t trail_grid = g_decode_trail ? std::min<uint32_t>(n_wb, (uint32_t)ws.n_cus * 4u) : 0u;
 #define PCO_FAST_DECODE(L, name)                                                                                                                          \
-      if (g_decode_fused) PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8, true>), dim3((cnt + 7) / 8), dim3(64 * (1 + kFuseExpWaves)), WalkCfg<8>::kFuseLdsBytes, stream,   \
+      if (g_decode_trail) {                                                                                                                               \
+        ScopedKernelTimer _span("dec_walk+trail<" name ">", stream);                                                                                      \
+        PCO_HIP_CHECK(hipEventRecord(ws.fork_event, stream));                                                                                             \
+        PCO_TIMED_LAUNCH("~dec_walk_kernel<" name ">", stream, (dec_walk_trail_kernel<L>), dim3(n_wb), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,       \
+                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_results, d_progress);                          \
+        hipStream_t ts = g_trail_debug == 's' ? stream : ws.side_stream;                                                                                  \
+        PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream, ws.fork_event, 0));                                                                              \
+        if (g_trail_debug != 'n') PCO_TIMED_LAUNCH("~dec_trail_kernel<" name ">", ts, (dec_trail_kernel<L>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
+                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);                               \
+        PCO_HIP_CHECK(hipEventRecord(ws.join_event, ws.side_stream));                                                                                     \
+        PCO_HIP_CHECK(hipStreamWaitEvent(stream, ws.join_event, 0));                                                                                      \
+      } else PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8>), dim3(n_wb), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,          \
                        d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results);                                    \
-      else PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8, false>), dim3((cnt + 7) / 8), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,   \
-                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results);                                    \
-      PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4, false>), dim3((cnt + 3) / 4), dim3(64), WalkCfg<4>::kWalkLdsBytes, stream,  \
+      PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4>), dim3((cnt + 3) / 4), dim3(64), WalkCfg<4>::kWalkLdsBytes, stream,   \
                        d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4, d_results);                       \
       PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, (dec_expand_kernel<L, false>), dim3(grid), dim3(256), kExpLdsBytes, stream,               \
                        d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);                                        \
@@ -445,6 +473,11 @@ enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size
 #include "pco_gfx_encode_api.inc"
 #include "pco_gfx_comm.inc"
 
+#ifdef PCO_TRAIL_TIMING
+extern "C" int pco_gfx_debug_trail_timing(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_trail_timing), 64);
+}
+#endif
 #ifdef PCO_WALK_TIMING
 extern "C" int pco_gfx_debug_walk_timing(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_walk_timing), 64);

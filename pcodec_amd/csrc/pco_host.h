@@ -68,6 +68,9 @@ struct Workspace {
   hipStream_t last_stream = nullptr; hipEvent_t last_event = nullptr; bool has_last = false;
   DevBuf tasks, results, tbl_ws;          // decode
   DevBuf dec_plans, dec_bins, dec_sym, dec_offpos;  // decode fast path
+  DevBuf dec_progress;                               // ... and the walker -> trailing-expander hand-over words (decode_trail.hip)
+  hipStream_t side_stream = nullptr; hipEvent_t fork_event = nullptr, join_event = nullptr;   // the expanders' stream (created on first use)
+  int n_cus = 0;
   DevBuf dec_hist;                                   // decode: scratch for a delta'd secondary variable's lookback history (rare)
   DevBuf io_in, io_out;                   // staging for the host-buffer entry points
   DevBuf compact_tasks;                   // pco_gfx_compact_chunks
@@ -77,7 +80,7 @@ struct Workspace {
   DevBuf auto_idx, auto_samp, auto_tasks, auto_sum, auto_log2;  // Auto spec resolution
   HostBuf h_samp, h_sum;                             // ... and its read-backs
   void release_all() {
-    tasks.release(); results.release(); tbl_ws.release(); dec_plans.release(); dec_bins.release(); dec_sym.release(); dec_offpos.release(); dec_hist.release(); io_in.release(); io_out.release(); compact_tasks.release();
+    tasks.release(); results.release(); tbl_ws.release(); dec_plans.release(); dec_bins.release(); dec_sym.release(); dec_offpos.release(); dec_progress.release(); dec_hist.release(); io_in.release(); io_out.release(); compact_tasks.release();
     enc_state.release(); enc_lat.release(); enc_sort.release(); enc_ans.release(); enc_small.release(); enc_lb.release(); enc_walk.release(); enc_sym.release(); enc_answ.release(); enc_bat.release(); enc_run.release(); enc_fstate.release(); enc_vlut.release(); auto_idx.release(); auto_samp.release(); auto_tasks.release(); auto_sum.release(); auto_log2.release(); h_samp.release(); h_sum.release();
   }
 };

@@ -3,9 +3,6 @@
 for F in 1 0; do
   for W in "c2 8192" "c3 8192" "c5 12288" "c1 16384"; do
     set -- $W
-    PCO_GFX_DEC_FUSED=$F python bench.py --workload $1 --chunks $2 --steps 5 --warmup 1 --no-cpu-baseline --no-others --verify-chunks 64 2>/dev/null | python -c "
-import json,sys
-d=json.load(sys.stdin); k=d['roofline']['per_kernel_ms_per_step']
-print('fused=$F $1 $2: value', d['value'], 'enc', d['config']['encode_GBps'], 'dec', d['config']['decode_GBps'], {x:k[x] for x in k if x.startswith('dec_') and k[x] > 0.05})"
+    PCO_GFX_DEC_FUSED=$F python bench.py --workload $1 --chunks $2 --steps 5 --warmup 1 --no-cpu-baseline --no-others --verify-chunks 64 2>/dev/null | python scripts/bench_brief.py 0.05 "fused=$F $1 $2:"
   done
 done
