@@ -413,6 +413,27 @@ __device__ unsigned long long g_walk_timing[8];
 // orders up to 2 on the primary variable only) are marked DecPlan::fused and their progress is published batch by batch (decode_trail.hip);
 // everything the expanders read -- symbols, section starts, progress -- leaves through agent-scope stores, the plans and bins through
 // one agent-scope release after the table build.
+// Does any of the (up to eight) chunks of walker block `wb` look like one the trailing expanders take?  A glance at the chunk preamble
+// (standalone/decompressor.rs:190-231: type byte, 24-bit count, then ChunkMeta's 4 mode bits and 4 delta bits): a plain one-chunk task in
+// classic mode without lookback / Conv1.  The two first-stage walkers split the blocks by this -- the one that publishes its progress pays
+// ~0.7 us a round for it (agent-scope stores, a wait), which a call of float-mult or lookback chunks should not.  The precise test (bins
+// that fit a wave's registers, delta order <= 2) is the publishing walker's, after it has parsed the metadata.
+__device__ __forceinline__ bool block_has_trail_candidate(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, uint32_t wb) {
+  const uint32_t lane = lane_id(), bi = wb * 8 + (lane & 7u);
+  bool cand = false;
+  if (lane < 8 && bi < n_ids) {
+    const PcoGfxDecodeTask t = tasks[task_ids ? task_ids[bi] : bi];
+    const uint32_t fmt = (t.flags & PCO_GFX_TASK_ONE_CHUNK) && ((t.flags >> 8) & 0xffu) ? (t.flags >> 8) & 0xffu : 4u;
+    if ((t.flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY | PCO_GFX_TASK_HAS_FILE_HEADER)) == 0 && t.src_len >= 12 && fmt >= 3) {
+      const uint64_t w = load_u64_le((gcptr_u8)t.src + 4);   // mode (4 bits) | delta variant (4) | [order (3) | secondary uses delta (1)] | ans_size_log (4) | n_bins (15)
+      const uint32_t mode = (uint32_t)w & 15u, dv = (uint32_t)(w >> 4) & 15u;
+      const uint32_t n_bins = (uint32_t)(w >> (dv == kDeltaConsecutive ? 16 : 12)) & 0x7fffu;
+      cand = mode == kClassic && (dv == kDeltaNone || dv == kDeltaConsecutive) && n_bins > 1 && n_bins <= kTrailMaxBins;   // (one bin: nothing to walk, nothing to hide the expansion under)
+    }
+  }
+  return uni((uint32_t)__any(cand)) != 0;
+}
+
 template <class L, uint32_t kWQ, bool kTrail>
 __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                               uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
@@ -424,6 +445,14 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
 #endif
   const uint32_t lane = lane_id();
   const uint32_t slot = lane >> 2, j = lane & 3;
+  if constexpr (kTrail) {   // the blocks without a candidate belong to the ordinary walker (launched beside this one); their expanders are told at once
+    if (!block_has_trail_candidate(tasks, task_ids, n_ids, blockIdx.x)) {
+      if (lane < 8) __hip_atomic_store(progress + (uint64_t)blockIdx.x * kTrailProgressStride + lane, kTrailDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  } else if constexpr (kWQ == 8) {
+    if (progress != nullptr && accept_status == 0 && block_has_trail_candidate(tasks, task_ids, n_ids, blockIdx.x)) return;   // (progress != nullptr: the publishing walker runs too and takes this block)
+  }
   // ---- phase 0: metadata + tables, one task at a time with the whole wave; slot q belongs to lanes 4q..4q+3 ----
   uint32_t my_ti = 0xffffffffu, my_active = 0, my_front_ok = 0, my_n = 0, my_flags = 0;
   uint32_t st0 = 0, st1 = 0, st2 = 0;   // this lane's chain state per variable, as an entry address
@@ -470,10 +499,10 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
   uint32_t PCO_GLOBAL* my_progress = nullptr;
   if constexpr (kTrail) {
     // which of the wave's chunks the trailing expanders take: ONE latent variable (classic mode, no lookback -- the state of eight chunks
-    // per SIMD has to fit the registers this kernel leaves), bins that fit one wave's registers, delta orders up to 2 (moments in
-    // registers).  The others go to dec_expand_kernel.
+    // per SIMD has to fit the registers this kernel leaves), 2..64 bins (they live in one wave's registers), offsets of up to 16 bits (a
+    // lane's four fields in one 64-bit window), delta orders up to 2 (moments in registers).  The others go to dec_expand_kernel.
     if (my_active && slot < kWQ) {
-      my_fused = vinfo[0].present == 0 && vinfo[2].present == 0 && vinfo[1].n_bins <= kTrailMaxBins;
+      my_fused = vinfo[0].present == 0 && vinfo[2].present == 0 && vinfo[1].n_bins > 1 && vinfo[1].n_bins <= kTrailMaxBins && vinfo[1].max_ob <= 16;   // (offsets beyond 16 bits: four windows per lane, a job for dec_expand_kernel's LDS staging; one bin: nothing to walk, nothing to hide under)
       if (vinfo[1].delta_kind == kDeltaConsecutive ? vinfo[1].delta_order > 2 : vinfo[1].delta_kind != kDeltaNone) my_fused = false;
     }
     if (slot < kWQ) my_progress = (uint32_t PCO_GLOBAL*)progress + (uint64_t)blockIdx.x * kTrailProgressStride + slot;
@@ -481,6 +510,7 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // plans and bins (plain stores of the table build) are visible to every XCD from here on
     if (j == 0 && slot < kWQ) __hip_atomic_store((uint32_t*)my_progress, my_fused ? 1u : kTrailDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   QuadMasks qm = {j >= 1 ? ~0u : 0u, j >= 2 ? ~0u : 0u, j >= 3 ? ~0u : 0u, 63u};
   asm volatile("" : "+v"(qm.m1), "+v"(qm.m2), "+v"(qm.m3), "+v"(qm.c63));   // opaque, so that they stay VGPR operands of v_and_b32_dpp
@@ -587,7 +617,8 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
     if (walk) {
       r.e = *(const uint32_t PCO_LDS*)(uintptr_t)r.saddr;
       walk_window(r, 0u);
-      if constexpr (kTrail && kTrailDefer) d_sym_out = sym_out;
+      constexpr bool defer = kTrail && kTrailDefer;
+      if constexpr (defer) d_sym_out = sym_out;
       if (__all(!walk || cnt == kBatchN)) {   // (lanes outside `walk` are masked off here anyway)
 #pragma unroll
         for (uint32_t grp = 0; grp < 4; grp++) {   // (unrolled: the trailing form keeps the four groups in registers until the next round)
@@ -600,12 +631,12 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
             walk_step<3, false>(r, qm, tbl_addr, true);
             acc[b] = r.symacc;
           }
-          if constexpr (kTrail && kTrailDefer) d_acc[grp] = acc; else store_syms<kTrail>(sym_out + 64 * grp, acc);
+          if constexpr (defer) d_acc[grp] = acc; else store_syms<kTrail>(sym_out + 64 * grp, acc);
         }
-        if constexpr (kTrail && kTrailDefer) d_ngrp = 4;
+        if constexpr (defer) d_ngrp = 4;
       } else {
         const uint32_t steps = (cnt + 3) >> 2;
-        if constexpr (kTrail && kTrailDefer) d_ngrp = (steps + 15) >> 4;
+        if constexpr (defer) d_ngrp = (steps + 15) >> 4;
 #pragma unroll
         for (uint32_t grp = 0; grp < 4; grp++) {
           if (grp * 16 >= steps) break;
@@ -622,7 +653,7 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
               acc[b] = r.symacc;
             }
           }
-          if constexpr (kTrail && kTrailDefer) d_acc[grp] = acc; else store_syms<kTrail>(sym_out + 64 * grp, acc);
+          if constexpr (defer) d_acc[grp] = acc; else store_syms<kTrail>(sym_out + 64 * grp, acc);
         }
       }
       if (cur_v == 0) st0 = r.saddr; else if (cur_v == 1) st1 = r.saddr; else st2 = r.saddr;
@@ -705,11 +736,12 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
   }
 }
 
+// split != nullptr (first stage only): the publishing walker runs beside this one and takes the blocks with a candidate for the trailing expanders
 template <class L, uint32_t kWQ>
 __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                                       uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
-                                                      uint32_t accept_status, PcoGfxTaskResult* results) {
-  dec_walk_body<L, kWQ, false>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, accept_status, results, nullptr);
+                                                      uint32_t accept_status, PcoGfxTaskResult* results, uint32_t* split) {
+  dec_walk_body<L, kWQ, false>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, accept_status, results, split);
 }
 // The walker that publishes its progress to the trailing expanders: at most 128 VGPRs (four waves per SIMD's worth -- what the ordinary
 // walker takes), so that two expander waves of up to 192 fit beside it on every SIMD.  Tighter caps do not pay: at 80 or 96 the per-round
@@ -721,6 +753,34 @@ __global__ __launch_bounds__(64) PCO_TRAIL_WALK_ATTR void dec_walk_trail_kernel(
                                                       uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
                                                       PcoGfxTaskResult* results, uint32_t* progress) {
   dec_walk_body<L, 8, true>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, 0u, results, progress);
+}
+
+// A full batch of 64-bit numbers, four per lane in element order, stored as two instructions that each cover one contiguous KB (lane l:
+// bytes [16 l, 16 l + 16) of the KB).  Written where they sit -- 32 bytes per lane, two 16-byte stores at a 32-byte lane stride -- every
+// store instruction touches half of each line it reaches: twice the write requests per byte, 3.4 TB/s of output where contiguous
+// instructions reach 6-7 (scripts/micro/bw_test.hip), and the walker's own loads queue behind them.  The 16-byte units 2 m (numbers 4 m,
+// 4 m + 1) and 2 m + 1 (4 m + 2, 4 m + 3) sit in lane m; v_permlane32_swap puts the units of lanes 0-31 into one register set (even units in
+// lanes 0-31, odd ones in lanes 32-63) and those of lanes 32-63 into the other, and one crossbar read per dword brings unit l to lane l.
+__device__ __forceinline__ void store_u64_batch(unsigned long long PCO_GLOBAL* batch_base, const unsigned long long (&x)[4]) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t lane = lane_id();
+  const uint32_t from = 4u * (((lane & 1u) << 5) + (lane >> 1));   // (byte address of the source lane for the crossbar)
+  const uint32_t a[4] = {(uint32_t)x[0], (uint32_t)(x[0] >> 32), (uint32_t)x[1], (uint32_t)(x[1] >> 32)};
+  const uint32_t b[4] = {(uint32_t)x[2], (uint32_t)(x[2] >> 32), (uint32_t)x[3], (uint32_t)(x[3] >> 32)};
+  u32x4 s1, s2;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a[j], b[j], false, false);   // r[0] = {a lanes 0-31, b lanes 0-31}, r[1] = {a lanes 32-63, b lanes 32-63}
+    s1[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from, (int)r[0]); s2[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from, (int)r[1]);
+  }
+  u32x4 PCO_GLOBAL* o = (u32x4 PCO_GLOBAL*)batch_base + lane;
+  // (non-temporal: nobody on this device reads the numbers back, and kept out of the L2 they leave the walker's prefetched lines alone --
+  //  11.1 -> 10.4 ms per 8192 chunks)
+#ifdef PCO_DEC_PLAINSTORE
+  o[0] = s1; o[64] = s2;
+#else
+  __builtin_nontemporal_store(s1, o); __builtin_nontemporal_store(s2, o + 64);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1090,7 +1150,9 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
 #ifdef PCO_EXP_NOSTORE   // (ablation builds only: the kernel without its output stream)
         if ((outv[0] ^ outv[1] ^ outv[2] ^ outv[3]) == (L)0x9e3779b97f4a7c15ull)
 #endif
-        if (i0 + 4 <= batch_n && (((uintptr_t)o) & 15) == 0) {
+        if (sizeof(L) == 8 && batch_n == kBatchN && (((uintptr_t)(dst + j0)) & 15) == 0) {   // (uniform: a full batch to an aligned place)
+          if constexpr (sizeof(L) == 8) { const unsigned long long y[4] = {outv[0], outv[1], outv[2], outv[3]}; store_u64_batch((unsigned long long PCO_GLOBAL*)(dst + j0), y); }
+        } else if (i0 + 4 <= batch_n && (((uintptr_t)o) & 15) == 0) {
           if constexpr (sizeof(L) == 8) {
             typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
             u64x2 PCO_GLOBAL* p = (u64x2 PCO_GLOBAL*)o;

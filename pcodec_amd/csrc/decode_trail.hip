@@ -1,24 +1,31 @@
 // decode_trail.hip -- the expanders that run UNDER the tANS walk.
 //
 // dec_walk_kernel is a latency chain: one wave per SIMD, the LDS full of tANS tables, 6.5 ms per launch whatever the launch holds, the
-// SIMDs nine tenths idle.  dec_expand_kernel then streamed for another 6 ms.  Two kernels from two streams do share the CUs
+// SIMDs more than half idle.  dec_expand_kernel then streamed for another 6 ms.  Two kernels from two streams do share the CUs
 // (scripts/micro/overlap_test.hip: a 6.6 ms LDS chase and a 6.1 ms streaming kernel finish together after 6.9 ms), so the expansion of
 // the common chunks now runs on a second stream WHILE the walk goes on, in a kernel that needs no LDS at all:
-//   * grid = one block of two waves per walker block (persistent: at most four blocks per CU, later walker blocks in later rounds); wave v
-//     follows chunk slots 4v .. 4v + 3 of its walker block, batch after batch, as the walker publishes them (progress words in global
-//     memory, 1 + completed batches; scripts/micro/handoff_test.hip is the hand-over on its own);
-//   * it takes the chunks of ONE latent variable (classic mode without lookback -- the walker marks them): the state of eight chunks per
-//     SIMD has to fit the registers the walker leaves, and a second variable per chunk does not;
-//   * a variable's bins (at most 64) live in registers, a bin per lane: bin lookup = ds_bpermute (the LDS crossbar, no LDS memory);
-//   * a lane cuts its offsets out of a 16-byte window it loads at its own bit position (one window for offsets of up to 16 bits, one
-//     per number beyond that);
+//   * grid = one block of four waves per walker block (persistent: at most four blocks per CU, later walker blocks in later rounds); wave v
+//     follows chunk slots 2v and 2v + 1 of its walker block, batch after batch, as the walker publishes them (progress words in global
+//     memory, 1 + completed batches; scripts/micro/handoff_test.hip is the hand-over on its own).  96 VGPRs a wave: four of them and the
+//     walker's 128 are a SIMD's 512;
+//   * it takes the chunks of ONE latent variable with 2..64 bins and offsets of up to 16 bits (classic mode without lookback -- the walker
+//     marks them): the state of eight chunks per SIMD has to fit the registers the walker leaves, and a second variable does not;
+//   * the bins live in registers, a bin per lane: bin lookup = ds_bpermute (the LDS crossbar, no LDS memory);
+//   * a batch's offset section is fetched with coalesced requests (lane l: dword l from the dword the section starts in) and a lane gets
+//     the three dwords its four fields lie in through the crossbar (a lane loading 12 bytes at its own bit position is 64 addresses an
+//     instruction: the address unit took ~700 cycles over each);
 //   * the delta moments are wave-uniform registers (one wave owns a chunk from its first batch to its last: no turn-taking);
 //   * what the walker wrote is read with agent-scope loads (the two kernels may sit on different XCDs, whose L2s are not coherent with
-//     one another for plain accesses); the numbers leave through plain 16-byte stores.
-// A wave stays one batch behind the walker where it can, so that the symbols and section starts of the batch it expands were requested
-// an iteration earlier; the four chunks of a wave are expanded in lockstep (their windows in flight together).  Every wait is bounded: a
-// wave that sees no progress for about a second gives its chunk back (DecPlan::fused = 0) and dec_expand_kernel expands it afterwards.
-// Reference semantics: page_latent_decompressor.rs:15-44,89-213, delta/consecutive.rs:35-50, mode/*.rs (as dec_expand_kernel).
+//     one another for plain accesses); the numbers leave as contiguous non-temporal KBs (store_u64_batch, decode_fast.hip).
+// A wave stays one batch behind the walker where it can, so that the symbols and section start of the batch it expands were requested
+// an iteration earlier; its two chunks are expanded in lockstep -- in the steady state as straight-line code (trail_fast_pair).  Loads are
+// unconditional and into registers nothing else writes: a register zeroed first and loaded under a condition makes the compiler wait, at
+// the zeroing, for every load but the last few, whatever is really in flight.  Every wait is bounded: a wave that sees no progress for
+// about a second gives its chunks back (DecPlan::fused = 0) and dec_expand_kernel expands them afterwards.
+// Measured (8192 chunks of 2^18 u64, delta 1): walk 6.5 + expand 6.2 ms back to back -> 10.6 ms together (the publishing walker alone 7.2,
+// these expanders alone 5.6; without the expanders' output stream the pair takes 9.2: what is left is the two kernels' contention for the
+// memory system and the issue slots, not the hand-over -- a build that ignores the progress words finishes in 10.0).
+// Reference semantics: page_latent_decompressor.rs:15-44,89-213, delta/consecutive.rs:35-50, mode/classic.rs:14-24 (as dec_expand_kernel).
 #include "decode_fast.hip"
 
 namespace pcogfx {
@@ -49,6 +56,7 @@ template <class T> __device__ __forceinline__ T bperm_t(uint32_t byte_index, T v
 
 template <class L> struct TrailChunk {
   bool live, have;                     // have: pf_* hold batch `next`
+  bool fast_ok;                        // the common shape: several bins, offsets of 1..7 bits (a full batch's section fits one register across the wave), aligned output
   uint32_t ti, n, n_batches, next;
   uint32_t num_kind, n_bins, max_ob, dord, nlps;
   gcptr_u8 src; uint64_t src_len; L PCO_GLOBAL* dst;
@@ -57,6 +65,7 @@ template <class L> struct TrailChunk {
   const uint8_t* syms; const uint64_t* starts;   // the walker's output: symbols (256 per batch), section start per batch
   uint32_t pf_syms, pf_start;          // requested for batch `next` (a section starts less than 2^32 bits into its chunk)
   uint32_t start_live;                 // the section start of the batch between its stages A and B (pf_start is requested anew in between)
+  uint32_t sec; bool sec_valid;        // fast path: batch `next`'s section (dword `lane` from the dword it starts in) was requested at the end of the batch before
 };
 // what stage A of a batch leaves for stage B (kept small: both chunks' worth are live across the section loads).  syms: the lane's four bin
 // symbols; obs: their offset-bit counts, a byte each; excl: bits of the section before this lane's first field; s*: the section itself for
@@ -67,14 +76,6 @@ template <class L> struct TrailChunk {
 struct TrailItem { uint32_t syms, obs, excl, s0, s1, s2; };
 
 typedef uint32_t trail_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t trail_u32x3 __attribute__((ext_vector_type(3)));
-typedef trail_u32x3 __attribute__((aligned(1))) trail_u32x3_unaligned;
-// the 96 bits from byte (bit >> 3) on; a read at any byte <= src_len stays inside the buffer's 16 bytes of slack
-__device__ __forceinline__ trail_u32x3 trail_window(gcptr_u8 src, uint64_t src_len, uint64_t bit) {
-  uint64_t byte = bit >> 3; if (byte > src_len) byte = src_len;
-  return *(const trail_u32x3_unaligned PCO_GLOBAL*)(src + byte);
-}
-
 template <class L> __device__ __forceinline__ uint32_t trail_cnt(const TrailChunk<L>& c, uint32_t batch) {
   const uint32_t n_remaining = c.n - batch * kBatchN;
   const uint32_t rem = n_remaining > c.nlps ? n_remaining - c.nlps : 0;
@@ -153,18 +154,9 @@ template <class L> __device__ __forceinline__ void trail_stage_b(const TrailChun
     }
     return;
   }
-  // wider offsets: a window per number, all four requested together (their latency is paid here: the chunks that need this are the ones
-  // with near-incompressible offsets, whose walk is short of work anyway)
-  trail_u32x3 w[4]; uint32_t shk[4];
+  // (offsets beyond 16 bits never come here: the walker leaves those chunks to dec_expand_kernel)
 #pragma unroll
-  for (int k = 0; k < 4; k++) { w[k] = trail_window(c.src, c.src_len, bit); shk[k] = (uint32_t)(bit & 7); bit += (it.obs >> (8 * k)) & 0xffu; }
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t o = (it.obs >> (8 * k)) & 0xffu;
-    const uint64_t v64 = ((uint64_t)__builtin_amdgcn_alignbit(w[k].z, w[k].y, shk[k]) << 32) | __builtin_amdgcn_alignbit(w[k].y, w[k].x, shk[k]);
-    const uint64_t val = o >= 64 ? v64 : (v64 & (((uint64_t)1 << o) - 1));
-    out[k] = (L)(low[k] + (L)val);
-  }
+  for (int k = 0; k < 4; k++) out[k] = low[k];
 }
 
 // consecutive_decode (decode_kernel.hip) with the moments in registers
@@ -180,6 +172,87 @@ template <class L> __device__ __forceinline__ void trail_delta(L x[4], uint32_t 
     x[0] = base; x[1] = (L)(base + e1); x[2] = (L)(base + e2); x[3] = (L)(base + e3);
     mom[m] = (L)(mom[m] + wave_last(incl));
   }
+}
+
+// The steady state of a wave -- both its chunks have a full batch ready, in the common shape (TrailChunk::fast_ok) -- as straight-line code:
+// no per-chunk branches, so that the two chunks' lookup / scan / fetch chains (each a string of crossbar and DPP round trips that nothing
+// else in the wave covers) are scheduled into one another.  Returns the progress words requested for the next iteration.
+template <class L>
+__device__ __forceinline__ uint32_t trail_fast_pair(TrailChunk<L> (&S)[kTrailSlotsPerWave], const uint32_t (&ready)[kTrailSlotsPerWave], const uint32_t* pline) {
+  static_assert(kTrailSlotsPerWave == 2, "written for two chunks per wave");
+  const uint32_t lane = lane_id();
+  const uint32_t layout = 4u * ((lane & 48u) + 4u * (lane & 3u) + ((lane >> 2) & 3u));
+  uint32_t syms[2], obs[2], excl[2];
+  auto request_section = [&](TrailChunk<L>& c) {   // one register: at most 56 + 3 dwords; reads clamped into the buffer's 16 bytes of slack
+    c.start_live = uni(c.pf_start);
+    const uint32_t d0 = c.start_live >> 5, last = (uint32_t)((c.src_len + 12) >> 2);
+    const uint32_t dw = d0 + lane < last ? d0 + lane : last;
+    c.sec = load_u32_le(c.src + 4ull * dw);
+  };
+  // ---- stage A of both: the section if the last iteration has not asked for it already, symbols -> offset bits -> their prefix ----
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    TrailChunk<L>& c = S[q];
+    if (!c.sec_valid) request_section(c);
+    syms[q] = quad_transpose_u8(bperm(layout, c.pf_syms), lane & 3);
+    uint32_t t = 0, o4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t o = bperm(4u * ((syms[q] >> (8 * k)) & 63u), c.tbl_ob); o4 |= o << (8 * k); t += o; }
+    obs[q] = o4; excl[q] = wave_incl_scan(t) - t;
+  }
+  // ---- behind the section loads: the next batches' requests, the next iteration's progress words ----
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    TrailChunk<L>& c = S[q];
+    c.have = false;
+    if (c.next + 1 < c.n_batches && ready[q] > c.next + 1) trail_request(c, c.next + 1);
+  }
+  const uint32_t pv_next = ld_agent(pline);
+  // ---- stage B of both.  Before a batch's numbers are stored the NEXT batch's section is asked for: the memory counter of a wave is one
+  // in-order queue of loads and stores, so a load issued behind the stores would be waited for together with their acknowledgement
+  // (written-through output: microseconds) -- this way the stores have a whole iteration to drain before anything behind them is needed.
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    TrailChunk<L>& c = S[q];
+    L x[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = bperm_t<L>(4u * ((syms[q] >> (8 * k)) & 63u), c.tbl_low);
+    const uint32_t rel = (c.start_live & 31u) + excl[q], di = rel >> 5, sh = rel & 31u;
+    const uint32_t w0 = bperm(4u * di, c.sec), w1 = bperm(4u * di + 4u, c.sec), w2 = bperm(4u * di + 8u, c.sec);
+    uint64_t v64 = ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t o = (obs[q] >> (8 * k)) & 0xffu;
+      x[k] = (L)(x[k] + (L)__builtin_amdgcn_ubfe((uint32_t)v64, 0u, o));
+      v64 >>= o;
+    }
+    if (c.dord) trail_delta<L>(x, c.dord, c.mom);
+    L PCO_GLOBAL* o = c.dst + (uint64_t)c.next * kBatchN + 4 * lane;
+    c.sec_valid = false;
+    if (c.have && c.n - (c.next + 1) * kBatchN >= kBatchN + c.nlps) { request_section(c); c.sec_valid = true; }   // (a full batch follows and its start has been asked for)
+#ifdef PCO_TRAIL_NOSTORE   // (measurement builds only)
+    if ((x[0] ^ x[1] ^ x[2] ^ x[3]) == (L)0x9e3779b97f4a7c15ull)
+#endif
+    if constexpr (sizeof(L) == 8) {
+#ifdef PCO_TRAIL_OLDSTORE
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      u64x2 a; a.x = from_latent_ordered<L>(x[0], c.num_kind); a.y = from_latent_ordered<L>(x[1], c.num_kind);
+      u64x2 b; b.x = from_latent_ordered<L>(x[2], c.num_kind); b.y = from_latent_ordered<L>(x[3], c.num_kind);
+      ((u64x2 PCO_GLOBAL*)o)[0] = a; ((u64x2 PCO_GLOBAL*)o)[1] = b;
+#else
+      const unsigned long long y[4] = {from_latent_ordered<L>(x[0], c.num_kind), from_latent_ordered<L>(x[1], c.num_kind), from_latent_ordered<L>(x[2], c.num_kind), from_latent_ordered<L>(x[3], c.num_kind)};
+      store_u64_batch((unsigned long long PCO_GLOBAL*)(c.dst + (uint64_t)c.next * kBatchN), y);
+#endif
+    } else if constexpr (sizeof(L) == 4) {
+      trail_u32x4 a; a.x = from_latent_ordered<L>(x[0], c.num_kind); a.y = from_latent_ordered<L>(x[1], c.num_kind); a.z = from_latent_ordered<L>(x[2], c.num_kind); a.w = from_latent_ordered<L>(x[3], c.num_kind);
+      __builtin_nontemporal_store(a, (trail_u32x4 PCO_GLOBAL*)o);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) o[k] = from_latent_ordered<L>(x[k], c.num_kind);
+    }
+    c.next++;
+  }
+  return pv_next;
 }
 
 #ifdef PCO_TRAIL_TIMING
@@ -225,7 +298,7 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
       auto word64 = [&](uint32_t i) -> uint64_t { return (uint64_t)word(i) | ((uint64_t)word(i + 1) << 32); };
       if (c.live && word(kPlanFused) == 0) c.live = false;
       // (the walker never marks a chunk this kernel cannot take; belt and braces)
-      if (c.live && (word(kPlanModeKind) != kClassic || word(kPlanPresent) != 0 || word(kPlanPresent + 2) != 0 || word(kPlanNBins + 1) > kTrailMaxBins)) c.live = false;
+      if (c.live && (word(kPlanModeKind) != kClassic || word(kPlanPresent) != 0 || word(kPlanPresent + 2) != 0 || word(kPlanNBins + 1) > kTrailMaxBins || word(kPlanMaxOb + 1) > 16)) c.live = false;
       const PcoGfxDecodeTask* task = tasks + c.ti;
       c.n = c.live ? word(kPlanN) : 0u; c.n_batches = (c.n + kBatchN - 1) / kBatchN;
       c.num_kind = word(kPlanNumKind);
@@ -236,6 +309,8 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
       c.mom[0] = (L)word64(kPlanMoments); c.mom[1] = (L)word64(kPlanMoments + 2);
       c.syms = sym_area + ((uint64_t)c.ti * 3 + 1) * sym_stride; c.starts = offpos_area + ((uint64_t)c.ti * 3 + 1) * offpos_stride;
       c.tbl_low = 0; c.tbl_ob = 0; c.pf_syms = 0; c.pf_start = 0; c.start_live = 0;
+      c.sec = 0; c.sec_valid = false;
+      c.fast_ok = c.n_bins > 1 && c.max_ob >= 1 && c.max_ob <= 7 && (((uintptr_t)c.dst) & 15) == 0;
       if (c.live && lane < c.n_bins) {
         const uint8_t* bins = bins_area + (uint64_t)c.ti * kBinsAreaPerTask + kBinsAreaPerVar;   // the primary variable's area
         c.tbl_low = (L)ld_agent((const uint64_t*)bins + lane);
@@ -259,7 +334,11 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
         any_live = true;
         const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)(wave * kTrailSlotsPerWave + q));
         if (p == kTrailDead) { c.live = false; continue; }   // the walker met an error: it reports it, nothing more to expand
+#ifdef PCO_TRAIL_CHEAT   // (measurement builds only: take the previous, identical call's symbols as if the walker had finished -- contention without the hand-over)
+        const uint32_t done = c.n_batches;
+#else
         const uint32_t done = p - 1;                          // batches whose symbols and section starts are out
+#endif
         if (done <= c.next) continue;
         if (!c.have) trail_request(c, c.next);
         // stay one batch behind the walker unless it has finished the chunk: the requests of the batch after this one can then go out
@@ -269,6 +348,17 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
       }
       if (!any_live) break;
       TT_ADD(1, tt0);
+#ifndef PCO_TRAIL_NOFAST
+      if (ready[0] && ready[1] && S[0].fast_ok && S[1].fast_ok && S[0].n - S[0].next * kBatchN >= kBatchN + S[0].nlps && S[1].n - S[1].next * kBatchN >= kBatchN + S[1].nlps) {
+        pv = trail_fast_pair<L>(S, ready, pline);
+        idle = 0;
+        TT_ADD(4, tt0);
+#ifdef PCO_TRAIL_TIMING
+        tt[0]++; tt[6]++;
+#endif
+        continue;
+      }
+#endif
       TrailItem it[kTrailSlotsPerWave];
       uint32_t cnts[kTrailSlotsPerWave];
 #pragma unroll
@@ -320,7 +410,7 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
             *(trail_u32x4 PCO_GLOBAL*)o = a;
           } else { for (int k = 0; k < 4; k++) o[k] = outv[k]; }
         } else { for (int k = 0; k < 4; k++) if (i0 + k < batch_n) o[k] = outv[k]; }
-        c.next = b + 1;
+        c.next = b + 1; c.sec_valid = false;
       }
       TT_ADD(4, tt0);
 #ifdef PCO_TRAIL_TIMING

@@ -125,6 +125,8 @@ static char g_trail_debug = [] { const char* e = std::getenv("PCO_GFX_TRAIL_DEBU
 // the workspace's second stream and the two events that fork it off the caller's stream and join it again
 static void ensure_side_stream(Workspace& ws) {
   if (!ws.side_stream) PCO_HIP_CHECK(hipStreamCreateWithFlags(&ws.side_stream, hipStreamNonBlocking));
+  if (!ws.side_stream2) PCO_HIP_CHECK(hipStreamCreateWithFlags(&ws.side_stream2, hipStreamNonBlocking));
+  if (!ws.join_event2) PCO_HIP_CHECK(hipEventCreateWithFlags(&ws.join_event2, hipEventDisableTiming));
   if (!ws.fork_event) PCO_HIP_CHECK(hipEventCreateWithFlags(&ws.fork_event, hipEventDisableTiming));
   if (!ws.join_event) PCO_HIP_CHECK(hipEventCreateWithFlags(&ws.join_event, hipEventDisableTiming));
   if (!ws.n_cus) { hipDeviceProp_t prop; PCO_HIP_CHECK(hipGetDeviceProperties(&prop, ws.device)); ws.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
@@ -201,12 +203,18 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
         PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream, ws.fork_event, 0));                                                                              \
         if (g_trail_debug != 'n') PCO_TIMED_LAUNCH("~dec_trail_kernel<" name ">", ts, (dec_trail_kernel<L>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
                          d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);                               \
+        /* the blocks without a candidate for the expanders: the ordinary walker, beside the two (every block runs in exactly one of the walkers) */ \
+        PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream2, ws.fork_event, 0));                                                                             \
+        PCO_TIMED_LAUNCH("~dec_walk_kernel(rest)<" name ">", ws.side_stream2, (dec_walk_kernel<L, 8>), dim3(n_wb), dim3(64), WalkCfg<8>::kWalkLdsBytes, ws.side_stream2, \
+                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results, d_progress);                      \
+        PCO_HIP_CHECK(hipEventRecord(ws.join_event2, ws.side_stream2));                                                                                   \
         PCO_HIP_CHECK(hipEventRecord(ws.join_event, ws.side_stream));                                                                                     \
         PCO_HIP_CHECK(hipStreamWaitEvent(stream, ws.join_event, 0));                                                                                      \
+        PCO_HIP_CHECK(hipStreamWaitEvent(stream, ws.join_event2, 0));                                                                                     \
       } else PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8>), dim3(n_wb), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,          \
-                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results);                                    \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results, (uint32_t*)nullptr);                \
       PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4>), dim3((cnt + 3) / 4), dim3(64), WalkCfg<4>::kWalkLdsBytes, stream,   \
-                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4, d_results);                       \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4, d_results, (uint32_t*)nullptr);   \
       PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, (dec_expand_kernel<L, false>), dim3(grid), dim3(256), kExpLdsBytes, stream,               \
                        d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);                                        \
       PCO_TIMED_LAUNCH("dec_expand_lb_kernel<" name ">", stream, (dec_expand_kernel<L, true>), dim3(grid), dim3(256), kExpLbLdsBytes, stream,           \

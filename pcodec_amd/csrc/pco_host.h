@@ -69,7 +69,7 @@ struct Workspace {
   DevBuf tasks, results, tbl_ws;          // decode
   DevBuf dec_plans, dec_bins, dec_sym, dec_offpos;  // decode fast path
   DevBuf dec_progress;                               // ... and the walker -> trailing-expander hand-over words (decode_trail.hip)
-  hipStream_t side_stream = nullptr; hipEvent_t fork_event = nullptr, join_event = nullptr;   // the expanders' stream (created on first use)
+  hipStream_t side_stream = nullptr, side_stream2 = nullptr; hipEvent_t fork_event = nullptr, join_event = nullptr, join_event2 = nullptr;   // the expanders' stream and the ordinary walker's (created on first use)
   int n_cus = 0;
   DevBuf dec_hist;                                   // decode: scratch for a delta'd secondary variable's lookback history (rare)
   DevBuf io_in, io_out;                   // staging for the host-buffer entry points
