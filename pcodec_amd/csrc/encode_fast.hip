@@ -1040,6 +1040,7 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
 }
 
 // grid pages * runs_per_page, 64 threads
+// (left at the ~124 VGPRs it wants: at 80 / 64 -- six / eight waves per SIMD -- it spills and takes 9.1 / 21 ms instead of 5.0)
 __global__ __launch_bounds__(64) void enc_pack_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
   const uint32_t p = blockIdx.x / fx.runs_per_page, run = blockIdx.x % fx.runs_per_page;
   if (p >= n_pages) return;

@@ -489,8 +489,11 @@ __device__ __forceinline__ void enc_split_mode(const EncWorkspace& ws, const Pco
 // 16-bit latents (EncChunk::c16_ok == 1).  enc_split_kernel<false>: full-width latents for the chunks whose c16_ok == want --
 // 0: never speculated (launched when the call has such chunks), 2: the speculation failed (launched after the <true> kernel;
 // the blocks of all other chunks leave at once, which several tiles per block keep cheap).
+// (Eight waves per SIMD -- 64 VGPRs -- for the one-tile kernels: a block issues its loads, computes, stores and leaves, so what is in flight per
+//  CU is what its resident blocks hold, and at 100 VGPRs (five blocks) the kernel sat at 3.9 TB/s of its own traffic; at 64: 5.7 TB/s,
+//  5.3 -> 3.8 ms per 8192 chunks.  The looping form spills at 64 and is launched for stragglers only.)
 template <bool kSpec, bool kLoop>
-__global__ __launch_bounds__(256) void enc_split_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, uint32_t tiles_per_page, uint32_t tiles_per_block, uint32_t want) {
+__global__ __launch_bounds__(256, kLoop ? 1 : 8) void enc_split_kernel(EncWorkspace ws, const PcoGfxEncodeTask* tasks, uint32_t tiles_per_page, uint32_t tiles_per_block, uint32_t want) {
   const uint32_t blocks_per_page = kLoop ? (tiles_per_page + tiles_per_block - 1) / tiles_per_block : tiles_per_page;
   const uint32_t page = blockIdx.x / blocks_per_page, tile0 = (blockIdx.x % blocks_per_page) * (kLoop ? tiles_per_block : 1u);
   EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + page;
