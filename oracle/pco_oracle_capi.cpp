@@ -247,6 +247,8 @@ int pco_oracle_quantize_weights_to(const uint32_t* counts, size_t n, size_t tota
 float pco_oracle_log2_approx(float x) { return log2_approx(x); }
 
 // histogram: rule = 0 literal (mutates a copy), 1 = multiset rule on sorted copy
+// TEST HOOK: 0 = the reference's literal histogram (default), 1 = the multiset rule in every encode of this thread (see train_infos)
+int pco_oracle_set_hist_rule(int rule) { hist_rule_hook() = rule; return 0; }
 int pco_oracle_histogram(const void* latents, size_t n, int latent_bits, uint32_t n_bins_log, int rule,
                          uint64_t* out_count, uint64_t* out_lower, uint64_t* out_upper, size_t* out_n, int* out_fallback) {
   return guard([&] {
@@ -255,6 +257,10 @@ int pco_oracle_histogram(const void* latents, size_t n, int latent_bits, uint32_
       std::vector<LTYPE> v((const LTYPE*)latents, (const LTYPE*)latents + n);
       std::vector<HistogramBin<LTYPE>> h; bool fb = false;
       if (rule == 0) h = histogram<LTYPE>(v.data(), n, n_bins_log, &fb);
+      else if (rule == 2) {   // the heapsort branch's tie rule on its own: apply_sorted (histograms.rs:164-206) over the whole sorted input
+        std::sort(v.begin(), v.end());
+        HistogramBuilder<LTYPE> hb(n, n_bins_log); hb.apply_sorted(v.data(), n); h = hb.dst; fb = true;
+      }
       else { std::sort(v.begin(), v.end()); h = histogram_multiset_rule<LTYPE>(v.data(), n, n_bins_log); }
       for (size_t i = 0; i < h.size(); i++) { out_count[i] = h[i].count; out_lower[i] = h[i].lower; out_upper[i] = h[i].upper; }
       *out_n = h.size(); if (out_fallback) *out_fallback = fb;

@@ -323,11 +323,17 @@ template <class L> std::vector<BinCompressionInfo<L>> optimize_bins(const std::v
 // train_infos (wrapped/chunk_compressor.rs:38-99)
 // ----------------------------------------------------------------------------
 template <class L> struct TrainedBins { std::vector<BinCompressionInfo<L>> infos; Bitlen ans_size_log = 0; std::vector<uint32_t> counts; bool hist_fallback = false; };
+// TEST HOOK (not the reference's behaviour): 1 = the encoder takes its histograms by the multiset rule, i.e. the quickselect path's result as
+// a function of the sorted latents, whatever their order -- what the GPU computes.  On an order that sends the literal algorithm into its
+// heapsort branch the two differ on ties; with the hook the tests can say EXACTLY what the GPU's bytes are in that case.
+inline int& hist_rule_hook() { static thread_local int rule = 0; return rule; }
 template <class L> TrainedBins<L> train_infos(std::vector<L> latents, Bitlen unoptimized_bins_log) {
   TrainedBins<L> t;
   if (latents.empty()) return t;
   size_t n_latents = latents.size();
-  auto unopt = histogram<L>(latents.data(), n_latents, unoptimized_bins_log, &t.hist_fallback);
+  std::vector<HistogramBin<L>> unopt;
+  if (hist_rule_hook() == 1) { std::sort(latents.begin(), latents.end()); unopt = histogram_multiset_rule<L>(latents.data(), n_latents, unoptimized_bins_log); }
+  else unopt = histogram<L>(latents.data(), n_latents, unoptimized_bins_log, &t.hist_fallback);
   Bitlen n_log_ceil = n_latents <= 1 ? 0 : ilog2_u64(n_latents - 1) + 1;
   Bitlen estimated_ans_size_log = std::min(std::min(unoptimized_bins_log + 2, (Bitlen)MAX_COMPRESSION_LEVEL), n_log_ceil);
   t.infos = optimize_bins<L>(unopt, estimated_ans_size_log);

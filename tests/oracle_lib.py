@@ -197,6 +197,12 @@ def inspect_first_chunk(data, max_bins=4096):
     return info, [bins[v, : info.n_bins[v]] for v in range(3)]
 
 
+def set_hist_rule(rule):
+    """TEST HOOK of the oracle: 1 = every encode of this thread takes its histograms by the multiset rule (what the GPU computes), 0 = the
+    reference's literal algorithm (default)."""
+    lib().pco_oracle_set_hist_rule(C.c_int(rule))
+
+
 def chunk_plan(arr, config, max_bins=4096):
     arr = np.ascontiguousarray(arr)
     info = ChunkInfo()

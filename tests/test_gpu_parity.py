@@ -563,6 +563,36 @@ def test_unsupported_requests_fail_loudly(L):
         U.gpu_simple_compress(nums, G.make_config(mode=2, mode_f64=0.1, delta=1))  # float mode on ints
 
 
+def test_the_heapsort_branch_of_the_reference_histogram(L):
+    """The one documented divergence, pinned by an input (histograms.rs:248-258).  On the two adversarial orders of
+    tests/golden/hist_fallback.npz the reference's histogram heapsorts and applies apply_sorted's tie rule; the GPU computes the quickselect
+    path's result as a function of the sorted numbers (the multiset rule).  What the GPU writes then is EXACTLY what the reference would
+    write with that rule in the histogram and everything else unchanged (the oracle's test hook) -- it differs from the reference's bytes
+    in the bins of ChunkMeta and what follows from them -- and either stream decodes to the input, on the GPU and in the oracle.
+    On the same numbers in sorted order the branch does not run and the GPU's bytes are the reference's."""
+    fx = np.load(os.path.join(HERE, "golden", "hist_fallback.npz"))
+    kw = dict(mode=1, delta=1)
+    for key in ("n5000", "n262144"):
+        x = fx[key]
+        literal = O.simple_compress(x, O.make_config(**kw))
+        O.set_hist_rule(1)
+        try:
+            multiset = O.simple_compress(x, O.make_config(**kw))
+        finally:
+            O.set_hist_rule(0)
+        _, _, fb = O.chunk_plan(x, O.make_config(**kw))
+        assert fb and literal != multiset, key
+        got = U.gpu_simple_compress(x, G.make_config(**kw))
+        assert got == multiset, key
+        info_l, bins_l = O.inspect_first_chunk(literal); info_g, bins_g = O.inspect_first_chunk(got)
+        assert info_l.n_bins[1] != info_g.n_bins[1] or not np.array_equal(bins_l[1], bins_g[1])   # where the two part: the bins
+        for blob in (got, literal):
+            assert U.bits_equal(U.gpu_simple_decompress(blob, np.uint32, x.size), x)
+            assert np.array_equal(O.simple_decompress(blob, np.uint32), x)
+        xs = np.sort(x)
+        assert U.gpu_simple_compress(xs, G.make_config(**kw)) == O.simple_compress(xs, O.make_config(**kw))
+
+
 # ------------------------------------------------------------------------------------------------ errors
 def test_truncation_and_corruption_are_reported(L):
     nums = np.array([0] * 50 + [1000] * 50, np.uint32)

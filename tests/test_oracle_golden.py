@@ -137,3 +137,36 @@ def test_asset_metadata_matches_survey():
     assert info.delta_kind == 2 and info.window_n_log == 10 and info.state_n_log == 0
     assert info.ans_size_log[0] == 7 and bins[0].tolist() == [[1, 1, 4], [127, 10, 0]]
     assert info.ans_size_log[1] == 8 and len(bins[1]) == 3
+
+
+def test_adversarial_order_sends_the_oracle_into_the_heapsort_branch():
+    """histograms.rs:248-258: after 1 + floor(log2(n + 1)) bad pivots on one recursion path the reference heapsorts and switches to
+    apply_sorted, whose tie rule differs from the quickselect path's.  No natural input reaches the branch (0 of 68 200 chunks in the
+    census); tests/golden/hist_fallback.npz holds two orders built against the literal algorithm by a McIlroy-style adversary
+    (scripts/make_hist_fallback_fixture.py) that do: the oracle reports the branch on them, its bins differ there from the multiset rule's
+    (the quickselect path's result as a function of the sorted numbers -- what the GPU computes), and both encodings decode to the input."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    fx = np.load(os.path.join(here, "golden", "hist_fallback.npz"))
+    spec = importlib.util.spec_from_file_location("mkfix", os.path.join(here, "..", "scripts", "make_hist_fallback_fixture.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    differs = lambda x: O.histogram(x.copy(), 8, rule=0)[0] != O.histogram(x.copy(), 8, rule=1)[0]
+    again, _, decided = mk.build(5000, 4, differs)          # the construction is deterministic: the committed array is its output
+    assert np.array_equal(again, fx["n5000"]) and decided == 66
+    cfg = O.make_config(mode=O.MODE_CLASSIC, delta=O.DELTA_NOOP)
+    for key in ("n5000", "n262144"):
+        x = fx[key]
+        lit, fb = O.histogram(x.copy(), 8, rule=0)
+        mul, _ = O.histogram(x.copy(), 8, rule=1)
+        assert fb and lit != mul, key
+        assert O.histogram(np.sort(x), 8, rule=0) == (mul, False)   # the same numbers in sorted order: no bad pivot, and the literal algorithm IS the multiset rule
+        _, _, plan_fb = O.chunk_plan(x, cfg)
+        assert plan_fb
+        literal = O.simple_compress(x, cfg)
+        O.set_hist_rule(1)
+        try:
+            multiset = O.simple_compress(x, cfg)
+        finally:
+            O.set_hist_rule(0)
+        assert literal != multiset
+        assert np.array_equal(O.simple_decompress(literal, np.uint32), x) and np.array_equal(O.simple_decompress(multiset, np.uint32), x)
