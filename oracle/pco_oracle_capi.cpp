@@ -247,6 +247,34 @@ int pco_oracle_quantize_weights_to(const uint32_t* counts, size_t n, size_t tota
 float pco_oracle_log2_approx(float x) { return log2_approx(x); }
 
 // histogram: rule = 0 literal (mutates a copy), 1 = multiset rule on sorted copy
+// wrapped::PageDecompressor, batch after batch (wrapped/page_decompressor.rs:115-221): decodes the page `page` of `page_n` numbers of a chunk
+// whose ChunkMeta bytes are `meta` until it is done or a batch fails.  *n_ok = the numbers of the batches decoded before the failure,
+// *err = 0 or the ErrKind of the failure, *in_meta = 1 when the page's own metadata already failed (PageDecompressor::new would have).
+int pco_oracle_wrapped_page_prefix(const uint8_t* meta, size_t meta_len, const uint8_t* page, size_t page_len, uint8_t dtype, uint8_t fmt_major,
+                                   size_t page_n, void* dst, size_t* n_ok, int* err, int* in_meta) {
+  return guard([&] {
+    dispatch_bits(dtype_bits(dtype), [&](auto tag) {
+      typedef decltype(tag) LTYPE;
+      *n_ok = 0; *err = 0; *in_meta = 0;
+      std::vector<uint8_t> pm(meta_len + MAX_BATCH_LATENT_VAR_SIZE + 64, 0);
+      std::memcpy(pm.data(), meta, meta_len);
+      BitReader rm{pm.data(), meta_len * 8, pm.size(), 0};
+      ChunkMeta cm = read_chunk_meta(rm, fmt_major, LT<LTYPE>::BITS);
+      std::vector<uint8_t> pp(page_len + MAX_BATCH_LATENT_VAR_SIZE + 64, 0);
+      if (page_len) std::memcpy(pp.data(), page, page_len);
+      BitReader r{pp.data(), page_len * 8, pp.size(), 0};
+      std::unique_ptr<ChunkDecoder<LTYPE>> cd(new ChunkDecoder<LTYPE>());
+      cd->init(cm, dtype);
+      try { cd->start_page(r, page_n); } catch (const PcoErr& e) { *err = (int)e.kind; *in_meta = 1; return; }
+      size_t done = 0;
+      while (done < page_n) {
+        const size_t bn = std::min(FULL_BATCH_N, page_n - done);
+        try { cd->read_batch(r, (LTYPE*)dst + done, bn); } catch (const PcoErr& e) { *err = (int)e.kind; break; }
+        done += bn; *n_ok = done;
+      }
+    });
+  });
+}
 // TEST HOOK: 0 = the reference's literal histogram (default), 1 = the multiset rule in every encode of this thread (see train_infos)
 int pco_oracle_set_hist_rule(int rule) { hist_rule_hook() = rule; return 0; }
 int pco_oracle_histogram(const void* latents, size_t n, int latent_bits, uint32_t n_bins_log, int rule,

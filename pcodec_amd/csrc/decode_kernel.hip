@@ -300,6 +300,7 @@ struct PageParams {
   uint64_t dict_byte; uint32_t dict_n;     // Dict mode: the dictionary's first byte in src and its length (metadata/mode.rs:138-165)
   uint32_t conv_order, conv_quant;         // Conv1 delta (metadata/delta_encoding.rs): weights and bias live in LDS (kLdsConvOff)
   void PCO_GLOBAL* sec_hist;               // lookback with a delta'd SECONDARY variable: n latents of scratch for its history (else null)
+  uint32_t* progress = nullptr;            // (wrapped pages) where to say how far a page got that then failed: 1 + the numbers of the batches before the failing one, 0 = before its first batch was reached
 };
 // Conv1 parameters in LDS, in the lookback path's "parent" area (the two deltas exclude each other): i64 bias | i64 weights[32]
 constexpr uint32_t kLdsConvOff = kLdsParentOff;
@@ -435,7 +436,7 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
           else { const L l0 = lw[0]; for (int k = 0; k < 4; k++) tmp[k] = 4 * lane + k < cnt ? l0 : (L)0; }
           if (vi == 1) { for (int k = 0; k < 4; k++) prim[k] = tmp[k]; prim_cnt = cnt; } else { for (int k = 0; k < 4; k++) sec[k] = tmp[k]; }
         }
-        if (bitpos > src_len * 8) { status = PCO_GFX_INSUFFICIENT_DATA; return; }
+        if (bitpos > src_len * 8) { status = PCO_GFX_INSUFFICIENT_DATA; if (pp.progress && n_pass == 1) *pp.progress = 1u + j0; return; }
       }
       // delta decode (delta/mod.rs:125-159)
       if (vi >= 1 && dk[vi] == kDeltaConsecutive) {
@@ -551,10 +552,11 @@ __device__ __noinline__ void decode_page_body(gcptr_u8 src, uint64_t src_len, Me
   }
   }
   if (uni(wave_or_u32(lb_oob))) { status = PCO_GFX_CORRUPTION; return; }
-  // trailing bits of the page must be zero (page_decompressor.rs:184-188)
+  // trailing bits of the page must be zero (page_decompressor.rs:184-188: checked by the call that reads the page's last batch)
   mr.bit = bitpos;
   if (!mr.drain_empty_byte()) status = PCO_GFX_CORRUPTION;
   if (!mr.in_bounds()) status = PCO_GFX_INSUFFICIENT_DATA;
+  if (status && pp.progress && n_pass == 1) *pp.progress = 1u + (n == 0 ? 0u : ((n - 1) / kBatchN) * kBatchN);
 }
 
 // Dict mode page (mode/dict.rs:70-90): the primary variable holds u32 indices into the chunk's dictionary (ChunkMeta, uncompressed, in
@@ -698,7 +700,7 @@ __device__ __noinline__ void decode_page_body_dict(gcptr_u8 src, uint64_t src_le
 template <class L>
 __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaReader& mr, uint32_t lds_table_budget,
                                          gptr_u8 tbl_ws, uint32_t format_major, uint32_t dtype, uint32_t n, L PCO_GLOBAL* dst, uint32_t& status,
-                                         bool meta_only, void PCO_GLOBAL* sec_hist = nullptr, uint32_t need_hist_status = PCO_GFX_UNSUPPORTED) {
+                                         bool meta_only, void PCO_GLOBAL* sec_hist = nullptr, uint32_t need_hist_status = PCO_GFX_UNSUPPORTED, uint32_t* progress = nullptr) {
   const uint32_t lane = lane_id();
   const uint32_t num_kind = dtype_kind(dtype);
   constexpr uint32_t LB = LBits<L>::v;
@@ -841,7 +843,7 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
   // (the only kind an encoder writes, mode/dict.rs:12-33) always does; a padded one on an 8- / 16-bit type is refused.
   if (dict && dkind == kDeltaLookback && LB < 32 && dict_n > (1u << LB)) { status = PCO_GFX_UNSUPPORTED; return; }
   if (meta_only) return;
-  PageParams pp{mode_kind, mode_k, num_kind, n, (uint64_t)mode_base, dict_byte, dict_n, dorder, conv_quant, sec_hist};
+  PageParams pp{mode_kind, mode_k, num_kind, n, (uint64_t)mode_base, dict_byte, dict_n, dorder, conv_quant, sec_hist, progress};
   if (dict) {
     if (lds_tables) decode_page_body_dict<L, true>(src, src_len, mr, tbl_lds, pp, dst, status);
     else decode_page_body_dict<L, false>(src, src_len, mr, tbl_ws, pp, dst, status);
@@ -880,15 +882,20 @@ __global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const
       format_major = (flags >> 8) & 0xffu;
       const bool meta_only = (flags & PCO_GFX_TASK_META_ONLY) != 0;
       const uint32_t n = meta_only ? 1u : (uint32_t)dst_cap;
+      uint32_t aux_body = 0;
       if (!meta_only && (dst_cap == 0 || dst_cap > kMaxEntries)) status = PCO_GFX_INVALID_ARGUMENT;
       if (!status) {
         gptr_u8 tbl_ws = tbl_ws_base ? (gptr_u8)tbl_ws_base + (uint64_t)blockIdx.x * kTblWsBytes : (gptr_u8) nullptr;
+        uint32_t progress = 0;
         decode_chunk<L>(src, src_len, mr, lds_table_budget, tbl_ws, format_major, dtype, n, (L PCO_GLOBAL*)task.dst, status, meta_only,
-                        hist_base ? (void PCO_GLOBAL*)(hist_base + hist_off[bi]) : (void PCO_GLOBAL*)nullptr, need_hist_status);
-        status = uni(status);
+                        hist_base ? (void PCO_GLOBAL*)(hist_base + hist_off[bi]) : (void PCO_GLOBAL*)nullptr, need_hist_status, &progress);
+        status = uni(status); progress = uni(progress);
         if (!status && !meta_only) n_out = n;
+        // a page that failed inside its body: the batches before the failing one are in dst (page_decompressor.rs:115-221 hands them out
+        // and fails on the call that reaches the bad batch) -- n_out says how many numbers that is, aux bit 0 that the body was reached
+        if (status && progress) { n_out = progress - 1; aux_body = 1; }
       }
-      if (lane == 0) { PcoGfxTaskResult r; r.n_out = n_out; r.consumed = mr.bit >> 3; r.status = status; r.aux = 0; results[ti] = r; }
+      if (lane == 0) { PcoGfxTaskResult r; r.n_out = n_out; r.consumed = mr.bit >> 3; r.status = status; r.aux = aux_body; results[ti] = r; }
       wave_sync_lds();
       continue;
     }

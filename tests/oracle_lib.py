@@ -197,6 +197,20 @@ def inspect_first_chunk(data, max_bins=4096):
     return info, [bins[v, : info.n_bins[v]] for v in range(3)]
 
 
+def wrapped_page_prefix(meta, page, np_dtype, page_n, fmt_major=4):
+    """wrapped::PageDecompressor batch after batch on a (possibly damaged) page: (numbers of the batches decoded before the first failure,
+    error kind or 0, whether the page's own metadata already failed)."""
+    dt = np.dtype(np_dtype)
+    out = np.zeros(max(page_n, 1), dt)
+    m = np.frombuffer(bytes(meta), np.uint8); p = np.frombuffer(bytes(page), np.uint8) if len(page) else np.zeros(1, np.uint8)
+    n_ok = C.c_size_t(0); err = C.c_int(0); in_meta = C.c_int(0)
+    rc = lib().pco_oracle_wrapped_page_prefix(m.ctypes.data_as(C.c_void_p), C.c_size_t(len(meta)), p.ctypes.data_as(C.c_void_p), C.c_size_t(len(page)),
+                                              C.c_uint8(dtype_byte(out)), C.c_uint8(fmt_major), C.c_size_t(page_n), out.ctypes.data_as(C.c_void_p),
+                                              C.byref(n_ok), C.byref(err), C.byref(in_meta))
+    _check(rc)
+    return out[: n_ok.value], int(err.value), bool(in_meta.value)
+
+
 def set_hist_rule(rule):
     """TEST HOOK of the oracle: 1 = every encode of this thread takes its histograms by the multiset rule (what the GPU computes), 0 = the
     reference's literal algorithm (default)."""

@@ -269,3 +269,50 @@ def test_standalone_exact_paging(L):
         code = L.pco_gfx_simple_compress_into_exact(nums.ctypes.data_as(C.c_void_p), C.c_size_t(10), C.c_ubyte(1), C.byref(cfg), C.c_int(0), arr, C.c_size_t(2),
                                                     dst.ctypes.data_as(C.c_void_p), C.c_size_t(4096), C.byref(w))
         assert code == G.PcoCompressionError and L.pco_gfx_last_status() == G.ST_INVALID_ARGUMENT
+
+
+def test_a_page_that_fails_in_batch_k_hands_out_the_batches_before_k(L):
+    """wrapped/page_decompressor.rs:115-221: the reference decodes a page batch by batch, so a truncated page yields its intact batches and
+    fails on the call that reaches the first batch it cannot finish; a page whose own metadata is cut fails in PageDecompressor::new.  The GPU
+    decodes the page when the handle is made and reproduces that timing: same number of good numbers, same numbers, same error kind as the
+    oracle's batch-by-batch decoder, for reads of one batch, of several, and of the whole rest."""
+    rng = np.random.default_rng(21)
+    cases = [(U.synth("c2", 70000), dict(mode=1, delta=2, delta_order=1)),
+             ((rng.integers(1000, 10000, 40000) / 100.0), dict(mode=2, mode_f64=0.01, delta=1)),
+             (rng.integers(0, 1 << 32, 5000, dtype=np.uint64).astype(np.uint32), dict(mode=1, delta=1))]
+    for nums, kw in cases:
+        meta, pages, page_ns = gpu_wrapped_exact(L, nums, G.make_config(**kw), [nums.size])
+        page = pages[0]; n = page_ns[0]
+        dt = G.DTYPE_BYTE[nums.dtype.name]
+        mbuf = np.frombuffer(meta, np.uint8)
+        cd = C.c_void_p(); used = C.c_size_t(0)
+        G.check(L.pco_chunk_decompressor_new(mbuf.ctypes.data_as(C.c_void_p), C.c_size_t(len(meta)), C.c_ubyte(dt), C.c_uint8(4), C.byref(cd), C.byref(used)))
+        try:
+            for cut in sorted({3, 9, len(page) // 7, len(page) // 3, len(page) // 2, (len(page) * 9) // 10, len(page) - 1}):
+                want, err, in_meta = O.wrapped_page_prefix(meta, page[:cut], nums.dtype, n)
+                assert err == 2, (cut, err)   # InsufficientData
+                pbuf = np.frombuffer(page[:cut] if cut else b"\0", np.uint8)
+                for step in (256, 1024, n):   # one batch a call, four, everything that is left
+                    pd = C.c_void_p()
+                    code = L.pco_page_decompressor_new(cd, pbuf.ctypes.data_as(C.c_void_p), C.c_size_t(cut), C.c_size_t(n), C.byref(pd))
+                    if in_meta:
+                        assert code != 0 and L.pco_gfx_last_status() == G.ST_INSUFFICIENT_DATA, (cut, step)
+                        continue
+                    assert code == 0, (cut, step, L.pco_gfx_last_status())
+                    try:
+                        got = []
+                        while True:
+                            dst = np.zeros(step, nums.dtype); k = C.c_size_t(0); fin = C.c_int(0)
+                            code = L.pco_page_decompressor_read(pd, dst.ctypes.data_as(C.c_void_p), C.c_size_t(step), C.byref(k), C.byref(fin))
+                            if code != 0:
+                                assert L.pco_gfx_last_status() == G.ST_INSUFFICIENT_DATA
+                                break
+                            got.append(dst[: k.value]); assert not fin.value
+                        got = np.concatenate(got) if got else np.zeros(0, nums.dtype)
+                        # whole calls only: the call that reaches the bad batch fails, whatever it had decoded in front of it
+                        assert got.size == (want.size // step) * step, (cut, step, got.size, want.size)
+                        assert U.bits_equal(got, want[: got.size])
+                    finally:
+                        L.pco_page_decompressor_free(pd)
+        finally:
+            L.pco_chunk_decompressor_free(cd)
