@@ -257,6 +257,28 @@ enum PcoError pco_page_decompressor_read(PcoGfxPageDecompressor*, void* dst, siz
 size_t pco_page_decompressor_consumed(const PcoGfxPageDecompressor*);
 void pco_page_decompressor_free(PcoGfxPageDecompressor*);
 
+/* ChunkMeta accessors (wrapped/chunk_compressor.rs:549 ChunkCompressor::meta, wrapped/chunk_decompressor.rs:62 ChunkDecompressor::meta,
+ * standalone/decompressor.rs:288): what the reference's `ChunkMeta` says about a chunk -- mode, delta encoding, and per latent variable the
+ * tANS size and bin count -- read back from the metadata BYTES (the bytes pco_chunk_compressor_write_meta writes / the prefix
+ * pco_chunk_decompressor_new consumed), so a host that wants the full `ChunkMeta` (every bin) can equally hand those bytes to the
+ * reference's own ChunkMeta::read_from.  Dict mode and Conv1 delta (never written by this encoder) report their kinds; the per-variable
+ * fields are filled as far as the layout is parsed (n_vars_parsed). */
+typedef struct PcoGfxChunkMetaInfo {
+  uint32_t mode_kind;            /* 0 Classic, 1 IntMult, 2 FloatMult, 3 FloatQuant, 4 Dict (metadata/mode.rs) */
+  uint32_t mode_k;               /* FloatQuant: k */
+  uint64_t mode_base_latent;     /* IntMult / FloatMult: the base as the number type's ordered latent (to_latent_ordered) */
+  uint32_t delta_kind;           /* 0 None, 1 Consecutive, 2 Lookback, 3 Conv1 (metadata/delta_encoding.rs) */
+  uint32_t delta_order;          /* Consecutive */
+  uint32_t window_n_log, state_n_log;   /* Lookback */
+  uint32_t secondary_uses_delta;
+  uint32_t n_vars_parsed;        /* 3 when every present variable's header was reached */
+  uint32_t present[3], ans_size_log[3], n_bins[3];   /* [0] delta variable, [1] primary, [2] secondary */
+  uint64_t meta_bytes;           /* length of the ChunkMeta in bytes (when n_vars_parsed == 3) */
+} PcoGfxChunkMetaInfo;
+enum PcoError pco_gfx_chunk_meta_info(const void* meta, size_t len, unsigned char dtype, uint8_t format_major, PcoGfxChunkMetaInfo* out);
+enum PcoError pco_chunk_compressor_meta_info(const PcoGfxChunkCompressor*, unsigned char dtype, PcoGfxChunkMetaInfo* out);
+enum PcoError pco_chunk_decompressor_meta_info(const PcoGfxChunkDecompressor*, PcoGfxChunkMetaInfo* out);
+
 /* ------------------------------------------------------------------------------------------
  * 5. Chunk-sharded files over RCCL / xGMI (one process per GPU).  Chunks are independent (standalone/simple.rs:62-91: header |
  *    chunk | chunk ... | 0x00), so ranks encode contiguous blocks of chunks with no collective on the data path; assembling ONE

@@ -152,3 +152,38 @@ def test_traffic_tables_are_only_quoted_for_the_build_and_the_kernels_they_were_
     assert label("enc_lookback_kernel<LbCfg<256u, 25") == "enc_lookback_kernel<small>" and label("enc_lookback_kernel<LbCfg<1024u, 1") == "enc_lookback_kernel"
     assert label("enc_lookback_pipe_kernel<LbPipe<fa") == "enc_lookback_pipe_kernel" and label("enc_hist_select_kernel<unsigned in") == "enc_hist_select_kernel"
     assert label("enc_split_kernel<true, false>") == "enc_split_kernel<c16>" and label("pco_decode_kernel<unsigned long>") == "pco_decode_kernel<u64>"
+
+
+def test_chunk_meta_accessor_reads_what_the_oracle_wrote():
+    """include/pco_gfx.h PcoGfxChunkMetaInfo (ChunkCompressor::meta / ChunkDecompressor::meta): a host-side parse of the ChunkMeta bytes --
+    no device involved -- compared with the oracle's own reading of the same chunks; cut metadata is InsufficientData."""
+    import ctypes as C
+    import oracle_lib as O
+    from pcodec_amd import _lib as G
+
+    class Info(C.Structure):
+        _fields_ = [("mode_kind", C.c_uint32), ("mode_k", C.c_uint32), ("mode_base_latent", C.c_uint64), ("delta_kind", C.c_uint32), ("delta_order", C.c_uint32),
+                    ("window_n_log", C.c_uint32), ("state_n_log", C.c_uint32), ("secondary_uses_delta", C.c_uint32), ("n_vars_parsed", C.c_uint32),
+                    ("present", C.c_uint32 * 3), ("ans_size_log", C.c_uint32 * 3), ("n_bins", C.c_uint32 * 3), ("meta_bytes", C.c_uint64)]
+    L = G.lib()
+    rng = np.random.default_rng(8)
+    ramp = (np.uint64(1 << 40) + np.uint64(1000) * np.arange(9000, dtype=np.uint64) + rng.integers(0, 512, 9000).astype(np.uint64))
+    season = (rng.integers(-(1 << 40), 1 << 40, 365)[np.arange(9000) % 365] + rng.integers(-3, 4, 9000)).astype(np.int64)
+    cases = [(ramp, dict(mode=1, delta=2, delta_order=1)), (ramp, dict(mode=1, delta=2, delta_order=3)), (rng.integers(1000, 10000, 9000) / 100.0, dict(mode=2, mode_f64=0.01, delta=1)),
+             (season, dict(mode=1, delta=3)), ((rng.integers(0, 5000, 9000) * 77).astype(np.uint32), dict(mode=4, mode_u64=77, delta=1)),
+             (rng.standard_normal(9000).astype(np.float32), dict(mode=3, mode_u64=8, delta=1)), (ramp, dict())]
+    for nums, kw in cases:
+        meta, pages, _ = O.wrapped_compress(nums, O.make_config(**kw))
+        whole = O.simple_compress(nums, O.make_config(**kw))
+        want, _ = O.inspect_first_chunk(whole)
+        got = Info()
+        mb = np.frombuffer(meta, np.uint8)
+        assert L.pco_gfx_chunk_meta_info(mb.ctypes.data_as(C.c_void_p), C.c_size_t(len(meta)), C.c_ubyte(G.DTYPE_BYTE[nums.dtype.name]), C.c_uint8(4), C.byref(got)) == 0, kw
+        assert (got.mode_kind, got.mode_k, got.mode_base_latent, got.delta_kind, got.delta_order) == (want.mode_kind, want.mode_k, want.mode_base_latent, want.delta_kind, want.delta_order), kw
+        if got.delta_kind == 2:
+            assert (got.window_n_log, got.state_n_log) == (want.window_n_log, want.state_n_log)
+        assert got.n_vars_parsed == 3 and got.meta_bytes == len(meta)
+        assert list(got.present) == [int(bool(x)) for x in want.var_present] and list(got.n_bins) == list(want.n_bins) and list(got.ans_size_log) == list(want.ans_size_log), kw
+        for cut in (0, 1, len(meta) // 2, len(meta) - 1):
+            assert L.pco_gfx_chunk_meta_info(mb.ctypes.data_as(C.c_void_p), C.c_size_t(cut), C.c_ubyte(G.DTYPE_BYTE[nums.dtype.name]), C.c_uint8(4), C.byref(got)) != 0
+            assert L.pco_gfx_last_status() == G.ST_INSUFFICIENT_DATA, (kw, cut)
