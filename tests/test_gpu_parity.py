@@ -563,6 +563,80 @@ def test_unsupported_requests_fail_loudly(L):
         U.gpu_simple_compress(nums, G.make_config(mode=2, mode_f64=0.1, delta=1))  # float mode on ints
 
 
+def test_decode_expanders_under_the_walk(L):
+    """decode_trail.hip: the chunks of one latent variable with 2..64 bins and offsets of up to 16 bits are expanded on a second stream
+    while the tANS walk runs, eight chunks per walker block, two per expander wave.  One batched decode call whose walker blocks mix
+    such chunks with every kind the expanders must leave alone (two variables, lookback, one bin, wide offsets, more than 64 bins),
+    with short and ragged chunks (fewer than two batches, a last batch of one number, delta orders 0..3 so that the tail batches hold
+    only delta state), more chunks than one round of walker blocks, and a damaged chunk in the middle of a block -- every number must come
+    back, the damaged chunk must report its error and nothing else may be disturbed.  Decoded twice: with the expanders and with
+    PCO_GFX_DEC_TRAIL=0 semantics (the same library cannot switch in-process: the reference result is the oracle's decoder)."""
+    import torch
+    rng = np.random.default_rng(77)
+    L_ = G.lib()
+    arrays = []; cfgs = []
+    def ramp(n, dt, step=1000, noise=512):
+        return (np.arange(n, dtype=np.int64) * step + rng.integers(0, noise, n) + (1 << 30)).astype(dt)
+    sizes = [700, 2, 255, 256, 257, 511, 513, 1000, 4096, 4097, 70000, 3, 258, 769, 1]
+    for rep in range(40):
+        n = sizes[rep % len(sizes)]
+        kind = rep % 10
+        if kind == 0: a, kw = ramp(n, np.uint64), dict(mode=1, delta=2, delta_order=1)
+        elif kind == 1: a, kw = ramp(n, np.int32, 7, 40), dict(mode=1, delta=2, delta_order=2)
+        elif kind == 2: a, kw = ramp(n, np.uint32, 3, 9), dict(mode=1, delta=2, delta_order=3)                       # order 3: left to dec_expand_kernel
+        elif kind == 3: a, kw = (rng.integers(1000, 10000, n) / 100.0), dict(mode=2, mode_f64=0.01, delta=1)          # two variables
+        elif kind == 4: a, kw = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32), dict(mode=1, delta=1) # one bin, 32-bit offsets
+        elif kind == 5: a, kw = (rng.integers(-(1 << 40), 1 << 40, 365)[np.arange(n) % 365] + rng.integers(-3, 4, n)).astype(np.int64), dict(mode=1, delta=3)   # lookback
+        elif kind == 6: a, kw = (rng.pareto(0.5, n) * 10).clip(0, 2e9).astype(np.int32), dict(mode=1, delta=1)         # many bins, wide offsets
+        elif kind == 7: a, kw = rng.integers(0, 40, n).astype(np.uint16), dict(mode=1, delta=1)                        # a few bins, no offsets at all
+        elif kind == 8: a, kw = ramp(n, np.int64, 5, 100), dict(mode=1, delta=1)                                       # no delta, narrow offsets
+        else: a, kw = rng.standard_normal(n).astype(np.float32), dict(mode=1, delta=2, delta_order=1)
+        arrays.append(np.ascontiguousarray(a)); cfgs.append(kw)
+    blobs = [U.chunk_of_file(f, len(f) - O_header_len(f) - 1) for f in (O.simple_compress(a, O.make_config(**kw)) for a, kw in zip(arrays, cfgs))]
+    # many copies, so that the call needs more than one round of walker blocks per width; one damaged chunk per width in the middle
+    reps = 30
+    srcs, tasks_spec, want = [], [], []
+    for r in range(reps):
+        for i, (a, b) in enumerate(zip(arrays, blobs)):
+            damaged = (r == reps // 2 and i % 10 in (0, 9) and len(b) > 64)
+            bb = b[: len(b) // 2] if damaged else b
+            srcs.append(bb); tasks_spec.append((a.dtype, a.size, damaged)); want.append(a)
+    k = len(srcs)
+    d_src = [torch.from_numpy(np.frombuffer(bb + b"\0" * 16, np.uint8).copy()).cuda() for bb in srcs]
+    outs = [torch.full((max(a.nbytes, 1) + 16,), 0xAB, dtype=torch.uint8, device="cuda") for a in want]
+    dtasks = (G.DecodeTask * k)(*[G.DecodeTask(d_src[i].data_ptr(), len(srcs[i]), outs[i].data_ptr(), tasks_spec[i][1], G.DTYPE_BYTE[np.dtype(tasks_spec[i][0]).name], 0) for i in range(k)])
+    dres = (G.TaskResult * k)()
+    rc = L_.pco_gfx_decompress_chunks(k, dtasks, dres, None, None)
+    assert rc != 0   # (the damaged chunks)
+    n_bad = 0
+    for i in range(k):
+        dt, n, damaged = tasks_spec[i]
+        if damaged:
+            assert dres[i].status == G.ST_INSUFFICIENT_DATA, (i, dres[i].status); n_bad += 1
+            continue
+        assert dres[i].status == 0 and dres[i].n_out == n and dres[i].consumed == len(srcs[i]), (i, dres[i].status, dres[i].n_out, n)
+        got = outs[i][: want[i].nbytes].cpu().numpy().view(dt)
+        assert U.bits_equal(got, want[i]), (i, cfgs[i % len(arrays)], n)
+        assert bool((outs[i][want[i].nbytes:] == 0xAB).all()), i   # nothing written past the chunk's numbers
+    assert n_bad >= 2
+    # more walker blocks than the persistent expander grid holds (4 blocks per CU): the expander blocks take a second walker block each
+    a, b = arrays[0], blobs[0]   # (700 u64 of a noisy ramp, delta order 1: a chunk the expanders take)
+    k2 = 9000
+    src = torch.from_numpy(np.frombuffer(b + b"\0" * 16, np.uint8).copy()).cuda()
+    out = torch.zeros((k2, max(a.nbytes, 8)), dtype=torch.uint8, device="cuda")
+    dt2 = (G.DecodeTask * k2)(*[G.DecodeTask(src.data_ptr(), len(b), out[i].data_ptr(), a.size, G.DTYPE_BYTE[a.dtype.name], 0) for i in range(k2)])
+    dr2 = (G.TaskResult * k2)()
+    G.check(L_.pco_gfx_decompress_chunks(k2, dt2, dr2, None, None))
+    host = out.cpu().numpy()
+    assert all(dr2[i].n_out == a.size for i in range(k2))
+    assert (host[:, : a.nbytes] == a.view(np.uint8).reshape(1, -1)).all()
+
+
+def O_header_len(f):
+    bits = int.from_bytes(f[6:16], "little")
+    return 6 + (6 + 1 + (bits & 63) + 7) // 8 + 2
+
+
 def test_the_heapsort_branch_of_the_reference_histogram(L):
     """The one documented divergence, pinned by an input (histograms.rs:248-258).  On the two adversarial orders of
     tests/golden/hist_fallback.npz the reference's histogram heapsorts and applies apply_sorted's tie rule; the GPU computes the quickselect
