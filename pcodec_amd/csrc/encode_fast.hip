@@ -784,9 +784,13 @@ struct PackSink {
     const uint32_t pos = (uint32_t)(outbit & 31) + pend + rel;
     const uint32_t dw = pos >> 5, sh = pos & 31;
     const uint64_t lo = val << sh;
+#ifdef PCO_PACK_NOATOMIC   // (measurement builds only: what the LDS atomics of the sink cost; the output is garbage)
+    stg[dw] = (uint32_t)lo ^ (uint32_t)(lo >> 32) ^ (uint32_t)((val >> 1) >> (63 - sh));
+#else
     atomicOr((uint32_t*)&stg[dw], (uint32_t)lo);
     atomicOr((uint32_t*)&stg[dw + 1], (uint32_t)(lo >> 32));
     atomicOr((uint32_t*)&stg[dw + 2], (uint32_t)((val >> 1) >> (63 - sh)));   // val >> (64 - sh), 0 when sh == 0
+#endif
   }
   __device__ __forceinline__ void commit(uint32_t total) { pend += total; }
   __device__ __forceinline__ void flush() {
@@ -823,32 +827,38 @@ __host__ __device__ constexpr uint32_t pack_lds_bytes(uint32_t n_slots) { return
 // what one lane holds of one (batch, variable) item: 4 symbols, 4 tANS fields, 4 latents
 struct PackItem { uint32_t syms, a, b; uint64_t x[4]; };
 
-template <class LV>
+// kRaw16: the compact 16-bit latents of a full batch stay packed in x[0] (four per lane: one 8-byte load, cut up where they are used --
+// cutting them up here would wait for the load here)
+template <class LV, bool kRaw16 = false>
 __device__ __forceinline__ void pack_load(PackItem& it, const LV PCO_GLOBAL* lat, const uint8_t PCO_GLOBAL* sym, const uint16_t PCO_GLOBAL* answ,
                                           uint32_t cnt, bool needs_ans, bool single_bin, bool has_offsets) {
   const uint32_t lane = lane_id();
   typedef uint64_t __attribute__((aligned(2))) u64_align2;
-  it.syms = 0; it.a = it.b = 0; it.x[0] = it.x[1] = it.x[2] = it.x[3] = 0;
-  if (cnt == kBatchN) {   // the common case carries no per-lane predicates
-    if (!single_bin) it.syms = *(const u32_unaligned PCO_GLOBAL*)(sym + 4 * lane);
-    if (needs_ans) { const uint64_t w = *(const u64_align2 PCO_GLOBAL*)(answ + 4 * lane); it.a = (uint32_t)w; it.b = (uint32_t)(w >> 32); }
-    if (has_offsets) {
-      if constexpr (sizeof(LV) == 2) {
-        const uint64_t w = *(const u64_align2 PCO_GLOBAL*)(lat + 4 * lane);
-        it.x[0] = w & 0xffffu; it.x[1] = (w >> 16) & 0xffffu; it.x[2] = (w >> 32) & 0xffffu; it.x[3] = w >> 48;
-      } else {
+  if (cnt == kBatchN) {
+    // The common case: every load unconditional, into registers nothing else writes.  (Zeroing the item first and loading under the
+    // variable's flags made the compiler wait -- at the zeroing and at the branches -- for every load in flight: the "prefetch" of the next
+    // batch was waited for on the spot, and the kernel sat at 2.7 TB/s of its own traffic with four waves per SIMD to hide a batch's
+    // round trip to HBM.  What a variable without symbols / tANS fields / offsets reads here is never looked at.)
+    it.syms = *(const u32_unaligned PCO_GLOBAL*)(sym + 4 * lane);
+    { const uint64_t w = *(const u64_align2 PCO_GLOBAL*)(answ + 4 * lane); it.a = (uint32_t)w; it.b = (uint32_t)(w >> 32); }
+    if constexpr (sizeof(LV) == 2) {
+      const uint64_t w = *(const u64_align2 PCO_GLOBAL*)(lat + 4 * lane);
+      if constexpr (kRaw16) it.x[0] = w;
+      else { it.x[0] = w & 0xffffu; it.x[1] = (w >> 16) & 0xffffu; it.x[2] = (w >> 32) & 0xffffu; it.x[3] = w >> 48; }
+    } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) it.x[k] = (uint64_t)lat[4 * lane + k];
-      }
+      for (int k = 0; k < 4; k++) it.x[k] = (uint64_t)lat[4 * lane + k];
     }
     return;
   }
+  it.syms = 0; it.a = it.b = 0; it.x[0] = it.x[1] = it.x[2] = it.x[3] = 0;
   const bool blk_on = 4 * lane < ((cnt + 15u) & ~15u);
   if (!single_bin && blk_on) it.syms = *(const u32_unaligned PCO_GLOBAL*)(sym + 4 * lane);
   if (needs_ans && blk_on) { const uint64_t w = *(const u64_align2 PCO_GLOBAL*)(answ + 4 * lane); it.a = (uint32_t)w; it.b = (uint32_t)(w >> 32); }
   if (has_offsets) {
 #pragma unroll
     for (int k = 0; k < 4; k++) it.x[k] = 4 * lane + k < cnt ? (uint64_t)lat[4 * lane + k] : 0ull;
+    if constexpr (kRaw16) it.x[0] = it.x[0] | (it.x[1] << 16) | (it.x[2] << 32) | (it.x[3] << 48);
   }
 }
 
@@ -882,7 +892,7 @@ __device__ __forceinline__ void pack_item_t(PackSink& sink, const uint8_t PCO_LD
     for (int k = 0; k < 4; k++) {
       const uint32_t e = cpk[(syms >> (8 * k)) & 0xffu];
       const uint32_t o = (kFull || 4 * lane + k < cnt) ? e >> 16 : 0u;
-      acc |= (uint64_t)__builtin_amdgcn_ubfe((uint32_t)it.x[k] - (e & 0xffffu), 0u, o) << t;
+      acc |= (uint64_t)__builtin_amdgcn_ubfe(((uint32_t)(it.x[0] >> (16 * k)) & 0xffffu) - (e & 0xffffu), 0u, o) << t;   // (compact latents arrive packed, four in x[0])
       t += o;
     }
     const uint32_t incl = wave_incl_scan(t);
@@ -1016,7 +1026,7 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
       if (!on[v] || base >= pv[v].n_lat) continue;
       const uint32_t cnt = pv[v].n_lat - base < kBatchN ? pv[v].n_lat - base : kBatchN;
       const uint64_t at = pstart + pv[v].skip + base, fat = fast_at(pg, pv[v].skip) + base;
-      if (pv[v].compact) pack_load<uint16_t>(dstv[v], clat_ptr(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, fansw_ptr(ws, fx, t, v) + fat, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
+      if (pv[v].compact) pack_load<uint16_t, true>(dstv[v], clat_ptr(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, fansw_ptr(ws, fx, t, v) + fat, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
       else if (v == 0) pack_load<uint32_t>(dstv[v], lat_ptr<uint32_t>(ws, t, 0) + at, fsym_ptr(ws, fx, t, 0) + fat, fansw_ptr(ws, fx, t, 0) + fat, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
       else pack_load<L>(dstv[v], lat_ptr<L>(ws, t, v) + at, fsym_ptr(ws, fx, t, v) + fat, fansw_ptr(ws, fx, t, v) + fat, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
     }
