@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
           } else if constexpr (sizeof(L) == 4) {
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             u32x4 a; a.x = outv[0]; a.y = outv[1]; a.z = outv[2]; a.w = outv[3];
-            *(u32x4 PCO_GLOBAL*)o = a;
+            __builtin_nontemporal_store(a, (u32x4 PCO_GLOBAL*)o);   // (a contiguous KB per instruction, and nobody on the device reads the numbers back)
           } else { for (int k = 0; k < 4; k++) o[k] = outv[k]; }
         } else { for (int k = 0; k < 4; k++) if (i0 + k < batch_n) o[k] = outv[k]; }
       }
