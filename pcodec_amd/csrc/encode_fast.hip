@@ -471,6 +471,14 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
   uint32_t my_n_lat = 0, my_T = 0, my_p = 0, my_v = 0, my_task = 0, my_info_off = 0, my_m0 = 0, my_finds = 0;   // (a gathering lane's n_lat is 0 for an item it has nothing to find for)
   uint64_t my_at = 0, my_clat = 0;
   uint32_t max_nb = 0;   // batches of the block's longest item: what every wave's loop runs to (uniform)
+  // Value -> bin through LDS (kWdLdsLut): between an item's info words and its symbol buffers the slot has room to spare (1.9 KB at
+  // ans_size_log 10 with 20 bins); a variable whose values span at most that many bytes keeps its value -> bin table THERE, a byte per value
+  // (copied once from enc_vlut_kernel's table), with the bins' offset-bit counts behind it -- and the gathering wave's four texture-path
+  // gathers per lane and item (~88 cycles each whatever the table's size) become eight LDS byte reads.  Taken when EVERY item of the block
+  // qualifies (uniform code: a branch per item around a load makes the compiler wait for the load where it is issued).  Worth 0.1 ms of
+  // 4.8 on the headline workload: what bounded the gathering wave was not the texture path but the sixteen items' dependent chains, each
+  // behind a branch of its own (see the straight-line form below).
+  bool all_lds = true; uint32_t my_vtab = 0, my_obtab = 0, my_range = 0;
   for (uint32_t q = 0; q < kWdQ; q++) {
     const uint32_t item = blockIdx.x * kWdQ + q;
     if (item >= n_items) break;
@@ -501,7 +509,20 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
         ((uint64_t PCO_LDS*)(slot + info_off))[b] = (uint64_t)(((minb + 1u) << 16) - cutoff) | ((uint64_t)row_addr << 32);
       }
     }
+    // the slot's slack: [info_off + 8 n_bins, kWdSymOff): offset bits u8[n_bins] | bins u8[range + 1]
+    const uint32_t ob_off = info_off + 8u * pv.n_bins, vt_off = ob_off + ((pv.n_bins + 3u) & ~3u);
+    const bool fits = finds && pv.n_bins <= 256 && pv.range < 4096 && vt_off + (uint32_t)pv.range + 1u <= kWdSymOff;
+    if (!(finds && fits)) all_lds = false;   // (a block of mixed items keeps the global tables for all of them: measured on the mixed stream, the LDS reads of sixteen items for the sake of five cost more than the gathers -- 8.3 against 7.4 ms)
+    if (all_lds && wave == 1) {   // (the first gathering wave fills the tables of all sixteen items; kWdHelpers > 1: the others wait at the barrier below)
+      const PlanRef plan = plan_ref(ws, t, v);
+      uint8_t PCO_LDS* slot = smem + q * kWdSlot;
+      for (uint32_t b = lane; b < pv.n_bins; b += 64) slot[ob_off + b] = (uint8_t)plan.bob()[b];
+      const uint16_t PCO_GLOBAL* lut = vlut_ptr(ws, fx, t, v);
+      const uint32_t base = (uint32_t)(pv.minv - pv.rel) + vlut_rot(t * ws.n_slots + ws.slot_of_var[v]);
+      for (uint32_t i = lane; i <= (uint32_t)pv.range; i += 64) slot[vt_off + i] = (uint8_t)lut[(base + i) & (kDirectHistRange - 1)];
+    }
     if (my_q == q) {
+      my_vtab = lds0 + q * kWdSlot + (fits ? vt_off : 0u); my_obtab = lds0 + q * kWdSlot + (fits ? ob_off : 0u); my_range = fits ? (uint32_t)pv.range : 0u;   // (an item without a table: every index reads the slot's first byte, and nothing looks at it)
       my_finds = finds ? 1u : 0u;
       my_n_lat = wave == 0 || finds ? pv.n_lat : 0u; my_T = 1u << pv.asl; my_p = p; my_v = v; my_task = t; my_info_off = info_off; my_m0 = (uint32_t)(pv.minv - pv.rel);
       my_at = fast_at(pg, pv.skip); my_clat = uni((uint64_t)pg->start) + pv.skip;
@@ -544,6 +565,22 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
         e[q][2] = lut[hi & (kDirectHistRange - 1)]; e[q][3] = lut[(hi >> 16) & (kDirectHistRange - 1)];
       }
     };
+    // the same from the slots' own tables (all_lds): index = latent - the variable's minimum (as a 16-bit latent), clamped into the table
+    // (what lies behind a page's last batch is never looked at, but must not index out of the slot)
+    auto gather_lds = [&](const uint64_t (&w)[kWdH], uint32_t (&e)[kWdH][4]) {
+#pragma unroll
+      for (uint32_t q = 0; q < kWdH; q++) {
+        const uint32_t vt = bcast(my_vtab, q), ot = bcast(my_obtab, q), rg = bcast(my_range, q), m0 = bcast(my_m0, q);
+        const uint32_t lo = (uint32_t)w[q], hi = (uint32_t)(w[q] >> 32);
+        uint32_t idx[4] = {(lo & 0xffffu) - m0, (lo >> 16) - m0, (hi & 0xffffu) - m0, (hi >> 16) - m0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          idx[k] = idx[k] > rg ? 0u : idx[k];
+          const uint32_t bin = *(const uint8_t PCO_LDS*)(uintptr_t)(vt + idx[k]);
+          e[q][k] = bin | ((uint32_t)*(const uint8_t PCO_LDS*)(uintptr_t)(ot + bin) << 8);
+        }
+      }
+    };
     // software pipeline: at step `it` the table entries of step it + 1 are gathered (from latents loaded during step it - 1) and the
     // latents of step it + 2 requested, in that order -- loads return in order, so nothing below waits for HBM -- while the entries gathered
     // during step it - 1 are turned into symbols
@@ -551,7 +588,7 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
     const bool lookups = (fx.fused & kFusedLookups) != 0;   // (no tables in this call: the wave only keeps the walker's barriers company)
     if (lookups) {
       load_batches(0, wnxt);
-      gather(wnxt, enxt);
+      if (all_lds) gather_lds(wnxt, enxt); else gather(wnxt, enxt);
       if (1 < max_nb) load_batches(1, wnxt);
     }
     for (uint32_t it = 0; it <= max_nb; it++) {   // it == max_nb: nothing left to find, only the barrier
@@ -559,7 +596,7 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
 #pragma unroll
         for (uint32_t q = 0; q < kWdH; q++) { e[q][0] = enxt[q][0]; e[q][1] = enxt[q][1]; e[q][2] = enxt[q][2]; e[q][3] = enxt[q][3]; }
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < max_nb) gather(wnxt, enxt);
+        if (it + 1 < max_nb) { if (all_lds) gather_lds(wnxt, enxt); else gather(wnxt, enxt); }
         __builtin_amdgcn_sched_barrier(0);
         if (it + 2 < max_nb) load_batches(it + 2, wnxt);
         __builtin_amdgcn_sched_barrier(0);
@@ -568,6 +605,21 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
         const uint32_t my_cnt = my_on ? (my_n_lat - my_base < kBatchN ? my_n_lat - my_base : kBatchN) : 0u;
         const uint32_t my_buf = lds0 + my_q * kWdSlot + kWdSymOff + (my_hb & 1) * 256;   // this step's symbol buffer of the lane's item
         uint32_t my_total = 0;
+        if (__all(my_cnt == kBatchN || my_cnt == 0)) {
+          // every item the wave looks up has a full batch at this step (all but a page's last): straight-line code -- no branch per item, so that the sixteen
+          // items' chains (table reads, byte shuffles, a six-step sum over the wave, a quad transpose) are scheduled into one another
+          // instead of each paying its latencies alone
+#pragma unroll
+          for (uint32_t q = 0; q < kWdH; q++) {
+            const uint32_t e01 = e[q][0] | (e[q][1] << 16), e23 = e[q][2] | (e[q][3] << 16);
+            const uint32_t packed = __builtin_amdgcn_perm(e23, e01, 0x06040200u);               // the four bin bytes
+            const uint32_t obs4 = __builtin_amdgcn_perm(e23, e01, 0x07050301u);                 // the four offset-bit counts (<= 64 each)
+            const uint32_t total = wave_sum(__builtin_amdgcn_sad_u8(obs4, 0u, 0u));
+            my_total = (lane & (kWdH - 1)) == q ? total : my_total;
+            const uint32_t tr = quad_transpose_u8(packed, lane & 3);
+            if (bcast(my_cnt, q) != 0) *(uint32_t PCO_LDS*)(uintptr_t)(bcast(my_buf, q) + 4 * lane) = tr;   // (an item the wave does not look up: its buffer is the walker's own)
+          }
+        } else {
 #pragma unroll
         for (uint32_t q = 0; q < kWdH; q++) {
           const uint32_t cnt = bcast(my_cnt, q);
@@ -582,6 +634,7 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
           const uint32_t total = wave_sum(__builtin_amdgcn_sad_u8(obs4, 0u, 0u));
           my_total = (lane & (kWdH - 1)) == q ? total : my_total;
           *(uint32_t PCO_LDS*)(uintptr_t)(bcast(my_buf, q) + 4 * lane) = quad_transpose_u8(packed, lane & 3);
+        }
         }
         // the symbols go on to enc_pack_kernel's scratch from the LDS buffers: a lane copies a quarter (64 bytes) of its own item's batch,
         // whole 16-latent blocks as enc_dissect_kernel writes them; lanes 0..15 leave the batch's offset-bit total
