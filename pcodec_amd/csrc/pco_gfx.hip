@@ -199,15 +199,18 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
         PCO_HIP_CHECK(hipEventRecord(ws.fork_event, stream));                                                                                             \
         PCO_TIMED_LAUNCH("~dec_walk_kernel<" name ">", stream, (dec_walk_trail_kernel<L>), dim3(n_wb), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,       \
                          d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_results, d_progress);                          \
-        hipStream_t ts = g_trail_debug == 's' ? stream : ws.side_stream;                                                                                  \
-        PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream, ws.fork_event, 0));                                                                              \
-        if (g_trail_debug != 'n') PCO_TIMED_LAUNCH("~dec_trail_kernel<" name ">", ts, (dec_trail_kernel<L>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
-                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);                               \
-        /* the blocks without a candidate for the expanders: the ordinary walker, beside the two (every block runs in exactly one of the walkers) */ \
+        /* the blocks without a candidate for the expanders: the ordinary walker, beside the two (every block runs in exactly one of the walkers).       \
+           Launched second: where no block is a candidate the publishing walker's blocks say so and leave at once, and the expanders with them         \
+           (launched first it held the LDS, they queued behind it: 1.8 instead of 1.3 ms per 16384 one-bin chunks).  Where every block is a        \
+           candidate its own blocks queue behind the publishing walker's LDS and then leave at once: its time in a profile is that wait */          \
         PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream2, ws.fork_event, 0));                                                                             \
         PCO_TIMED_LAUNCH("~dec_walk_kernel(rest)<" name ">", ws.side_stream2, (dec_walk_kernel<L, 8>), dim3(n_wb), dim3(64), WalkCfg<8>::kWalkLdsBytes, ws.side_stream2, \
                          d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results, d_progress);                      \
         PCO_HIP_CHECK(hipEventRecord(ws.join_event2, ws.side_stream2));                                                                                   \
+        hipStream_t ts = g_trail_debug == 's' ? stream : ws.side_stream;                                                                                  \
+        PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream, ws.fork_event, 0));                                                                              \
+        if (g_trail_debug != 'n') PCO_TIMED_LAUNCH("~dec_trail_kernel<" name ">", ts, (dec_trail_kernel<L>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
+                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);                               \
         PCO_HIP_CHECK(hipEventRecord(ws.join_event, ws.side_stream));                                                                                     \
         PCO_HIP_CHECK(hipStreamWaitEvent(stream, ws.join_event, 0));                                                                                      \
         PCO_HIP_CHECK(hipStreamWaitEvent(stream, ws.join_event2, 0));                                                                                     \

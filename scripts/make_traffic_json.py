@@ -21,18 +21,35 @@ NARROW = ("enc_lookback_pipe_kernel", "enc_lookback_kernel")
 TY = {"unsigned long": "u64", "unsigned int": "u32", "unsigned short": "u16", "unsigned char": "u8"}
 
 
+def ty(t):
+    """number type of a (possibly truncated) template argument: 'unsigned long', 'unsigned lon', ..."""
+    t = t.strip()
+    for k, v in sorted(TY.items(), key=lambda kv: -len(kv[0])):
+        if t == k or (len(t) >= 10 and k.startswith(t)):
+            return v
+    return TY.get(t, t)
+
+
 def label(name):
     name = name.strip()
+    # the decode walker that publishes its progress and the expanders under it (decode_trail.hip); bench.py reports them as "~dec_walk_kernel<..>"
+    # / "~dec_trail_kernel<..>" and strips the "~"
+    m = re.match(r"dec_walk_trail_kernel<([^,>]*)", name)
+    if m:
+        return f"dec_walk_kernel<{ty(m.group(1))}>"
+    m = re.match(r"dec_trail_kernel<([^,>]*)", name)
+    if m:
+        return f"dec_trail_kernel<{ty(m.group(1))}>"
     # (pmc_summary.py cuts the names at 34 characters: "dec_walk_kernel<unsigned long, 8u," / "dec_expand_kernel<unsigned long, f")
     m = re.match(r"dec_walk_kernel<([^,>]*), (\d)u", name)
     if m:
-        return ("dec_walk_kernel" if m.group(2) == "8" else "dec_walk4_kernel") + f"<{TY.get(m.group(1), m.group(1))}>"
+        return ("dec_walk_kernel" if m.group(2) == "8" else "dec_walk4_kernel") + f"<{ty(m.group(1))}>"   # (the ordinary first-stage walker adds to the publishing one's label)
     m = re.match(r"dec_expand_kernel<([^,>]*)(, (t|f))?", name)
     if m:
-        return ("dec_expand_lb_kernel" if m.group(3) == "t" else "dec_expand_kernel") + f"<{TY.get(m.group(1), m.group(1))}>"
+        return ("dec_expand_lb_kernel" if m.group(3) == "t" else "dec_expand_kernel") + f"<{ty(m.group(1))}>"
     m = re.match(r"pco_decode_kernel<([^,>]*)>?", name)
     if m:
-        return f"pco_decode_kernel<{TY.get(m.group(1), m.group(1))}>"
+        return f"pco_decode_kernel<{ty(m.group(1))}>"
     if name.startswith("enc_walk_kernel"):
         return "enc_walk16_kernel" if name.startswith("enc_walk_kernel<16") else "enc_walk_kernel"
     if name.startswith("enc_lookback_pipe_kernel"):
