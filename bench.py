@@ -476,6 +476,8 @@ class Bench:
                            "encode_GBps": round(total_bytes * steps / t_enc / 1e9, 2),
                            "decode_GBps": round(total_bytes * steps / t_dec / 1e9, 2),
                            "median_step_ms_rank0": round(float(np.median(step_ms)), 3),
+                           # the library's device scratch after the timed steps (it grows to what the calls needed and stays) per byte of numbers
+                           "workspace_bytes_per_input_byte": round(L.pco_gfx_workspace_bytes() / rank_bytes, 3),
                            "oracle_verified_chunks": verified, **({"UNVERIFIED_ablation_run": True} if no_verify else {})},
                 "roofline": roof,
             }
@@ -488,7 +490,7 @@ class Bench:
                     rec["cpu_baseline"]["sample"] += f"; timed on rank 0 while the other {world - 1} ranks were idle"
         if with_cpu and self.use_dist:
             dist.barrier()
-        # give the memory back before the next workload (the library's workspace is ~8 B per input byte)
+        # give the memory back before the next workload
         del data, out, comp, d_res
         if gather:
             del payload, d_offs, recv, file_body
@@ -507,7 +509,7 @@ OTHER_WORKLOADS = [("c3", "c3", None, 4, False), ("c4", "c4", 4096, 3, False), (
 def flat_workload(name, r):
     """The scalars of one extra workload that must survive in the driver's record: config.<name>_<key>."""
     d = r["roofline"]
-    out = {"value": r["value"], "ms_per_step": r["ms_per_step"], "chunks": r["config"]["chunks_per_gpu"], "steps": r["steps"],
+    out = {"value": r["value"], "ms_per_step": r["ms_per_step"], "chunks": r["config"]["chunks_per_gpu"], "steps": r["steps"], "workspace_x": r["config"]["workspace_bytes_per_input_byte"],
            "encode_GBps": r["config"]["encode_GBps"], "decode_GBps": r["config"]["decode_GBps"],
            "frac_encode": d["frac_encode"], "frac_decode": d["frac_decode"], "frac_step": d["frac_step"],
            "traffic_x_encode": d["traffic_over_algorithmic_encode"], "traffic_x_decode": d["traffic_over_algorithmic_decode"],

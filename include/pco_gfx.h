@@ -205,6 +205,10 @@ size_t pco_gfx_write_standalone_footer(void* dst, size_t dst_cap);
 
 /* Release this thread's device workspace. */
 void pco_gfx_release_workspace(void);
+/* Bytes of device memory this thread's workspace holds right now (the library's scratch: it grows to what the largest call so far needed and
+ * stays until released).  For capacity planning and for the benchmark's `workspace_bytes_per_input_byte`; the reference has no counterpart
+ * (its scratch is the host heap). */
+size_t pco_gfx_workspace_bytes(void);
 
 /* Per-kernel timing (HIP events on the launch stream): begin() arms it for this thread; end()
  * synchronises and returns the number of kernels launched since begin(), writing their names

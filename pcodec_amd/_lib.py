@@ -75,6 +75,8 @@ def lib():
         L.pco_gfx_guarantee_file_size.restype = C.c_size_t
         L.pco_gfx_guarantee_file_size.argtypes = [C.c_size_t, C.c_ubyte, C.c_uint64]
         L.pco_gfx_guarantee_chunk_size.restype = C.c_size_t
+        L.pco_gfx_workspace_bytes.restype = C.c_size_t
+        L.pco_gfx_workspace_bytes.argtypes = []
         L.pco_gfx_guarantee_chunk_size.argtypes = [C.c_size_t, C.c_ubyte]
         L.pco_standalone_simple_compress_into.argtypes = [C.c_void_p, C.c_size_t, C.c_ubyte, C.c_void_p, C.c_void_p,
                                                           C.c_size_t, C.POINTER(C.c_size_t)]

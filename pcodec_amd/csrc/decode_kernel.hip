@@ -784,7 +784,9 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
   }
   wave_sync_lds();
   const bool lds_tables = total_tbl <= lds_table_budget;
-  if (!lds_tables && tbl_ws == nullptr) { status = PCO_GFX_DEVICE_ERROR; return; }
+  // (no global table scratch in this pass: a synchronous call hands the task back and runs it again with the scratch, like a task that
+  //  needs a second history buffer -- tANS tables beyond the LDS budget are rare, 832 KB of scratch per block for every call were not)
+  if (!lds_tables && tbl_ws == nullptr) { status = need_hist_status == (uint32_t)PCO_GFX_UNSUPPORTED ? (uint32_t)PCO_GFX_DEVICE_ERROR : need_hist_status; return; }
   uint8_t PCO_LDS* tbl_lds = lds_base() + kLdsFixed;
 #pragma unroll
   for (int vi = 0; vi < 3; vi++) {

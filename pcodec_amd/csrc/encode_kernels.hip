@@ -96,8 +96,14 @@ struct EncWorkspace {
   uint8_t* plans;           // [task][3] plan regions of plan_bytes_for(plan_cap) bytes each (PlanRef)
   uint32_t plan_cap, pad_cap;   // bin capacity of every plan region of this call: 256 or 4096
   EncPage* pages;           // [n_pages_total]
-  uint8_t* lat;             // [task][n_slots][n_stride] 8-byte elements
-  uint8_t* sort;            // [task][2][n_stride] 8-byte elements
+  uint8_t* lat;             // [lat slot][n_slots][n_stride] elements of lat_esz bytes: slots 0 .. lat_cap1 - 1 (see lat_slot)
+  uint8_t* lat2;            // ... and slots lat_cap1 .. (the chunks whose 16-bit speculation failed in the split, allocated once their number is known)
+  uint32_t* lat_slot;       // [task] the chunk's slot in lat / lat2, handed out on the device (enc_lat_slots_kernel) to the chunks that write full-width
+                            // latents; kNoLatSlot for the others (16-bit latents only: most chunks of most calls -- they cost no full-width scratch)
+  uint32_t* lat_used;       // device counter: slots handed out
+  uint32_t lat_cap1;
+  uint32_t lat_esz;         // bytes per element of lat / sort: 8 when the call has a 64-bit chunk, else 4 (the lookback variable's latents are u32 whatever the type)
+  uint8_t* sort;            // [task][2][n_stride] elements of lat_esz bytes
   uint8_t* walk;            // [task][3] kWalkRecBytes: rank records + tables of a deferred bin walk (enc_hist_walk_kernel), or null
   uint32_t* dissect;        // [task][n_slots][n_stride]
   uint64_t n_stride;
@@ -119,8 +125,15 @@ __device__ __forceinline__ void enc_wave_sync() {
 __device__ __forceinline__ PlanRef plan_ref(const EncWorkspace& ws, uint32_t task, uint32_t var) {
   return PlanRef{(uint8_t PCO_GLOBAL*)ws.plans + ((uint64_t)task * 3 + var) * plan_bytes_for(ws.plan_cap), ws.plan_cap};
 }
+constexpr uint32_t kNoLatSlot = 0xffffffffu;
+// (a chunk without a slot gets slot 0's address: every dereference is behind the chunk's c16_ok, so nothing reads or writes it, and a
+//  pointer that is only computed must not fault)
 template <class L> __device__ __forceinline__ L PCO_GLOBAL* lat_ptr(const EncWorkspace& ws, uint32_t task, uint32_t var) {
-  return (L PCO_GLOBAL*)(ws.lat + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * ws.n_stride * 8);
+  uint32_t s = ws.lat_slot[task];
+  if (s == kNoLatSlot) s = 0;
+  const uint64_t per_var = ws.n_stride * ws.lat_esz, per_slot = (uint64_t)ws.n_slots * per_var;
+  uint8_t* base = s < ws.lat_cap1 ? ws.lat + (uint64_t)s * per_slot : ws.lat2 + (uint64_t)(s - ws.lat_cap1) * per_slot;
+  return (L PCO_GLOBAL*)(base + (uint64_t)ws.slot_of_var[var] * per_var);
 }
 __device__ __forceinline__ uint32_t PCO_GLOBAL* dissect_ptr(const EncWorkspace& ws, uint32_t task, uint32_t var) {
   return (uint32_t PCO_GLOBAL*)(ws.dissect + ((uint64_t)task * ws.n_slots + ws.slot_of_var[var]) * ws.n_stride);
@@ -132,7 +145,7 @@ __device__ __forceinline__ uint16_t PCO_GLOBAL* clat_ptr(const EncWorkspace& ws,
   return (uint16_t PCO_GLOBAL*)dissect_ptr(ws, task, var);
 }
 template <class L> __device__ __forceinline__ L PCO_GLOBAL* sort_ptr(const EncWorkspace& ws, uint32_t task, uint32_t which) {
-  return (L PCO_GLOBAL*)(ws.sort + ((uint64_t)task * 2 + which) * ws.n_stride * 8);
+  return (L PCO_GLOBAL*)(ws.sort + ((uint64_t)task * 2 + which) * ws.n_stride * ws.lat_esz);
 }
 
 // wrapped/chunk_compressor.rs:362-371
@@ -577,6 +590,16 @@ __global__ __launch_bounds__(64) void enc_presample_kernel(EncWorkspace ws, cons
   else if (bits == 32) bad = presample_mode<uint32_t>(task, ch, mode_kind);
   else if (bits == 16) bad = presample_mode<uint16_t>(task, ch, mode_kind);
   if (bad && lane_id() == 0) { ch->c16_ok = 0; atomicAdd(ws.need_full0, 1u); }
+}
+// Full-width latent scratch goes to the chunks that write it, and only to them: every chunk whose c16_ok is `want` and that has no slot yet
+// takes the next one.  Run twice: want = 0 behind enc_presample_kernel (chunks that never speculate: lookback, more than 256 bins, taken out by
+// the sample, calls without the speculation), want = 2 behind the 16-bit split (chunks in which a tile did not fit).  A synchronous call
+// reads the counter back after each and allocates exactly that many slots; an asynchronous one has a slot per chunk up front.
+__global__ __launch_bounds__(64) void enc_lat_slots_kernel(EncWorkspace ws, uint32_t n_tasks, uint32_t want) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tasks) return;
+  if (ws.chunks[t].c16_ok != want || ws.lat_slot[t] != kNoLatSlot) return;
+  ws.lat_slot[t] = atomicAdd(ws.lat_used, 1u);
 }
 
 // =========================================================================================================

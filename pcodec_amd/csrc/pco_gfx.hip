@@ -159,8 +159,12 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
   }
   const uint32_t budget = g_decode_lds_bytes - kLdsFixed;
   size_t max_grid = 0;
-  for (int g = 0; g < 4; g++) max_grid = std::max(max_grid, std::min<size_t>(ids[g].size(), 16384));
-  uint8_t* tbl = (uint8_t*)ws.tbl_ws.ensure(max_grid * kTblWsBytes);
+  // blocks of the general one-wave-per-task kernel: each owns kTblWsBytes (832 KB) of global table scratch for tANS tables beyond its LDS,
+  // so the grid is what that scratch scales with -- 4096 blocks are four rounds of what the CUs hold at once, the kernel strides over the rest
+  constexpr size_t kGeneralGrid = 4096;
+  for (int g = 0; g < 4; g++) max_grid = std::max(max_grid, std::min<size_t>(ids[g].size(), kGeneralGrid));
+  // (synchronous calls: the table scratch only in the second pass, for the tasks that asked for it -- kStatusNeedHist covers both kinds of scratch)
+  uint8_t* tbl = results ? nullptr : (uint8_t*)ws.tbl_ws.ensure(max_grid * kTblWsBytes);
   // Fast path (decode_fast.hip): walk 8 chunks per wave, then expand one chunk per wave; whatever it cannot take
   // (multi-chunk streams, big tANS tables, wrapped pages, ...) is finished by the single-kernel decoder.
   uint64_t max_cap = 0; bool plain = true;
@@ -178,7 +182,7 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
   for (int g = 0; g < 4; g++) {
     if (ids[g].empty()) continue;
     const uint32_t cnt = (uint32_t)ids[g].size();
-    const uint32_t grid = (uint32_t)std::min<size_t>(cnt, 16384);
+    const uint32_t grid = (uint32_t)std::min<size_t>(cnt, kGeneralGrid);
     const uint32_t* idp = mixed ? d_ids + id_off[g] : nullptr;
     const uint32_t* filt = fast ? (const uint32_t*)d_plans : nullptr;
     const uint32_t fstride = (uint32_t)(sizeof(DecPlan) / 4);
@@ -234,7 +238,7 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
   if (results) {
     PCO_HIP_CHECK(hipMemcpyAsync(results, d_results, n_tasks * sizeof(PcoGfxTaskResult), hipMemcpyDeviceToHost, stream));
     PCO_HIP_CHECK(hipStreamSynchronize(stream));
-    // Tasks handed back for want of scratch (a lookback delta whose secondary variable is delta'd too: its history needs dst_cap latents):
+    // Tasks handed back for want of scratch (tANS tables beyond the LDS budget; a lookback delta whose secondary variable is delta'd too: its history needs dst_cap latents):
     // once more through the single-kernel decoder, with the scratch.  The format allows the combination; no encoder writes it.
     std::vector<uint32_t> again[4]; size_t n_again = 0;
     for (size_t i = 0; i < n_tasks; i++) if (results[i].status == kStatusNeedHist) {
@@ -250,10 +254,10 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
       uint32_t* d_again = (uint32_t*)(d_hoff + n_again);
       PCO_HIP_CHECK(hipMemcpyAsync(d_hoff, offs.data(), n_again * 8, hipMemcpyHostToDevice, stream));
       PCO_HIP_CHECK(hipMemcpyAsync(d_again, flat_ids.data(), n_again * 4, hipMemcpyHostToDevice, stream));
-      uint8_t* tbl2 = (uint8_t*)ws.tbl_ws.ensure(std::max<size_t>(max_grid, std::min<size_t>(n_again, 16384)) * kTblWsBytes);
+      uint8_t* tbl2 = (uint8_t*)ws.tbl_ws.ensure(std::min<size_t>(n_again, kGeneralGrid) * kTblWsBytes);
       for (int g = 0; g < 4; g++) {
         if (again[g].empty()) continue;
-        const uint32_t cnt = (uint32_t)again[g].size(), grid = (uint32_t)std::min<size_t>(cnt, 16384);
+        const uint32_t cnt = (uint32_t)again[g].size(), grid = (uint32_t)std::min<size_t>(cnt, kGeneralGrid);
         const uint32_t* idp = d_again + goff[g]; const uint64_t* hop = d_hoff + goff[g];
         if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED);
         else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED);
@@ -278,6 +282,14 @@ const char* pco_gfx_last_error(void) { return g_err.msg.c_str(); }
 int pco_gfx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 void pco_gfx_release_workspace(void) {   // this thread's workspace on the current device
   try { Workspace& w = workspace(); if (w.has_last && w.last_event) (void)hipEventSynchronize(w.last_event); w.release_all(); } catch (...) {}
+}
+
+size_t pco_gfx_workspace_bytes(void) {
+  try {
+    static const bool trace = std::getenv("PCO_GFX_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[pco_gfx trace] workspace: %s\n", workspace().device_report().c_str());
+    return workspace().device_bytes();
+  } catch (...) { return 0; }
 }
 
 // Kernel timing: begin() arms per-launch HIP events on this thread; end() synchronises and returns one

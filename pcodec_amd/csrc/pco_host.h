@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -33,7 +34,7 @@ struct DevBuf {
   void* ensure(size_t bytes) {
     if (bytes > cap) {
       if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-      size_t want = bytes + bytes / 8 + 256;
+      size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)64 << 20) + 256;   // (slack against calls that grow a little; bounded: an eighth of 10 GB is real memory)
       hipError_t e = hipMalloc(&p, want);
       if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); throw HostError{PCO_GFX_DEVICE_ERROR, std::string("hipMalloc failed: ") + hipGetErrorString(e), true}; }
       cap = want;
@@ -75,13 +76,29 @@ struct Workspace {
   DevBuf io_in, io_out;                   // staging for the host-buffer entry points
   DevBuf compact_tasks;                   // pco_gfx_compact_chunks
   DevBuf enc_state;                       // encode: per chunk plans etc. (see encode_kernels.hip)
-  DevBuf enc_lat, enc_sort, enc_ans, enc_small, enc_lb, enc_walk;
+  DevBuf enc_lat, enc_lat2, enc_sort, enc_ans, enc_small, enc_lb, enc_walk;
   DevBuf enc_sym, enc_answ, enc_bat, enc_run, enc_fstate, enc_vlut;   // encode fast path (encode_fast.hip)
   DevBuf auto_idx, auto_samp, auto_tasks, auto_sum, auto_log2;  // Auto spec resolution
   HostBuf h_samp, h_sum;                             // ... and its read-backs
+#define PCO_WS_BUFS(X) X(tasks) X(results) X(tbl_ws) X(dec_plans) X(dec_bins) X(dec_sym) X(dec_offpos) X(dec_progress) X(dec_hist) X(io_in) X(io_out) X(compact_tasks) X(enc_state) \
+  X(enc_lat) X(enc_lat2) X(enc_sort) X(enc_ans) X(enc_small) X(enc_lb) X(enc_walk) X(enc_sym) X(enc_answ) X(enc_bat) X(enc_run) X(enc_fstate) X(enc_vlut) X(auto_idx) X(auto_samp) X(auto_tasks) X(auto_sum) X(auto_log2)
+  size_t device_bytes() const {   // what the workspace holds on the device right now (pco_gfx_workspace_bytes)
+    size_t b = 0;
+#define PCO_WS_ADD(name) b += name.cap;
+    PCO_WS_BUFS(PCO_WS_ADD)
+#undef PCO_WS_ADD
+    return b;
+  }
+  std::string device_report() const {   // "name=bytes ..." of the buffers that hold anything (PCO_GFX_TRACE)
+    std::string r;
+#define PCO_WS_REP(name) if (name.cap) r += std::string(#name) + "=" + std::to_string(name.cap) + " ";
+    PCO_WS_BUFS(PCO_WS_REP)
+#undef PCO_WS_REP
+    return r;
+  }
   void release_all() {
     tasks.release(); results.release(); tbl_ws.release(); dec_plans.release(); dec_bins.release(); dec_sym.release(); dec_offpos.release(); dec_progress.release(); dec_hist.release(); io_in.release(); io_out.release(); compact_tasks.release();
-    enc_state.release(); enc_lat.release(); enc_sort.release(); enc_ans.release(); enc_small.release(); enc_lb.release(); enc_walk.release(); enc_sym.release(); enc_answ.release(); enc_bat.release(); enc_run.release(); enc_fstate.release(); enc_vlut.release(); auto_idx.release(); auto_samp.release(); auto_tasks.release(); auto_sum.release(); auto_log2.release(); h_samp.release(); h_sum.release();
+    enc_state.release(); enc_lat.release(); enc_lat2.release(); enc_sort.release(); enc_ans.release(); enc_small.release(); enc_lb.release(); enc_walk.release(); enc_sym.release(); enc_answ.release(); enc_bat.release(); enc_run.release(); enc_fstate.release(); enc_vlut.release(); auto_idx.release(); auto_samp.release(); auto_tasks.release(); auto_sum.release(); auto_log2.release(); h_samp.release(); h_sum.release();
   }
 };
 Workspace& workspace();
