@@ -32,6 +32,13 @@ template <uint32_t KQ> struct WalkCfg {
   static_assert(kGrpBytes % 16 == 0, "chunk slices must stay 16-byte aligned");
   static_assert(kWalkLdsBytes < 65536, "walk entries hold 16-bit LDS addresses");
 };
+// A walker "block" is one wave and its LDS.  The publishing walker's workgroups hold FOUR of them (256 threads, 4 x 40608 B of LDS: the whole
+// CU), because a four-wave workgroup is dealt one wave to each SIMD, while four one-wave workgroups land wherever the dispatcher's pointer
+// stands -- with a second kernel's blocks arriving in between, two walkers on one SIMD and none on another was common: the two slowed each
+// other (8.4 ms instead of 7.5), and their 256 registers left that SIMD room for two expander waves instead of four, so one expander block
+// in twenty started when the walk was over and expanded its eight chunks alone (scripts/trail_timing.py: the 2.6 ms tail of round 4's first form).
+template <uint32_t KQ> __device__ __forceinline__ uint8_t PCO_LDS* walk_lds() { return lds_base() + uni((uint32_t)(threadIdx.x >> 6)) * WalkCfg<KQ>::kWalkLdsBytes; }
+__device__ __forceinline__ uint32_t walk_block_id() { return blockIdx.x * (blockDim.x >> 6) + uni((uint32_t)(threadIdx.x >> 6)); }
 // Trailing expanders (decode_trail.hip): dec_walk_kernel<L, 8, true> publishes, per chunk slot, how many batches of the chunk are complete
 // in global memory -- progress[block * 8 + slot] = 1 + batches once the metadata is parsed, kTrailDead for a chunk the expanders must
 // leave alone -- and a second kernel on a second stream expands them while the walk is still going on.
@@ -74,15 +81,15 @@ template <class LV, uint32_t KQ>
 __device__ __forceinline__ bool fast_build_var_impl(uint32_t q, uint32_t vi, MetaReader& mr, uint8_t PCO_GLOBAL* bins_out, uint32_t& status) {
   constexpr uint32_t kGrpBytes = WalkCfg<KQ>::kGrpBytes, kWalkTmpOff = WalkCfg<KQ>::kWalkTmpOff;
   const uint32_t lane = lane_id();
-  uint8_t PCO_LDS* grp = lds_base() + q * kGrpBytes;
+  uint8_t PCO_LDS* grp = walk_lds<KQ>() + q * kGrpBytes;
   VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(grp + kGrpVarOff) + vi;
   const uint32_t asl = uni(vinfo->ans_size_log), n_bins = uni(vinfo->n_bins), latent_bits = uni(vinfo->latent_bits);
   const uint32_t T = 1u << asl;
-  const uint32_t tbl_addr = (uint32_t)(uintptr_t)lds_base() + q * kGrpBytes + kGrpTblOff + uni(vinfo->off_nodes);   // absolute LDS byte address
+  const uint32_t tbl_addr = (uint32_t)(uintptr_t)walk_lds<KQ>() + q * kGrpBytes + kGrpTblOff + uni(vinfo->off_nodes);   // absolute LDS byte address
   uint32_t PCO_LDS* entries = (uint32_t PCO_LDS*)(grp + kGrpTblOff + uni(vinfo->off_nodes));
-  uint8_t PCO_LDS* obs = lds_base() + WalkCfg<KQ>::kWalkTmpObOff;   // every bin's offset bits, for the entries being built
+  uint8_t PCO_LDS* obs = walk_lds<KQ>() + WalkCfg<KQ>::kWalkTmpObOff;   // every bin's offset bits, for the entries being built
   uint8_t PCO_LDS* ob0 = grp + kGrpTblOff + uni(vinfo->off_ob);      // the slice keeps bin 0's only (what a single-bin variable needs)
-  uint32_t PCO_LDS* cum = (uint32_t PCO_LDS*)(lds_base() + kWalkTmpOff);
+  uint32_t PCO_LDS* cum = (uint32_t PCO_LDS*)(walk_lds<KQ>() + kWalkTmpOff);
   uint64_t PCO_GLOBAL* g_low = (uint64_t PCO_GLOBAL*)(bins_out + (uint64_t)vi * kBinsAreaPerVar);
   uint8_t PCO_GLOBAL* g_ob = bins_out + (uint64_t)vi * kBinsAreaPerVar + kFastMaxBins * 8;
   const uint32_t obb = offset_bits_bits(latent_bits);
@@ -175,7 +182,7 @@ __device__ __forceinline__ void fast_front_impl(const PcoGfxDecodeTask& task, ui
   uint32_t status = PCO_GFX_OK, format_major = 4, uniform_type = 0;
   out.status = PCO_GFX_OK; out.n = 0; out.bitpos = 0;
   for (int v = 0; v < 3; v++) for (int j = 0; j < 4; j++) out.states[v][j] = 0;
-  VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(lds_base() + q * kGrpBytes + kGrpVarOff);
+  VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(walk_lds<KQ>() + q * kGrpBytes + kGrpVarOff);
   auto fail = [&](uint32_t s) { out.status = s; if (lane == 0) { plan->status = s; plan->consumed = mr.bit >> 3; plan->n = 0; plan->fused = 0; plan->more = 0; } };
   out.moments[0][0] = out.moments[0][1] = out.moments[1][0] = out.moments[1][1] = 0;
   if (dtype_bits(dtype) != (int)LB) { fail(PCO_GFX_INVALID_ARGUMENT); return; }
@@ -434,11 +441,20 @@ __device__ __forceinline__ bool block_has_trail_candidate(const PcoGfxDecodeTask
   return uni((uint32_t)__any(cand)) != 0;
 }
 
+#ifdef PCO_TRAIL_TIMING   // (measurement builds: when every walker block and every expander block started and ended, on the device-wide 100 MHz clock)
+constexpr uint32_t kTrailStampBlocks = 4096;
+__device__ unsigned long long g_trail_stamps[4][kTrailStampBlocks];   // walker start, walker end, expanders start, expanders end
+#define PCO_TRAIL_STAMP(which, idx) do { if (lane_id() == 0 && (idx) < kTrailStampBlocks) g_trail_stamps[which][idx] = wall_clock64(); } while (0)
+#else
+#define PCO_TRAIL_STAMP(which, idx) do { } while (0)
+#endif
 template <class L, uint32_t kWQ, bool kTrail>
 __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                               uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
                                               uint32_t accept_status, PcoGfxTaskResult* results, uint32_t* progress) {
   static_assert(!kTrail || kWQ == 8, "the trailing expanders follow the eight-chunk walker");
+  const uint32_t wb = walk_block_id();   // (the wave's "block": blockIdx.x in the one-wave kernels)
+  if ((uint64_t)wb * kWQ >= n_ids) return;   // (the spare waves of the last four-wave workgroup)
   constexpr uint32_t kGrpBytes = WalkCfg<kWQ>::kGrpBytes;
 #ifndef PCO_TRAIL_NOPRIO
   if constexpr (kTrail) __builtin_amdgcn_s_setprio(3);   // the walker's chain sets the duration of the decode: it goes first whenever it can issue
@@ -446,13 +462,14 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
   const uint32_t lane = lane_id();
   const uint32_t slot = lane >> 2, j = lane & 3;
   if constexpr (kTrail) {   // the blocks without a candidate belong to the ordinary walker (launched beside this one); their expanders are told at once
-    if (!block_has_trail_candidate(tasks, task_ids, n_ids, blockIdx.x)) {
-      if (lane < 8) __hip_atomic_store(progress + (uint64_t)blockIdx.x * kTrailProgressStride + lane, kTrailDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!block_has_trail_candidate(tasks, task_ids, n_ids, wb)) {
+      if (lane < 8) __hip_atomic_store(progress + (uint64_t)wb * kTrailProgressStride + lane, kTrailDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
   } else if constexpr (kWQ == 8) {
-    if (progress != nullptr && accept_status == 0 && block_has_trail_candidate(tasks, task_ids, n_ids, blockIdx.x)) return;   // (progress != nullptr: the publishing walker runs too and takes this block)
+    if (progress != nullptr && accept_status == 0 && block_has_trail_candidate(tasks, task_ids, n_ids, wb)) return;   // (progress != nullptr: the publishing walker runs too and takes this block)
   }
+  if constexpr (kTrail) PCO_TRAIL_STAMP(0, wb);
   // ---- phase 0: metadata + tables, one task at a time with the whole wave; slot q belongs to lanes 4q..4q+3 ----
   uint32_t my_ti = 0xffffffffu, my_active = 0, my_front_ok = 0, my_n = 0, my_flags = 0;
   uint32_t st0 = 0, st1 = 0, st2 = 0;   // this lane's chain state per variable, as an entry address
@@ -460,7 +477,7 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
   uint64_t my_mom[2][2] = {{0, 0}, {0, 0}};
   gcptr_u8 my_src = nullptr;
   for (uint32_t q = 0; q < kWQ; q++) {
-    const uint32_t bi = blockIdx.x * kWQ + q;
+    const uint32_t bi = wb * kWQ + q;
     if (bi >= n_ids) break;
     const uint32_t ti = task_ids ? task_ids[bi] : bi;
     if (accept_status != 0 && uni(((const DecPlan PCO_GLOBAL*)plans + ti)->status) != accept_status) continue;   // an earlier stage dealt with this task
@@ -479,8 +496,8 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
     wave_sync_lds();
   }
   const uint32_t slice = (slot < kWQ ? slot : 0u) * kGrpBytes;   // LDS byte offset of this chunk's slice
-  uint8_t PCO_LDS* gbase = lds_base() + slice;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)lds_base();
+  uint8_t PCO_LDS* gbase = walk_lds<kWQ>() + slice;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)walk_lds<kWQ>();
   uint64_t PCO_LDS* win = (uint64_t PCO_LDS*)(gbase + kGrpWinOff);
   VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(gbase + kGrpVarOff);
   // ---- phase 1: rounds; in each round every active chunk handles its next (batch, variable) item ----
@@ -505,7 +522,7 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
       my_fused = vinfo[0].present == 0 && vinfo[2].present == 0 && vinfo[1].n_bins > 1 && vinfo[1].n_bins <= kTrailMaxBins && vinfo[1].max_ob <= 16;   // (offsets beyond 16 bits: four windows per lane, a job for dec_expand_kernel's LDS staging; one bin: nothing to walk, nothing to hide under)
       if (vinfo[1].delta_kind == kDeltaConsecutive ? vinfo[1].delta_order > 2 : vinfo[1].delta_kind != kDeltaNone) my_fused = false;
     }
-    if (slot < kWQ) my_progress = (uint32_t PCO_GLOBAL*)progress + (uint64_t)blockIdx.x * kTrailProgressStride + slot;
+    if (slot < kWQ) my_progress = (uint32_t PCO_GLOBAL*)progress + (uint64_t)wb * kTrailProgressStride + slot;
     if (j == 0 && my_fused) ((DecPlan PCO_GLOBAL*)plans + my_ti)->fused = 1u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // plans and bins (plain stores of the table build) are visible to every XCD from here on
     if (j == 0 && slot < kWQ) __hip_atomic_store((uint32_t*)my_progress, my_fused ? 1u : kTrailDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -599,7 +616,7 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
     // chunk's four lanes touch eight 128-byte lines around it.  The loaded values get their (dummy) use one round later,
     // right here, where this round's staging loads have already been waited for -- VMEM returns in order, so that use
     // never waits.
-    ((uint32_t PCO_LDS*)(lds_base() + WalkCfg<kWQ>::kWalkTmpOff))[lane] = touch_r0 ^ touch_r1;   // (the table-build scratch is idle during the walk)
+    ((uint32_t PCO_LDS*)(walk_lds<kWQ>() + WalkCfg<kWQ>::kWalkTmpOff))[lane] = touch_r0 ^ touch_r1;   // (the table-build scratch is idle during the walk)
     if (walk) {
       const uint64_t cur = q0 * 8, pred = cur + (cur - touch_prev);
       touch_prev = cur;
@@ -693,12 +710,13 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
 #endif
   }
 #ifdef PCO_WALK_TIMING
-  if (blockIdx.x == 0 && lane == 0 && wt_rounds > 0) { g_walk_timing[0] = wt_stage; g_walk_timing[1] = wt_walk; g_walk_timing[2] = wt_tail; g_walk_timing[3] = wt_rounds; g_walk_timing[4] = wt_start; g_walk_timing[5] = WT_NOW(); g_walk_timing[6] = wt_s1; g_walk_timing[7] = wt_s2 | (wt_s3 << 32); }
+  if (wb == 0 && lane == 0 && wt_rounds > 0) { g_walk_timing[0] = wt_stage; g_walk_timing[1] = wt_walk; g_walk_timing[2] = wt_tail; g_walk_timing[3] = wt_rounds; g_walk_timing[4] = wt_start; g_walk_timing[5] = WT_NOW(); g_walk_timing[6] = wt_s1; g_walk_timing[7] = wt_s2 | (wt_s3 << 32); }
 #endif
   if constexpr (kTrail) {
     flush_deferred();
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (my_fused && j == 0) __hip_atomic_store((uint32_t*)my_progress, status == PCO_GFX_OK ? 1u + batch : kTrailDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PCO_TRAIL_STAMP(1, wb);
   }
   // ---- page end (page_decompressor.rs:184-188) and stream end ----
   if (my_ti != 0xffffffffu && j == 0 && slot < kWQ) {
@@ -749,7 +767,7 @@ __global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* ta
 // (10.8 ms per launch against 7.2).
 #define PCO_TRAIL_WALK_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 template <class L>
-__global__ __launch_bounds__(64) PCO_TRAIL_WALK_ATTR void dec_walk_trail_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
+__global__ __launch_bounds__(256) PCO_TRAIL_WALK_ATTR void dec_walk_trail_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                                       uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
                                                       PcoGfxTaskResult* results, uint32_t* progress) {
   dec_walk_body<L, 8, true>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, 0u, results, progress);

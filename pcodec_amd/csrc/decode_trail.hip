@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
                                                                      uint32_t n_walk_blocks) {
   const uint32_t lane = lane_id(), wave = uni(threadIdx.x >> 6);
   for (uint32_t wb = blockIdx.x; wb < n_walk_blocks; wb += gridDim.x) {
+    if (wave == 0) PCO_TRAIL_STAMP(2, wb);
     TrailChunk<L> S[kTrailSlotsPerWave];
     const uint32_t* pline = progress + (uint64_t)wb * kTrailProgressStride + (lane & 7u);
     // ---- the chunks' constants, once their walker has parsed the metadata (it publishes all eight slots together) ----
@@ -429,6 +430,8 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
     }
 #ifdef PCO_TRAIL_TIMING
     if (blockIdx.x == 0 && wave == 0 && lane == 0) for (int i = 0; i < 8; i++) g_trail_timing[i] = tt[i];
+    __syncthreads();   // (the block's last wave)
+    if (wave == 0) PCO_TRAIL_STAMP(3, wb);
 #endif
   }
 }

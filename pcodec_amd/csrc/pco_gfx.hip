@@ -201,7 +201,10 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
       if (g_decode_trail) {                                                                                                                               \
         ScopedKernelTimer _span("dec_walk+trail<" name ">", stream);                                                                                      \
         PCO_HIP_CHECK(hipEventRecord(ws.fork_event, stream));                                                                                             \
-        PCO_TIMED_LAUNCH("~dec_walk_kernel<" name ">", stream, (dec_walk_trail_kernel<L>), dim3(n_wb), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,       \
+        /* four walker waves per workgroup, the CU's whole LDS: one walker per SIMD by construction (decode_fast.hip, walk_lds) */                      \
+        static const bool _quad_ok = hipFuncSetAttribute((const void*)dec_walk_trail_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * WalkCfg<8>::kWalkLdsBytes)) == hipSuccess; \
+        if (!_quad_ok) throw HostError{PCO_GFX_DEVICE_ERROR, "cannot reserve LDS for dec_walk_trail_kernel"};                                             \
+        PCO_TIMED_LAUNCH("~dec_walk_kernel<" name ">", stream, (dec_walk_trail_kernel<L>), dim3((n_wb + 3) / 4), dim3(256), 4 * WalkCfg<8>::kWalkLdsBytes, stream, \
                          d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_results, d_progress);                          \
         /* the blocks without a candidate for the expanders: the ordinary walker, beside the two (every block runs in exactly one of the walkers).       \
            Launched second: where no block is a candidate the publishing walker's blocks say so and leave at once, and the expanders with them         \
@@ -499,6 +502,9 @@ enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size
 #ifdef PCO_TRAIL_TIMING
 extern "C" int pco_gfx_debug_trail_timing(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_trail_timing), 64);
+}
+extern "C" int pco_gfx_debug_trail_stamps(unsigned long long* out) {   // [4][kTrailStampBlocks]
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_trail_stamps), sizeof(unsigned long long) * 4 * pcogfx::kTrailStampBlocks);
 }
 #endif
 #ifdef PCO_WALK_TIMING

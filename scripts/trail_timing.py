@@ -39,3 +39,17 @@ buf = (C.c_ulonglong * 8)()
 L.pco_gfx_debug_trail_timing(buf)
 it = max(int(buf[0]), 1)
 print(f"iterations {buf[0]} (idle {buf[5]}): per iteration -- poll {buf[1] / it:.0f} stageA {buf[2] / it:.0f} requests {buf[3] / it:.0f} stageB {buf[4] / it:.0f} | roundtrip_ok {ok}")
+
+# per-block start / end stamps of the two kernels (device-wide 100 MHz clock): how far behind their walkers the expanders end
+st = np.zeros((4, 4096), np.uint64)
+if L.pco_gfx_debug_trail_stamps(st.ctypes.data_as(C.c_void_p)) == 0:
+    nb = (chunks + 7) // 8
+    s = st[:, :min(nb, 4096)].astype(np.int64)
+    t0 = s[s > 0].min()
+    us = lambda a: (a - t0) / 100.0
+    q = lambda a: " ".join(f"{np.percentile(a, p):8.0f}" for p in (0, 10, 50, 90, 100))
+    print("microseconds from the first stamp; percentiles 0 10 50 90 100 over the blocks")
+    for name, row in zip(("walker start", "walker end", "expanders start", "expanders end"), s):
+        print(f"  {name:16s} {q(us(row))}")
+    print(f"  {'end lag':16s} {q((s[3] - s[1]) / 100.0)}")
+    print(f"  {'walker duration':16s} {q((s[1] - s[0]) / 100.0)}")
