@@ -162,7 +162,7 @@ template <class LV, uint32_t KQ>
 __device__ __noinline__ bool fast_build_var(uint32_t q, uint32_t vi, MetaReader& mr, uint8_t PCO_GLOBAL* bins_out, uint32_t& status) { return fast_build_var_impl<LV, KQ>(q, vi, mr, bins_out, status); }
 
 struct FrontOut {
-  uint32_t status, n;
+  uint32_t status, n, mode_kind;
   uint64_t bitpos;          // first bit of the page body
   uint32_t states[3][4];
   uint64_t moments[2][2];   // the first two delta moments of (primary, secondary)
@@ -182,6 +182,7 @@ __device__ __forceinline__ void fast_front_impl(const PcoGfxDecodeTask& task, ui
   uint32_t status = PCO_GFX_OK, format_major = 4, uniform_type = 0;
   out.status = PCO_GFX_OK; out.n = 0; out.bitpos = 0;
   for (int v = 0; v < 3; v++) for (int j = 0; j < 4; j++) out.states[v][j] = 0;
+  out.mode_kind = kClassic;
   VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(walk_lds<KQ>() + q * kGrpBytes + kGrpVarOff);
   auto fail = [&](uint32_t s) { out.status = s; if (lane == 0) { plan->status = s; plan->consumed = mr.bit >> 3; plan->n = 0; plan->fused = 0; plan->more = 0; } };
   out.moments[0][0] = out.moments[0][1] = out.moments[1][0] = out.moments[1][1] = 0;
@@ -321,6 +322,7 @@ __device__ __forceinline__ void fast_front_impl(const PcoGfxDecodeTask& task, ui
   if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
   const uint32_t n_in_body = n > nlps[1] ? n - nlps[1] : 0;
   if (n_in_body > 0) for (int vi = 0; vi < 3; vi++) if (present[vi] && uni(vinfo[vi].n_bins) == 0) { fail(PCO_GFX_CORRUPTION); return; }
+  out.mode_kind = mode_kind;
   if (lane == 0) {
     plan->status = PCO_GFX_OK; plan->n = n; plan->mode_kind = mode_kind; plan->mode_k = mode_k; plan->mode_base = (uint64_t)mode_base;
     plan->num_kind = num_kind; plan->dtype = dtype; plan->window_n_log = wlog; plan->state_n_log = slog; plan->consumed = 0; plan->fused = 0; plan->more = 0;
@@ -425,20 +427,33 @@ __device__ unsigned long long g_walk_timing[8];
 // classic mode without lookback / Conv1.  The two first-stage walkers split the blocks by this -- the one that publishes its progress pays
 // ~0.7 us a round for it (agent-scope stores, a wait), which a call of float-mult or lookback chunks should not.  The precise test (bins
 // that fit a wave's registers, delta order <= 2) is the publishing walker's, after it has parsed the metadata.
-__device__ __forceinline__ bool block_has_trail_candidate(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, uint32_t wb) {
+// Returns bit 0: a one-variable candidate (classic mode), bit 1: a two-variable candidate (int-mult / float-mult / float-quant: the blocks
+// dec_trail_kernel<L, true> follows).
+__device__ __forceinline__ uint32_t block_trail_kinds(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, uint32_t wb) {
   const uint32_t lane = lane_id(), bi = wb * 8 + (lane & 7u);
-  bool cand = false;
+  bool one = false, two = false;
   if (lane < 8 && bi < n_ids) {
     const PcoGfxDecodeTask t = tasks[task_ids ? task_ids[bi] : bi];
     const uint32_t fmt = (t.flags & PCO_GFX_TASK_ONE_CHUNK) && ((t.flags >> 8) & 0xffu) ? (t.flags >> 8) & 0xffu : 4u;
-    if ((t.flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY | PCO_GFX_TASK_HAS_FILE_HEADER)) == 0 && t.src_len >= 12 && fmt >= 3) {
-      const uint64_t w = load_u64_le((gcptr_u8)t.src + 4);   // mode (4 bits) | delta variant (4) | [order (3) | secondary uses delta (1)] | ans_size_log (4) | n_bins (15)
-      const uint32_t mode = (uint32_t)w & 15u, dv = (uint32_t)(w >> 4) & 15u;
-      const uint32_t n_bins = (uint32_t)(w >> (dv == kDeltaConsecutive ? 16 : 12)) & 0x7fffu;
-      cand = mode == kClassic && (dv == kDeltaNone || dv == kDeltaConsecutive) && n_bins > 1 && n_bins <= kTrailMaxBins;   // (one bin: nothing to walk, nothing to hide the expansion under)
+    if ((t.flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY | PCO_GFX_TASK_HAS_FILE_HEADER)) == 0 && t.src_len >= 24 && fmt >= 3) {
+      const uint64_t w = load_u64_le((gcptr_u8)t.src + 4);   // mode (4 bits) | [base (the type's bits) or k (8)] | delta variant (4) | [order (3) | secondary uses delta (1)] | ans_size_log (4) | n_bins (15)
+      const uint32_t mode = (uint32_t)w & 15u;
+      if (mode == kClassic) {
+        const uint32_t dv = (uint32_t)(w >> 4) & 15u;
+        const uint32_t n_bins = (uint32_t)(w >> (dv == kDeltaConsecutive ? 16 : 12)) & 0x7fffu;
+        one = (dv == kDeltaNone || dv == kDeltaConsecutive) && n_bins > 1 && n_bins <= kTrailMaxBins;   // (one bin: nothing to walk, nothing to hide the expansion under)
+      } else if (mode == kIntMult || mode == kFloatMult || mode == kFloatQuant) {
+        const uint32_t at = 4u + (mode == kFloatQuant ? kBitsQuantK : (uint32_t)dtype_bits(t.dtype));   // where the delta variant starts, in bits from byte 4
+        const uint64_t w2 = load_u64_le((gcptr_u8)t.src + 4 + (at >> 3));
+        const uint32_t dv = (uint32_t)(w2 >> (at & 7u)) & 15u;
+        two = dv == kDeltaNone || dv == kDeltaConsecutive;
+      }
     }
   }
-  return uni((uint32_t)__any(cand)) != 0;
+  return (uni((uint32_t)__any(one)) ? 1u : 0u) | (uni((uint32_t)__any(two)) ? 2u : 0u);
+}
+__device__ __forceinline__ bool block_has_trail_candidate(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, uint32_t wb) {
+  return block_trail_kinds(tasks, task_ids, n_ids, wb) != 0;
 }
 
 #ifdef PCO_TRAIL_TIMING   // (measurement builds: when every walker block and every expander block started and ended, on the device-wide 100 MHz clock)
@@ -471,7 +486,7 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
   }
   if constexpr (kTrail) PCO_TRAIL_STAMP(0, wb);
   // ---- phase 0: metadata + tables, one task at a time with the whole wave; slot q belongs to lanes 4q..4q+3 ----
-  uint32_t my_ti = 0xffffffffu, my_active = 0, my_front_ok = 0, my_n = 0, my_flags = 0;
+  uint32_t my_ti = 0xffffffffu, my_active = 0, my_front_ok = 0, my_n = 0, my_flags = 0, my_mode = kClassic;
   uint32_t st0 = 0, st1 = 0, st2 = 0;   // this lane's chain state per variable, as an entry address
   uint64_t my_bitpos = 0, my_len = 0;
   uint64_t my_mom[2][2] = {{0, 0}, {0, 0}};
@@ -486,7 +501,7 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
     if constexpr (kTrail) fast_front_impl<L, kWQ, true>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);
     else fast_front<L, kWQ>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);
     if (slot == q) {
-      my_ti = ti; my_active = fo.status == PCO_GFX_OK ? 1u : 0u; my_front_ok = my_active; my_n = fo.n; my_bitpos = fo.bitpos;
+      my_ti = ti; my_active = fo.status == PCO_GFX_OK ? 1u : 0u; my_front_ok = my_active; my_n = fo.n; my_bitpos = fo.bitpos; my_mode = fo.mode_kind;
       my_len = task.src_len; my_flags = task.flags; my_src = (gcptr_u8)task.src;
       my_mom[0][0] = fo.moments[0][0]; my_mom[0][1] = fo.moments[0][1]; my_mom[1][0] = fo.moments[1][0]; my_mom[1][1] = fo.moments[1][1];
       st0 = j == 0 ? fo.states[0][0] : (j == 1 ? fo.states[0][1] : (j == 2 ? fo.states[0][2] : fo.states[0][3]));
@@ -513,17 +528,23 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
     st2 = lds0 + slice + kGrpTblOff + vinfo[2].off_nodes + 4u * st2;
   }
   bool my_fused = false;
+  uint32_t my_fused_kind = 0;   // DecPlan::fused: 1 = one latent variable, 2 = two (dec_trail_kernel<L, true>)
   uint32_t PCO_GLOBAL* my_progress = nullptr;
   if constexpr (kTrail) {
-    // which of the wave's chunks the trailing expanders take: ONE latent variable (classic mode, no lookback -- the state of eight chunks
-    // per SIMD has to fit the registers this kernel leaves), 2..64 bins (they live in one wave's registers), offsets of up to 16 bits (a
-    // lane's four fields in one 64-bit window), delta orders up to 2 (moments in registers).  The others go to dec_expand_kernel.
+    // which of the wave's chunks the trailing expanders take: no lookback variable, every variable's bins in one wave's registers (<= 64),
+    // offsets of up to 16 bits (a lane's four fields in one 64-bit window), delta orders up to 2 on the primary variable (moments in
+    // registers) and none on the secondary.  One variable (classic mode): 2..64 bins -- with one bin there is nothing to walk and nothing to
+    // hide the expansion under.  Two (int-mult, float-mult, float-quant): the expanders of the second kind.  The others go to dec_expand_kernel.
     if (my_active && slot < kWQ) {
-      my_fused = vinfo[0].present == 0 && vinfo[2].present == 0 && vinfo[1].n_bins > 1 && vinfo[1].n_bins <= kTrailMaxBins && vinfo[1].max_ob <= 16;   // (offsets beyond 16 bits: four windows per lane, a job for dec_expand_kernel's LDS staging; one bin: nothing to walk, nothing to hide under)
-      if (vinfo[1].delta_kind == kDeltaConsecutive ? vinfo[1].delta_order > 2 : vinfo[1].delta_kind != kDeltaNone) my_fused = false;
+      const bool prim_ok = vinfo[0].present == 0 && vinfo[1].n_bins >= 1 && vinfo[1].n_bins <= kTrailMaxBins && vinfo[1].max_ob <= 16 &&
+                           (vinfo[1].delta_kind == kDeltaConsecutive ? vinfo[1].delta_order <= 2 : vinfo[1].delta_kind == kDeltaNone);
+      if (vinfo[2].present == 0) { if (prim_ok && my_mode == kClassic && vinfo[1].n_bins > 1) my_fused_kind = 1; }
+      else if (prim_ok && (my_mode == kIntMult || my_mode == kFloatMult || my_mode == kFloatQuant) && vinfo[2].n_bins >= 1 && vinfo[2].n_bins <= kTrailMaxBins &&
+               vinfo[2].max_ob <= 16 && vinfo[2].delta_kind == kDeltaNone && (vinfo[1].n_bins > 1 || vinfo[2].n_bins > 1)) my_fused_kind = 2;
+      my_fused = my_fused_kind != 0;
     }
     if (slot < kWQ) my_progress = (uint32_t PCO_GLOBAL*)progress + (uint64_t)wb * kTrailProgressStride + slot;
-    if (j == 0 && my_fused) ((DecPlan PCO_GLOBAL*)plans + my_ti)->fused = 1u;
+    if (j == 0 && my_fused) ((DecPlan PCO_GLOBAL*)plans + my_ti)->fused = my_fused_kind;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // plans and bins (plain stores of the table build) are visible to every XCD from here on
     if (j == 0 && slot < kWQ) __hip_atomic_store((uint32_t*)my_progress, my_fused ? 1u : kTrailDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -755,8 +776,9 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
 }
 
 // split != nullptr (first stage only): the publishing walker runs beside this one and takes the blocks with a candidate for the trailing expanders
+// (four walker waves per workgroup like the publishing walker below: one per SIMD by construction)
 template <class L, uint32_t kWQ>
-__global__ __launch_bounds__(64) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
+__global__ __launch_bounds__(256) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                                       uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
                                                       uint32_t accept_status, PcoGfxTaskResult* results, uint32_t* split) {
   dec_walk_body<L, kWQ, false>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, accept_status, results, split);

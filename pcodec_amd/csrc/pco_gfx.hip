@@ -198,6 +198,11 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
       //  whatever the order in which the two kernels' blocks arrive)
       const uint32_t trail_grid = g_decode_trail ? std::min<uint32_t>(n_wb, (uint32_t)ws.n_cus * 4u) : 0u;
 #define PCO_FAST_DECODE(L, name)                                                                                                                          \
+      {                                                                                                                                                   \
+        static const bool _walk_ok = hipFuncSetAttribute((const void*)dec_walk_kernel<L, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * WalkCfg<8>::kWalkLdsBytes)) == hipSuccess && \
+                                     hipFuncSetAttribute((const void*)dec_walk_kernel<L, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * WalkCfg<4>::kWalkLdsBytes)) == hipSuccess;   \
+        if (!_walk_ok) throw HostError{PCO_GFX_DEVICE_ERROR, "cannot reserve LDS for dec_walk_kernel"};                                                   \
+      }                                                                                                                                                   \
       if (g_decode_trail) {                                                                                                                               \
         ScopedKernelTimer _span("dec_walk+trail<" name ">", stream);                                                                                      \
         PCO_HIP_CHECK(hipEventRecord(ws.fork_event, stream));                                                                                             \
@@ -211,19 +216,23 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
            (launched first it held the LDS, they queued behind it: 1.8 instead of 1.3 ms per 16384 one-bin chunks).  Where every block is a        \
            candidate its own blocks queue behind the publishing walker's LDS and then leave at once: its time in a profile is that wait */          \
         PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream2, ws.fork_event, 0));                                                                             \
-        PCO_TIMED_LAUNCH("~dec_walk_kernel(rest)<" name ">", ws.side_stream2, (dec_walk_kernel<L, 8>), dim3(n_wb), dim3(64), WalkCfg<8>::kWalkLdsBytes, ws.side_stream2, \
+        PCO_TIMED_LAUNCH("~dec_walk_kernel(rest)<" name ">", ws.side_stream2, (dec_walk_kernel<L, 8>), dim3((n_wb + 3) / 4), dim3(256), 4 * WalkCfg<8>::kWalkLdsBytes, ws.side_stream2, \
                          d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results, d_progress);                      \
         PCO_HIP_CHECK(hipEventRecord(ws.join_event2, ws.side_stream2));                                                                                   \
         hipStream_t ts = g_trail_debug == 's' ? stream : ws.side_stream;                                                                                  \
         PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream, ws.fork_event, 0));                                                                              \
-        if (g_trail_debug != 'n') PCO_TIMED_LAUNCH("~dec_trail_kernel<" name ">", ts, (dec_trail_kernel<L>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
+        /* one kernel per kind of walker block (classic chunks only / a chunk with two latent variables among them), one after the other on the    \
+           expanders' stream: the blocks of the kind a call does not have leave at once */                                                         \
+        if (g_trail_debug != 'n') PCO_TIMED_LAUNCH("~dec_trail_kernel<" name ">", ts, (dec_trail_kernel<L, false>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
+                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);                               \
+        if (g_trail_debug != 'n') PCO_TIMED_LAUNCH("~dec_trail2_kernel<" name ">", ts, (dec_trail_kernel<L, true>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
                          d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);                               \
         PCO_HIP_CHECK(hipEventRecord(ws.join_event, ws.side_stream));                                                                                     \
         PCO_HIP_CHECK(hipStreamWaitEvent(stream, ws.join_event, 0));                                                                                      \
         PCO_HIP_CHECK(hipStreamWaitEvent(stream, ws.join_event2, 0));                                                                                     \
-      } else PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8>), dim3(n_wb), dim3(64), WalkCfg<8>::kWalkLdsBytes, stream,          \
+      } else PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8>), dim3((n_wb + 3) / 4), dim3(256), 4 * WalkCfg<8>::kWalkLdsBytes, stream, \
                        d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results, (uint32_t*)nullptr);                \
-      PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4>), dim3((cnt + 3) / 4), dim3(64), WalkCfg<4>::kWalkLdsBytes, stream,   \
+      PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4>), dim3((cnt + 15) / 16), dim3(256), 4 * WalkCfg<4>::kWalkLdsBytes, stream, \
                        d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4, d_results, (uint32_t*)nullptr);   \
       PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, (dec_expand_kernel<L, false>), dim3(grid), dim3(256), kExpLdsBytes, stream,               \
                        d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);                                        \

@@ -578,9 +578,9 @@ def test_decode_expanders_under_the_walk(L):
     def ramp(n, dt, step=1000, noise=512):
         return (np.arange(n, dtype=np.int64) * step + rng.integers(0, noise, n) + (1 << 30)).astype(dt)
     sizes = [700, 2, 255, 256, 257, 511, 513, 1000, 4096, 4097, 70000, 3, 258, 769, 1]
-    for rep in range(40):
+    for rep in range(64):
         n = sizes[rep % len(sizes)]
-        kind = rep % 10
+        kind = rep % 16
         if kind == 0: a, kw = ramp(n, np.uint64), dict(mode=1, delta=2, delta_order=1)
         elif kind == 1: a, kw = ramp(n, np.int32, 7, 40), dict(mode=1, delta=2, delta_order=2)
         elif kind == 2: a, kw = ramp(n, np.uint32, 3, 9), dict(mode=1, delta=2, delta_order=3)                       # order 3: left to dec_expand_kernel
@@ -590,15 +590,22 @@ def test_decode_expanders_under_the_walk(L):
         elif kind == 6: a, kw = (rng.pareto(0.5, n) * 10).clip(0, 2e9).astype(np.int32), dict(mode=1, delta=1)         # many bins, wide offsets
         elif kind == 7: a, kw = rng.integers(0, 40, n).astype(np.uint16), dict(mode=1, delta=1)                        # a few bins, no offsets at all
         elif kind == 8: a, kw = ramp(n, np.int64, 5, 100), dict(mode=1, delta=1)                                       # no delta, narrow offsets
-        else: a, kw = rng.standard_normal(n).astype(np.float32), dict(mode=1, delta=2, delta_order=1)
+        elif kind == 9: a, kw = rng.standard_normal(n).astype(np.float32), dict(mode=1, delta=2, delta_order=1)
+        # two latent variables: the expanders of the second kind (dec_trail_kernel<L, true>)
+        elif kind == 10: a, kw = (np.cumsum(rng.integers(-50, 60, n)) / 100.0 + 500.0), dict(mode=2, mode_f64=0.01, delta=2, delta_order=1)   # float-mult, delta'd multiples
+        elif kind == 11: a, kw = (rng.integers(0, 5000, n).astype(np.int64) * 1000 + rng.integers(0, 3, n)), dict(mode=4, mode_u64=1000, delta=1)   # int-mult with remainders
+        elif kind == 12: a, kw = (rng.integers(8, 16, n) * 2.0 ** rng.integers(-3, 4, n)).astype(np.float32), dict(mode=3, mode_u64=20, delta=1)   # float-quant
+        elif kind == 13: a, kw = ((rng.integers(10, 4000, n) * 0.1).astype(np.float32) * (1 + rng.integers(-2, 3, n).astype(np.float32) * np.float32(2 ** -22))), dict(mode=2, mode_f64=0.1, delta=1)   # f32 float-mult, adjustments of a few ulps
+        elif kind == 14: a, kw = (rng.integers(-300, 300, n).astype(np.int32) * 7), dict(mode=4, mode_u64=7, delta=2, delta_order=2)   # int-mult, order 2, secondary constant
+        else: a, kw = (rng.integers(1, 1 << 40, n).astype(np.float64) * 0.25), dict(mode=2, mode_f64=0.25, delta=1)   # float-mult whose multiples need offsets beyond 16 bits: left to dec_expand_kernel
         arrays.append(np.ascontiguousarray(a)); cfgs.append(kw)
     blobs = [U.chunk_of_file(f, len(f) - O_header_len(f) - 1) for f in (O.simple_compress(a, O.make_config(**kw)) for a, kw in zip(arrays, cfgs))]
     # many copies, so that the call needs more than one round of walker blocks per width; one damaged chunk per width in the middle
-    reps = 30
+    reps = 20
     srcs, tasks_spec, want = [], [], []
     for r in range(reps):
         for i, (a, b) in enumerate(zip(arrays, blobs)):
-            damaged = (r == reps // 2 and i % 10 in (0, 9) and len(b) > 64)
+            damaged = (r == reps // 2 and i % 16 in (0, 9, 10, 11) and len(b) > 64)
             bb = b[: len(b) // 2] if damaged else b
             srcs.append(bb); tasks_spec.append((a.dtype, a.size, damaged)); want.append(a)
     k = len(srcs)
