@@ -217,7 +217,7 @@ def load_traffic(workload, nch, kernel_names):
             return None, f"{os.path.basename(cands[0])} was measured on other kernel sources (csrc_sha16 {tj.get('csrc_sha16')}); re-run scripts/pmc_run.sh"
         tab = {k: int((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * nch / tj["chunks"]) for k, v in tj["kernels"].items()}
         kernel_names = [k.lstrip("~") for k in kernel_names if "+" not in k]   # (spans of concurrent kernels are not kernels)
-        missing = [k for k in kernel_names if k not in tab and not k.startswith(("pco_decode_kernel", "enc_page_kernel", "enc_init", "enc_presample", "enc_scan", "dec_walk4", "dec_walk_kernel(rest)"))]
+        missing = [k for k in kernel_names if k not in tab and not k.startswith(("pco_decode_kernel", "enc_page_kernel", "enc_init", "enc_presample", "enc_scan", "enc_lat_slots", "dec_walk4", "dec_walk_kernel(rest)"))]
         if missing:
             return None, f"{os.path.basename(cands[0])} lacks kernels that ran: {missing}"
         return tab, os.path.basename(cands[0])

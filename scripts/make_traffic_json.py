@@ -37,9 +37,9 @@ def label(name):
     m = re.match(r"dec_walk_trail_kernel<([^,>]*)", name)
     if m:
         return f"dec_walk_kernel<{ty(m.group(1))}>"
-    m = re.match(r"dec_trail_kernel<([^,>]*)", name)
+    m = re.match(r"dec_trail_kernel<([^,>]*)(, (t|f))?", name)   # (<L, true>: the expanders of the walker blocks with a two-variable chunk; names are cut at 34 characters)
     if m:
-        return f"dec_trail_kernel<{ty(m.group(1))}>"
+        return ("dec_trail2_kernel" if m.group(3) == "t" else "dec_trail_kernel") + f"<{ty(m.group(1))}>"
     # (pmc_summary.py cuts the names at 34 characters: "dec_walk_kernel<unsigned long, 8u," / "dec_expand_kernel<unsigned long, f")
     m = re.match(r"dec_walk_kernel<([^,>]*), (\d)u", name)
     if m:

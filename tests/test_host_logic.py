@@ -148,7 +148,7 @@ def test_traffic_tables_are_only_quoted_for_the_build_and_the_kernels_they_were_
     label = ns["label"]
     assert label("dec_walk_kernel<unsigned long, 8u,") == "dec_walk_kernel<u64>" and label("dec_walk_kernel<unsigned int, 4u, ") == "dec_walk4_kernel<u32>"
     assert label("dec_expand_kernel<unsigned long, f") == "dec_expand_kernel<u64>" and label("dec_expand_kernel<unsigned long, t") == "dec_expand_lb_kernel<u64>"
-    assert label("dec_walk_trail_kernel<unsigned lon") == "dec_walk_kernel<u64>" and label("dec_trail_kernel<unsigned long>") == "dec_trail_kernel<u64>" and label("dec_trail_kernel<unsigned int>") == "dec_trail_kernel<u32>"
+    assert label("dec_walk_trail_kernel<unsigned lon") == "dec_walk_kernel<u64>" and label("dec_trail_kernel<unsigned long>") == "dec_trail_kernel<u64>" and label("dec_trail_kernel<unsigned int>") == "dec_trail_kernel<u32>" and label("dec_trail_kernel<unsigned long, tr") == "dec_trail2_kernel<u64>" and label("dec_trail_kernel<unsigned long, fa") == "dec_trail_kernel<u64>" and label("dec_trail_kernel<unsigned short, t") == "dec_trail2_kernel<u16>"
     assert label("enc_walk_kernel<16u>") == "enc_walk16_kernel" and label("enc_walk_kernel<8u>") == "enc_walk_kernel" and label("enc_walkd_kernel") == "enc_walkd_kernel"
     assert label("enc_lookback_kernel<LbCfg<256u, 25") == "enc_lookback_kernel<small>" and label("enc_lookback_kernel<LbCfg<1024u, 1") == "enc_lookback_kernel"
     assert label("enc_lookback_pipe_kernel<LbPipe<fa") == "enc_lookback_pipe_kernel" and label("enc_hist_select_kernel<unsigned in") == "enc_hist_select_kernel"
