@@ -383,8 +383,14 @@ __device__ __forceinline__ void store_syms(uint8_t PCO_GLOBAL* p, uint32_t __att
 #else
   if constexpr (kAgent) {
 #endif
+#ifdef PCO_TRAIL_ST8
     __hip_atomic_store((uint64_t*)p, (uint64_t)acc.x | ((uint64_t)acc.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store((uint64_t*)p + 1, (uint64_t)acc.z | ((uint64_t)acc.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    // one 16-byte store with the scope bit the compiler gives an agent-scope atomic store (sc1: written through to where every XCD reads it);
+    // there is no 16-byte atomic to ask for, and the reader takes the sixteen bytes as four independent dwords anyway
+    __asm__ volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(acc) : "memory");
+#endif
   } else *(u32x4 PCO_GLOBAL*)p = acc;
 }
 
