@@ -121,6 +121,7 @@ static bool g_decode_fast = std::getenv("PCO_GFX_NO_FAST_DECODE") == nullptr;  /
 static bool g_decode_trail = [] { const char* e = std::getenv("PCO_GFX_DEC_TRAIL"); return !(e && e[0] == '0'); }();
 // measurement switches: 's' = the expanders on the walker's own stream (after it, nothing overlaps), 'n' = no expanders at all (the output is garbage)
 static char g_trail_debug = [] { const char* e = std::getenv("PCO_GFX_TRAIL_DEBUG"); return e ? e[0] : '\0'; }();
+static bool g_trail_always = [] { const char* e = std::getenv("PCO_GFX_DEC_TRAIL"); return e && e[0] == '2'; }();   // PCO_GFX_DEC_TRAIL=2: the expanders for calls of any size (tests)
 
 // the workspace's second stream and the two events that fork it off the caller's stream and join it again
 static void ensure_side_stream(Workspace& ws) {
@@ -189,21 +190,26 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     if (fast) {  // walk with 8 chunks per wave (the common chunks expanded on the side stream meanwhile), then with 4 for the chunks whose tables did not fit, then expand the rest
       const uint32_t n_wb = (cnt + 7) / 8;
       uint32_t* d_progress = nullptr;
-      if (g_decode_trail) {
+      // The expanders under the walk pay from about a thousand chunks on: the publishing walker's chain is ~0.9 ms longer than the plain
+      // one's whatever the call holds, and that buys the expansion -- 0.7 us a chunk at scale.  Smaller calls (the host-buffer entry points
+      // decode one chunk per call) walk, then expand.
+      constexpr uint32_t kTrailMinChunks = 1024;
+      const bool use_trail = g_decode_trail && (cnt >= kTrailMinChunks || g_trail_debug != '\0' || g_trail_always);
+      if (use_trail) {
         ensure_side_stream(ws);
         d_progress = (uint32_t*)ws.dec_progress.ensure((size_t)n_wb * kTrailProgressStride * sizeof(uint32_t));
         PCO_HIP_CHECK(hipMemsetAsync(d_progress, 0, (size_t)n_wb * kTrailProgressStride * sizeof(uint32_t), stream));
       }
       // (persistent expander grid: at most four blocks of four waves per CU, so that every walker block finds its wave slot, registers and LDS
       //  whatever the order in which the two kernels' blocks arrive)
-      const uint32_t trail_grid = g_decode_trail ? std::min<uint32_t>(n_wb, (uint32_t)ws.n_cus * 4u) : 0u;
+      const uint32_t trail_grid = use_trail ? std::min<uint32_t>(n_wb, (uint32_t)ws.n_cus * 4u) : 0u;
 #define PCO_FAST_DECODE(L, name)                                                                                                                          \
       {                                                                                                                                                   \
         static const bool _walk_ok = hipFuncSetAttribute((const void*)dec_walk_kernel<L, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * WalkCfg<8>::kWalkLdsBytes)) == hipSuccess && \
                                      hipFuncSetAttribute((const void*)dec_walk_kernel<L, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * WalkCfg<4>::kWalkLdsBytes)) == hipSuccess;   \
         if (!_walk_ok) throw HostError{PCO_GFX_DEVICE_ERROR, "cannot reserve LDS for dec_walk_kernel"};                                                   \
       }                                                                                                                                                   \
-      if (g_decode_trail) {                                                                                                                               \
+      if (use_trail) {                                                                                                                                    \
         ScopedKernelTimer _span("dec_walk+trail<" name ">", stream);                                                                                      \
         PCO_HIP_CHECK(hipEventRecord(ws.fork_event, stream));                                                                                             \
         /* four walker waves per workgroup, the CU's whole LDS: one walker per SIMD by construction (decode_fast.hip, walk_lds) */                      \

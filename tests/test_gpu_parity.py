@@ -601,7 +601,7 @@ def test_decode_expanders_under_the_walk(L):
         arrays.append(np.ascontiguousarray(a)); cfgs.append(kw)
     blobs = [U.chunk_of_file(f, len(f) - O_header_len(f) - 1) for f in (O.simple_compress(a, O.make_config(**kw)) for a, kw in zip(arrays, cfgs))]
     # many copies, so that the call needs more than one round of walker blocks per width; one damaged chunk per width in the middle
-    reps = 20
+    reps = 40   # (the expanders take calls of at least 1024 chunks per number width: 28 of the 64 arrays are 64-bit, 32 are 32-bit; the four 16-bit ones stay below and walk, then expand)
     srcs, tasks_spec, want = [], [], []
     for r in range(reps):
         for i, (a, b) in enumerate(zip(arrays, blobs)):
