@@ -409,8 +409,13 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
   if (my_n_lat > 0 && slot < kEwQ) fx.fstate[((uint64_t)my_p * 3 + my_v) * 4 + j] = state;
 }
 
+// Gathering waves per walk block.  One was right while every lookup went through the texture path (a second changed nothing: the path's rate
+// is the bound there).  With the value -> bin tables in LDS (homogeneous blocks, the headline's case) the gathering wave is a chain of LDS
+// round trips per item, and the sixteen items split over more waves: enc_walkd_kernel 4.64 ms per 8192 chunks with one, 3.65 with two,
+// 3.47 with four (the walk alone: 3.4).  Blocks of mixed items, which keep the texture path, lose a little with four (the mixed stream: 7.4 /
+// 7.1 / 7.6 ms).
 #ifndef PCO_WD_HELPERS
-#define PCO_WD_HELPERS 1
+#define PCO_WD_HELPERS 4
 #endif
 // =========================================================================================================
 // walk + dissect in one block
@@ -419,8 +424,8 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
 // walk.  enc_vlut_kernel writes the variable's value -> (bin | offset bits << 8) table once (<= 8 KB, L2-resident); the second wave
 // of the walker's block gathers from it, one batch ahead of the walk: it leaves the symbols in the LDS buffer the walker reads and
 // (for enc_pack_kernel) in the symbol scratch, and adds up the batch's offset bits.  16 items per block, 4.5 KB of LDS each
-// (enc_walk_kernel<8>'s slot): two blocks per CU, one wave per SIMD -- the walker's chain of dependent steps shares its issue slots
-// with nobody, and the gathers run on the texture path the walker does not use.
+// (enc_walk_kernel<8>'s slot): two blocks per CU -- the walker's chain of dependent steps and, beside it, the gathering waves (texture path or
+// LDS reads: nothing the walker's steps wait for).
 constexpr uint32_t kWdHelpers = PCO_WD_HELPERS, kWdH = 16 / kWdHelpers;   // gathering waves per block, items per gathering wave
 constexpr uint32_t kWdQ = 16, kWdSlot = EwCfg<8>::kSlotBytes, kWdSymOff = EwCfg<8>::kSymOff, kWdLdsBytes = kWdQ * kWdSlot;
 static_assert(2 * kWdLdsBytes <= 160 * 1024, "two blocks per CU");
