@@ -63,6 +63,10 @@ WORKLOADS = {
     "c3auto": (["f64cents"], dict(), "f64", "f64 decimals, default ChunkConfig (Auto mode + Auto delta), 2^18-element chunks (SURVEY 8d C3, Auto)"),
     "c5": (["u64ramp", "f32normal", "i32lomax"], dict(mode=1, delta=2, delta_order=1), "u64/f32/i32",
            "mixed u64 ramp / f32 normal / i32 lomax chunks of 2^18, one call per rank, Classic + TryConsecutive(1) (BASELINE configs[4], explicit specs)"),
+    # the headline's data with PCO_GFX_CFG_STRICT_HISTOGRAM (the reference's quickselect histogram replayed pivot by pivot: what bit-identity on
+    # adversarial input ORDERS costs) and at compression level 12 (a published data point of the reference: 4096 histogram bins per chunk)
+    "c2strict": (["u64ramp"], dict(mode=1, delta=2, delta_order=1, strict_histogram=True), "u64", "u64 classic delta-1 noisy ramp, strict (literal) histograms, 2^18-element chunks"),
+    "c2l12": (["u64ramp"], dict(mode=1, delta=2, delta_order=1, level=12), "u64", "u64 classic delta-1 noisy ramp, compression level 12, 2^18-element chunks"),
     "c5auto": (["u64ramp", "f32normal", "i32lomax"], dict(), "u64/f32/i32",
                "mixed u64 ramp / f32 normal / i32 lomax chunks of 2^18, one call per rank, default ChunkConfig (BASELINE configs[4], Auto/Auto)"),
 }
@@ -137,6 +141,11 @@ def cpu_info():
     return info
 
 
+def oracle_kw(cfg_kw):
+    """The reference's ChunkConfig has no strict flag: its histogram IS the literal one."""
+    return {k: v for k, v in cfg_kw.items() if k != "strict_histogram"}
+
+
 def cpu_baseline(kinds, cfg_kw, seconds=14.0):
     """The oracle (a C++ restatement of the reference's algorithm, NOT the Rust binary) on the host cores: a native
     std::thread driver inside oracle/ (pco_oracle_bench) -- every thread loops compress -> decompress over a private copy
@@ -144,7 +153,7 @@ def cpu_baseline(kinds, cfg_kw, seconds=14.0):
     import oracle_lib as O
 
     L = O.lib()
-    ocfg = O.make_config(**cfg_kw)
+    ocfg = O.make_config(**oracle_kw(cfg_kw))
     info = cpu_info()
     # one thread per CPU this process may actually use: more threads than the cgroup quota only get throttled (measured on the
     # round-2 GPU box: cpu.max = 16 CPUs of a 2 x 64-core EPYC 9575F; linear to 16 threads, 13.7 GB/s, then falling)
@@ -276,7 +285,7 @@ class Bench:
         pick = np.sort(np.random.default_rng(99).choice(nch, size=min(k_verify, nch), replace=False))
         info = cpu_info()
         threads = int(min(info["logical_cpus"], info.get("affinity_cpus", 1 << 30), max(1, int(info.get("cgroup_cpu_quota", 1 << 30)))))
-        OL = O.lib(); ocfg = O.make_config(**cfg_kw)
+        OL = O.lib(); ocfg = O.make_config(**oracle_kw(cfg_kw))
         checked = 0
         for k, kind in enumerate(kinds):
             idx = pick[kind_of[pick] == k]
@@ -468,7 +477,7 @@ class Bench:
                     "traffic_over_algorithmic_encode": enc_d["traffic_over_algorithmic"], "traffic_over_algorithmic_decode": dec_d["traffic_over_algorithmic"]}
             rec = {
                 "workload": workload, "value": round(value, 2), "ms_per_step": round(ms_per_step, 3), "dtype": dtype_label, "steps": steps, "warmup": warmup,
-                "config": {"workload": desc, "chunks_per_gpu": nch, "chunk_n": N18, "compression_level": 8,
+                "config": {"workload": desc, "chunks_per_gpu": nch, "chunk_n": N18, "compression_level": cfg_kw.get("level", 8), **({"strict_histogram": True} if cfg_kw.get("strict_histogram") else {}),
                            "mode_spec": MODE_NAMES[cfg_kw.get("mode", 0)] + (f"({cfg_kw['mode_f64']})" if "mode_f64" in cfg_kw else ""),
                            "delta_spec": DELTA_NAMES[cfg_kw.get("delta", 0)] + (f"({cfg_kw['delta_order']})" if "delta_order" in cfg_kw else ""),
                            "parallelism": f"chunk-sharded x{world}, contiguous chunk blocks" + ((f", device compaction + RCCL gather-v / scatter of the chunk bytes ({'C ABI pco_gfx_gather_chunks / _scatter_chunks' if carrier == 'cabi' else 'torch.distributed carrier'})" if gather else ", no data-path collective")),
@@ -503,7 +512,12 @@ class Bench:
 # headline's and the f64 data + configs[4] WITH its compaction / gather / scatter leg): (name, workload, chunks per GPU (None = 16 GiB
 # of numbers), steps, gather)
 OTHER_WORKLOADS = [("c3", "c3", None, 4, False), ("c4", "c4", 4096, 3, False), ("c5", "c5", None, 3, False), ("c5gather", "c5", None, 3, True),
-                   ("c2auto", "c2auto", None, 3, False), ("c3auto", "c3auto", None, 3, False), ("c1", "c1", None, 3, False)]
+                   ("c2auto", "c2auto", None, 3, False), ("c3auto", "c3auto", None, 3, False), ("c1", "c1", None, 3, False),
+                   ("c2strict", "c2strict", 4096, 2, False), ("c2l12", "c2l12", 2048, 2, False),
+                   # the headline's dependence on the call size (the walkers' flat cost: profiles/r04_c2_chunk_scaling.txt); 4096 chunks per GPU is
+                   # what configs[4]'s "~64 GiB over 8 GPUs" comes to
+                   ("c2_1k", "c2", 1024, 3, False), ("c2_4k", "c2", 4096, 3, False), ("c2_12k", "c2", 12288, 3, False)]
+LIGHT_WORKLOADS = ("c2strict", "c2l12", "c2_1k", "c2_4k", "c2_12k")   # no CPU leg of their own (the headline's / c2's applies), fewer verified chunks
 
 
 def flat_workload(name, r):
@@ -547,7 +561,8 @@ def main():
     if args.workload == "c2" and args.chunks is None and not args.no_others and not args.gather:
         for name, wl, chunks, steps, gather in OTHER_WORKLOADS:
             try:
-                r = B.run(wl, chunks, steps, 1, gather, min(args.verify_chunks, 256), not args.no_cpu_baseline and not gather, cpu_seconds=6.0, carrier=args.gather_carrier)
+                light = name in LIGHT_WORKLOADS
+                r = B.run(wl, chunks, steps, 1, gather, min(args.verify_chunks, 64 if light else 256), not args.no_cpu_baseline and not gather and not light, cpu_seconds=6.0, carrier=args.gather_carrier)
             except Exception as e:   # an extra workload must not cost the headline its line
                 if B.world > 1:
                     raise           # (one rank leaving a collective workload would hang the others)

@@ -98,8 +98,13 @@ typedef struct PcoChunkConfigEx {
   uint32_t delta_order;
   uint64_t max_page_n;        /* PagingSpec::EqualPagesUpTo; 0 => 2^18 */
   uint32_t enable_8_bit;
-  uint32_t reserved;
+  uint32_t flags;             /* PCO_GFX_CFG_* bits; 0 = the reference's ChunkConfig and nothing else */
 } PcoChunkConfigEx;
+/* Strict histograms: replay the reference's quickselect (histograms.rs:208-280, sort_utils.rs) pivot by pivot on the device, so that
+ * the chunk's bytes equal the reference's even on input ORDERS that send its histogram into the heapsort branch (histograms.rs:248-258),
+ * the one place where the default (sort-free, order-independent) histogram kernels can differ from it.  Costs several passes over a
+ * private copy of every latent variable; see DESIGN.md section 2 for when it matters (an order built against the pivot rule). */
+#define PCO_GFX_CFG_STRICT_HISTOGRAM 1u
 
 /* Detailed status of the last failing call on this thread (errors.rs:8-24). */
 enum PcoGfxStatus {
@@ -209,6 +214,14 @@ void pco_gfx_release_workspace(void);
  * stays until released).  For capacity planning and for the benchmark's `workspace_bytes_per_input_byte`; the reference has no counterpart
  * (its scratch is the host heap). */
 size_t pco_gfx_workspace_bytes(void);
+/* How many (chunk, latent variable) histograms of this thread's PCO_GFX_CFG_STRICT_HISTOGRAM calls on the current device replayed the
+ * reference's heapsort branch (histograms.rs:248-258) since the workspace was created: 0 on any data that was not ordered against the
+ * pivot rule.  Waits for the thread's last call. */
+unsigned long long pco_gfx_strict_histogram_fallbacks(void);
+/* How many chunks of this thread's decode calls on the current device were marked for the expander kernel that runs UNDER the tANS walk
+ * (decode_trail.hip) and had to be expanded after it instead, because their expander wave saw no walker beside it for ~55 ms (a device shared with
+ * another process' kernels) or left early: such a call is correct but slower.  0 on an idle device.  Waits for the thread's last call. */
+unsigned long long pco_gfx_trail_givebacks(void);
 
 /* Per-kernel timing (HIP events on the launch stream): begin() arms it for this thread; end()
  * synchronises and returns the number of kernels launched since begin(), writing their names

@@ -16,6 +16,8 @@ TASK_HAS_FILE_HEADER = 1
 MODE_AUTO, MODE_CLASSIC, MODE_TRY_FLOAT_MULT, MODE_TRY_FLOAT_QUANT, MODE_TRY_INT_MULT, MODE_TRY_DICT = range(6)
 DELTA_AUTO, DELTA_NOOP, DELTA_TRY_CONSECUTIVE, DELTA_TRY_LOOKBACK, DELTA_TRY_CONV1 = range(5)
 
+CFG_STRICT_HISTOGRAM = 1  # PCO_GFX_CFG_STRICT_HISTOGRAM: replay the reference's quickselect histogram pivot by pivot
+
 DTYPE_BYTE = {"uint32": 1, "uint64": 2, "int32": 3, "int64": 4, "float32": 5, "float64": 6,
               "uint16": 7, "int16": 8, "float16": 9, "uint8": 10, "int8": 11}
 DTYPE_BYTES = {1: 4, 2: 8, 3: 4, 4: 8, 5: 4, 6: 8, 7: 2, 8: 2, 9: 2, 10: 1, 11: 1}
@@ -28,7 +30,7 @@ class PcoChunkConfig(C.Structure):  # pco_c/src/lib.rs:21-32
 class PcoChunkConfigEx(C.Structure):
     _fields_ = [("compression_level", C.c_uint32), ("mode_kind", C.c_uint32), ("mode_f64", C.c_double),
                 ("mode_u64", C.c_uint64), ("delta_kind", C.c_uint32), ("delta_order", C.c_uint32),
-                ("max_page_n", C.c_uint64), ("enable_8_bit", C.c_uint32), ("reserved", C.c_uint32)]
+                ("max_page_n", C.c_uint64), ("enable_8_bit", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class EncodeTask(C.Structure):
@@ -77,6 +79,10 @@ def lib():
         L.pco_gfx_guarantee_chunk_size.restype = C.c_size_t
         L.pco_gfx_workspace_bytes.restype = C.c_size_t
         L.pco_gfx_workspace_bytes.argtypes = []
+        L.pco_gfx_strict_histogram_fallbacks.restype = C.c_ulonglong
+        L.pco_gfx_strict_histogram_fallbacks.argtypes = []
+        L.pco_gfx_trail_givebacks.restype = C.c_ulonglong
+        L.pco_gfx_trail_givebacks.argtypes = []
         L.pco_gfx_guarantee_chunk_size.argtypes = [C.c_size_t, C.c_ubyte]
         L.pco_standalone_simple_compress_into.argtypes = [C.c_void_p, C.c_size_t, C.c_ubyte, C.c_void_p, C.c_void_p,
                                                           C.c_size_t, C.POINTER(C.c_size_t)]
@@ -103,5 +109,6 @@ def check(code):
 
 
 def make_config(level=8, mode=MODE_AUTO, mode_f64=0.0, mode_u64=0, delta=DELTA_AUTO, delta_order=0, max_page_n=0,
-                enable_8_bit=False):
-    return PcoChunkConfigEx(level, mode, mode_f64, mode_u64, delta, delta_order, max_page_n, 1 if enable_8_bit else 0, 0)
+                enable_8_bit=False, strict_histogram=False):
+    return PcoChunkConfigEx(level, mode, mode_f64, mode_u64, delta, delta_order, max_page_n, 1 if enable_8_bit else 0,
+                            CFG_STRICT_HISTOGRAM if strict_histogram else 0)

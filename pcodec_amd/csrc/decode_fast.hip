@@ -43,6 +43,7 @@ __device__ __forceinline__ uint32_t walk_block_id() { return blockIdx.x * (block
 // in global memory -- progress[block * 8 + slot] = 1 + batches once the metadata is parsed, kTrailDead for a chunk the expanders must
 // leave alone -- and a second kernel on a second stream expands them while the walk is still going on.
 constexpr uint32_t kTrailDead = 0xffffffffu;
+constexpr uint32_t kTrailDoneWord = 8;          // ... and words 8..15 of that line: slot's chunk has been expanded to the end by its expander wave (decode_trail.hip)
 constexpr uint32_t kTrailProgressStride = 32;   // words per walker block: its eight progress words have a 128-byte line to themselves (the expanders of other blocks poll theirs)
 #ifdef PCO_TRAIL_NODEFER
 constexpr bool kTrailDefer = false;
@@ -949,7 +950,8 @@ __device__ __forceinline__ void expand_item(const ExpPre& pre, uint32_t PCO_LDS*
 template <class L, bool kLb>
 __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids, uint32_t n_ids,
                                                          const DecPlan* plans, const uint8_t* bins_area, const uint8_t* sym_area, uint64_t sym_stride,
-                                                         const uint64_t* offpos_area, uint64_t offpos_stride) {
+                                                         const uint64_t* offpos_area, uint64_t offpos_stride,
+                                                         const uint32_t* progress /* the trailing expanders' done marks, or null */, uint32_t* givebacks) {
   const uint32_t lane = lane_id(), tid = threadIdx.x, wave = tid >> 6;
   uint8_t PCO_LDS* smem = lds_base();
   for (uint32_t bi = blockIdx.x; bi < n_ids; bi += gridDim.x) {
@@ -957,7 +959,12 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
     const DecPlan PCO_GLOBAL* plan = (const DecPlan PCO_GLOBAL*)plans + ti;
     const uint32_t pstatus = uni(plan->status);
     if (pstatus == kStatusRetryLegacy) continue;   // the single-kernel decoder finishes this task
-    if (uni(plan->fused)) continue;                // expanded inside dec_walk_kernel, result written there
+    if (uni(plan->fused)) {   // marked for the trailing expanders by the publishing walker (which also wrote its result): skipped only if one of them
+                              // expanded it to the end -- a chunk nobody finished (late walker, timed-out or refusing expander) is expanded here
+      const bool done = progress != nullptr && uni(progress[(uint64_t)(bi >> 3) * kTrailProgressStride + kTrailDoneWord + (bi & 7u)]) != 0;
+      if (done) continue;
+      if (!kLb && tid == 0 && givebacks != nullptr && pstatus == PCO_GFX_OK) atomicAdd(givebacks, 1u);
+    }
     if ((uni(plan->delta_kind[1]) == kDeltaLookback) != kLb) continue;   // the other form's
     if (pstatus != PCO_GFX_OK) {
       if (tid == 0) { PcoGfxTaskResult r; r.n_out = 0; r.consumed = plan->consumed; r.status = pstatus; r.aux = 0; results[ti] = r; }

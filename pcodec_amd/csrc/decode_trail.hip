@@ -21,7 +21,10 @@
 // an iteration earlier; its two chunks are expanded in lockstep -- in the steady state as straight-line code (trail_fast_pair).  Loads are
 // unconditional and into registers nothing else writes: a register zeroed first and loaded under a condition makes the compiler wait, at
 // the zeroing, for every load but the last few, whatever is really in flight.  Every wait is bounded: a wave that sees no progress for
-// about a second gives its chunks back (DecPlan::fused = 0) and dec_expand_kernel expands them afterwards.
+// about 55 ms gives its chunks back and dec_expand_kernel expands them afterwards: ownership is explicit -- an expander wave marks every chunk it
+// has expanded to the end in the walker block's progress line (word kTrailDoneWord + slot), and dec_expand_kernel, which runs when both kernels
+// have ended, takes every fused chunk WITHOUT that mark (the walker started late, the expander timed out at any point, or the expander kernel
+// refused the chunk) and counts it (pco_gfx_trail_givebacks).
 // Measured (8192 chunks of 2^18 u64, delta 1): walk 6.5 + expand 6.2 ms back to back -> 10.6 ms together (the publishing walker alone 7.2,
 // these expanders alone 5.6; without the expanders' output stream the pair takes 9.2: what is left is the two kernels' contention for the
 // memory system and the issue slots, not the hand-over -- a build that ignores the progress words finishes in 10.0).
@@ -32,7 +35,9 @@ namespace pcogfx {
 
 constexpr uint32_t kTrailWaves = 4;            // per walker block
 constexpr uint32_t kTrailSlotsPerWave = 2;     // wave v: chunk slots 2 v, 2 v + 1
-constexpr uint32_t kTrailSpinLimit = 1u << 18; // polls (~3.4 us apart) without progress before a wave gives up
+constexpr uint32_t kTrailSpinLimit = 1u << 14; // polls (~3.4 us apart, ~55 ms) without progress before a wave gives up.  Giving up is always safe since round 5: a chunk is
+                                               // skipped by dec_expand_kernel only when its expander wave has marked it DONE (kTrailDoneWord), so the limit only bounds how long
+                                               // a call can stall when the walker is not running beside the expanders (a device shared with another process)
 // DecPlan as 64 words (the expanders fetch it with one request, a word per lane)
 constexpr uint32_t kPlanN = 1, kPlanModeKind = 2, kPlanModeK = 3, kPlanModeBase = 4, kPlanNumKind = 6, kPlanPresent = 8, kPlanNBins = 11, kPlanMaxOb = 14,
                    kPlanDeltaKind = 17, kPlanDeltaOrder = 20, kPlanNlps = 23, kPlanMoments = 28, kPlanFused = 62;
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
       const uint32_t slot = wave * kTrailSlotsPerWave + q, bi = wb * 8 + slot;
       c.fl = bi < n_ids ? kFlLive : 0u; c.next = 0;
       const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)slot);
-      if (p0 == 0 || p0 == kTrailDead) c.fl = 0;   // (0: never started within the time limit -- the walker still owns the chunk, DecPlan::fused is not set)
+      if (p0 == 0 || p0 == kTrailDead) c.fl = 0;   // (0: the walker did not start within the time limit -- it may still mark the chunk fused later; without this wave's done mark dec_expand_kernel takes it)
       c.ti = c.live() ? (task_ids ? uni(task_ids[bi]) : bi) : 0u;
       // the plan is 64 words: lane i fetches word i (one request), the fields come out of the lanes
       const uint32_t pw = ld_agent((const uint32_t*)(plans + c.ti) + lane);
@@ -498,7 +503,10 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
         TrailChunk<L>& c = S[q];
         ready[q] = 0;
         if (!c.live()) continue;
-        if (c.next >= c.n_batches) { c.set(kFlLive, false); continue; }
+        if (c.next >= c.n_batches) {   // expanded to the end: the mark dec_expand_kernel looks for
+          if (lane == 0) __hip_atomic_store((uint32_t*)progress + (uint64_t)wb * kTrailProgressStride + kTrailDoneWord + wave * kTrailSlotsPerWave + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          c.set(kFlLive, false); continue;
+        }
         any_live = true;
         const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)(wave * kTrailSlotsPerWave + q));
         if (p == kTrailDead) { c.set(kFlLive, false); continue; }   // the walker met an error: it reports it, nothing more to expand
@@ -649,10 +657,8 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
       __builtin_amdgcn_s_sleep(127);
       pv = ld_agent(pline);
       if (++idle > kTrailSpinLimit) {
-        // no progress for about a second: the walker is not running beside us (or is stuck).  Give the chunks back: dec_expand_kernel
-        // expands a chunk whose plan says fused = 0 from its first batch, after both kernels have ended.
-#pragma unroll
-        for (int q = 0; q < (int)kTrailSlotsPerWave; q++) if (S[q].live() && lane == 0) __hip_atomic_store(&plans[S[q].ti].fused, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // no progress for ~55 ms: the walker is not running beside us (or is stuck).  Leave: the chunks this wave has not marked done are
+        // expanded by dec_expand_kernel from their first batch, after both kernels have ended.
         break;
       }
     }

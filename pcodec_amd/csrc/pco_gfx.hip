@@ -26,6 +26,7 @@
 #include "encode_kernels.hip"
 #include "encode_lookback.hip"
 #include "encode_hist_select.hip"
+#include "encode_hist_literal.hip"
 #include "auto_mode_kernels.hip"
 #include "encode_fast.hip"
 #include "stream_kernels.hip"
@@ -119,7 +120,8 @@ static bool g_decode_fast = std::getenv("PCO_GFX_NO_FAST_DECODE") == nullptr;  /
 // The expanders of the common chunks run on a second stream UNDER the walk (decode_trail.hip); PCO_GFX_DEC_TRAIL=0 keeps the two kernels
 // back to back (A/B switch).
 static bool g_decode_trail = [] { const char* e = std::getenv("PCO_GFX_DEC_TRAIL"); return !(e && e[0] == '0'); }();
-// measurement switches: 's' = the expanders on the walker's own stream (after it, nothing overlaps), 'n' = no expanders at all (the output is garbage)
+// measurement / test switches: 's' = the expanders on the walker's own stream (after it, nothing overlaps), 'n' = no expanders at all, 'd' = the expanders
+// BEFORE the walkers (they time out waiting): in the last two every chunk marked for the expanders is given back to dec_expand_kernel
 static char g_trail_debug = [] { const char* e = std::getenv("PCO_GFX_TRAIL_DEBUG"); return e ? e[0] : '\0'; }();
 static bool g_trail_always = [] { const char* e = std::getenv("PCO_GFX_DEC_TRAIL"); return e && e[0] == '2'; }();   // PCO_GFX_DEC_TRAIL=2: the expanders for calls of any size (tests)
 
@@ -190,6 +192,7 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
     if (fast) {  // walk with 8 chunks per wave (the common chunks expanded on the side stream meanwhile), then with 4 for the chunks whose tables did not fit, then expand the rest
       const uint32_t n_wb = (cnt + 7) / 8;
       uint32_t* d_progress = nullptr;
+      uint32_t* d_givebacks = nullptr;   // device counter: chunks marked for the expanders under the walk that dec_expand_kernel had to take (pco_gfx_trail_givebacks)
       // The expanders under the walk pay from about a thousand chunks on: the publishing walker's chain is ~0.9 ms longer than the plain
       // one's whatever the call holds, and that buys the expansion -- 0.7 us a chunk at scale.  Smaller calls (the host-buffer entry points
       // decode one chunk per call) walk, then expand.
@@ -199,6 +202,8 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
         ensure_side_stream(ws);
         d_progress = (uint32_t*)ws.dec_progress.ensure((size_t)n_wb * kTrailProgressStride * sizeof(uint32_t));
         PCO_HIP_CHECK(hipMemsetAsync(d_progress, 0, (size_t)n_wb * kTrailProgressStride * sizeof(uint32_t), stream));
+        if (!ws.dec_stats.p) { ws.dec_stats.ensure(256); PCO_HIP_CHECK(hipMemset(ws.dec_stats.p, 0, 256)); }
+        d_givebacks = (uint32_t*)ws.dec_stats.p;
       }
       // (persistent expander grid: at most four blocks of four waves per CU, so that every walker block finds its wave slot, registers and LDS
       //  whatever the order in which the two kernels' blocks arrive)
@@ -211,6 +216,10 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
       }                                                                                                                                                   \
       if (use_trail) {                                                                                                                                    \
         ScopedKernelTimer _span("dec_walk+trail<" name ">", stream);                                                                                      \
+        if (g_trail_debug == 'd') {   /* test switch: the expanders BEFORE the walkers on the caller's stream -- every wave times out waiting for a walker that has not started */ \
+          hipLaunchKernelGGL((dec_trail_kernel<L, false>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb); \
+          hipLaunchKernelGGL((dec_trail_kernel<L, true>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);  \
+        }                                                                                                                                                 \
         PCO_HIP_CHECK(hipEventRecord(ws.fork_event, stream));                                                                                             \
         /* four walker waves per workgroup, the CU's whole LDS: one walker per SIMD by construction (decode_fast.hip, walk_lds) */                      \
         static const bool _quad_ok = hipFuncSetAttribute((const void*)dec_walk_trail_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * WalkCfg<8>::kWalkLdsBytes)) == hipSuccess; \
@@ -229,9 +238,9 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
         PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream, ws.fork_event, 0));                                                                              \
         /* one kernel per kind of walker block (classic chunks only / a chunk with two latent variables among them), one after the other on the    \
            expanders' stream: the blocks of the kind a call does not have leave at once */                                                         \
-        if (g_trail_debug != 'n') PCO_TIMED_LAUNCH("~dec_trail_kernel<" name ">", ts, (dec_trail_kernel<L, false>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
+        if (g_trail_debug != 'n' && g_trail_debug != 'd') PCO_TIMED_LAUNCH("~dec_trail_kernel<" name ">", ts, (dec_trail_kernel<L, false>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
                          d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);                               \
-        if (g_trail_debug != 'n') PCO_TIMED_LAUNCH("~dec_trail2_kernel<" name ">", ts, (dec_trail_kernel<L, true>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
+        if (g_trail_debug != 'n' && g_trail_debug != 'd') PCO_TIMED_LAUNCH("~dec_trail2_kernel<" name ">", ts, (dec_trail_kernel<L, true>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
                          d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);                               \
         PCO_HIP_CHECK(hipEventRecord(ws.join_event, ws.side_stream));                                                                                     \
         PCO_HIP_CHECK(hipStreamWaitEvent(stream, ws.join_event, 0));                                                                                      \
@@ -241,9 +250,9 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
       PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4>), dim3((cnt + 15) / 16), dim3(256), 4 * WalkCfg<4>::kWalkLdsBytes, stream, \
                        d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4, d_results, (uint32_t*)nullptr);   \
       PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, (dec_expand_kernel<L, false>), dim3(grid), dim3(256), kExpLdsBytes, stream,               \
-                       d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);                                        \
+                       d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, (const uint32_t*)d_progress, d_givebacks);    \
       PCO_TIMED_LAUNCH("dec_expand_lb_kernel<" name ">", stream, (dec_expand_kernel<L, true>), dim3(grid), dim3(256), kExpLbLdsBytes, stream,           \
-                       d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride);
+                       d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, (const uint32_t*)d_progress, d_givebacks);
       if (g == 0) { PCO_FAST_DECODE(uint64_t, "u64") } else if (g == 1) { PCO_FAST_DECODE(uint32_t, "u32") } else if (g == 2) { PCO_FAST_DECODE(uint16_t, "u16") } else { PCO_FAST_DECODE(uint8_t, "u8") }
 #undef PCO_FAST_DECODE
     }
@@ -307,6 +316,27 @@ size_t pco_gfx_workspace_bytes(void) {
     static const bool trace = std::getenv("PCO_GFX_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[pco_gfx trace] workspace: %s\n", workspace().device_report().c_str());
     return workspace().device_bytes();
+  } catch (...) { return 0; }
+}
+
+unsigned long long pco_gfx_trail_givebacks(void) {
+  try {
+    Workspace& w = workspace();
+    if (!w.dec_stats.p) return 0;
+    if (w.has_last && w.last_event) (void)hipEventSynchronize(w.last_event);
+    uint32_t v = 0;
+    if (hipMemcpy(&v, w.dec_stats.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return v;
+  } catch (...) { return 0; }
+}
+unsigned long long pco_gfx_strict_histogram_fallbacks(void) {
+  try {
+    Workspace& w = workspace();
+    if (!w.enc_strict.p) return 0;
+    if (w.has_last && w.last_event) (void)hipEventSynchronize(w.last_event);
+    uint32_t v = 0;
+    if (hipMemcpy(&v, w.enc_strict.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return v;
   } catch (...) { return 0; }
 }
 

@@ -82,9 +82,10 @@ SIZES = [1, 2, 3, 17, 255, 256, 257, 513, 1025, 1000, 4099, 20000, 70000, 1 << 1
 SIZE_P = [.04, .03, .03, .04, .04, .04, .05, .04, .04, .18, .18, .17, .08, .02, .02]
 
 
-def run(n_cases, seed, only_8bit=False, max_level=8):
+def run(n_cases, seed, only_8bit=False, max_level=8, strict=False):
     """Returns (bad, skipped, fails): `skipped` maps a reason to the number of cases that were not compared -- callers assert a
-    budget on it (a regression that refuses more inputs must not pass as green)."""
+    budget on it (a regression that refuses more inputs must not pass as green).  strict: the GPU runs with PCO_GFX_CFG_STRICT_HISTOGRAM,
+    and then its bytes are compared with the oracle's whatever branch the reference's histogram took (no fallback skip)."""
     rng = np.random.default_rng(seed)
     bad = []; skipped = {}; fails = {}
 
@@ -107,12 +108,12 @@ def run(n_cases, seed, only_8bit=False, max_level=8):
                 pass
             skip("oracle refused: " + str(e)[:60]); continue
         try:
-            got = U.gpu_simple_compress(nums, G.make_config(enable_8_bit=True, **kw))
+            got = U.gpu_simple_compress(nums, G.make_config(enable_8_bit=True, strict_histogram=strict, **kw))
         except G.PcoGfxError as e:
             if e.status == G.ST_UNSUPPORTED: skip("gpu unsupported: " + str(e)[-60:]); continue
             bad.append(("gpu error", case, np.dtype(dt).name, n, kw, str(e))); continue
         if got != want:
-            if not fb:
+            if not fb or strict:
                 bad.append(("bytes", case, np.dtype(dt).name, n, kw))
                 fails[f"case{case}_nums"] = nums; fails[f"case{case}_got"] = np.frombuffer(got, np.uint8); fails[f"case{case}_kw"] = np.array(repr(kw))
                 continue
@@ -134,7 +135,7 @@ def run(n_cases, seed, only_8bit=False, max_level=8):
     return bad, skipped, fails
 
 
-def run_batched(n_calls, seed, max_level=8):
+def run_batched(n_calls, seed, max_level=8, strict=False):
     """Many chunks of mixed dtype / size / distribution in ONE pco_gfx_compress_chunks call (the path the benchmark and a
     row-group writer use): every chunk's bytes against the oracle, every chunk decoded back by the batched decoder."""
     rng = np.random.default_rng(seed)
@@ -147,14 +148,14 @@ def run_batched(n_calls, seed, max_level=8):
         kw = draw_config(rng, np.uint32, 0, max_level)
         if kw.get("mode") not in (0, 1): kw["mode"] = int(rng.integers(0, 2))   # a mode every dtype accepts
         try:
-            chunks, back = U.gpu_batched(arrays, G.make_config(**kw))
+            chunks, back = U.gpu_batched(arrays, G.make_config(strict_histogram=strict, **kw))
         except G.PcoGfxError as e:
             if e.status == G.ST_UNSUPPORTED: skipped["gpu unsupported: " + str(e)[-60:]] = skipped.get("gpu unsupported: " + str(e)[-60:], 0) + 1; continue
             bad.append(("gpu error", call, kw, str(e))); continue
         for i, a in enumerate(arrays):
             # (a batched task is ONE chunk whatever its size; the oracle's file writer needs max_page_n >= n to keep it in one)
             want = O.simple_compress(a, O.make_config(max_page_n=max(a.size, 1 << 18), **kw))
-            if chunks[i] != U.chunk_of_file(want, len(chunks[i])) and not hist_fallback_ran(a, kw):
+            if chunks[i] != U.chunk_of_file(want, len(chunks[i])) and (strict or not hist_fallback_ran(a, kw)):
                 bad.append(("bytes", call, i, a.dtype.name, a.size, kw))
             if not U.bits_equal(back[i], a): bad.append(("decode", call, i, a.dtype.name, a.size, kw))
     return bad, skipped
