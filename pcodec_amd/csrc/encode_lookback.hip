@@ -35,8 +35,12 @@
 
 namespace pcogfx {
 
-template <bool kSmall> struct LbPipe {
-  static constexpr uint32_t kWaves = 5, kThreads = 64 * kWaves;
+// kProps: the hash proposals come from enc_lookback_hash_kernel (below) as six u16 streams per page; the two H waves are replaced by one
+// loader wave (latents into the ring, proposals into the queue) and the kernel has no random global access left but far candidates' latents.
+template <bool kSmall, bool kPropsT = false> struct LbPipe {
+  static constexpr bool kProps = kPropsT;
+  static constexpr uint32_t kFront = kPropsT ? 1u : 2u;                 // waves in front of stage C: H0 / H1, or the loader
+  static constexpr uint32_t kWaves = kFront + 3, kThreads = 64 * kWaves;
   static constexpr uint32_t kRing = kSmall ? 1024u : 2048u;            // latents of the last kRing positions (u64 each)
   static constexpr uint32_t kNear = kRing - 64 * kWaves;               // lookbacks below this are served from the ring by every stage (they run up to four tiles apart)
   static constexpr uint32_t kCounts = kSmall ? 8192u : 4096u;          // lookback_counts kept in LDS (small pages: all of them, as u16)
@@ -60,7 +64,9 @@ __device__ unsigned long long g_lbp_timing[16];
 #endif
 
 template <class L, class Cfg>
-__device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, uint16_t PCO_GLOBAL* hash_tbl, uint32_t PCO_GLOBAL* gcounts) {
+__device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, uint16_t PCO_GLOBAL* hash_tbl, uint32_t PCO_GLOBAL* gcounts,
+                                   const uint16_t PCO_GLOBAL* props = nullptr /* kProps: u16[6][prop_stride] */, uint64_t prop_stride = 0) {
+  constexpr uint32_t kFront = Cfg::kFront;
   typedef typename Cfg::CountT CountT;
   constexpr uint32_t kRing = Cfg::kRing, kNear = Cfg::kNear, kCounts = Cfg::kCounts;
   // (tables in LDS were tried for small pages -- u16 entries, 64 KB: one page then fills a CU, and a page on which stage D is the whole cost
@@ -88,7 +94,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
   const uint32_t n_counts = window_n < n ? window_n : n;
   for (uint32_t i = tid; i < kCounts; i += Cfg::kThreads) lcounts[i] = (CountT)1;
   for (uint32_t i = kCounts + tid; i < n_counts; i += Cfg::kThreads) gcounts[i] = 1;
-  for (uint32_t i = tid; i < hash_table_n / 2; i += Cfg::kThreads) ((uint64_t PCO_GLOBAL*)hash_tbl)[i] = 0ull;   // 2 tables x hash_table_n u16
+  if constexpr (!Cfg::kProps) for (uint32_t i = tid; i < hash_table_n / 2; i += Cfg::kThreads) ((uint64_t PCO_GLOBAL*)hash_tbl)[i] = 0ull;   // 2 tables x hash_table_n u16
   __threadfence_block();
   __syncthreads();
   const uint32_t n_tiles = (n - state_n + 63) / 64;
@@ -106,9 +112,16 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
   uint32_t ring_lb0 = 1, ring_lb1 = 1, ring_lb2 = 1, ring_lb3 = 1, ring_c0 = 1, ring_c1 = 1, ring_c2 = 1, ring_c3 = 1, cnt_best = 1;
   // A: the ranges of the delta'd primary and of the lookbacks
   L mn1 = (L)~(L)0, mx1 = 0; uint32_t mn0 = 0xffffffffu, mx0 = 0;
-  if (wave < 2) {
+  uint32_t h_pp[6] = {0, 0, 0, 0, 0, 0};   // (loader) the next tile's six proposals, in flight
+  auto tile_props = [&](uint32_t i0t, uint32_t (&pp)[6]) {
+    const bool a = i0t < n && lane < n - i0t;
+#pragma unroll
+    for (int r = 0; r < 6; r++) pp[r] = a ? (uint32_t)props[(uint64_t)r * prop_stride + i0t + lane] : 1u;
+  };
+  if (wave < kFront) {
     h_lv = tile_latent(state_n); h_lv2 = tile_latent(state_n + 64);
-    {
+    if constexpr (Cfg::kProps) tile_props(state_n, h_pp);
+    else {
       const uint32_t c = wave;
       const uint64_t bucket = h_lv >> (c == 0 ? 0 : 8);
       const bool a = lane < n - state_n;
@@ -120,7 +133,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
   }
   uint32_t next_sweep = kLbSweepPeriod;   // (H waves)
   uint32_t d_rounds = 0;                  // (D wave) rounds over the page's first tiles
-  if (wave == 3 && lane < 16) proposed = (lane + 1) < state_n ? (lane + 1) : state_n;
+  if (wave == kFront + 1 && lane < 16) proposed = (lane + 1) < state_n ? (lane + 1) : state_n;
 #ifdef PCO_LBP_TIMING
   unsigned long long tm_acc = 0, tm_rounds = 0;
 #endif
@@ -129,7 +142,19 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
 #ifdef PCO_LBP_TIMING
     const unsigned long long tm0 = __builtin_readcyclecounter();
 #endif
-    if (wave < 2) {
+    if (Cfg::kProps && wave < kFront) {
+      // ============================================================ L: the latents and the six hash proposals of tile `step`, from their streams
+      if (step < n_tiles) {
+        const uint32_t i0 = state_n + 64 * step, tile_n = n - i0 < 64 ? n - i0 : 64, ie = i0 + lane;
+        const bool act = lane < tile_n;
+        if (act) ring[ie & (kRing - 1)] = h_lv;
+        uint16_t PCO_LDS* qp = q_plb + (step % 3u) * 6 * 64;
+#pragma unroll
+        for (int r = 0; r < 6; r++) qp[r * 64 + lane] = (uint16_t)(act ? h_pp[r] : 1u);
+        h_lv = h_lv2; h_lv2 = tile_latent(i0 + 128);
+        tile_props(i0 + 64, h_pp);
+      }
+    } else if (wave < kFront) {
       // ============================================================ H0 / H1: hash proposals of tile `step` from table `wave`
       const uint32_t c = wave;
       if (step < n_tiles) {
@@ -218,7 +243,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
           qp[(3 * c + r) * 64 + lane] = (uint16_t)(act ? plb : 1u);
         }
       }
-    } else if (wave == 2) {
+    } else if (wave == kFront) {
       // ============================================================ C: the decision-independent candidates of tile step - 1
       if (step >= 1 && step - 1 < n_tiles) {
         const uint32_t ts = step - 1, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
@@ -246,7 +271,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
           ql[k * 64 + lane] = (uint8_t)lz_of(l, (k >= 6 && b >= kNear) ? c_far[k] : c_near[k]);
         }
       }
-    } else if (wave == 3) {
+    } else if (wave == kFront + 1) {
       // ============================================================ D: the decisions of tile step - 2
       if (step >= 2 && step - 2 < n_tiles) {
         const uint32_t ts = step - 2, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
@@ -408,9 +433,9 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
     if (uni(*abort_flag)) return true;   // (every wave sees the flag after the same barrier; nothing global but the page's own slices was written)
   }
 #ifdef PCO_LBP_TIMING
-  if (lane == 0) { atomicAdd(&g_lbp_timing[wave], tm_acc); if (wave == 3) { atomicAdd(&g_lbp_timing[5], tm_rounds); atomicAdd(&g_lbp_timing[6], (unsigned long long)n_tiles); atomicAdd(&g_lbp_timing[7], 1ull); } }
+  if (lane == 0) { atomicAdd(&g_lbp_timing[wave + 2 - kFront], tm_acc); if (wave == kFront + 1) { atomicAdd(&g_lbp_timing[5], tm_rounds); atomicAdd(&g_lbp_timing[6], (unsigned long long)n_tiles); atomicAdd(&g_lbp_timing[7], 1ull); } }
 #endif
-  if (wave == 4) {
+  if (wave == kFront + 2) {
     for (int dlt = 32; dlt >= 1; dlt >>= 1) {
       L o1 = shfl_idx(mn1, (int)(lane ^ dlt)); mn1 = o1 < mn1 ? o1 : mn1;
       L o2 = shfl_idx(mx1, (int)(lane ^ dlt)); mx1 = o2 > mx1 ? o2 : mx1;
@@ -429,7 +454,8 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
 // slot takes pages blockIdx.x, blockIdx.x + gridDim.x, ... of the lookback pages (page_ids lists them).  redo[k] = 1: lookback page k
 // was handed back to enc_lookback_kernel.
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::kThreads) void enc_lookback_pipe_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32, uint32_t* redo) {
+__global__ __launch_bounds__(Cfg::kThreads) void enc_lookback_pipe_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32, uint32_t* redo,
+                                                                          const uint16_t* props = nullptr, uint64_t prop_stride = 0) {
   uint32_t PCO_GLOBAL* base = (uint32_t PCO_GLOBAL*)lb_scratch + (uint64_t)blockIdx.x * scratch_stride_u32;
   for (uint32_t k = blockIdx.x; k < n_lb_pages; k += gridDim.x) {
     const uint32_t p = page_ids[k];
@@ -442,14 +468,186 @@ __global__ __launch_bounds__(Cfg::kThreads) void enc_lookback_pipe_kernel(EncWor
     const uint32_t wlog = uni(ch->window_n_log);
     uint16_t PCO_GLOBAL* hash_tbl = (uint16_t PCO_GLOBAL*)base; uint32_t PCO_GLOBAL* gcounts = base + (2ull << wlog);   // u16[2][2 << wlog], then u32[1 << wlog]
     const int bits = dtype_bits(uni(ch->dtype));
+    const uint16_t PCO_GLOBAL* pk = (const uint16_t PCO_GLOBAL*)props + (uint64_t)k * 6 * prop_stride;   // (kProps: lookback page k's six proposal streams)
     bool aborted;
-    if (bits == 64) aborted = lookback_page_pipe<uint64_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
-    else if (bits == 32) aborted = lookback_page_pipe<uint32_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
-    else if (bits == 16) aborted = lookback_page_pipe<uint16_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
-    else aborted = lookback_page_pipe<uint8_t, Cfg>(ws, t, pg, hash_tbl, gcounts);
+    if (bits == 64) aborted = lookback_page_pipe<uint64_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride);
+    else if (bits == 32) aborted = lookback_page_pipe<uint32_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride);
+    else if (bits == 16) aborted = lookback_page_pipe<uint16_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride);
+    else aborted = lookback_page_pipe<uint8_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride);
     if (aborted && threadIdx.x == 0) redo[k] = 1;
     __syncthreads();   // the next page re-initialises the LDS every wave of this one may still be reading
   }
+}
+
+// =========================================================================================================
+// The hash proposals as a pre-pass (round 5).  Slots 10..15 of an element's proposals (lookback.rs:22-64) depend on nothing but the
+// latents and the two last-index tables' own earlier updates, and ONE table of a 2^18-number page is 2^16 u16 entries = 128 KB: it fits
+// the LDS of a CU.  One workgroup per (page, table): the table lives in LDS for the whole page, the latents are streamed once, and three
+// u16 proposals per element and table leave as coalesced streams (12 B per element for both tables, where the tables in HBM cost ~450 B
+// of 64-byte-line traffic per element: profiles/r04_c4_pmc_hbm_traffic.txt).  The pipeline above then reads them like the latents.
+//
+// Only the table accesses are ordered by element; everything else is a function of the tile.  Seven worker waves and one sequencer wave
+// advance in lockstep, seven tiles per step:
+//   worker w, step s     S1 on tile 7 s + w: latents -> the three slots (hash of bucket - 1, bucket, bucket + 1), and the tile's OWN
+//                        hazards by eight wave votes (for each of my slots the last earlier lane of the tile whose centre slot is the
+//                        same; whether a later lane writes my centre slot) -- into the step's queue
+//   sequencer, step s    S2 on the seven tiles of step s - 1, in order: three table reads per lane, the in-tile hits put in their
+//                        place, the centre slot written by the lanes no later lane shadows.  LDS operations of one wave execute in the
+//                        order they are issued, so the seven tiles' reads and writes are sent back to back without a wait between them
+//   worker w, step s     S3 on its tile of step s - 2: entry -> age -> proposal (lookback.rs:50-54), stored to the page's streams
+// Entries are positions mod 2^16 with the pipeline's sweep (every 2^14 positions every entry older than the window becomes "window + 1
+// positions old"), done by the whole block at a step boundary.
+// =========================================================================================================
+constexpr uint32_t kLhWorkers = 7, kLhWaves = kLhWorkers + 1, kLhThreads = 64 * kLhWaves;
+constexpr uint32_t kLhQTile = 3 * 64 * 2 + 64 * 4;                      // u16 slot / entry [3][64] | u32 hazards [64]
+constexpr uint32_t kLhOffQueue = 2u << 16;                               // behind the largest table (u16[2 << 15])
+constexpr uint32_t kLhLdsBytes = kLhOffQueue + 2 * kLhWorkers * kLhQTile;   // 140 032 B: one block per CU
+
+template <class L>
+__device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const EncPage PCO_GLOBAL* pg, uint32_t c, uint16_t PCO_GLOBAL* props, uint64_t prop_stride) {
+  const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = uni(tid >> 6);
+  const uint32_t wlog = uni(ch->window_n_log), state_n = 1u << uni(ch->state_n_log);
+  const uint32_t window_n = 1u << wlog, hash_table_n = 2u << wlog, hash_mask = hash_table_n - 1;
+  const uint32_t n = (uint32_t)uni((uint64_t)pg->n); const uint64_t pstart = uni((uint64_t)pg->start);
+  if (n <= state_n) return;
+  const L PCO_GLOBAL* pre = sort_ptr<L>(ws, t, 0) + pstart;
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  uint16_t PCO_LDS* tbl = (uint16_t PCO_LDS*)smem;
+  for (uint32_t i = tid; i < hash_table_n / 4; i += kLhThreads) ((uint64_t PCO_LDS*)tbl)[i] = 0ull;
+  __syncthreads();
+  const uint32_t n_tiles = (n - state_n + 63) / 64, n_steps = (n_tiles + kLhWorkers - 1) / kLhWorkers + 2;
+  auto hash_fn = [&](uint64_t x) { x = (x ^ (x >> 32)) * 11400714819323197441ull; x = x ^ (x >> 32); return (uint32_t)x & hash_mask; };
+  auto tile_latent = [&](uint32_t tile) { const uint32_t i0t = state_n + 64 * tile; return tile < n_tiles && lane < n - i0t ? (uint64_t)pre[i0t + lane] : 0ull; };
+  auto queue = [&](uint32_t parity, uint32_t w) { return smem + kLhOffQueue + (parity * kLhWorkers + w) * kLhQTile; };
+  uint64_t lv_next = wave < kLhWorkers ? tile_latent(wave) : 0ull;
+  uint32_t next_sweep = kLbSweepPeriod;
+  for (uint32_t step = 0; step < n_steps; step++) {
+    // ---- the sweep, by everybody, when the sequencer's next tile has passed the mark (it keeps every age below 2^16; when exactly it
+    //      happens changes no proposal: an entry it rewrites is stale before and after) ----
+    const uint32_t p2 = state_n + 64 * (step > 0 ? (step - 1) * kLhWorkers : 0u);   // position of the sequencer's first tile of this step
+    if (p2 >= next_sweep) {
+      const uint32_t T = p2 & 0xffffu, marker = (p2 - window_n - 1) & 0xffffu;
+      for (uint32_t v = tid; v < hash_table_n / 4; v += kLhThreads) {
+        uint64_t q = ((uint64_t PCO_LDS*)tbl)[v];
+        bool changed = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t e = (uint32_t)(q >> (16 * k)) & 0xffffu;
+          if (((T - e) & 0xffffu) > window_n) { q = (q & ~(0xffffull << (16 * k))) | ((uint64_t)marker << (16 * k)); changed = true; }
+        }
+        if (changed) ((uint64_t PCO_LDS*)tbl)[v] = q;
+      }
+      next_sweep += kLbSweepPeriod;
+      __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (wave < kLhWorkers) {
+      // ---- S3: the tile this wave prepared two steps ago; its entries are in the queue buffer S1 is about to reuse ----
+      if (step >= 2) {
+        const uint32_t tile = (step - 2) * kLhWorkers + wave;
+        if (tile < n_tiles) {
+          const uint8_t PCO_LDS* q = queue(step & 1u, wave);
+          const uint32_t i0 = state_n + 64 * tile, ie = i0 + lane;
+          if (lane < n - i0) {
+#pragma unroll
+            for (uint32_t r = 0; r < 3; r++) {
+              const uint32_t val = ((const uint16_t PCO_LDS*)q)[r * 64 + lane];
+              const uint32_t lb = (ie - val) & 0xffffu;   // the entry's age (no entry is ever 2^16 positions old: the sweep)
+              const uint32_t pidx = 10 + 3 * c + r;
+              const uint32_t plb = lb <= window_n ? lb : (pidx < ie ? pidx : ie);   // lookback.rs:50-54
+              props[(uint64_t)(3 * c + r) * prop_stride + ie] = (uint16_t)plb;
+            }
+          }
+        }
+      }
+      // ---- S1: slots and in-tile hazards of tile step * W + wave ----
+      const uint32_t tile = step * kLhWorkers + wave;
+      if (tile < n_tiles) {
+        const uint32_t i0 = state_n + 64 * tile, tile_n = n - i0 < 64 ? n - i0 : 64;
+        const bool act = lane < tile_n;
+        const uint64_t bucket = lv_next >> (c == 0 ? 0 : 8);
+        lv_next = tile_latent(tile + kLhWorkers);   // (travels across the barrier)
+        uint32_t slot[3];
+        slot[0] = hash_fn(bucket - 1); slot[1] = hash_fn(bucket); slot[2] = hash_fn(bucket + 1);
+        // for each of my three slots the LAST earlier lane whose centre slot equals it: eight votes give the lanes whose centre slot agrees
+        // with a slot of mine in its low 8 bits (usually nobody); the few candidates are checked newest first
+        uint32_t hit[3] = {0, 0, 0}; bool has[3] = {false, false, false};
+        {
+          uint64_t vote[8];
+#pragma unroll
+          for (int b = 0; b < 8; b++) vote[b] = __ballot(act && ((slot[1] >> b) & 1u));
+          const uint64_t earlier = __ballot(act) & (((uint64_t)1 << lane) - 1);
+          uint64_t cand[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            uint64_t m = earlier;
+#pragma unroll
+            for (int b = 0; b < 8; b++) m &= ((slot[r] >> b) & 1u) ? vote[b] : ~vote[b];
+            cand[r] = act ? m : 0ull;
+          }
+          for (;;) {
+            if (!__any(cand[0] != 0 || cand[1] != 0 || cand[2] != 0)) break;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+              const uint32_t j = cand[r] ? 63u - (uint32_t)__builtin_clzll(cand[r]) : 0u;
+              const uint32_t theirs = (uint32_t)__shfl((int)slot[1], (int)j, 64);   // (every lane takes part in the exchange)
+              if (cand[r]) {
+                if (theirs == slot[r]) { hit[r] = j; has[r] = true; cand[r] = 0; }
+                else cand[r] &= ~((uint64_t)1 << j);
+              }
+            }
+          }
+        }
+        // of the lanes that share a centre slot only the last may write (lookback.rs:57-62 in element order): I am shadowed if a later lane's
+        // centre-slot hit is me
+        bool shadowed = false;
+        {
+          uint64_t mm = __ballot(act && has[1]);
+          while (mm) { const uint32_t k = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1; if ((uint32_t)__builtin_amdgcn_readlane((int)hit[1], (int)k) == lane) shadowed = true; }
+        }
+        uint8_t PCO_LDS* q = queue(step & 1u, wave);
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) ((uint16_t PCO_LDS*)q)[r * 64 + lane] = (uint16_t)slot[r];
+        ((uint32_t PCO_LDS*)(q + 384))[lane] = hit[0] | (hit[1] << 6) | (hit[2] << 12) | ((has[0] ? 1u : 0u) << 18) | ((has[1] ? 1u : 0u) << 19) | ((has[2] ? 1u : 0u) << 20) |
+                                                ((shadowed ? 1u : 0u) << 21) | ((act ? 1u : 0u) << 22);
+      }
+    } else if (step >= 1) {
+      // ---- S2: the table, tile after tile ----
+#pragma unroll
+      for (uint32_t w = 0; w < kLhWorkers; w++) {
+        const uint32_t tile = (step - 1) * kLhWorkers + w;
+        if (tile >= n_tiles) break;
+        uint8_t PCO_LDS* q = queue((step - 1) & 1u, w);
+        uint16_t PCO_LDS* qs = (uint16_t PCO_LDS*)q;
+        const uint32_t i0 = state_n + 64 * tile, ie = i0 + lane;
+        const uint32_t s0 = qs[lane], s1 = qs[64 + lane], s2 = qs[128 + lane], hz = ((const uint32_t PCO_LDS*)(q + 384))[lane];
+        uint32_t v0 = tbl[s0], v1 = tbl[s1], v2 = tbl[s2];
+        if ((hz >> 22) & 1u) { if (!((hz >> 21) & 1u)) tbl[s1] = (uint16_t)ie; }
+        if ((hz >> 18) & 1u) v0 = (i0 + (hz & 63u)) & 0xffffu;
+        if ((hz >> 19) & 1u) v1 = (i0 + ((hz >> 6) & 63u)) & 0xffffu;
+        if ((hz >> 20) & 1u) v2 = (i0 + ((hz >> 12) & 63u)) & 0xffffu;
+        qs[lane] = (uint16_t)v0; qs[64 + lane] = (uint16_t)v1; qs[128 + lane] = (uint16_t)v2;
+      }
+    }
+    __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
+
+// grid = 2 x the lookback pages (item = 2 k + table), one block per CU (the table)
+__global__ __launch_bounds__(kLhThreads) void enc_lookback_hash_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint16_t* props, uint64_t prop_stride) {
+  const uint32_t k = blockIdx.x >> 1, c = blockIdx.x & 1u;
+  if (k >= n_lb_pages) return;
+  const EncPage PCO_GLOBAL* pg = (const EncPage PCO_GLOBAL*)ws.pages + page_ids[k];
+  if (uni(pg->flags) & kPageFlagMetaOnly) return;
+  const uint32_t t = uni(pg->chunk);
+  const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (uni(ch->status) != PCO_GFX_OK || uni(ch->delta_kind) != kDeltaLookback) return;
+  uint16_t PCO_GLOBAL* pk = (uint16_t PCO_GLOBAL*)props + (uint64_t)k * 6 * prop_stride;
+  const int bits = dtype_bits(uni(ch->dtype));
+  if (bits == 64) lookback_hash_page<uint64_t>(ws, t, pg, c, pk, prop_stride);
+  else if (bits == 32) lookback_hash_page<uint32_t>(ws, t, pg, c, pk, prop_stride);
+  else if (bits == 16) lookback_hash_page<uint16_t>(ws, t, pg, c, pk, prop_stride);
+  else lookback_hash_page<uint8_t>(ws, t, pg, c, pk, prop_stride);
 }
 
 }  // namespace pcogfx

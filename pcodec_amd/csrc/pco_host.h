@@ -78,12 +78,13 @@ struct Workspace {
   DevBuf compact_tasks;                   // pco_gfx_compact_chunks
   DevBuf enc_state;                       // encode: per chunk plans etc. (see encode_kernels.hip)
   DevBuf enc_lat, enc_lat2, enc_sort, enc_ans, enc_small, enc_lb, enc_walk;
+  DevBuf enc_lbprops;                     // lookback: the hash proposals of every page (six u16 streams), enc_lookback_hash_kernel -> enc_lookback_pipe_kernel
   DevBuf enc_sym, enc_answ, enc_bat, enc_run, enc_fstate, enc_vlut;   // encode fast path (encode_fast.hip)
   DevBuf enc_strict;                      // strict histograms: how many variables took the reference's heapsort branch (a device counter)
   DevBuf auto_idx, auto_samp, auto_tasks, auto_sum, auto_log2;  // Auto spec resolution
   HostBuf h_samp, h_sum;                             // ... and its read-backs
 #define PCO_WS_BUFS(X) X(tasks) X(results) X(tbl_ws) X(dec_plans) X(dec_bins) X(dec_sym) X(dec_offpos) X(dec_progress) X(dec_stats) X(dec_hist) X(io_in) X(io_out) X(compact_tasks) X(enc_state) \
-  X(enc_lat) X(enc_lat2) X(enc_sort) X(enc_ans) X(enc_small) X(enc_lb) X(enc_walk) X(enc_sym) X(enc_answ) X(enc_bat) X(enc_run) X(enc_fstate) X(enc_vlut) X(enc_strict) X(auto_idx) X(auto_samp) X(auto_tasks) X(auto_sum) X(auto_log2)
+  X(enc_lat) X(enc_lat2) X(enc_sort) X(enc_ans) X(enc_small) X(enc_lb) X(enc_lbprops) X(enc_walk) X(enc_sym) X(enc_answ) X(enc_bat) X(enc_run) X(enc_fstate) X(enc_vlut) X(enc_strict) X(auto_idx) X(auto_samp) X(auto_tasks) X(auto_sum) X(auto_log2)
   size_t device_bytes() const {   // what the workspace holds on the device right now (pco_gfx_workspace_bytes)
     size_t b = 0;
 #define PCO_WS_ADD(name) b += name.cap;
@@ -106,7 +107,7 @@ struct Workspace {
     if (join_event) { (void)hipEventDestroy(join_event); join_event = nullptr; }
     if (join_event2) { (void)hipEventDestroy(join_event2); join_event2 = nullptr; }
     tasks.release(); results.release(); tbl_ws.release(); dec_plans.release(); dec_bins.release(); dec_sym.release(); dec_offpos.release(); dec_progress.release(); dec_stats.release(); dec_hist.release(); io_in.release(); io_out.release(); compact_tasks.release();
-    enc_state.release(); enc_lat.release(); enc_lat2.release(); enc_sort.release(); enc_ans.release(); enc_small.release(); enc_lb.release(); enc_walk.release(); enc_sym.release(); enc_answ.release(); enc_bat.release(); enc_run.release(); enc_fstate.release(); enc_vlut.release(); enc_strict.release(); auto_idx.release(); auto_samp.release(); auto_tasks.release(); auto_sum.release(); auto_log2.release(); h_samp.release(); h_sum.release();
+    enc_state.release(); enc_lat.release(); enc_lat2.release(); enc_sort.release(); enc_ans.release(); enc_small.release(); enc_lb.release(); enc_lbprops.release(); enc_walk.release(); enc_sym.release(); enc_answ.release(); enc_bat.release(); enc_run.release(); enc_fstate.release(); enc_vlut.release(); enc_strict.release(); auto_idx.release(); auto_samp.release(); auto_tasks.release(); auto_sum.release(); auto_log2.release(); h_samp.release(); h_sum.release();
   }
 };
 Workspace& workspace();
