@@ -222,6 +222,8 @@ unsigned long long pco_gfx_strict_histogram_fallbacks(void);
  * (decode_trail.hip) and had to be expanded after it instead, because their expander wave saw no walker beside it for ~55 ms (a device shared with
  * another process' kernels) or left early: such a call is correct but slower.  0 on an idle device.  Waits for the thread's last call. */
 unsigned long long pco_gfx_trail_givebacks(void);
+/* ... and how many chunks the walker marked for that kernel in the first place (the denominator). */
+unsigned long long pco_gfx_trail_marked(void);
 
 /* Per-kernel timing (HIP events on the launch stream): begin() arms it for this thread; end()
  * synchronises and returns the number of kernels launched since begin(), writing their names

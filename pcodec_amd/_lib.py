@@ -83,6 +83,8 @@ def lib():
         L.pco_gfx_strict_histogram_fallbacks.argtypes = []
         L.pco_gfx_trail_givebacks.restype = C.c_ulonglong
         L.pco_gfx_trail_givebacks.argtypes = []
+        L.pco_gfx_trail_marked.restype = C.c_ulonglong
+        L.pco_gfx_trail_marked.argtypes = []
         L.pco_gfx_guarantee_chunk_size.argtypes = [C.c_size_t, C.c_ubyte]
         L.pco_standalone_simple_compress_into.argtypes = [C.c_void_p, C.c_size_t, C.c_ubyte, C.c_void_p, C.c_void_p,
                                                           C.c_size_t, C.POINTER(C.c_size_t)]

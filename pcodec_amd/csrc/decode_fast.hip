@@ -962,6 +962,7 @@ __global__ __launch_bounds__(256) void dec_expand_kernel(const PcoGfxDecodeTask*
     if (uni(plan->fused)) {   // marked for the trailing expanders by the publishing walker (which also wrote its result): skipped only if one of them
                               // expanded it to the end -- a chunk nobody finished (late walker, timed-out or refusing expander) is expanded here
       const bool done = progress != nullptr && uni(progress[(uint64_t)(bi >> 3) * kTrailProgressStride + kTrailDoneWord + (bi & 7u)]) != 0;
+      if (!kLb && tid == 0 && givebacks != nullptr) atomicAdd(givebacks + 1, 1u);   // (marked for the expanders)
       if (done) continue;
       if (!kLb && tid == 0 && givebacks != nullptr && pstatus == PCO_GFX_OK) atomicAdd(givebacks, 1u);
     }

@@ -319,16 +319,18 @@ size_t pco_gfx_workspace_bytes(void) {
   } catch (...) { return 0; }
 }
 
-unsigned long long pco_gfx_trail_givebacks(void) {
+static unsigned long long trail_stat(int which) {
   try {
     Workspace& w = workspace();
     if (!w.dec_stats.p) return 0;
     if (w.has_last && w.last_event) (void)hipEventSynchronize(w.last_event);
-    uint32_t v = 0;
-    if (hipMemcpy(&v, w.dec_stats.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    return v;
+    uint32_t v[2] = {0, 0};
+    if (hipMemcpy(v, w.dec_stats.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return v[which];
   } catch (...) { return 0; }
 }
+unsigned long long pco_gfx_trail_givebacks(void) { return trail_stat(0); }
+unsigned long long pco_gfx_trail_marked(void) { return trail_stat(1); }
 unsigned long long pco_gfx_strict_histogram_fallbacks(void) {
   try {
     Workspace& w = workspace();

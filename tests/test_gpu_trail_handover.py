@@ -66,7 +66,7 @@ def test_chunks_nobody_expanded_under_the_walk_are_expanded_after_it(switch):
     """The whole mixed batch of test_decode_expanders_under_the_walk (2560 chunks of every kind, ragged, damaged ones among them, then 9000
     chunks through the persistent grid) and the small mixed blocks, with the expanders too early / absent: bit-exact, and the library
     reports how many chunks were given back."""
-    out = child("T.test_decode_expanders_under_the_walk(None)\nprint('after the mixed batch', G.lib().pco_gfx_trail_givebacks())\nk = H.small_mixed_blocks()\nprint('givebacks', G.lib().pco_gfx_trail_givebacks(), k)\n",
+    out = child("T.test_decode_expanders_under_the_walk(None)\nprint('after the mixed batch', G.lib().pco_gfx_trail_givebacks(), 'marked', G.lib().pco_gfx_trail_marked())\nk = H.small_mixed_blocks()\nprint('givebacks', G.lib().pco_gfx_trail_givebacks(), k, 'marked', G.lib().pco_gfx_trail_marked())\n",
                 PCO_GFX_TRAIL_DEBUG=switch, PCO_GFX_DEC_TRAIL="2")
     gb = int(out.split("givebacks")[1].split()[0])
     assert gb >= 9000, out   # (every chunk of the persistent-grid case alone is one)
