@@ -37,8 +37,9 @@ namespace pcogfx {
 
 // kProps: the hash proposals come from enc_lookback_hash_kernel (below) as six u16 streams per page; the two H waves are replaced by one
 // loader wave (latents into the ring, proposals into the queue) and the kernel has no random global access left but far candidates' latents.
-template <bool kSmall, bool kPropsT = false> struct LbPipe {
+template <bool kSmall, bool kPropsT = false, bool kFastDT = false> struct LbPipe {
   static constexpr bool kProps = kPropsT;
+  static constexpr bool kFastD = kFastDT;   // stage D takes the best of the brute-force and of the hashed proposals ready-made from the stages in front of it (below)
   static constexpr uint32_t kFront = kPropsT ? 1u : 2u;                 // waves in front of stage C: H0 / H1, or the loader
   static constexpr uint32_t kWaves = kFront + 3, kThreads = 64 * kWaves;
   static constexpr uint32_t kRing = kSmall ? 1024u : 2048u;            // latents of the last kRing positions (u64 each)
@@ -50,7 +51,8 @@ template <bool kSmall, bool kPropsT = false> struct LbPipe {
   static constexpr uint32_t kOffPlb = kOffRing + kRing * 8;             // u16[3][6][64]
   static constexpr uint32_t kOffLz = kOffPlb + 3 * 6 * 64 * 2;          // u8[2][12][64]
   static constexpr uint32_t kOffLb = kOffLz + 2 * 12 * 64;              // u32[2][64], then the abort flag
-  static constexpr uint32_t kLdsBytes = kOffLb + 2 * 64 * 4 + 16;       // 37 KB (four pages per CU) / 28.5 KB (five)
+  static constexpr uint32_t kOffGrp = kOffLb + 2 * 64 * 4 + 16;         // u32[2][2][64]: goodness | lookback << 8 of the best brute-force / hashed proposal (kFastD)
+  static constexpr uint32_t kLdsBytes = kOffGrp + (kFastDT ? 2 * 2 * 64 * 4 : 0);   // 37-38 KB (four pages per CU) / 28.5 KB (five)
 };
 constexpr uint32_t kLbPipeSmallMaxPage = 8192;
 constexpr uint32_t kLbSweepPeriod = 1u << 14;      // positions between two sweeps of the u16 tables (window_n + 1 + period + a tile < 2^16)
@@ -86,6 +88,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
   uint8_t PCO_LDS* q_lz = (uint8_t PCO_LDS*)(smem + Cfg::kOffLz);
   uint32_t PCO_LDS* q_lb = (uint32_t PCO_LDS*)(smem + Cfg::kOffLb);
   uint32_t PCO_LDS* abort_flag = q_lb + 2 * 64;   // (one word behind the lookback queue)
+  uint32_t PCO_LDS* q_grp = (uint32_t PCO_LDS*)(smem + Cfg::kOffGrp);
   // delta state = the first state_n latents, right aligned (lookback.rs:179-181); state_n == 1 from this encoder
   if (tid == 0) for (uint32_t i = 0; i < state_n && i < 8; i++) pg->moments[i] = i < n ? (uint64_t)pre[i] : 0ull;
   if (n <= state_n) return false;   // (uniform over the block)
@@ -133,6 +136,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
   }
   uint32_t next_sweep = kLbSweepPeriod;   // (H waves)
   uint32_t d_rounds = 0;                  // (D wave) rounds over the page's first tiles
+  uint32_t fast_from = kLbSeqTiles + 1;   // (D wave, kFastD) the first tile that may take the ready-made group maxima: two tiles behind the last count that crossed a power of two
   if (wave == kFront + 1 && lane < 16) proposed = (lane + 1) < state_n ? (lane + 1) : state_n;
 #ifdef PCO_LBP_TIMING
   unsigned long long tm_acc = 0, tm_rounds = 0;
@@ -153,6 +157,27 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
         for (int r = 0; r < 6; r++) qp[r * 64 + lane] = (uint16_t)(act ? h_pp[r] : 1u);
         h_lv = h_lv2; h_lv2 = tile_latent(i0 + 128);
         tile_props(i0 + 64, h_pp);
+      }
+      if constexpr (Cfg::kFastD) {
+        // ... and, for tile step - 1 (stage C's tile), the brute-force proposals 1..6: leading-zero counts for stage D's full evaluation, and
+        // the best of the six as the counts stand (see stage D: exact whenever no count has crossed a power of two since)
+        if (step >= 1 && step - 1 < n_tiles) {
+          const uint32_t ts = step - 1, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
+          const bool act = lane < tile_n;
+          const uint32_t ie = act ? i0 + lane : i0;
+          uint8_t PCO_LDS* ql = q_lz + (ts & 1u) * 12 * 64;
+          const L l = (L)ring[ie & (kRing - 1)];
+          uint32_t best_g = 0, best = 0;
+#pragma unroll
+          for (uint32_t k = 0; k < 6; k++) {
+            const uint32_t b = k + 1 <= ie ? k + 1 : ie;
+            const uint32_t lz = lz_of(l, (L)ring[(ie - b) & (kRing - 1)]);
+            ql[k * 64 + lane] = (uint8_t)lz;
+            const uint32_t g = (32u - clz_u32((uint32_t)lcounts[k])) + lz;
+            if (g > best_g) { best_g = g; best = k + 1; }
+          }
+          q_grp[(ts & 1u) * 128 + lane] = best_g | (best << 8);
+        }
       }
     } else if (wave < kFront) {
       // ============================================================ H0 / H1: hash proposals of tile `step` from table `wave`
@@ -257,19 +282,29 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
         for (int k = 0; k < 6; k++) lb[k] = (uint32_t)k + 1;   // brute force: 1..6 (clamped to the position on the page's first tile by stage D itself)
 #pragma unroll
         for (int r = 0; r < 6; r++) lb[6 + r] = (uint32_t)qp[r * 64 + lane];
+        constexpr int kFirst = Cfg::kFastD ? 6 : 0;   // (kFastD: the loader wave takes the brute-force half)
         L c_near[12], c_far[12];
 #pragma unroll
-        for (int k = 0; k < 12; k++) {   // both sources are read for every candidate, unconditionally (a per-lane branch around each read serialises them)
+        for (int k = kFirst; k < 12; k++) {   // both sources are read for every candidate, unconditionally (a per-lane branch around each read serialises them)
           const uint32_t b = lb[k] <= ie ? lb[k] : ie;
           const bool far = b >= kNear;
           c_near[k] = (L)ring[(ie - b) & (kRing - 1)];
           c_far[k] = k < 6 ? (L)0 : pre[ie - (far ? b : 0u)];
         }
+        uint32_t best_g = 0, best = 0; bool far_count = false;
 #pragma unroll
-        for (int k = 0; k < 12; k++) {
+        for (int k = kFirst; k < 12; k++) {
           const uint32_t b = lb[k] <= ie ? lb[k] : ie;
-          ql[k * 64 + lane] = (uint8_t)lz_of(l, (k >= 6 && b >= kNear) ? c_far[k] : c_near[k]);
+          const uint32_t lz = lz_of(l, (k >= 6 && b >= kNear) ? c_far[k] : c_near[k]);
+          ql[k * 64 + lane] = (uint8_t)lz;
+          if constexpr (Cfg::kFastD) {   // the best of the six hashed proposals as the counts stand (counts beyond the LDS ones: the tile takes the full evaluation)
+            const bool near_cnt = kCounts >= (1u << 15) || lb[k] - 1 < kCounts;
+            far_count = far_count || !near_cnt;
+            const uint32_t g = (32u - clz_u32((uint32_t)lcounts[near_cnt ? lb[k] - 1 : 0u])) + lz;
+            if (g > best_g) { best_g = g; best = lb[k]; }
+          }
         }
+        if constexpr (Cfg::kFastD) q_grp[(ts & 1u) * 128 + 64 + lane] = best_g | (best << 8) | ((act && far_count ? 1u : 0u) << 31);
       }
     } else if (wave == kFront + 1) {
       // ============================================================ D: the decisions of tile step - 2
@@ -327,29 +362,52 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
           //      date and the rest of the tile is decided again.  Exactly choose_lookbacks' sequence (lookback.rs:101-159). ----
           const uint32_t ie_s = act ? ie : i0;
           const L l = (L)ring[ie_s & (kRing - 1)];
+          // kFastD: an element's goodness is bitlen(count of the lookback) + leading zeros of the delta, and a count's bit length only moves
+          // when it crosses a power of two -- a few hundred times per page on data with few distinct lookbacks.  The stages in front have
+          // evaluated the six brute-force and the six hashed proposals of this tile with the counts as they stood one or two tiles ago and
+          // left the first maximum of either group; while no count has crossed a power of two since (fast_from), those maxima ARE what the
+          // loop below would find, and a round only has to evaluate the four repeating slots and to combine: group order = proposal order
+          // (brute force 0..5, repeating 6..9, hashed 10..15), strict > keeps the first maximum (lookback.rs:88-96).  A crossing -- B's
+          // virtual increments inside a round included -- sends the rest of the tile and the next tile through the full evaluation.
+          uint32_t g_a = 0, lb_a = 0, g_c = 0, lb_c = 0;
+          bool fast = false;
+          if constexpr (Cfg::kFastD) {
+            if (ts >= fast_from) {
+              const uint32_t a = q_grp[(ts & 1u) * 128 + lane], c = q_grp[(ts & 1u) * 128 + 64 + lane];
+              g_a = a & 255u; lb_a = a >> 8; g_c = c & 255u; lb_c = (c >> 8) & 0xffffu;
+              fast = !__any(act && (c >> 31) != 0);
+            }
+          }
+          bool have_full = false;
           uint32_t s_lb[12], s_lz[12], c_far[6];
 #pragma unroll
-          for (int k = 0; k < 6; k++) s_lb[k] = (uint32_t)k + 1;
+          for (int k = 0; k < 12; k++) { s_lb[k] = 1; s_lz[k] = 0; }
 #pragma unroll
-          for (int r = 0; r < 6; r++) s_lb[6 + r] = (uint32_t)qp[r * 64 + lane];
+          for (int r = 0; r < 6; r++) c_far[r] = 0;
+          auto load_full = [&]() {
+            have_full = true;
 #pragma unroll
-          for (int k = 0; k < 12; k++) s_lz[k] = act ? (uint32_t)ql[k * 64 + lane] : 0u;
-          // the four repeating slots are the one part of the candidate set that depends on the previous tile's decisions
-          uint32_t r_lz0 = act ? lz_of(l, latent_back(ie_s, ring_lb0 <= ie_s ? ring_lb0 : ie_s)) : 0u, r_lz1 = act ? lz_of(l, latent_back(ie_s, ring_lb1 <= ie_s ? ring_lb1 : ie_s)) : 0u;
-          uint32_t r_lz2 = act ? lz_of(l, latent_back(ie_s, ring_lb2 <= ie_s ? ring_lb2 : ie_s)) : 0u, r_lz3 = act ? lz_of(l, latent_back(ie_s, ring_lb3 <= ie_s ? ring_lb3 : ie_s)) : 0u;
-          // counts of far hashed proposals (beyond the LDS counts): from HBM, as of the end of the previous tile
-          {
+            for (int k = 0; k < 6; k++) s_lb[k] = (uint32_t)k + 1;
+#pragma unroll
+            for (int r = 0; r < 6; r++) s_lb[6 + r] = (uint32_t)qp[r * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 12; k++) s_lz[k] = act ? (uint32_t)ql[k * 64 + lane] : 0u;
+            // counts of far hashed proposals (beyond the LDS counts): from HBM, as of now (nothing of this tile has touched them: a tile that
+            // has far proposals at all is never fast)
             bool far_any = false;
 #pragma unroll
             for (int r = 0; r < 6; r++) far_any = far_any || (act && s_lb[6 + r] - 1 >= kCounts);
-#pragma unroll
-            for (int r = 0; r < 6; r++) c_far[r] = 0u;
             if (kCounts < (1u << 15) && __any(far_any)) {
 #pragma unroll
               for (int r = 0; r < 6; r++) { const uint32_t lb = s_lb[6 + r]; if (act && lb - 1 >= kCounts) c_far[r] = __hip_atomic_load(&gcounts[lb - 1], __ATOMIC_RELAXED, kLbScope); }
             }
-          }
+          };
+          if (!fast) load_full();
+          // the four repeating slots are the one part of the candidate set that depends on the previous tile's decisions
+          uint32_t r_lz0 = act ? lz_of(l, latent_back(ie_s, ring_lb0 <= ie_s ? ring_lb0 : ie_s)) : 0u, r_lz1 = act ? lz_of(l, latent_back(ie_s, ring_lb1 <= ie_s ? ring_lb1 : ie_s)) : 0u;
+          uint32_t r_lz2 = act ? lz_of(l, latent_back(ie_s, ring_lb2 <= ie_s ? ring_lb2 : ie_s)) : 0u, r_lz3 = act ? lz_of(l, latent_back(ie_s, ring_lb3 <= ie_s ? ring_lb3 : ie_s)) : 0u;
           uint32_t e_start = 0;
+          bool crossed = false;   // a count's bit length changed in this tile
           auto add_count = [&](uint32_t lb, uint32_t k) -> uint32_t {   // count `lb` += k for everything that mirrors it; returns the new count
             if (k == 0) return 0u;
             uint32_t now;
@@ -360,6 +418,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
 #pragma unroll
               for (int r = 0; r < 6; r++) c_far[r] += s_lb[6 + r] == lb ? k : 0u;
             }
+            if (clz_u32(now) != clz_u32(now - k)) crossed = true;
             if (ring_lb0 == lb) ring_c0 = now; if (ring_lb1 == lb) ring_c1 = now; if (ring_lb2 == lb) ring_c2 = now; if (ring_lb3 == lb) ring_c3 = now;
             return now;
           };
@@ -373,15 +432,23 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
             const uint32_t cb = cnt_best + (lane - e_start);   // B's count as this element sees it
             uint32_t best_g = 0, best = 0;
             auto consider = [&](uint32_t lb, uint32_t lz, uint32_t cnt) { const uint32_t g = (32u - clz_u32(lb == B ? cb : cnt)) + lz; if (g > best_g) { best_g = g; best = lb; } };
+            // (the ready-made maxima hold while no bit length has moved: not in this tile so far, and not by B's increments inside this round)
+            if (Cfg::kFastD && fast && !crossed && clz_u32(cnt_best + (tile_n - e_start)) == clz_u32(cnt_best)) {
+              best_g = g_a; best = lb_a;
+              consider(ring_lb0, r_lz0, ring_c0); consider(ring_lb1, r_lz1, ring_c1); consider(ring_lb2, r_lz2, ring_c2); consider(ring_lb3, r_lz3, ring_c3);
+              if (g_c > best_g) { best_g = g_c; best = lb_c; }
+            } else {
+              if (!have_full) load_full();
 #pragma unroll
-            for (int k = 0; k < 6; k++) consider(s_lb[k], s_lz[k], (uint32_t)lcounts[k]);
-            consider(ring_lb0, r_lz0, ring_c0); consider(ring_lb1, r_lz1, ring_c1); consider(ring_lb2, r_lz2, ring_c2); consider(ring_lb3, r_lz3, ring_c3);
+              for (int k = 0; k < 6; k++) consider(s_lb[k], s_lz[k], (uint32_t)lcounts[k]);
+              consider(ring_lb0, r_lz0, ring_c0); consider(ring_lb1, r_lz1, ring_c1); consider(ring_lb2, r_lz2, ring_c2); consider(ring_lb3, r_lz3, ring_c3);
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-              const uint32_t lb = s_lb[6 + r];
-              const bool near_cnt = kCounts >= (1u << 15) || lb - 1 < kCounts;
-              const uint32_t nearv = (uint32_t)lcounts[near_cnt ? lb - 1 : 0u];
-              consider(lb, s_lz[6 + r], near_cnt ? nearv : c_far[r]);
+              for (int r = 0; r < 6; r++) {
+                const uint32_t lb = s_lb[6 + r];
+                const bool near_cnt = kCounts >= (1u << 15) || lb - 1 < kCounts;
+                const uint32_t nearv = (uint32_t)lcounts[near_cnt ? lb - 1 : 0u];
+                consider(lb, s_lz[6 + r], near_cnt ? nearv : c_far[r]);
+              }
             }
             const uint64_t mism = __ballot(act && lane >= e_start && best != B);
             const uint32_t e_star = mism ? (uint32_t)__builtin_ctzll(mism) : tile_n;
@@ -404,6 +471,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
             if (e_start >= tile_n) break;
           }
           lb_sync();
+          if (crossed) fast_from = ts + 2;
         }
         q_lb[(ts & 1u) * 64 + lane] = my_lb;
         d_rounds = 0;
@@ -454,7 +522,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
 // slot takes pages blockIdx.x, blockIdx.x + gridDim.x, ... of the lookback pages (page_ids lists them).  redo[k] = 1: lookback page k
 // was handed back to enc_lookback_kernel.
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::kThreads) void enc_lookback_pipe_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32, uint32_t* redo,
+__global__ __launch_bounds__(Cfg::kThreads, Cfg::kProps ? 4 : 1) void enc_lookback_pipe_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32, uint32_t* redo,
                                                                           const uint16_t* props = nullptr, uint64_t prop_stride = 0) {
   uint32_t PCO_GLOBAL* base = (uint32_t PCO_GLOBAL*)lb_scratch + (uint64_t)blockIdx.x * scratch_stride_u32;
   for (uint32_t k = blockIdx.x; k < n_lb_pages; k += gridDim.x) {
@@ -486,22 +554,25 @@ __global__ __launch_bounds__(Cfg::kThreads) void enc_lookback_pipe_kernel(EncWor
 // u16 proposals per element and table leave as coalesced streams (12 B per element for both tables, where the tables in HBM cost ~450 B
 // of 64-byte-line traffic per element: profiles/r04_c4_pmc_hbm_traffic.txt).  The pipeline above then reads them like the latents.
 //
-// Only the table accesses are ordered by element; everything else is a function of the tile.  Seven worker waves and one sequencer wave
-// advance in lockstep, seven tiles per step:
-//   worker w, step s     S1 on tile 7 s + w: latents -> the three slots (hash of bucket - 1, bucket, bucket + 1), and the tile's OWN
+// Only the table accesses are ordered by element; everything else is a function of the tile.  Fifteen worker waves and one sequencer wave
+// advance in lockstep, fifteen tiles per step (16 waves: four per SIMD -- with eight, two per SIMD, a step took 6.3 k cycles and the launch
+// 49 ms per 4096 pages):
+//   worker w, step s     S1 on tile 15 s + w: latents -> the three slots (hash of bucket - 1, bucket, bucket + 1), and the tile's OWN
 //                        hazards by eight wave votes (for each of my slots the last earlier lane of the tile whose centre slot is the
 //                        same; whether a later lane writes my centre slot) -- into the step's queue
-//   sequencer, step s    S2 on the seven tiles of step s - 1, in order: three table reads per lane, the in-tile hits put in their
+//   sequencer, step s    S2 on the fifteen tiles of step s - 1, in order: three table reads per lane, the in-tile hits put in their
 //                        place, the centre slot written by the lanes no later lane shadows.  LDS operations of one wave execute in the
-//                        order they are issued, so the seven tiles' reads and writes are sent back to back without a wait between them
+//                        order they are issued, so five tiles' reads and writes at a time are sent back to back without a wait between them
 //   worker w, step s     S3 on its tile of step s - 2: entry -> age -> proposal (lookback.rs:50-54), stored to the page's streams
 // Entries are positions mod 2^16 with the pipeline's sweep (every 2^14 positions every entry older than the window becomes "window + 1
 // positions old"), done by the whole block at a step boundary.
 // =========================================================================================================
-constexpr uint32_t kLhWorkers = 7, kLhWaves = kLhWorkers + 1, kLhThreads = 64 * kLhWaves;
-constexpr uint32_t kLhQTile = 3 * 64 * 2 + 64 * 4;                      // u16 slot / entry [3][64] | u32 hazards [64]
+constexpr uint32_t kLhWorkers = 15, kLhWaves = kLhWorkers + 1, kLhThreads = 64 * kLhWaves, kLhChunk = 5;   // (the sequencer takes the step's tiles five at a time)
+static_assert(kLhWorkers % kLhChunk == 0, "whole chunks");
+constexpr uint32_t kLhQTile = 3 * 64 * 4;                               // per lane: slot0 | slot1 << 16, slot2 | flags << 16, the in-tile hits -- S2 leaves entry0 | entry1 << 16, entry2 in the first two
 constexpr uint32_t kLhOffQueue = 2u << 16;                               // behind the largest table (u16[2 << 15])
-constexpr uint32_t kLhLdsBytes = kLhOffQueue + 2 * kLhWorkers * kLhQTile;   // 140 032 B: one block per CU
+constexpr uint32_t kLhLdsBytes = kLhOffQueue + 2 * kLhWorkers * kLhQTile;   // 154 112 B: one block per CU
+constexpr uint32_t kLhHas = 7u, kLhShadowed = 8u, kLhAct = 16u;          // flags: has[r] = 1 << r
 
 template <class L>
 __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const EncPage PCO_GLOBAL* pg, uint32_t c, uint16_t PCO_GLOBAL* props, uint64_t prop_stride) {
@@ -519,7 +590,7 @@ __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
   const uint32_t n_tiles = (n - state_n + 63) / 64, n_steps = (n_tiles + kLhWorkers - 1) / kLhWorkers + 2;
   auto hash_fn = [&](uint64_t x) { x = (x ^ (x >> 32)) * 11400714819323197441ull; x = x ^ (x >> 32); return (uint32_t)x & hash_mask; };
   auto tile_latent = [&](uint32_t tile) { const uint32_t i0t = state_n + 64 * tile; return tile < n_tiles && lane < n - i0t ? (uint64_t)pre[i0t + lane] : 0ull; };
-  auto queue = [&](uint32_t parity, uint32_t w) { return smem + kLhOffQueue + (parity * kLhWorkers + w) * kLhQTile; };
+  auto queue = [&](uint32_t parity, uint32_t w) { return (uint32_t PCO_LDS*)(smem + kLhOffQueue + (parity * kLhWorkers + w) * kLhQTile); };
   uint64_t lv_next = wave < kLhWorkers ? tile_latent(wave) : 0ull;
   uint32_t next_sweep = kLbSweepPeriod;
   for (uint32_t step = 0; step < n_steps; step++) {
@@ -546,12 +617,13 @@ __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
       if (step >= 2) {
         const uint32_t tile = (step - 2) * kLhWorkers + wave;
         if (tile < n_tiles) {
-          const uint8_t PCO_LDS* q = queue(step & 1u, wave);
+          const uint32_t PCO_LDS* q = queue(step & 1u, wave);
           const uint32_t i0 = state_n + 64 * tile, ie = i0 + lane;
+          const uint32_t e01 = q[lane], e2 = q[64 + lane];
           if (lane < n - i0) {
 #pragma unroll
             for (uint32_t r = 0; r < 3; r++) {
-              const uint32_t val = ((const uint16_t PCO_LDS*)q)[r * 64 + lane];
+              const uint32_t val = r == 0 ? (e01 & 0xffffu) : (r == 1 ? (e01 >> 16) : (e2 & 0xffffu));
               const uint32_t lb = (ie - val) & 0xffffu;   // the entry's age (no entry is ever 2^16 positions old: the sweep)
               const uint32_t pidx = 10 + 3 * c + r;
               const uint32_t plb = lb <= window_n ? lb : (pidx < ie ? pidx : ie);   // lookback.rs:50-54
@@ -571,7 +643,7 @@ __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
         slot[0] = hash_fn(bucket - 1); slot[1] = hash_fn(bucket); slot[2] = hash_fn(bucket + 1);
         // for each of my three slots the LAST earlier lane whose centre slot equals it: eight votes give the lanes whose centre slot agrees
         // with a slot of mine in its low 8 bits (usually nobody); the few candidates are checked newest first
-        uint32_t hit[3] = {0, 0, 0}; bool has[3] = {false, false, false};
+        uint32_t hit[3] = {0, 0, 0}, flags = act ? kLhAct : 0u;
         {
           uint64_t vote[8];
 #pragma unroll
@@ -592,7 +664,7 @@ __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
               const uint32_t j = cand[r] ? 63u - (uint32_t)__builtin_clzll(cand[r]) : 0u;
               const uint32_t theirs = (uint32_t)__shfl((int)slot[1], (int)j, 64);   // (every lane takes part in the exchange)
               if (cand[r]) {
-                if (theirs == slot[r]) { hit[r] = j; has[r] = true; cand[r] = 0; }
+                if (theirs == slot[r]) { hit[r] = j; flags |= 1u << r; cand[r] = 0; }
                 else cand[r] &= ~((uint64_t)1 << j);
               }
             }
@@ -600,33 +672,51 @@ __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
         }
         // of the lanes that share a centre slot only the last may write (lookback.rs:57-62 in element order): I am shadowed if a later lane's
         // centre-slot hit is me
-        bool shadowed = false;
         {
-          uint64_t mm = __ballot(act && has[1]);
-          while (mm) { const uint32_t k = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1; if ((uint32_t)__builtin_amdgcn_readlane((int)hit[1], (int)k) == lane) shadowed = true; }
+          uint64_t mm = __ballot((flags & 2u) != 0);
+          while (mm) { const uint32_t k = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1; if ((uint32_t)__builtin_amdgcn_readlane((int)hit[1], (int)k) == lane) flags |= kLhShadowed; }
         }
-        uint8_t PCO_LDS* q = queue(step & 1u, wave);
-#pragma unroll
-        for (uint32_t r = 0; r < 3; r++) ((uint16_t PCO_LDS*)q)[r * 64 + lane] = (uint16_t)slot[r];
-        ((uint32_t PCO_LDS*)(q + 384))[lane] = hit[0] | (hit[1] << 6) | (hit[2] << 12) | ((has[0] ? 1u : 0u) << 18) | ((has[1] ? 1u : 0u) << 19) | ((has[2] ? 1u : 0u) << 20) |
-                                                ((shadowed ? 1u : 0u) << 21) | ((act ? 1u : 0u) << 22);
+        uint32_t PCO_LDS* q = queue(step & 1u, wave);
+        q[lane] = slot[0] | (slot[1] << 16); q[64 + lane] = slot[2] | (flags << 16); q[128 + lane] = hit[0] | (hit[1] << 6) | (hit[2] << 12);
       }
     } else if (step >= 1) {
-      // ---- S2: the table, tile after tile ----
+      // ---- S2: the table, tile after tile, five tiles' operations in flight (a tile's three reads, then its write, then the next tile's
+      //      reads: the LDS executes a wave's operations in the order they were issued, so nothing waits in between) ----
+      for (uint32_t chunk = 0; chunk < kLhWorkers / kLhChunk; chunk++) {
+        const uint32_t tile0 = (step - 1) * kLhWorkers + chunk * kLhChunk;
+        if (tile0 >= n_tiles) break;
+        uint32_t d0[kLhChunk], d1[kLhChunk], v0[kLhChunk], v1[kLhChunk], v2[kLhChunk];
 #pragma unroll
-      for (uint32_t w = 0; w < kLhWorkers; w++) {
-        const uint32_t tile = (step - 1) * kLhWorkers + w;
-        if (tile >= n_tiles) break;
-        uint8_t PCO_LDS* q = queue((step - 1) & 1u, w);
-        uint16_t PCO_LDS* qs = (uint16_t PCO_LDS*)q;
-        const uint32_t i0 = state_n + 64 * tile, ie = i0 + lane;
-        const uint32_t s0 = qs[lane], s1 = qs[64 + lane], s2 = qs[128 + lane], hz = ((const uint32_t PCO_LDS*)(q + 384))[lane];
-        uint32_t v0 = tbl[s0], v1 = tbl[s1], v2 = tbl[s2];
-        if ((hz >> 22) & 1u) { if (!((hz >> 21) & 1u)) tbl[s1] = (uint16_t)ie; }
-        if ((hz >> 18) & 1u) v0 = (i0 + (hz & 63u)) & 0xffffu;
-        if ((hz >> 19) & 1u) v1 = (i0 + ((hz >> 6) & 63u)) & 0xffffu;
-        if ((hz >> 20) & 1u) v2 = (i0 + ((hz >> 12) & 63u)) & 0xffffu;
-        qs[lane] = (uint16_t)v0; qs[64 + lane] = (uint16_t)v1; qs[128 + lane] = (uint16_t)v2;
+        for (uint32_t w = 0; w < kLhChunk; w++) {
+          const uint32_t PCO_LDS* q = queue((step - 1) & 1u, chunk * kLhChunk + w);
+          const bool valid = tile0 + w < n_tiles;   // (uniform)
+          d0[w] = valid ? q[lane] : 0u; d1[w] = valid ? q[64 + lane] : 0u;
+        }
+        bool hits = false;
+#pragma unroll
+        for (uint32_t w = 0; w < kLhChunk; w++) {
+          const uint32_t s0 = d0[w] & 0xffffu, s1 = d0[w] >> 16, s2 = d1[w] & 0xffffu, fl = d1[w] >> 16;
+          v0[w] = tbl[s0]; v1[w] = tbl[s1]; v2[w] = tbl[s2];
+          if ((fl & (kLhAct | kLhShadowed)) == kLhAct) tbl[s1] = (uint16_t)(state_n + 64 * (tile0 + w) + lane);
+          hits = hits || (fl & kLhHas) != 0;
+        }
+        if (__any(hits)) {   // (rare: an earlier lane of the same tile had written the slot)
+#pragma unroll
+          for (uint32_t w = 0; w < kLhChunk; w++) {
+            const uint32_t fl = d1[w] >> 16, i0 = state_n + 64 * (tile0 + w);
+            const uint32_t hz = (fl & kLhHas) ? queue((step - 1) & 1u, chunk * kLhChunk + w)[128 + lane] : 0u;
+            if (fl & 1u) v0[w] = (i0 + (hz & 63u)) & 0xffffu;
+            if (fl & 2u) v1[w] = (i0 + ((hz >> 6) & 63u)) & 0xffffu;
+            if (fl & 4u) v2[w] = (i0 + ((hz >> 12) & 63u)) & 0xffffu;
+          }
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < kLhChunk; w++) {
+          if (tile0 + w < n_tiles) {
+            uint32_t PCO_LDS* q = queue((step - 1) & 1u, chunk * kLhChunk + w);
+            q[lane] = v0[w] | (v1[w] << 16); q[64 + lane] = v2[w];
+          }
+        }
       }
     }
     __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
