@@ -67,14 +67,17 @@ __device__ unsigned long long g_lbp_timing[16];
 
 template <class L, class Cfg>
 __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, uint16_t PCO_GLOBAL* hash_tbl, uint32_t PCO_GLOBAL* gcounts,
-                                   const uint16_t PCO_GLOBAL* props = nullptr /* kProps: u16[6][prop_stride] */, uint64_t prop_stride = 0) {
+                                   const uint16_t PCO_GLOBAL* props = nullptr /* kProps: u16[6][prop_stride] */, uint64_t prop_stride = 0, uint32_t role_shift = 0) {
   constexpr uint32_t kFront = Cfg::kFront;
   typedef typename Cfg::CountT CountT;
   constexpr uint32_t kRing = Cfg::kRing, kNear = Cfg::kNear, kCounts = Cfg::kCounts;
   // (tables in LDS were tried for small pages -- u16 entries, 64 KB: one page then fills a CU, and a page on which stage D is the whole cost
   //  gets a twelfth of the throughput of sixteen one-wave pages: 144 ms instead of 20 for the 8192 trial pages of f64 decimals)
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = uni(tid >> 6);
+  // role_shift: a workgroup's waves are dealt to the SIMDs in order, so with every block's wave k in the same role all four pages of a CU
+  // have their stage D on one SIMD and their stage C on another (a step cost four D's worth of issue whatever the other SIMDs did); the
+  // blocks rotate the roles instead -- each SIMD gets one wave of every stage
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uni(tid >> 6) + role_shift) % Cfg::kWaves;
   const uint32_t wlog = uni(ch->window_n_log), state_n = 1u << uni(ch->state_n_log);
   const uint32_t window_n = 1u << wlog, hash_table_n = 2u << wlog, hash_mask = hash_table_n - 1;
   const uint32_t n = (uint32_t)uni((uint64_t)pg->n); const uint64_t pstart = uni((uint64_t)pg->start);
@@ -523,7 +526,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
 // was handed back to enc_lookback_kernel.
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::kThreads, Cfg::kProps ? 4 : 1) void enc_lookback_pipe_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32, uint32_t* redo,
-                                                                          const uint16_t* props = nullptr, uint64_t prop_stride = 0) {
+                                                                          const uint16_t* props = nullptr, uint64_t prop_stride = 0, uint32_t role_rotate = 0) {
   uint32_t PCO_GLOBAL* base = (uint32_t PCO_GLOBAL*)lb_scratch + (uint64_t)blockIdx.x * scratch_stride_u32;
   for (uint32_t k = blockIdx.x; k < n_lb_pages; k += gridDim.x) {
     const uint32_t p = page_ids[k];
@@ -538,10 +541,10 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kProps ? 4 : 1) void enc_lookba
     const int bits = dtype_bits(uni(ch->dtype));
     const uint16_t PCO_GLOBAL* pk = (const uint16_t PCO_GLOBAL*)props + (uint64_t)k * 6 * prop_stride;   // (kProps: lookback page k's six proposal streams)
     bool aborted;
-    if (bits == 64) aborted = lookback_page_pipe<uint64_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride);
-    else if (bits == 32) aborted = lookback_page_pipe<uint32_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride);
-    else if (bits == 16) aborted = lookback_page_pipe<uint16_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride);
-    else aborted = lookback_page_pipe<uint8_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride);
+    if (bits == 64) aborted = lookback_page_pipe<uint64_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride, role_rotate ? blockIdx.x % Cfg::kWaves : 0u);
+    else if (bits == 32) aborted = lookback_page_pipe<uint32_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride, role_rotate ? blockIdx.x % Cfg::kWaves : 0u);
+    else if (bits == 16) aborted = lookback_page_pipe<uint16_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride, role_rotate ? blockIdx.x % Cfg::kWaves : 0u);
+    else aborted = lookback_page_pipe<uint8_t, Cfg>(ws, t, pg, hash_tbl, gcounts, pk, prop_stride, role_rotate ? blockIdx.x % Cfg::kWaves : 0u);
     if (aborted && threadIdx.x == 0) redo[k] = 1;
     __syncthreads();   // the next page re-initialises the LDS every wave of this one may still be reading
   }
@@ -647,15 +650,20 @@ __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
         {
           uint64_t vote[8];
 #pragma unroll
-          for (int b = 0; b < 8; b++) vote[b] = __ballot(act && ((slot[1] >> b) & 1u));
+          for (int b = 0; b < 8; b++) vote[b] = __ballot(((slot[1] >> b) & 1u) != 0);   // (lanes beyond the tile: masked out by `earlier`)
           const uint64_t earlier = __ballot(act) & (((uint64_t)1 << lane) - 1);
+          // (a lane j differs from my slot r in bit b iff vote_b's bit j differs from that bit of mine: the differences OR'd over the eight
+          //  bits, one three-input bit operation per half and bit -- as selects and ANDs of 64-bit masks this block was 250 instructions)
           uint64_t cand[3];
 #pragma unroll
           for (int r = 0; r < 3; r++) {
-            uint64_t m = earlier;
+            uint32_t dlo = 0, dhi = 0;
 #pragma unroll
-            for (int b = 0; b < 8; b++) m &= ((slot[r] >> b) & 1u) ? vote[b] : ~vote[b];
-            cand[r] = act ? m : 0ull;
+            for (int b = 0; b < 8; b++) {
+              const uint32_t ext = (uint32_t)((int32_t)(slot[r] << (31 - b)) >> 31);   // my bit b, on every bit position
+              dlo |= (uint32_t)vote[b] ^ ext; dhi |= (uint32_t)(vote[b] >> 32) ^ ext;
+            }
+            cand[r] = act ? earlier & ~(((uint64_t)dhi << 32) | dlo) : 0ull;
           }
           for (;;) {
             if (!__any(cand[0] != 0 || cand[1] != 0 || cand[2] != 0)) break;

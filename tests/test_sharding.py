@@ -328,7 +328,20 @@ def _collective_failures(L, comm, rank, world, root):
     got = C.c_uint64(0)
     rc = L.pco_gfx_scatter_chunks(comm, root, big.data_ptr(), 0, offsets, recv.data_ptr(), 10 if rank == victim else 1 << 14, C.byref(got), None)
     ok = ok and rc != 0 and L.pco_gfx_last_status() == G.ST_INVALID_ARGUMENT
-    # 4. and the communicator still works
+    # 4. per-rank argument errors travel with the size exchange too (round 4 threw them locally and left the peers in the all-gather):
+    #    one rank without an offsets table, one rank with bytes but no buffer, one rank naming a root that does not exist -- in the gather
+    #    and in the scatter
+    bad = (root + 1) % world
+    offs2 = (C.c_uint64 * (world + 1))()
+    for variant in range(3):
+        a_off = None if (variant == 0 and rank == bad) else offs2
+        a_buf = None if (variant == 1 and rank == bad) else payload.data_ptr()
+        a_root = world + 3 if (variant == 2 and rank == bad) else root
+        rc = L.pco_gfx_gather_chunks(comm, a_root, a_buf, mine, big.data_ptr(), 1 << 16, 0, a_off, None)
+        ok = ok and rc != 0 and L.pco_gfx_last_status() == G.ST_INVALID_ARGUMENT
+    rc = L.pco_gfx_scatter_chunks(comm, root, big.data_ptr(), 0, None if rank == bad else offsets, recv.data_ptr(), 1 << 14, C.byref(got), None)
+    ok = ok and rc != 0 and L.pco_gfx_last_status() == G.ST_INVALID_ARGUMENT
+    # 5. and the communicator still works
     G.check(L.pco_gfx_scatter_chunks(comm, root, big.data_ptr(), 0, offsets, recv.data_ptr(), 1 << 14, C.byref(got), None))
     torch.cuda.synchronize()
     ok = ok and got.value == mine and bool((recv[:mine] == rank + 1).all())
@@ -337,11 +350,8 @@ def _collective_failures(L, comm, rank, world, root):
 
 def _fake_rccl_lib():
     """tests/fake_rccl.so: the loopback transport (tests/fake_rccl.cpp); built by __graft_entry__.build(), or here when it is missing."""
-    import subprocess
-    so, src = os.path.join(HERE, "fake_rccl.so"), os.path.join(HERE, "fake_rccl.cpp")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so])
-    return so
+    import fake_rccl_build
+    return fake_rccl_build.build()
 
 
 def _run_ranks(tmp_path, world, extra, env_extra=None):
