@@ -627,7 +627,12 @@ def test_decode_expanders_under_the_walk(L):
         assert bool((outs[i][want[i].nbytes:] == 0xAB).all()), i   # nothing written past the chunk's numbers
     assert n_bad >= 2
     # more walker blocks than the persistent expander grid holds (4 blocks per CU): the expander blocks take a second walker block each
-    a, b = arrays[0], blobs[0]   # (700 u64 of a noisy ramp, delta order 1: a chunk the expanders take)
+    # (4096 u64 of a noisy ramp, delta order 1: five bins, 8-bit offsets -- a chunk the expanders take.  Round 4 used the 700-number chunk of the
+    #  mix here, whose single bin makes the walker leave it to dec_expand_kernel: pco_gfx_trail_marked() showed that nothing of that call ever
+    #  reached the expanders)
+    a = ramp(4096, np.uint64); f2 = O.simple_compress(a, O.make_config(mode=1, delta=2, delta_order=1)); b = U.chunk_of_file(f2, len(f2) - O_header_len(f2) - 1)
+    assert O.inspect_first_chunk(f2)[0].n_bins[1] > 1
+    marked_before = L_.pco_gfx_trail_marked()
     k2 = 9000
     src = torch.from_numpy(np.frombuffer(b + b"\0" * 16, np.uint8).copy()).cuda()
     out = torch.zeros((k2, max(a.nbytes, 8)), dtype=torch.uint8, device="cuda")
@@ -637,6 +642,7 @@ def test_decode_expanders_under_the_walk(L):
     host = out.cpu().numpy()
     assert all(dr2[i].n_out == a.size for i in range(k2))
     assert (host[:, : a.nbytes] == a.view(np.uint8).reshape(1, -1)).all()
+    assert L_.pco_gfx_trail_marked() - marked_before == k2   # every one of them was marked for the expanders under the walk
 
 
 def O_header_len(f):

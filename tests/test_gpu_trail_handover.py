@@ -69,7 +69,8 @@ def test_chunks_nobody_expanded_under_the_walk_are_expanded_after_it(switch):
     out = child("T.test_decode_expanders_under_the_walk(None)\nprint('after the mixed batch', G.lib().pco_gfx_trail_givebacks(), 'marked', G.lib().pco_gfx_trail_marked())\nk = H.small_mixed_blocks()\nprint('givebacks', G.lib().pco_gfx_trail_givebacks(), k, 'marked', G.lib().pco_gfx_trail_marked())\n",
                 PCO_GFX_TRAIL_DEBUG=switch, PCO_GFX_DEC_TRAIL="2")
     gb = int(out.split("givebacks")[1].split()[0]); marked = int(out.split("marked")[-1].split()[0])
-    assert gb == marked and marked >= 800, out   # every chunk the walker marked for the expanders came back; none was lost on the way
+    # every chunk the walker marked for the expanders came back (all but the handful of damaged ones, which report their error instead); none was lost
+    assert marked >= 9800 and marked - 8 <= gb <= marked, out
 
 
 def test_small_mixed_blocks_with_the_expanders_running():
