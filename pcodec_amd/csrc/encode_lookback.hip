@@ -37,22 +37,19 @@ namespace pcogfx {
 
 // kProps: the hash proposals come from enc_lookback_hash_kernel (below) as six u16 streams per page; the two H waves are replaced by one
 // loader wave (latents into the ring, proposals into the queue) and the kernel has no random global access left but far candidates' latents.
-template <bool kSmall, bool kPropsT = false, bool kFastDT = false, uint32_t kPagesT = 4> struct LbPipe {
-  static constexpr uint32_t kPagesPerCu = kPagesT;   // (kProps) the register budget: 128 VGPRs at four blocks per CU, 170 at three
+template <bool kSmall, bool kPropsT = false, bool kFastDT = false> struct LbPipe {
   static constexpr bool kProps = kPropsT;
   static constexpr bool kFastD = kFastDT;   // stage D takes the best of the brute-force and of the hashed proposals ready-made from the stages in front of it (below)
   static constexpr uint32_t kFront = kPropsT ? 1u : 2u;                 // waves in front of stage C: H0 / H1, or the loader
   static constexpr uint32_t kWaves = kFront + 3, kThreads = 64 * kWaves;
   static constexpr uint32_t kRing = kSmall ? 1024u : 2048u;            // latents of the last kRing positions (u64 each)
-  static constexpr uint32_t kLag = kPropsT ? 1u : 0u;                  // kProps: stages C, D, A run one more tile behind the loader, so that C can send a tile's far reads a whole step before it needs them
-  static constexpr uint32_t kNear = kRing - 64 * (kWaves + kLag);      // lookbacks below this are served from the ring by every stage (they run up to four / five tiles apart)
-  static constexpr uint32_t kPlbBufs = 3 + kLag;                       // proposal queue: written by the front at tile t's step, last read by stage D
+  static constexpr uint32_t kNear = kRing - 64 * kWaves;               // lookbacks below this are served from the ring by every stage (they run up to four tiles apart)
   static constexpr uint32_t kCounts = kSmall ? 8192u : 4096u;          // lookback_counts kept in LDS (small pages: all of them, as u16)
   typedef std::conditional_t<kSmall, uint16_t, uint32_t> CountT;
   static constexpr uint32_t kOffCounts = 0;
   static constexpr uint32_t kOffRing = kOffCounts + kCounts * sizeof(CountT);
-  static constexpr uint32_t kOffPlb = kOffRing + kRing * 8;             // u16[kPlbBufs][6][64]
-  static constexpr uint32_t kOffLz = kOffPlb + kPlbBufs * 6 * 64 * 2;   // u8[2][12][64]
+  static constexpr uint32_t kOffPlb = kOffRing + kRing * 8;             // u16[3][6][64]
+  static constexpr uint32_t kOffLz = kOffPlb + 3 * 6 * 64 * 2;          // u8[2][12][64]
   static constexpr uint32_t kOffLb = kOffLz + 2 * 12 * 64;              // u32[2][64], then the abort flag
   static constexpr uint32_t kOffGrp = kOffLb + 2 * 64 * 4 + 16;         // u32[2][2][64]: goodness | lookback << 8 of the best brute-force / hashed proposal (kFastD)
   static constexpr uint32_t kLdsBytes = kOffGrp + (kFastDT ? 2 * 2 * 64 * 4 : 0);   // 37-38 KB (four pages per CU) / 28.5 KB (five)
@@ -71,7 +68,7 @@ __device__ unsigned long long g_lbp_timing[16];
 template <class L, class Cfg>
 __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, uint16_t PCO_GLOBAL* hash_tbl, uint32_t PCO_GLOBAL* gcounts,
                                    const uint16_t PCO_GLOBAL* props = nullptr /* kProps: u16[6][prop_stride] */, uint64_t prop_stride = 0, uint32_t role_shift = 0) {
-  constexpr uint32_t kFront = Cfg::kFront, kLag = Cfg::kLag, kPlbBufs = Cfg::kPlbBufs;
+  constexpr uint32_t kFront = Cfg::kFront;
   typedef typename Cfg::CountT CountT;
   constexpr uint32_t kRing = Cfg::kRing, kNear = Cfg::kNear, kCounts = Cfg::kCounts;
   // (tables in LDS were tried for small pages -- u16 entries, 64 KB: one page then fills a CU, and a page on which stage D is the whole cost
@@ -145,11 +142,13 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
   uint32_t fast_from = kLbSeqTiles + 1;   // (D wave, kFastD) the first tile that may take the ready-made group maxima: two tiles behind the last count that crossed a power of two
   if (wave == kFront + 1 && lane < 16) proposed = (lane + 1) < state_n ? (lane + 1) : state_n;
 #ifdef PCO_LBP_TIMING
-  unsigned long long tm_acc = 0, tm_rounds = 0;
+  unsigned long long tm_acc = 0, tm_rounds = 0, tm_d[5] = {0, 0, 0, 0, 0}, tm_x = 0, tm_bar = 0;
+#define LBP_STAMP(i) do { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long _n = __builtin_readcyclecounter(); tm_d[i] += _n - tm_x; tm_x = _n; } while (0)
+#else
+#define LBP_STAMP(i) do { } while (0)
 #endif
 
-  L far_a[6] = {0, 0, 0, 0, 0, 0}, far_b[6] = {0, 0, 0, 0, 0, 0};   // (stage C, kProps) far candidates' latents in flight: sent at one step, used at the next, two register sets by step parity
-  for (uint32_t step = 0; step < n_tiles + 3 + kLag; step++) {
+  for (uint32_t step = 0; step < n_tiles + 3; step++) {
 #ifdef PCO_LBP_TIMING
     const unsigned long long tm0 = __builtin_readcyclecounter();
 #endif
@@ -159,17 +158,17 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
         const uint32_t i0 = state_n + 64 * step, tile_n = n - i0 < 64 ? n - i0 : 64, ie = i0 + lane;
         const bool act = lane < tile_n;
         if (act) ring[ie & (kRing - 1)] = h_lv;
-        uint16_t PCO_LDS* qp = q_plb + (step % kPlbBufs) * 6 * 64;
+        uint16_t PCO_LDS* qp = q_plb + (step % 3u) * 6 * 64;
 #pragma unroll
         for (int r = 0; r < 6; r++) qp[r * 64 + lane] = (uint16_t)(act ? h_pp[r] : 1u);
         h_lv = h_lv2; h_lv2 = tile_latent(i0 + 128);
         tile_props(i0 + 64, h_pp);
       }
       if constexpr (Cfg::kFastD) {
-        // ... and, for stage C's tile, the brute-force proposals 1..6: leading-zero counts for stage D's full evaluation, and
+        // ... and, for tile step - 1 (stage C's tile), the brute-force proposals 1..6: leading-zero counts for stage D's full evaluation, and
         // the best of the six as the counts stand (see stage D: exact whenever no count has crossed a power of two since)
-        if (step >= 1 + kLag && step - 1 - kLag < n_tiles) {
-          const uint32_t ts = step - 1 - kLag, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
+        if (step >= 1 && step - 1 < n_tiles) {
+          const uint32_t ts = step - 1, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
           const bool act = lane < tile_n;
           const uint32_t ie = act ? i0 + lane : i0;
           uint8_t PCO_LDS* ql = q_lz + (ts & 1u) * 12 * 64;
@@ -266,7 +265,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
           h_val[1] = a1 ? (uint32_t)__hip_atomic_load(&hash_tbl[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
           h_val[2] = a1 ? (uint32_t)__hip_atomic_load(&hash_tbl[s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
-        uint16_t PCO_LDS* qp = q_plb + (step % kPlbBufs) * 6 * 64;
+        uint16_t PCO_LDS* qp = q_plb + (step % 3u) * 6 * 64;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
           const uint32_t lb = (ie - val[r]) & 0xffffu;   // the entry's age (no entry is ever 2^16 positions old: the sweep)
@@ -276,70 +275,64 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
         }
       }
     } else if (wave == kFront) {
-      // ============================================================ C: the decision-independent candidates of tile step - 1 - kLag
-      // kProps: the far candidates' latents (a hashed proposal beyond the ring: the common case on seasonal data, where the last equal value
-      // lies a few periods back) are read from global memory a STEP ahead -- for tile step - 1, whose proposals the loader queued one step ago --
-      // into one of two register sets, while the tile of the step before is worked on from the other.  (Read where they are used, the
-      // step waited for that round trip: 44 ms per 4096 pages whatever stage D cost.)
-      auto c_stage = [&](L (&f_use)[6], L (&f_send)[6]) {
-        if constexpr (Cfg::kProps) {
-          if (step >= 1 && step - 1 < n_tiles) {
-            const uint32_t ts = step - 1, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
-            const uint32_t ie = lane < tile_n ? i0 + lane : i0;
-            const uint16_t PCO_LDS* qp = q_plb + (ts % kPlbBufs) * 6 * 64;
+      // ============================================================ C: the decision-independent candidates of tile step - 1
+      if (step >= 1 && step - 1 < n_tiles) {
+        const uint32_t ts = step - 1, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
+        const bool act = lane < tile_n;
+        const uint32_t ie = act ? i0 + lane : i0;
+        const uint16_t PCO_LDS* qp = q_plb + (ts % 3u) * 6 * 64;
+        uint8_t PCO_LDS* ql = q_lz + (ts & 1u) * 12 * 64;
+        const L l = (L)ring[ie & (kRing - 1)];
+        uint32_t lb[12];
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-              const uint32_t p = (uint32_t)qp[r * 64 + lane], b = p <= ie ? p : ie;
-              f_send[r] = pre[ie - (b >= kNear ? b : 0u)];
-            }
+        for (int k = 0; k < 6; k++) lb[k] = (uint32_t)k + 1;   // brute force: 1..6 (clamped to the position on the page's first tile by stage D itself)
+#pragma unroll
+        for (int r = 0; r < 6; r++) lb[6 + r] = (uint32_t)qp[r * 64 + lane];
+        constexpr int kFirst = Cfg::kFastD ? 6 : 0;   // (kFastD: the loader wave takes the brute-force half)
+        L c_near[12], c_far[12];
+#pragma unroll
+        for (int k = kFirst; k < 12; k++) {   // both sources are read for every candidate, unconditionally (a per-lane branch around each read serialises them)
+          const uint32_t b = lb[k] <= ie ? lb[k] : ie;
+          const bool far = b >= kNear;
+          c_near[k] = (L)ring[(ie - b) & (kRing - 1)];
+          c_far[k] = k < 6 ? (L)0 : pre[ie - (far ? b : 0u)];
+        }
+        uint32_t best_g = 0, best = 0;
+        // kFastD: the counts of hashed proposals beyond the LDS counts come from global memory (stage D's atomics land in the L2; read past the
+        // L1).  On seasonal data a fifth of the elements have such a proposal -- the last equal value, a dozen periods back -- so a tile-wide
+        // "has a far count" flag sent every tile through stage D's full evaluation; this stage has the time for the round trip (it waits
+        // 3 k cycles at the barrier), stage D has not.
+        uint32_t cnt_far[6] = {1, 1, 1, 1, 1, 1};
+        if constexpr (Cfg::kFastD && kCounts < (1u << 15)) {
+          bool far_any = false;
+#pragma unroll
+          for (int r = 0; r < 6; r++) far_any = far_any || (act && lb[6 + r] - 1 >= kCounts);
+          if (__any(far_any)) {
+#pragma unroll
+            for (int r = 0; r < 6; r++) if (act && lb[6 + r] - 1 >= kCounts) cnt_far[r] = __hip_atomic_load(&gcounts[lb[6 + r] - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        if (step >= 1 + kLag && step - 1 - kLag < n_tiles) {
-          const uint32_t ts = step - 1 - kLag, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
-          const bool act = lane < tile_n;
-          const uint32_t ie = act ? i0 + lane : i0;
-          const uint16_t PCO_LDS* qp = q_plb + (ts % kPlbBufs) * 6 * 64;
-          uint8_t PCO_LDS* ql = q_lz + (ts & 1u) * 12 * 64;
-          const L l = (L)ring[ie & (kRing - 1)];
-          uint32_t lb[12];
 #pragma unroll
-          for (int k = 0; k < 6; k++) lb[k] = (uint32_t)k + 1;   // brute force: 1..6 (clamped to the position on the page's first tile by stage D itself)
-#pragma unroll
-          for (int r = 0; r < 6; r++) lb[6 + r] = (uint32_t)qp[r * 64 + lane];
-          constexpr int kFirst = Cfg::kFastD ? 6 : 0;   // (kFastD: the loader wave takes the brute-force half)
-          L c_near[12], c_far[12];
-#pragma unroll
-          for (int k = kFirst; k < 12; k++) {   // both sources are read for every candidate, unconditionally (a per-lane branch around each read serialises them)
-            const uint32_t b = lb[k] <= ie ? lb[k] : ie;
-            const bool far = b >= kNear;
-            c_near[k] = (L)ring[(ie - b) & (kRing - 1)];
-            if constexpr (Cfg::kProps) c_far[k] = k < 6 ? (L)0 : f_use[k < 6 ? 0 : k - 6];
-            else c_far[k] = k < 6 ? (L)0 : pre[ie - (far ? b : 0u)];
+        for (int k = kFirst; k < 12; k++) {
+          const uint32_t b = lb[k] <= ie ? lb[k] : ie;
+          const uint32_t lz = lz_of(l, (k >= 6 && b >= kNear) ? c_far[k] : c_near[k]);
+          ql[k * 64 + lane] = (uint8_t)lz;
+          if constexpr (Cfg::kFastD) {   // the best of the six hashed proposals as the counts stand
+            const bool near_cnt = kCounts >= (1u << 15) || lb[k] - 1 < kCounts;
+            const uint32_t cnt = near_cnt ? (uint32_t)lcounts[near_cnt ? lb[k] - 1 : 0u] : cnt_far[k < 6 ? 0 : k - 6];
+            const uint32_t g = (32u - clz_u32(cnt)) + lz;
+            if (g > best_g) { best_g = g; best = lb[k]; }
           }
-          uint32_t best_g = 0, best = 0; bool far_count = false;
-#pragma unroll
-          for (int k = kFirst; k < 12; k++) {
-            const uint32_t b = lb[k] <= ie ? lb[k] : ie;
-            const uint32_t lz = lz_of(l, (k >= 6 && b >= kNear) ? c_far[k] : c_near[k]);
-            ql[k * 64 + lane] = (uint8_t)lz;
-            if constexpr (Cfg::kFastD) {   // the best of the six hashed proposals as the counts stand (counts beyond the LDS ones: the tile takes the full evaluation)
-              const bool near_cnt = kCounts >= (1u << 15) || lb[k] - 1 < kCounts;
-              far_count = far_count || !near_cnt;
-              const uint32_t g = (32u - clz_u32((uint32_t)lcounts[near_cnt ? lb[k] - 1 : 0u])) + lz;
-              if (g > best_g) { best_g = g; best = lb[k]; }
-            }
-          }
-          if constexpr (Cfg::kFastD) q_grp[(ts & 1u) * 128 + 64 + lane] = best_g | (best << 8) | ((act && far_count ? 1u : 0u) << 31);
         }
-      };
-      if (step & 1u) c_stage(far_a, far_b); else c_stage(far_b, far_a);
+        if constexpr (Cfg::kFastD) q_grp[(ts & 1u) * 128 + 64 + lane] = best_g | (best << 8);
+      }
     } else if (wave == kFront + 1) {
-      // ============================================================ D: the decisions of tile step - 2 - kLag
-      if (step >= 2 + kLag && step - 2 - kLag < n_tiles) {
-        const uint32_t ts = step - 2 - kLag, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
+      // ============================================================ D: the decisions of tile step - 2
+      if (step >= 2 && step - 2 < n_tiles) {
+        const uint32_t ts = step - 2, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
         const bool act = lane < tile_n;
         const uint32_t ie = i0 + lane;
-        const uint16_t PCO_LDS* qp = q_plb + (ts % kPlbBufs) * 6 * 64;
+        const uint16_t PCO_LDS* qp = q_plb + (ts % 3u) * 6 * 64;
         const uint8_t PCO_LDS* ql = q_lz + (ts & 1u) * 12 * 64;
         uint32_t my_lb = 1;   // lane e keeps the lookback chosen for element e of the tile
         auto count_of = [&](uint32_t lb) -> uint32_t {   // lookback_counts[lb - 1] as of now (far ones live in HBM; only this wave touches them)
@@ -388,6 +381,9 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
           //      ends the round: everything before it, and its own decision, were made on the true state; the state is brought up to
           //      date and the rest of the tile is decided again.  Exactly choose_lookbacks' sequence (lookback.rs:101-159). ----
           const uint32_t ie_s = act ? ie : i0;
+#ifdef PCO_LBP_TIMING
+          tm_x = __builtin_readcyclecounter();
+#endif
           const L l = (L)ring[ie_s & (kRing - 1)];
           // kFastD: an element's goodness is bitlen(count of the lookback) + leading zeros of the delta, and a count's bit length only moves
           // when it crosses a power of two -- a few hundred times per page on data with few distinct lookbacks.  The stages in front have
@@ -402,7 +398,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
             if (ts >= fast_from) {
               const uint32_t a = q_grp[(ts & 1u) * 128 + lane], c = q_grp[(ts & 1u) * 128 + 64 + lane];
               g_a = a & 255u; lb_a = a >> 8; g_c = c & 255u; lb_c = (c >> 8) & 0xffffu;
-              fast = !__any(act && (c >> 31) != 0);
+              fast = true;
             }
           }
           bool have_full = false;
@@ -430,9 +426,14 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
             }
           };
           if (!fast) load_full();
+          LBP_STAMP(0);
+#ifdef PCO_LBP_TIMING
+          if (fast) tm_d[3]++;
+#endif
           // the four repeating slots are the one part of the candidate set that depends on the previous tile's decisions
           uint32_t r_lz0 = act ? lz_of(l, latent_back(ie_s, ring_lb0 <= ie_s ? ring_lb0 : ie_s)) : 0u, r_lz1 = act ? lz_of(l, latent_back(ie_s, ring_lb1 <= ie_s ? ring_lb1 : ie_s)) : 0u;
           uint32_t r_lz2 = act ? lz_of(l, latent_back(ie_s, ring_lb2 <= ie_s ? ring_lb2 : ie_s)) : 0u, r_lz3 = act ? lz_of(l, latent_back(ie_s, ring_lb3 <= ie_s ? ring_lb3 : ie_s)) : 0u;
+          LBP_STAMP(1);   // (0: groups / full data loaded; 1: + the repeating slots' latents)
           uint32_t e_start = 0;
           bool crossed = false;   // a count's bit length changed in this tile
           auto add_count = [&](uint32_t lb, uint32_t k) -> uint32_t {   // count `lb` += k for everything that mirrors it; returns the new count
@@ -498,15 +499,16 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
             if (e_start >= tile_n) break;
           }
           lb_sync();
+          LBP_STAMP(2);   // the rounds
           if (crossed) fast_from = ts + 2;
         }
         q_lb[(ts & 1u) * 64 + lane] = my_lb;
         d_rounds = 0;
       }
     } else {
-      // ============================================================ A: lookback.rs:166-185 on tile step - 3 - kLag
-      if (step >= 3 + kLag && step - 3 - kLag < n_tiles) {
-        const uint32_t ts = step - 3 - kLag, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
+      // ============================================================ A: lookback.rs:166-185 on tile step - 3
+      if (step >= 3 && step - 3 < n_tiles) {
+        const uint32_t ts = step - 3, i0 = state_n + 64 * ts, tile_n = n - i0 < 64 ? n - i0 : 64;
         const bool act = lane < tile_n;
         const uint32_t ie = i0 + lane;
         const uint32_t my_lb = q_lb[(ts & 1u) * 64 + lane];
@@ -521,14 +523,18 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
     }
 #ifdef PCO_LBP_TIMING
     tm_acc += __builtin_readcyclecounter() - tm0;
+    const unsigned long long tm_b0 = __builtin_readcyclecounter();
 #endif
     // step barrier: what the stages hand over lives in LDS, so only the LDS queue has to drain -- the global loads a stage sent ahead
     // (next tile's latents and table entries, far latents) and its stores stay in flight across it (__syncthreads would wait for them all)
     __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef PCO_LBP_TIMING
+    tm_bar += __builtin_readcyclecounter() - tm_b0;
+#endif
     if (uni(*abort_flag)) return true;   // (every wave sees the flag after the same barrier; nothing global but the page's own slices was written)
   }
 #ifdef PCO_LBP_TIMING
-  if (lane == 0) { atomicAdd(&g_lbp_timing[wave + 2 - kFront], tm_acc); if (wave == kFront + 1) { atomicAdd(&g_lbp_timing[5], tm_rounds); atomicAdd(&g_lbp_timing[6], (unsigned long long)n_tiles); atomicAdd(&g_lbp_timing[7], 1ull); } }
+  if (lane == 0) { atomicAdd(&g_lbp_timing[wave + 2 - kFront], tm_acc); if (wave == kFront + 1) { atomicAdd(&g_lbp_timing[5], tm_rounds); atomicAdd(&g_lbp_timing[6], (unsigned long long)n_tiles); atomicAdd(&g_lbp_timing[7], 1ull); atomicAdd(&g_lbp_timing[8], tm_d[0]); atomicAdd(&g_lbp_timing[9], tm_d[1]); atomicAdd(&g_lbp_timing[10], tm_d[2]); atomicAdd(&g_lbp_timing[11], tm_bar); atomicAdd(&g_lbp_timing[13], tm_d[3]); } if (wave == kFront) atomicAdd(&g_lbp_timing[12], tm_bar); }
 #endif
   if (wave == kFront + 2) {
     for (int dlt = 32; dlt >= 1; dlt >>= 1) {
@@ -549,7 +555,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
 // slot takes pages blockIdx.x, blockIdx.x + gridDim.x, ... of the lookback pages (page_ids lists them).  redo[k] = 1: lookback page k
 // was handed back to enc_lookback_kernel.
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::kThreads, Cfg::kProps ? Cfg::kPagesPerCu : 1) void enc_lookback_pipe_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32, uint32_t* redo,
+__global__ __launch_bounds__(Cfg::kThreads, Cfg::kProps ? 4 : 1) void enc_lookback_pipe_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32, uint32_t* redo,
                                                                           const uint16_t* props = nullptr, uint64_t prop_stride = 0, uint32_t role_rotate = 0) {
   uint32_t PCO_GLOBAL* base = (uint32_t PCO_GLOBAL*)lb_scratch + (uint64_t)blockIdx.x * scratch_stride_u32;
   for (uint32_t k = blockIdx.x; k < n_lb_pages; k += gridDim.x) {

@@ -24,6 +24,7 @@ def run(tag, arrays, kw):
     lbk = {k: round(t, 3) for k, t in kt.items() if "lookback" in k}
     print(tag, "pages", v[7], "tiles/page", round(v[6] / max(v[7], 1), 1), "rounds/tile", round(v[5] / tiles, 2), lbk)
     for k in range(5): print(f"   {names[k]:24s} {v[k] / tiles:10.0f} busy cycles per step")
+    print(f"   D: load {v[8] / tiles:.0f}, slots {v[9] / tiles:.0f}, rounds {v[10] / tiles:.0f}; barrier wait D {v[11] / tiles:.0f}, C {v[12] / tiles:.0f}; fast tiles {v[13] / tiles:.3f}")
 rng = np.random.default_rng(1)
 run("i64 seasonal x64", [U.synth("c4", seed=s) for s in range(64)], dict(mode=1, delta=3))
 run("i64 seasonal x1024", [U.synth("c4", seed=s) for s in range(1024)], dict(mode=1, delta=3))
