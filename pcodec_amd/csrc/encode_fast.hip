@@ -1075,6 +1075,49 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
     }
   }
   enc_wave_sync();
+  // One bin whose offsets are the latent's full width, nothing else to write (uniform random numbers -- BASELINE configs[0] --, the deltas of
+  // anything without structure): the page's body is the latents minus the bin's lower bound, byte for byte (chunk_latent_compressor.rs:272-329:
+  // no tANS fields, a batch is 256 whole offsets and ends on a byte).  A shifted copy: 16 bytes per lane and step from the full-width
+  // latents to wherever the run starts -- through the bit sink it ran at 2.6 TB/s of its own traffic (13.3 ms per 8192 chunks of configs[0]).
+  if (on[1] && !on[0] && !on[2] && pv[1].n_bins == 1 && !pv[1].needs_ans && pv[1].max_ob == LB && !pv[1].compact) {
+    const uint64_t body_bit = sink.outbit + sink.pend;   // (a whole byte: behind finish_byte, or a run start behind whole batches)
+    sink.close();
+    constexpr uint32_t kPer = 16 / sizeof(L);            // latents per lane and step
+    typedef L lvec __attribute__((ext_vector_type(kPer)));
+    typedef lvec __attribute__((aligned(1))) lvec_unaligned;
+    const L low0 = (L)plan_ref(ws, t, 1).blower()[0];
+    const uint32_t first = run * kRunBatches * kBatchN;
+    const uint32_t n_run = pv[1].n_lat - first < kRunBatches * kBatchN ? pv[1].n_lat - first : kRunBatches * kBatchN;
+    const L PCO_GLOBAL* src = lat_ptr<L>(ws, t, 1) + pstart + pv[1].skip + first;
+    uint8_t PCO_GLOBAL* out8 = (uint8_t PCO_GLOBAL*)pg->dst + (body_bit >> 3);
+    // (four steps' loads in flight before the first store: a step at a time the wave waited out a memory round trip per kilobyte)
+    uint32_t i = lane * kPer;
+    for (; i + 3 * 64 * kPer + kPer <= n_run; i += 4 * 64 * kPer) {
+      lvec v[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++)
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) v[u][k] = src[i + u * 64 * kPer + k];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) v[u][k] = (L)(v[u][k] - low0);
+        *(lvec_unaligned PCO_GLOBAL*)(out8 + (uint64_t)(i + u * 64 * kPer) * sizeof(L)) = v[u];
+      }
+    }
+    for (; i < n_run; i += 64 * kPer) {
+      if (i + kPer <= n_run) {
+        lvec v;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) v[k] = (L)(src[i + k] - low0);
+        *(lvec_unaligned PCO_GLOBAL*)(out8 + (uint64_t)i * sizeof(L)) = v;
+      } else {
+        typedef L __attribute__((aligned(1))) l_unaligned;
+        for (uint32_t k = 0; i + k < n_run; k++) *(l_unaligned PCO_GLOBAL*)(out8 + (uint64_t)(i + k) * sizeof(L)) = (L)(src[i + k] - low0);
+      }
+    }
+    return;
+  }
   // batches of the run; the next batch's loads are issued before the current one is packed
   PackItem cur[3], nxt[3];
   auto load_batch = [&](uint32_t bb, PackItem (&dstv)[3]) {
