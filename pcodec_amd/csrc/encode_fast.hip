@@ -1095,9 +1095,7 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
     for (; i + 3 * 64 * kPer + kPer <= n_run; i += 4 * 64 * kPer) {
       lvec v[4];
 #pragma unroll
-      for (uint32_t u = 0; u < 4; u++)
-#pragma unroll
-        for (uint32_t k = 0; k < kPer; k++) v[u][k] = src[i + u * 64 * kPer + k];
+      for (uint32_t u = 0; u < 4; u++) v[u] = *(const lvec_unaligned PCO_GLOBAL*)(src + i + u * 64 * kPer);   // (one 16-byte request per lane, whatever the page's first position)
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
 #pragma unroll

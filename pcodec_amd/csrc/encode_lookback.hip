@@ -137,6 +137,7 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
       h_val[2] = a ? (uint32_t)__hip_atomic_load(&hash_tbl[s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
   }
+  if constexpr (Cfg::kProps) { if (wave == kFront + 1) __builtin_amdgcn_s_setprio(3); else if (wave == kFront) __builtin_amdgcn_s_setprio(1); }   // stage D's chain sets the step: it issues first wherever it shares a SIMD
   uint32_t next_sweep = kLbSweepPeriod;   // (H waves)
   uint32_t d_rounds = 0;                  // (D wave) rounds over the page's first tiles
   uint32_t fast_from = kLbSeqTiles + 1;   // (D wave, kFastD) the first tile that may take the ready-made group maxima: two tiles behind the last count that crossed a power of two
@@ -626,7 +627,16 @@ __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
   auto queue = [&](uint32_t parity, uint32_t w) { return (uint32_t PCO_LDS*)(smem + kLhOffQueue + (parity * kLhWorkers + w) * kLhQTile); };
   uint64_t lv_next = wave < kLhWorkers ? tile_latent(wave) : 0ull;
   uint32_t next_sweep = kLbSweepPeriod;
+  // The sequencer's 500 instructions per step are the block's critical path, and it shares its SIMD with three workers: at equal priority it got
+  // a quarter of the issue slots (7.0 k busy cycles per step against the workers' 3.8 k)
+  if (wave == kLhWorkers) __builtin_amdgcn_s_setprio(3);
+#ifdef PCO_LBP_TIMING
+  unsigned long long th_busy = 0;
+#endif
   for (uint32_t step = 0; step < n_steps; step++) {
+#ifdef PCO_LBP_TIMING
+    const unsigned long long th0 = __builtin_readcyclecounter();
+#endif
     // ---- the sweep, by everybody, when the sequencer's next tile has passed the mark (it keeps every age below 2^16; when exactly it
     //      happens changes no proposal: an entry it rewrites is stale before and after) ----
     const uint32_t p2 = state_n + 64 * (step > 0 ? (step - 1) * kLhWorkers : 0u);   // position of the sequencer's first tile of this step
@@ -652,11 +662,12 @@ __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
         if (tile < n_tiles) {
           const uint32_t PCO_LDS* q = queue(step & 1u, wave);
           const uint32_t i0 = state_n + 64 * tile, ie = i0 + lane;
-          const uint32_t e01 = q[lane], e2 = q[64 + lane];
+          const uint32_t e01 = q[lane], e2 = q[64 + lane], hz = q[128 + lane], fl = e2 >> 16;
           if (lane < n - i0) {
 #pragma unroll
             for (uint32_t r = 0; r < 3; r++) {
-              const uint32_t val = r == 0 ? (e01 & 0xffffu) : (r == 1 ? (e01 >> 16) : (e2 & 0xffffu));
+              uint32_t val = r == 0 ? (e01 & 0xffffu) : (r == 1 ? (e01 >> 16) : (e2 & 0xffffu));
+              if ((fl >> r) & 1u) val = (i0 + ((hz >> (6 * r)) & 63u)) & 0xffffu;   // an earlier lane of this tile had written the slot: its position, not the table's entry
               const uint32_t lb = (ie - val) & 0xffffu;   // the entry's age (no entry is ever 2^16 positions old: the sweep)
               const uint32_t pidx = 10 + 3 * c + r;
               const uint32_t plb = lb <= window_n ? lb : (pidx < ie ? pidx : ie);   // lookback.rs:50-54
@@ -730,35 +741,32 @@ __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
           const bool valid = tile0 + w < n_tiles;   // (uniform)
           d0[w] = valid ? q[lane] : 0u; d1[w] = valid ? q[64 + lane] : 0u;
         }
-        bool hits = false;
 #pragma unroll
         for (uint32_t w = 0; w < kLhChunk; w++) {
           const uint32_t s0 = d0[w] & 0xffffu, s1 = d0[w] >> 16, s2 = d1[w] & 0xffffu, fl = d1[w] >> 16;
           v0[w] = tbl[s0]; v1[w] = tbl[s1]; v2[w] = tbl[s2];
           if ((fl & (kLhAct | kLhShadowed)) == kLhAct) tbl[s1] = (uint16_t)(state_n + 64 * (tile0 + w) + lane);
-          hits = hits || (fl & kLhHas) != 0;
         }
-        if (__any(hits)) {   // (rare: an earlier lane of the same tile had written the slot)
-#pragma unroll
-          for (uint32_t w = 0; w < kLhChunk; w++) {
-            const uint32_t fl = d1[w] >> 16, i0 = state_n + 64 * (tile0 + w);
-            const uint32_t hz = (fl & kLhHas) ? queue((step - 1) & 1u, chunk * kLhChunk + w)[128 + lane] : 0u;
-            if (fl & 1u) v0[w] = (i0 + (hz & 63u)) & 0xffffu;
-            if (fl & 2u) v1[w] = (i0 + ((hz >> 6) & 63u)) & 0xffffu;
-            if (fl & 4u) v2[w] = (i0 + ((hz >> 12) & 63u)) & 0xffffu;
-          }
-        }
+        // (the entries as read; the in-tile hits are put in their place by the worker that stores the proposals -- every instruction taken off
+        //  this wave is taken off the block's critical path)
 #pragma unroll
         for (uint32_t w = 0; w < kLhChunk; w++) {
           if (tile0 + w < n_tiles) {
             uint32_t PCO_LDS* q = queue((step - 1) & 1u, chunk * kLhChunk + w);
-            q[lane] = v0[w] | (v1[w] << 16); q[64 + lane] = v2[w];
+            q[lane] = v0[w] | (v1[w] << 16); q[64 + lane] = v2[w] | (d1[w] & 0xffff0000u);
           }
         }
       }
     }
+#ifdef PCO_LBP_TIMING
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    th_busy += __builtin_readcyclecounter() - th0;
+#endif
     __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+#ifdef PCO_LBP_TIMING
+  if (lane == 0 && (wave == 0 || wave == kLhWorkers)) { atomicAdd(&g_lbp_timing[wave == 0 ? 14 : 15], th_busy); if (wave == 0) atomicAdd(&g_lbp_timing[0], (unsigned long long)n_steps); }
+#endif
 }
 
 // grid = 2 x the lookback pages (item = 2 k + table), one block per CU (the table)

@@ -25,6 +25,7 @@ def run(tag, arrays, kw):
     print(tag, "pages", v[7], "tiles/page", round(v[6] / max(v[7], 1), 1), "rounds/tile", round(v[5] / tiles, 2), lbk)
     for k in range(5): print(f"   {names[k]:24s} {v[k] / tiles:10.0f} busy cycles per step")
     print(f"   D: load {v[8] / tiles:.0f}, slots {v[9] / tiles:.0f}, rounds {v[10] / tiles:.0f}; barrier wait D {v[11] / tiles:.0f}, C {v[12] / tiles:.0f}; fast tiles {v[13] / tiles:.3f}")
+    print(f"   hash pre-pass (per 15-tile step): worker 0 busy {v[14] / max(v[0], 1):.0f}, sequencer busy {v[15] / max(v[0], 1):.0f} cycles")
 rng = np.random.default_rng(1)
 run("i64 seasonal x64", [U.synth("c4", seed=s) for s in range(64)], dict(mode=1, delta=3))
 run("i64 seasonal x1024", [U.synth("c4", seed=s) for s in range(1024)], dict(mode=1, delta=3))
