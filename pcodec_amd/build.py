@@ -8,7 +8,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpco_gfx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
-         "-Wno-unused-result"]
+         "-Wno-unused-result",
+         "-Wno-pass-failed"]   # (hipcc refuses a few `#pragma unroll` requests inside the lookback and select kernels' data-dependent loops: measured kernels, the warnings say nothing new)
 
 
 def sources():

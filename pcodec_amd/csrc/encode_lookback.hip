@@ -557,11 +557,12 @@ __device__ bool lookback_page_pipe(const EncWorkspace& ws, uint32_t t, EncPage P
 // was handed back to enc_lookback_kernel.
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::kThreads, Cfg::kProps ? 4 : 1) void enc_lookback_pipe_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint32_t* lb_scratch, uint64_t scratch_stride_u32, uint32_t* redo,
-                                                                          const uint16_t* props = nullptr, uint64_t prop_stride = 0, uint32_t role_rotate = 0) {
+                                                                          const uint16_t* props = nullptr, uint64_t prop_stride = 0, uint32_t role_rotate = 0, const uint32_t* skip = nullptr) {
   uint32_t PCO_GLOBAL* base = (uint32_t PCO_GLOBAL*)lb_scratch + (uint64_t)blockIdx.x * scratch_stride_u32;
   for (uint32_t k = blockIdx.x; k < n_lb_pages; k += gridDim.x) {
     const uint32_t p = page_ids[k];
     EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+    if (skip != nullptr && uni(skip[k]) != 0) { if (threadIdx.x == 0) redo[k] = 1; continue; }   // (the pre-pass's screen: a page of the one-wave kernel)
     if (threadIdx.x == 0) redo[k] = 0;
     if (uni(pg->flags) & kPageFlagMetaOnly) continue;
     const uint32_t t = uni(pg->chunk);
@@ -604,27 +605,45 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kProps ? 4 : 1) void enc_lookba
 constexpr uint32_t kLhWorkers = 15, kLhWaves = kLhWorkers + 1, kLhThreads = 64 * kLhWaves, kLhChunk = 5;   // (the sequencer takes the step's tiles five at a time)
 static_assert(kLhWorkers % kLhChunk == 0, "whole chunks");
 constexpr uint32_t kLhQTile = 3 * 64 * 4;                               // per lane: slot0 | slot1 << 16, slot2 | flags << 16, the in-tile hits -- S2 leaves entry0 | entry1 << 16, entry2 in the first two
-constexpr uint32_t kLhOffQueue = 2u << 16;                               // behind the largest table (u16[2 << 15])
-constexpr uint32_t kLhLdsBytes = kLhOffQueue + 2 * kLhWorkers * kLhQTile;   // 154 112 B: one block per CU
+// LDS: the table, u16[2 << window_n_log] (128 KB for a full page: one block per CU; 32 KB for the Auto-delta trial samples: two), then the queue
+__host__ __device__ constexpr uint32_t lh_queue_off(uint32_t wlog_max) { return 4u << wlog_max; }
+__host__ __device__ constexpr uint32_t lh_lds_bytes(uint32_t wlog_max) { return lh_queue_off(wlog_max) + 2 * kLhWorkers * kLhQTile; }   // 154 112 B at window_n_log 15
 constexpr uint32_t kLhHas = 7u, kLhShadowed = 8u, kLhAct = 16u;          // flags: has[r] = 1 << r
 
 template <class L>
-__device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const EncPage PCO_GLOBAL* pg, uint32_t c, uint16_t PCO_GLOBAL* props, uint64_t prop_stride) {
+__device__ bool lookback_hash_page(const EncWorkspace& ws, uint32_t t, const EncPage PCO_GLOBAL* pg, uint32_t c, uint16_t PCO_GLOBAL* props, uint64_t prop_stride, uint32_t queue_off) {   // -> the page goes to the one-wave kernel instead
   const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = uni(tid >> 6);
   const uint32_t wlog = uni(ch->window_n_log), state_n = 1u << uni(ch->state_n_log);
   const uint32_t window_n = 1u << wlog, hash_table_n = 2u << wlog, hash_mask = hash_table_n - 1;
   const uint32_t n = (uint32_t)uni((uint64_t)pg->n); const uint64_t pstart = uni((uint64_t)pg->start);
-  if (n <= state_n) return;
+  if (n <= state_n) return false;
   const L PCO_GLOBAL* pre = sort_ptr<L>(ws, t, 0) + pstart;
   uint8_t PCO_LDS* smem = enc_lds_base();
   uint16_t PCO_LDS* tbl = (uint16_t PCO_LDS*)smem;
+  if (n <= kLbPipeSmallMaxPage) {
+    // A screen for the Auto-delta trial samples: latents that span fewer than 4 n values (the float-mult multiples of decimal data: small random
+    // integers) repeat exactly at ever-changing distances, nearly every element picks a lookback nobody picked before, and stage D's speculation
+    // fails every round (49 rounds a tile): those pages are the one-wave kernel's from the start -- sixteen of them per CU -- instead of being
+    // handed back after a pre-pass and sixteen tiles of pipeline (3.5 ms per 8192 pages, for nothing).  Which kernel takes a page changes no byte.
+    typedef typename std::conditional<sizeof(L) == 8, uint64_t, uint32_t>::type W;
+    W mn = (W)(L)~(L)0, mx = 0;
+    for (uint32_t i = tid; i < n; i += kLhThreads) { const W x = (W)pre[i]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
+    mn = wave_butterfly(mn, [](W a, W b) { return a < b ? a : b; }); mx = wave_butterfly(mx, [](W a, W b) { return a > b ? a : b; });
+    uint64_t PCO_LDS* red = (uint64_t PCO_LDS*)smem;
+    if (lane == 0) { red[2 * wave] = (uint64_t)mn; red[2 * wave + 1] = (uint64_t)mx; }
+    __syncthreads();
+    uint64_t lo = ~0ull, hi = 0;
+    for (uint32_t w = 0; w < kLhWaves; w++) { const uint64_t a = red[2 * w], b = red[2 * w + 1]; lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    __syncthreads();
+    if (hi - lo < 4ull * n) return true;
+  }
   for (uint32_t i = tid; i < hash_table_n / 4; i += kLhThreads) ((uint64_t PCO_LDS*)tbl)[i] = 0ull;
   __syncthreads();
   const uint32_t n_tiles = (n - state_n + 63) / 64, n_steps = (n_tiles + kLhWorkers - 1) / kLhWorkers + 2;
   auto hash_fn = [&](uint64_t x) { x = (x ^ (x >> 32)) * 11400714819323197441ull; x = x ^ (x >> 32); return (uint32_t)x & hash_mask; };
   auto tile_latent = [&](uint32_t tile) { const uint32_t i0t = state_n + 64 * tile; return tile < n_tiles && lane < n - i0t ? (uint64_t)pre[i0t + lane] : 0ull; };
-  auto queue = [&](uint32_t parity, uint32_t w) { return (uint32_t PCO_LDS*)(smem + kLhOffQueue + (parity * kLhWorkers + w) * kLhQTile); };
+  auto queue = [&](uint32_t parity, uint32_t w) { return (uint32_t PCO_LDS*)(smem + queue_off + (parity * kLhWorkers + w) * kLhQTile); };
   uint64_t lv_next = wave < kLhWorkers ? tile_latent(wave) : 0ull;
   uint32_t next_sweep = kLbSweepPeriod;
   // The sequencer's 500 instructions per step are the block's critical path, and it shares its SIMD with three workers: at equal priority it got
@@ -767,23 +786,28 @@ __device__ void lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
 #ifdef PCO_LBP_TIMING
   if (lane == 0 && (wave == 0 || wave == kLhWorkers)) { atomicAdd(&g_lbp_timing[wave == 0 ? 14 : 15], th_busy); if (wave == 0) atomicAdd(&g_lbp_timing[0], (unsigned long long)n_steps); }
 #endif
+  return false;
 }
 
 // grid = 2 x the lookback pages (item = 2 k + table), one block per CU (the table)
-__global__ __launch_bounds__(kLhThreads) void enc_lookback_hash_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint16_t* props, uint64_t prop_stride) {
+__global__ __launch_bounds__(kLhThreads) void enc_lookback_hash_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint16_t* props, uint64_t prop_stride, uint32_t queue_off /* lh_queue_off(the call's largest window_n_log) */,
+                                                                     uint32_t* skip /* [page]: 1 = left to the one-wave kernel (see the screen in lookback_hash_page) */) {
   const uint32_t k = blockIdx.x >> 1, c = blockIdx.x & 1u;
   if (k >= n_lb_pages) return;
+  if (c == 0 && threadIdx.x == 0) skip[k] = 0u;   // (rewritten below for the pages the screen takes out)
   const EncPage PCO_GLOBAL* pg = (const EncPage PCO_GLOBAL*)ws.pages + page_ids[k];
   if (uni(pg->flags) & kPageFlagMetaOnly) return;
   const uint32_t t = uni(pg->chunk);
   const EncChunk PCO_GLOBAL* ch = (const EncChunk PCO_GLOBAL*)ws.chunks + t;
-  if (uni(ch->status) != PCO_GFX_OK || uni(ch->delta_kind) != kDeltaLookback) return;
+  if (uni(ch->status) != PCO_GFX_OK || uni(ch->delta_kind) != kDeltaLookback || (4u << uni(ch->window_n_log)) > queue_off) return;
   uint16_t PCO_GLOBAL* pk = (uint16_t PCO_GLOBAL*)props + (uint64_t)k * 6 * prop_stride;
   const int bits = dtype_bits(uni(ch->dtype));
-  if (bits == 64) lookback_hash_page<uint64_t>(ws, t, pg, c, pk, prop_stride);
-  else if (bits == 32) lookback_hash_page<uint32_t>(ws, t, pg, c, pk, prop_stride);
-  else if (bits == 16) lookback_hash_page<uint16_t>(ws, t, pg, c, pk, prop_stride);
-  else lookback_hash_page<uint8_t>(ws, t, pg, c, pk, prop_stride);
+  bool skipped;
+  if (bits == 64) skipped = lookback_hash_page<uint64_t>(ws, t, pg, c, pk, prop_stride, queue_off);
+  else if (bits == 32) skipped = lookback_hash_page<uint32_t>(ws, t, pg, c, pk, prop_stride, queue_off);
+  else if (bits == 16) skipped = lookback_hash_page<uint16_t>(ws, t, pg, c, pk, prop_stride, queue_off);
+  else skipped = lookback_hash_page<uint8_t>(ws, t, pg, c, pk, prop_stride, queue_off);
+  if (c == 0 && threadIdx.x == 0) skip[k] = skipped ? 1u : 0u;
 }
 
 }  // namespace pcogfx
