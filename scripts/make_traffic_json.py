@@ -17,7 +17,7 @@ from bench import csrc_sha16  # noqa: E402  (the table is only quoted by bench.p
 
 d, chunks, workload, out_json, out_txt = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
 # kernels whose fetches are dominated by scattered 2- / 4-byte table probes: FETCH_SIZE is quoted raw for them
-NARROW = ("enc_lookback_pipe_kernel", "enc_lookback_kernel")
+NARROW = ("enc_lookback_pipe_kernel", "enc_lookback_kernel")   # (the round-5 pipeline reads streams, but the counter reading of its scattered far-candidate reads is kept raw: the smaller, safer figure)
 TY = {"unsigned long": "u64", "unsigned int": "u32", "unsigned short": "u16", "unsigned char": "u8"}
 
 
@@ -52,8 +52,12 @@ def label(name):
         return f"pco_decode_kernel<{ty(m.group(1))}>"
     if name.startswith("enc_walk_kernel"):
         return "enc_walk16_kernel" if name.startswith("enc_walk_kernel<16") else "enc_walk_kernel"
-    if name.startswith("enc_lookback_pipe_kernel"):
-        return "enc_lookback_pipe_kernel<small>" if name.startswith("enc_lookback_pipe_kernel<LbPipe<t") else "enc_lookback_pipe_kernel"
+    if name.startswith("enc_lookback_pipe_kernel"):   # LbPipe<kSmall, kProps, kFastD[, pages]>: the launch-timer labels of pco_gfx_encode_api.inc
+        m = re.match(r"enc_lookback_pipe_kernel<LbPipe<(t|f)\w*(, (t|f)\w*)?(, (t|f)\w*)?", name)
+        small = bool(m) and m.group(1) == "t"; props = bool(m) and m.group(3) == "t"; fastd = bool(m) and m.group(5) == "t"
+        if props:
+            return "enc_lookback_pipe_kernel<" + ("small," if small else "") + "props" + (",fastd" if fastd else "") + ">"
+        return "enc_lookback_pipe_kernel<small>" if small else "enc_lookback_pipe_kernel"
     if name.startswith("enc_lookback_kernel"):
         return "enc_lookback_kernel<small>" if name.startswith("enc_lookback_kernel<LbCfg<256") else "enc_lookback_kernel"
     if name.startswith("enc_split_kernel"):

@@ -9,7 +9,7 @@ for name, ctr, val, disp, d, gx, wx in cur.execute("select kernel_name, counter_
     if disp not in cnt[short]: dur[short] += d
     cnt[short].add(disp); grid[short] = (gx, wx)
 ctrs = sorted({c for k in acc for c in acc[k]})
-print("kernel".ljust(34), "calls", "avg_us".rjust(9), " ".join(c.replace("SQ_", "").rjust(14) for c in ctrs))
+print("kernel".ljust(60), "calls", "avg_us".rjust(9), " ".join(c.replace("SQ_", "").rjust(14) for c in ctrs))
 for k in sorted(acc, key=lambda k: -dur[k]):
     n = len(cnt[k])
-    print(k[:34].ljust(34), str(n).rjust(5), f"{dur[k] / n / 1e3:9.1f}", " ".join(f"{acc[k][c] / n:14.4g}" for c in ctrs), grid[k])
+    print(k[:60].ljust(60), str(n).rjust(5), f"{dur[k] / n / 1e3:9.1f}", " ".join(f"{acc[k][c] / n:14.4g}" for c in ctrs), grid[k])

@@ -188,3 +188,27 @@ def test_chunk_meta_accessor_reads_what_the_oracle_wrote():
         for cut in (0, 1, len(meta) // 2, len(meta) - 1):
             assert L.pco_gfx_chunk_meta_info(mb.ctypes.data_as(C.c_void_p), C.c_size_t(cut), C.c_ubyte(G.DTYPE_BYTE[nums.dtype.name]), C.c_uint8(4), C.byref(got)) != 0
             assert L.pco_gfx_last_status() == G.ST_INSUFFICIENT_DATA, (kw, cut)
+
+
+def test_chunk_meta_accessor_rejects_what_the_reference_rejects():
+    """metadata/delta_encoding.rs:143-176: a Consecutive order of 0, a lookback window log beyond MAX_DELTA_LOOKBACK_WINDOW_N_LOG (24) and a
+    state log beyond the window log are Corruption in ChunkMeta::read_from -- and here (round 4 returned PcoSuccess for all three)."""
+    import ctypes as C
+    from pcodec_amd import _lib as G
+    L = G.lib()
+    out = (C.c_uint8 * 256)()
+
+    def bits(fields):   # little-endian bit stream
+        v = 0; n = 0
+        for val, w in fields:
+            v |= (val & ((1 << w) - 1)) << n; n += w
+        return np.frombuffer(int(v).to_bytes((n + 7) // 8 + 16, "little"), np.uint8).copy()
+    cases = {"order 0": [(0, 4), (1, 4), (0, 3), (0, 1)],
+             "window 25": [(0, 4), (2, 4), (24, 5), (0, 4), (0, 1)],
+             "state beyond window": [(0, 4), (2, 4), (3, 5), (9, 4), (0, 1)]}
+    for name, f in cases.items():
+        b = bits(f)
+        assert L.pco_gfx_chunk_meta_info(b.ctypes.data_as(C.c_void_p), C.c_size_t(len(b)), C.c_ubyte(1), C.c_uint8(4), C.byref(out)) != 0, name
+        assert L.pco_gfx_last_status() == G.ST_CORRUPTION, name
+    ok = bits([(0, 4), (2, 4), (23, 5), (4, 4), (0, 1), (7, 4), (0, 15), (8, 4), (0, 15)])   # window 24, state 4: the largest the reference accepts
+    assert L.pco_gfx_chunk_meta_info(ok.ctypes.data_as(C.c_void_p), C.c_size_t(len(ok)), C.c_ubyte(1), C.c_uint8(4), C.byref(out)) == 0
