@@ -74,12 +74,13 @@ template <class L> __device__ __forceinline__ void lit_min_max(const L PCO_GLOBA
   b = wave_butterfly(b, [](W x, W y) { return x > y ? x : y; });
   mn = (L)lit_uni(a); mx = (L)lit_uni(b);
 }
-template <class L>
-__device__ __forceinline__ void lit_apply_incomplete(LitBuilder<L>& hb, const L PCO_GLOBAL* v, uint32_t len, bool lower_tight, L lower, bool upper_tight, L upper) {   // :82-106
+// (K: the type of the keys in the scratch copy -- the latents themselves, or 16-bit latents relative to `ref`; bounds and bins are latents)
+template <class K, class L>
+__device__ __forceinline__ void lit_apply_incomplete(LitBuilder<L>& hb, const K PCO_GLOBAL* v, L ref, uint32_t len, bool lower_tight, L lower, bool upper_tight, L upper) {   // :82-106
   if (len == 0) return;
   L mn = lower, mx = upper;
   const bool need_min = !hb.has_inc && !lower_tight, need_max = !upper_tight;
-  if (need_min || need_max) { L a, b; lit_min_max<L>(v, len, a, b); if (need_min) mn = a; if (need_max) mx = b; }
+  if (need_min || need_max) { K a, b; lit_min_max<K>(v, len, a, b); if (need_min) mn = (L)(ref + (L)a); if (need_max) mx = (L)(ref + (L)b); }
   if (hb.has_inc) { hb.inc_upper = mx; hb.inc_count += len; }
   else { hb.inc_lower = mn; hb.inc_upper = mx; hb.inc_count = len; hb.has_inc = true; }
   hb.n_applied += len;
@@ -89,7 +90,7 @@ __device__ __forceinline__ void lit_apply_constant_run(LitBuilder<L>& hb, uint32
   const uint32_t start = hb.n_applied, mid = start + len / 2, end = start + len;
   uint32_t b = hb.bin_idx(mid);
   if (b > hb.next_avail) { const uint32_t spare = b - 1; if (!hb.complete_bin(spare)) b = spare; }
-  lit_apply_incomplete<L>(hb, nullptr, len, true, value, true, value);
+  lit_apply_incomplete<L, L>(hb, nullptr, (L)0, len, true, value, true, value);
   if (end >= hb.c_count(b)) hb.complete_bin(b);
 }
 
@@ -211,28 +212,32 @@ template <class L> __device__ void lit_sort(L PCO_GLOBAL* v, L PCO_GLOBAL* tmp, 
 }
 
 // histograms.rs:164-206 on a sorted node; the scans over equal values are binary searches
-template <class L> __device__ void lit_apply_sorted(LitBuilder<L>& hb, const L PCO_GLOBAL* v, uint32_t len) {
+template <class K, class L> __device__ void lit_apply_sorted(LitBuilder<L>& hb, const K PCO_GLOBAL* v, L ref, uint32_t len) {
+  auto at = [&](uint32_t i) -> L { return (L)(ref + (L)lit_uni<K>(v[i])); };
   while (len > 0) {
     const uint32_t target = hb.bin_idx(hb.n_applied), target_c = hb.c_count(target), target_i = target_c - hb.n_applied;
     if (target_i >= len) {
-      lit_apply_incomplete<L>(hb, v, len, true, lit_uni<L>(v[0]), true, lit_uni<L>(v[len - 1]));
+      lit_apply_incomplete<K, L>(hb, v, ref, len, true, at(0), true, at(len - 1));
       if (target_i == len) hb.complete_bin(target);
       break;
     }
-    const L x = lit_uni<L>(v[target_i - 1]);
+    const L x = at(target_i - 1);
     uint32_t lo = 0, hi = target_i - 1;   // first index holding x: v[hi] == x
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lit_uni<L>(v[mid]) < x) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (at(mid) < x) lo = mid + 1; else hi = mid; }
     const uint32_t l = lo;
     lo = target_i; hi = len;              // first index >= target_i holding something else
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lit_uni<L>(v[mid]) == x) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (at(mid) == x) lo = mid + 1; else hi = mid; }
     const uint32_t r = lo;
-    if (l > 0) lit_apply_incomplete<L>(hb, v, l, true, lit_uni<L>(v[0]), true, lit_uni<L>(v[l - 1]));
+    if (l > 0) lit_apply_incomplete<K, L>(hb, v, ref, l, true, at(0), true, at(l - 1));
     lit_apply_constant_run<L>(hb, r - l, x);
     v += r; len -= r;
   }
 }
 
-template <class L>
+// K = uint16_t: the chunk's speculative 16-bit latents are the keys (latent = c16_ref + key; the order is the latents' order), a quarter of the
+// bytes a pass moves for 64-bit latents.  Everything the reference compares with a BOUND stays in latent space -- its root bounds are the latent
+// type's 0 and MAX, and `tentative > lower bound` decides which side of the pivot is tight -- so pivots go key -> latent -> key.
+template <class K, class L>
 __device__ void lit_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log, uint32_t PCO_GLOBAL* fell_back) {
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   EncVar PCO_GLOBAL* ev = &ch->v[var];
@@ -242,13 +247,15 @@ __device__ void lit_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32
   uint8_t PCO_LDS* smem = enc_lds_base();
   uint32_t PCO_LDS* stk32 = (uint32_t PCO_LDS*)(smem + kLitLdsStack);
   uint32_t PCO_LDS* cnt = (uint32_t PCO_LDS*)(smem + kLitLdsCnt);
-  L PCO_GLOBAL* A = sort_ptr<L>(ws, t, 0);
-  L PCO_GLOBAL* T = sort_ptr<L>(ws, t, 1);
+  K PCO_GLOBAL* A = sort_ptr<K>(ws, t, 0);
+  K PCO_GLOBAL* T = sort_ptr<K>(ws, t, 1);
+  constexpr bool kKeys16 = !std::is_same<K, L>::value;
+  const L ref = kKeys16 ? (L)uni((uint64_t)ch->c16_ref[var == 2 ? 1 : 0]) : (L)0;   // latent = ref + key
   {  // the stored latents in order (collect_contiguous_latents, wrapped/chunk_compressor.rs:128-140): every position that is not among the first `skip` of its page
     const L PCO_GLOBAL* lat = lat_ptr<L>(ws, t, var);
     const uint16_t PCO_GLOBAL* clat = clat_ptr(ws, t, var);
     const bool c16 = uni(ch->c16_ok) == 1 && var != 0;
-    const L ref = (L)uni((uint64_t)ch->c16_ref[var == 2 ? 1 : 0]);
+    const L cref = (L)uni((uint64_t)ch->c16_ref[var == 2 ? 1 : 0]);
     const uint32_t n_all = (uint32_t)uni((uint64_t)ch->n), skip = uni(ev->lat_start), plow = uni(ch->page_low), pr = uni(ch->page_r);
     const bool single_page = uni(ch->n_pages) == 1, exact_paging = uni(ch->exact_paging) != 0; const uint32_t n_pg = uni(ch->n_pages);
     const EncPage PCO_GLOBAL* pgl = (const EncPage PCO_GLOBAL*)ws.pages + uni(ch->page_first);
@@ -264,7 +271,7 @@ __device__ void lit_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32
       const uint32_t i = base + lane;
       const bool st = i < n_all && stored(i);
       const uint64_t bal = __ballot(st);
-      if (st) A[out + (uint32_t)__popcll(bal & below)] = c16 ? (L)(ref + (L)clat[i]) : lat[i];
+      if (st) A[out + (uint32_t)__popcll(bal & below)] = kKeys16 ? (K)clat[i] : (K)(c16 ? (L)(cref + (L)clat[i]) : lat[i]);
       out += (uint32_t)__popcll(bal);
     }
     lit_sync();
@@ -291,30 +298,30 @@ __device__ void lit_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32
     for (;;) {
       if (len == 0) break;
       if (++guard > 1024u + 4u * n_lat) { overflow = true; break; }
-      L PCO_GLOBAL* v = A + lo;
+      K PCO_GLOBAL* v = A + lo;
       const uint32_t target = hb.bin_idx(hb.n_applied), target_c = hb.c_count(target), end = hb.n_applied + len;
       if (end <= target_c) {
-        lit_apply_incomplete<L>(hb, v, len, lbt, lbx, ubt, ubx);
+        lit_apply_incomplete<K, L>(hb, v, ref, len, lbt, lbx, ubt, ubx);
         if (end == target_c) hb.complete_bin(target);
         break;
       }
-      if (lbx == ubx || len == 1) { lit_apply_constant_run<L>(hb, len, lit_uni<L>(v[0])); break; }
-      const L tentative = lit_choose_pivot<L>(v, len);
+      if (lbx == ubx || len == 1) { lit_apply_constant_run<L>(hb, len, (L)(ref + (L)lit_uni<K>(v[0]))); break; }
+      const L tentative = (L)(ref + (L)lit_choose_pivot<K>(v, len));
       L pivot, lhs_ubx, rhs_lbx; bool lhs_ubt, rhs_lbt;
       if (tentative > lbx) { pivot = tentative; lhs_ubx = (L)(tentative - 1); lhs_ubt = false; rhs_lbx = tentative; rhs_lbt = true; }
       else { pivot = (L)(tentative + 1); lhs_ubx = tentative; lhs_ubt = true; rhs_lbx = (L)(tentative + 1); rhs_lbt = false; }
-      const uint32_t lhs = lit_partition<L>(v, len, pivot);
+      const uint32_t lhs = lit_partition<K>(v, len, (K)(pivot - ref));   // (pivot - ref <= 2^15: tentative is a key of at most 15 bits)
       const uint32_t smaller = lhs < len - lhs ? lhs : len - lhs;
       if (1 + smaller < len / 8) {   // was_bad_pivot (sort_utils.rs:124)
         limit -= 1;
         if (limit == 0) {
           fell = true;
-          lit_sort<L>(v, T + lo, len, cnt);
-          lit_apply_sorted<L>(hb, v, len);
+          lit_sort<K>(v, T + lo, len, cnt);
+          lit_apply_sorted<K, L>(hb, v, ref, len);
           break;
         }
-        lit_break_patterns<L>(v, lhs);
-        lit_break_patterns<L>(v + lhs, len - lhs);
+        lit_break_patterns<K>(v, lhs);
+        lit_break_patterns<K>(v + lhs, len - lhs);
       }
       if (sp >= kLitStackCap) { overflow = true; break; }
       push(sp++, lo + lhs, len - lhs, rhs_lbx, rhs_lbt, ubx, ubt, limit);
@@ -341,11 +348,12 @@ __global__ __launch_bounds__(64) void enc_hist_literal_kernel(EncWorkspace ws, u
   for (uint32_t var = 0; var < 3; var++) {
     if (!uni(ch->v[var].present)) continue;
     const uint32_t bl = var == 2 ? (ubl < 6 ? ubl : 6) : ubl;   // (wrapped/chunk_compressor.rs:238-248)
-    if (var == 0) lit_var<uint32_t>(ws, t, var, bl, fb);
-    else if (bits == 64) lit_var<uint64_t>(ws, t, var, bl, fb);
-    else if (bits == 32) lit_var<uint32_t>(ws, t, var, bl, fb);
-    else if (bits == 16) lit_var<uint16_t>(ws, t, var, bl, fb);
-    else lit_var<uint8_t>(ws, t, var, bl, fb);
+    const bool keys16 = var != 0 && uni(ch->c16_ok) == 1;   // the split's 16-bit latents held: they are the keys
+    if (var == 0) lit_var<uint32_t, uint32_t>(ws, t, var, bl, fb);
+    else if (bits == 64) { if (keys16) lit_var<uint16_t, uint64_t>(ws, t, var, bl, fb); else lit_var<uint64_t, uint64_t>(ws, t, var, bl, fb); }
+    else if (bits == 32) { if (keys16) lit_var<uint16_t, uint32_t>(ws, t, var, bl, fb); else lit_var<uint32_t, uint32_t>(ws, t, var, bl, fb); }
+    else if (bits == 16) lit_var<uint16_t, uint16_t>(ws, t, var, bl, fb);
+    else lit_var<uint8_t, uint8_t>(ws, t, var, bl, fb);
   }
 }
 
