@@ -513,11 +513,12 @@ class Bench:
 # of numbers), steps, gather)
 OTHER_WORKLOADS = [("c3", "c3", None, 4, False), ("c4", "c4", 4096, 3, False), ("c5", "c5", None, 3, False), ("c5gather", "c5", None, 3, True),
                    ("c2auto", "c2auto", None, 3, False), ("c3auto", "c3auto", None, 3, False), ("c1", "c1", None, 3, False),
+                   ("c5auto", "c5auto", None, 2, False),   # configs[4] under the default ChunkConfig (Auto mode + Auto delta per chunk)
                    ("c2strict", "c2strict", 4096, 2, False), ("c2l12", "c2l12", 2048, 2, False),
                    # the headline's dependence on the call size (the walkers' flat cost: profiles/r04_c2_chunk_scaling.txt); 4096 chunks per GPU is
                    # what configs[4]'s "~64 GiB over 8 GPUs" comes to
                    ("c2_1k", "c2", 1024, 3, False), ("c2_4k", "c2", 4096, 3, False), ("c2_12k", "c2", 12288, 3, False)]
-LIGHT_WORKLOADS = ("c2strict", "c2l12", "c2_1k", "c2_4k", "c2_12k")   # no CPU leg of their own (the headline's / c2's applies), fewer verified chunks
+LIGHT_WORKLOADS = ("c5auto", "c2strict", "c2l12", "c2_1k", "c2_4k", "c2_12k")   # no CPU leg of their own (the headline's / c2's applies), fewer verified chunks
 
 
 def flat_workload(name, r):
