@@ -621,11 +621,12 @@ __device__ bool lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
   const L PCO_GLOBAL* pre = sort_ptr<L>(ws, t, 0) + pstart;
   uint8_t PCO_LDS* smem = enc_lds_base();
   uint16_t PCO_LDS* tbl = (uint16_t PCO_LDS*)smem;
+  bool screened = false;
   if (n <= kLbPipeSmallMaxPage) {
     // A screen for the Auto-delta trial samples: latents that span fewer than 4 n values (the float-mult multiples of decimal data: small random
     // integers) repeat exactly at ever-changing distances, nearly every element picks a lookback nobody picked before, and stage D's speculation
-    // fails every round (49 rounds a tile): those pages are the one-wave kernel's from the start -- sixteen of them per CU -- instead of being
-    // handed back after a pre-pass and sixteen tiles of pipeline (3.5 ms per 8192 pages, for nothing).  Which kernel takes a page changes no byte.
+    // fails every round (49 rounds a tile): the pipeline leaves those pages alone (instead of handing them back after sixteen tiles, 3.5 ms per
+    // 8192 pages for nothing) and enc_lookback_seq_kernel decides them element by element.  Which kernel takes a page changes no byte.
     typedef typename std::conditional<sizeof(L) == 8, uint64_t, uint32_t>::type W;
     W mn = (W)(L)~(L)0, mx = 0;
     for (uint32_t i = tid; i < n; i += kLhThreads) { const W x = (W)pre[i]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
@@ -636,7 +637,7 @@ __device__ bool lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
     uint64_t lo = ~0ull, hi = 0;
     for (uint32_t w = 0; w < kLhWaves; w++) { const uint64_t a = red[2 * w], b = red[2 * w + 1]; lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
     __syncthreads();
-    if (hi - lo < 4ull * n) return true;
+    screened = hi - lo < 4ull * n;   // (the proposals are computed all the same: enc_lookback_seq_kernel reads them)
   }
   for (uint32_t i = tid; i < hash_table_n / 4; i += kLhThreads) ((uint64_t PCO_LDS*)tbl)[i] = 0ull;
   __syncthreads();
@@ -786,7 +787,7 @@ __device__ bool lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
 #ifdef PCO_LBP_TIMING
   if (lane == 0 && (wave == 0 || wave == kLhWorkers)) { atomicAdd(&g_lbp_timing[wave == 0 ? 14 : 15], th_busy); if (wave == 0) atomicAdd(&g_lbp_timing[0], (unsigned long long)n_steps); }
 #endif
-  return false;
+  return screened;
 }
 
 // grid = 2 x the lookback pages (item = 2 k + table), one block per CU (the table)
@@ -808,6 +809,145 @@ __global__ __launch_bounds__(kLhThreads) void enc_lookback_hash_kernel(EncWorksp
   else if (bits == 16) skipped = lookback_hash_page<uint16_t>(ws, t, pg, c, pk, prop_stride, queue_off);
   else skipped = lookback_hash_page<uint8_t>(ws, t, pg, c, pk, prop_stride, queue_off);
   if (c == 0 && threadIdx.x == 0) skip[k] = skipped ? 1u : 0u;
+}
+
+// =========================================================================================================
+// The screened pages, element by element (round 5).  A page the pre-pass's screen took out -- at most 8192 latents that span fewer than
+// 32768 values -- changes its best lookback at nearly every element, so nothing is gained by deciding 64 elements on a guess: what counts is
+// the latency of ONE element's decision.  The one-wave kernel paid two HBM round trips per round on such a page (the count of a lookback
+// beyond its 256 LDS counters, the latent at a freshly chosen distance: 9.9 ms a page, 19.7 ms per 8192 trial pages of decimal data).  Here
+// everything a decision reads is in LDS: the page's latents as their low 16 bits (two latents of the page differ by less than 2^15, so the
+// difference of the low halves, sign-extended, IS the difference), every lookback's count as u16 (a count never exceeds the page), the tile's
+// hash proposals from the pre-pass.  Lanes 0..15 hold the sixteen proposals of lookback.rs:101-159 and choose by a DPP arg-max, exactly as
+// the one-wave kernel's first tile does; 27 KB of LDS for a 6554-number trial page, five pages per CU.
+// =========================================================================================================
+constexpr uint32_t kLbSeqMaxPage = 8192;
+constexpr uint32_t kLbSeqHpBytes = 2 * 64 * 8 * 2;   // u16[2][64][8]: this tile's and the next one's six hash proposals per element
+__host__ __device__ constexpr uint32_t lbseq_round(uint32_t page_max) { return (page_max + 63u) & ~63u; }
+__host__ __device__ constexpr uint32_t lbseq_lds_bytes(uint32_t page_max) { return kLbSeqHpBytes + 4u * lbseq_round(page_max); }
+
+template <class L>
+__device__ void lookback_seq_page(const EncWorkspace& ws, uint32_t t, EncPage PCO_GLOBAL* pg, const uint16_t PCO_GLOBAL* props, uint64_t prop_stride, uint32_t n_round) {
+  const uint32_t lane = lane_id();
+  const uint32_t n = (uint32_t)uni((uint64_t)pg->n); const uint64_t pstart = uni((uint64_t)pg->start);
+  const L PCO_GLOBAL* pre = sort_ptr<L>(ws, t, 0) + pstart;
+  uint32_t PCO_GLOBAL* lbs = lat_ptr<uint32_t>(ws, t, 0) + pstart;
+  L PCO_GLOBAL* out = lat_ptr<L>(ws, t, 1) + pstart;
+  uint16_t PCO_LDS* hp = (uint16_t PCO_LDS*)enc_lds_base();
+  uint16_t PCO_LDS* lat = hp + kLbSeqHpBytes / 2;
+  uint16_t PCO_LDS* cnt = lat + n_round;
+  if (lane == 0) pg->moments[0] = n ? (uint64_t)pre[0] : 0ull;   // the delta state (lookback.rs:179-181), state_n == 1
+  if (n <= 1) return;
+  for (uint32_t i = lane; i < n; i += 64) { lat[i] = (uint16_t)pre[i]; cnt[i] = 1; }
+  auto tile_props = [&](uint32_t i0t, uint32_t (&pp)[6]) {
+    const bool a = i0t < n && lane < n - i0t;
+#pragma unroll
+    for (int r = 0; r < 6; r++) pp[r] = a ? (uint32_t)props[(uint64_t)r * prop_stride + i0t + lane] : 1u;
+  };
+  auto hp_store = [&](uint32_t tile, const uint32_t (&pp)[6]) {   // the six proposals of element 1 + 64 tile + lane: row ((tile & 1) * 64 + lane)
+    uint64_t PCO_LDS* h8 = (uint64_t PCO_LDS*)(hp + ((tile & 1u) * 64u + lane) * 8u);
+    h8[0] = (uint64_t)(pp[0] | (pp[1] << 16)) | ((uint64_t)(pp[2] | (pp[3] << 16)) << 32); h8[1] = (uint64_t)(pp[4] | (pp[5] << 16));
+  };
+  const uint32_t hl = lane >= 10 && lane < 16 ? lane - 10 : 0u;   // (my column of a row)
+  auto hp_row = [&](uint32_t i) { return (uint32_t)hp[((i - 1u) & 127u) * 8u + hl]; };
+  uint32_t pf[6]; tile_props(1, pf); hp_store(0, pf); tile_props(65, pf); hp_store(1, pf); tile_props(129, pf);   // (two tiles' rows in LDS, the third in flight)
+  uint32_t P = 1, best_lookback = 1, repeating_idx = 0;   // lanes 0..15: proposed_lookbacks[lane] = min(lane + 1, state_n)
+  L mn1 = (L)~(L)0, mx1 = 0; uint32_t mn0 = 0xffffffffu, mx0 = 0, my_lb = 1;
+  const bool hashed = lane >= 10 && lane < 16;
+  auto lz_part = [&](uint32_t l, uint32_t other) {   // leading zeros of |l - other| as an L (lookback.rs:76-80), from the low halves
+    const int32_t d = (int32_t)(int16_t)(uint16_t)(l - other);
+    const uint32_t a = (uint32_t)(d < 0 ? -d : d);
+    return LBits<L>::v - (32u - clz_u32(a));
+  };
+  auto arg_max = [&](uint32_t key) {   // over lanes 0..15 on the DPP network (row 0): after row_shr 1, 2, 4, 8 lane 15 holds the maximum
+    uint32_t o = dpp0<0x111, 0xf>(key); key = o > key ? o : key; o = dpp0<0x112, 0xf>(key); key = o > key ? o : key;
+    o = dpp0<0x114, 0xf>(key); key = o > key ? o : key; o = dpp0<0x118, 0xf>(key); key = o > key ? o : key;
+    return 15u - ((uint32_t)__builtin_amdgcn_readlane((int)key, 15) & 15u);
+  };
+  auto flush_tile = [&](uint32_t i0, uint32_t tile_n) {   // (lookback.rs:166-185)
+    if (lane < tile_n) {
+      const uint32_t ie = i0 + lane;
+      const int32_t d = (int32_t)(int16_t)(uint16_t)((uint32_t)lat[ie] - (uint32_t)lat[ie - my_lb]);
+      const L dl = (L)((L)(int64_t)d + lmid<L>());
+      lbs[ie] = my_lb; out[ie] = dl;
+      mn0 = my_lb < mn0 ? my_lb : mn0; mx0 = my_lb > mx0 ? my_lb : mx0; mn1 = dl < mn1 ? dl : mn1; mx1 = dl > mx1 ? dl : mx1;
+    }
+  };
+  lb_sync();
+  // ---- positions 1..16: the brute-force slots fill up and overwrite the "repeating" slots on the way (lookback.rs:129-130) ----
+  const uint32_t n_head = n - 1 < 16 ? n - 1 : 16;
+  for (uint32_t i = 1; i <= n_head; i++) {
+    const uint32_t l = lat[i];   // uniform
+    { const uint32_t new_brute = i < 16 ? i : 16; if (lane == new_brute - 1) P = new_brute; }
+    if (hashed) P = hp_row(i);
+    const uint32_t key = lane < 16 ? ((((32u - clz_u32((uint32_t)cnt[P - 1])) + lz_part(l, lat[i - P])) << 4) | (15u - lane)) : 0u;   // max key = max goodness, first proposal on ties (lookback.rs:88-96)
+    const uint32_t best_p = arg_max(key);
+    const uint32_t new_best = (uint32_t)__builtin_amdgcn_readlane((int)P, (int)best_p);
+    if (new_best != best_lookback) repeating_idx++;
+    if (lane == 6 + (repeating_idx & 3u)) P = new_best;
+    best_lookback = new_best;
+    if (lane == i - 1) my_lb = new_best;
+    if (lane == 0) cnt[new_best - 1] += 1;
+    lb_sync();
+  }
+  if (n - 1 <= 16) flush_tile(1, n - 1);
+  else {
+    // ---- from position 17 on nothing but the decisions changes a proposal.  One wave per SIMD issues every instruction of the loop back to
+    //      back, so the loop is kept SHORT rather than latency-free: the element's latent and hash proposals (which depend on no decision) are
+    //      fetched one element ahead, each proposal's latent and count after the previous decision (one LDS round trip), and the winner's
+    //      count comes back by readlane instead of a read-modify-write.  (Fetching everything ahead and patching it with the decision --
+    //      110 instructions an element instead of 60 -- was slower: 14.9 ms against 13.6 per 8192 trial pages.) ----
+    uint32_t l = lat[17], H1 = hp_row(17);
+    for (uint32_t i = 17; i < n; i++) {
+      const uint32_t e = (i - 1u) & 63u;
+      if (e == 0) { hp_store((i >> 6) + 1u, pf); tile_props(i + 128u, pf); lb_sync(); }   // the next tile's rows; the one after it in flight
+      if (hashed) P = H1;
+      const uint32_t O = lat[i - P], C = cnt[P - 1];
+      const uint32_t ln = lat[i + 1], H2 = hp_row(i + 1);
+      const uint32_t key = lane < 16 ? ((((32u - clz_u32(C)) + lz_part(l, O)) << 4) | (15u - lane)) : 0u;
+      const uint32_t best_p = arg_max(key);
+      const uint32_t new_best = (uint32_t)__builtin_amdgcn_readlane((int)P, (int)best_p);
+      const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)C, (int)best_p) + 1u;
+      if (lane == 0) cnt[new_best - 1] = (uint16_t)cw;
+      if (new_best != best_lookback) repeating_idx++;
+      best_lookback = new_best;
+      if (lane == e) my_lb = new_best;
+      if (lane == 6 + (repeating_idx & 3u)) P = new_best;
+      l = ln; H1 = H2;
+      lb_sync();
+      if (e == 63u || i + 1 == n) flush_tile(i - e, e + 1u);
+    }
+  }
+  for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+    L o1 = shfl_idx(mn1, (int)(lane ^ dlt)); mn1 = o1 < mn1 ? o1 : mn1;
+    L o2 = shfl_idx(mx1, (int)(lane ^ dlt)); mx1 = o2 > mx1 ? o2 : mx1;
+    uint32_t o3 = __shfl_xor(mn0, dlt, 64); mn0 = o3 < mn0 ? o3 : mn0;
+    uint32_t o4 = __shfl_xor(mx0, dlt, 64); mx0 = o4 > mx0 ? o4 : mx0;
+  }
+  if (lane == 0) {
+    atomicMin((unsigned long long*)&ws.chunks[t].v[1].minv, (unsigned long long)mn1); atomicMax((unsigned long long*)&ws.chunks[t].v[1].maxv, (unsigned long long)mx1);
+    atomicMin((unsigned long long*)&ws.chunks[t].v[0].minv, (unsigned long long)mn0); atomicMax((unsigned long long*)&ws.chunks[t].v[0].maxv, (unsigned long long)mx0);
+  }
+}
+
+// grid = the lookback pages, one wave each; takes the pages the pre-pass's screen marked (skip[k] == 1) and clears their redo flag, so that
+// enc_lookback_kernel behind it is left with the pages the pipeline handed back
+__global__ __launch_bounds__(64) void enc_lookback_seq_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, const uint16_t* props, uint64_t prop_stride, const uint32_t* skip, uint32_t* redo, uint32_t n_round) {
+  const uint32_t k = blockIdx.x;
+  if (k >= n_lb_pages || uni(skip[k]) == 0) return;
+  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + page_ids[k];
+  if (uni(pg->flags) & kPageFlagMetaOnly) return;
+  const uint32_t t = uni(pg->chunk);
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (uni(ch->status) != PCO_GFX_OK || uni(ch->delta_kind) != kDeltaLookback || uni(ch->state_n_log) != 0) return;
+  if ((uint32_t)uni((uint64_t)pg->n) > n_round) return;
+  const uint16_t PCO_GLOBAL* pk = (const uint16_t PCO_GLOBAL*)props + (uint64_t)k * 6 * prop_stride;
+  const int bits = dtype_bits(uni(ch->dtype));
+  if (bits == 64) lookback_seq_page<uint64_t>(ws, t, pg, pk, prop_stride, n_round);
+  else if (bits == 32) lookback_seq_page<uint32_t>(ws, t, pg, pk, prop_stride, n_round);
+  else if (bits == 16) lookback_seq_page<uint16_t>(ws, t, pg, pk, prop_stride, n_round);
+  else lookback_seq_page<uint8_t>(ws, t, pg, pk, prop_stride, n_round);
+  if (threadIdx.x == 0) redo[k] = 0;
 }
 
 }  // namespace pcogfx

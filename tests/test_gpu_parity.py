@@ -108,6 +108,35 @@ def test_lookback_matrix(L):
         assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums)
 
 
+def test_lookback_on_duplicate_heavy_pages(L):
+    """Pages of at most 8192 latents that span fewer than 4 n values (the float-mult multiples of decimal data, small counts): the
+    pre-pass's screen hands them to enc_lookback_seq_kernel, which keeps the page's latents as their low 16 bits and every count as u16
+    in LDS.  Every dtype, sizes around the tile and the 16-position start-up, ranges at the screen's edge, values around a 2^16 boundary
+    (the low halves wrap, their difference does not)."""
+    rng = np.random.default_rng(29)
+    cases = []
+    for dt in (np.uint16, np.int16, np.uint32, np.int32, np.int64, np.uint64):
+        for n in (2, 3, 16, 17, 18, 64, 65, 66, 129, 1000, 6554, 8191, 8192):
+            span = int(rng.choice([2, 7, 50, n, 2 * n, 4 * n - 1, 4 * n]))
+            base = int(rng.choice([0, 65536 - span // 2, (1 << 31) - span // 2 if np.dtype(dt).itemsize >= 8 else 0]))
+            if np.dtype(dt).itemsize == 2: base = int(rng.choice([0, 32768 - span // 2])) if np.dtype(dt).kind == "u" else -(span // 2)
+            cases.append((base + rng.integers(0, max(span, 1), n)).astype(dt))
+    walk = np.cumsum(rng.integers(-1, 2, 8000)) + 70000; cases.append(walk.astype(np.int64))   # a random walk: near-duplicates next to each other
+    cases.append(np.repeat(rng.integers(0, 9, 700), 9).astype(np.uint32))                       # runs
+    cases.append((rng.integers(0, 40, 6554) * 3.0 + 1000.0).astype(np.float32))                 # floats through the classic mode: not screened unless close
+    for nums in cases:
+        kw = dict(mode=1, delta=3)
+        want = O.simple_compress(nums, O.make_config(**kw))
+        got = U.gpu_simple_compress(nums, G.make_config(**kw))
+        assert got == want, (nums.dtype, nums.size, int(nums.min()), int(nums.max()))
+        assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, nums.size), nums)
+    # many such pages in one call, beside pages the pipeline keeps (the redo / skip lists are per page)
+    batch = [rng.integers(0, 3000, 6554).astype(np.int64) if k % 3 else (np.arange(6554) * 5 + rng.integers(0, 3, 6554)).astype(np.int64) for k in range(40)]
+    chunks, back = U.gpu_batched(batch, G.make_config(mode=1, delta=3))
+    for x, ch, b in zip(batch, chunks, back):
+        assert ch == U.chunk_of_file(O.simple_compress(x, O.make_config(mode=1, delta=3)), len(ch)) and U.bits_equal(x, b)
+
+
 def test_lookback_with_two_variable_modes(L):
     """Lookback delta on the primary of int-mult / float-mult / float-quant chunks (delta_encoding.rs:303-304): the decoder keeps
     the primary latents in dst on a first pass and joins on a second."""
