@@ -80,6 +80,12 @@ __device__ __forceinline__ bool wd_walks(uint32_t fused, const PageVar& pv) {
   const uint32_t mode = fused & 0xffu;
   return mode != 0 && pv.present && pv.n_bins > 1 && pv.n_lat > 0 && (mode == 1 || !ew_fits16(pv.asl, pv.n_bins));
 }
+// enc_walkseg_kernel (encode_walkseg.hip) walks the long items, sixteen segments side by side; the kernels here leave those alone
+constexpr uint32_t kFusedSegments = 0x200u;   // EncFast::fused flag
+constexpr uint32_t kWsSegs = 16, kWsMinBatches = 64, kWsMaxItems = 3072;           // segments per item; items shorter than 64 batches (16 384 latents) stay with the unsegmented kernels
+__device__ __forceinline__ bool ws_walks(uint32_t fused, const PageVar& pv) {
+  return (fused & 0xffu) != 0 && (fused & kFusedSegments) != 0 && pv.present && pv.n_bins > 1 && pv.n_lat >= kWsMinBatches * kBatchN;
+}
 __device__ __forceinline__ bool wd_takes(uint32_t fused, const PageVar& pv) { return (fused & kFusedLookups) != 0 && wd_walks(fused, pv) && pv.compact && pv.range < kDirectHistRange; }
 // Where a table's window of used slots starts is rotated from table to table: the tables sit 8 KB apart and a narrow variable uses a
 // quarter of its table or less -- at the same offset in every table of similar chunks, i.e. in the same few L2 sets.
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(64) void enc_walk_kernel(EncWorkspace ws, EncFast f
       if (pv.present && lane < 4 && stage != 2) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
       continue;
     }
-    if (wd_walks(fx.fused, pv)) continue;                                        // enc_walkd_kernel's item
+    if (wd_walks(fx.fused, pv) || ws_walks(fx.fused, pv)) continue;             // enc_walkd_kernel's / enc_walkseg_kernel's item
     if (stage != 0 && ew_fits16(pv.asl, pv.n_bins) != (stage == 1)) continue;   // the other stage's item
     const uint32_t kEwInfoOff = ew_info_off(pv.asl);
     const PlanRef plan = plan_ref(ws, t, v);
@@ -499,6 +505,7 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
       if ((fx.fused & 0xffu) == 1 && pv.present && (pv.n_bins <= 1 || pv.n_lat == 0) && wave == 0 && lane < 4) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
       continue;
     }
+    if (ws_walks(fx.fused, pv)) continue;        // enc_walkseg_kernel's item
     const bool finds = wd_takes(fx.fused, pv);   // its symbols come from the gathering wave; else from enc_dissect_kernel, staged by the walker itself
     const uint32_t info_off = ew_info_off(pv.asl);
     { const uint32_t nbq = (pv.n_lat + kBatchN - 1) / kBatchN; max_nb = nbq > max_nb ? nbq : max_nb; }

@@ -856,7 +856,8 @@ __device__ void lookback_seq_page(const EncWorkspace& ws, uint32_t t, EncPage PC
   const bool hashed = lane >= 10 && lane < 16;
   auto lz_part = [&](uint32_t l, uint32_t other) {   // leading zeros of |l - other| as an L (lookback.rs:76-80), from the low halves
     const int32_t d = (int32_t)(int16_t)(uint16_t)(l - other);
-    const uint32_t a = (uint32_t)(d < 0 ? -d : d);
+    uint32_t a = (uint32_t)(d < 0 ? -d : d);
+    if (LBits<L>::v == 8) a = a > 128u ? 256u - a : a;   // (the reference takes the smaller of the two WRAPPING differences: an 8-bit page can span more than half its type)
     return LBits<L>::v - (32u - clz_u32(a));
   };
   auto arg_max = [&](uint32_t key) {   // over lanes 0..15 on the DPP network (row 0): after row_shr 1, 2, 4, 8 lane 15 holds the maximum

@@ -29,6 +29,7 @@
 #include "encode_hist_literal.hip"
 #include "auto_mode_kernels.hip"
 #include "encode_fast.hip"
+#include "encode_walkseg.hip"
 #include "stream_kernels.hip"
 
 namespace pcogfx {
@@ -626,6 +627,10 @@ extern "C" int pco_gfx_debug_occupancy(int which, int* blocks) {
   else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, enc_pack_kernel, 64, 6144);
   return (int)e;
 }
+#endif
+
+#ifdef PCO_WS_TRACE
+extern "C" int pco_gfx_debug_ws_trace(unsigned long long* out, int n_blocks) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_ws_trace), (size_t)n_blocks * 24); }
 #endif
 
 #ifdef PCO_HIST_TIMING

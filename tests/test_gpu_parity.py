@@ -121,11 +121,15 @@ def test_lookback_on_duplicate_heavy_pages(L):
             base = int(rng.choice([0, 65536 - span // 2, (1 << 31) - span // 2 if np.dtype(dt).itemsize >= 8 else 0]))
             if np.dtype(dt).itemsize == 2: base = int(rng.choice([0, 32768 - span // 2])) if np.dtype(dt).kind == "u" else -(span // 2)
             cases.append((base + rng.integers(0, max(span, 1), n)).astype(dt))
+    for dt in (np.uint8, np.int8):   # an 8-bit page may span more than half its type: the smaller WRAPPING difference counts (lookback.rs:76-80)
+        for n in (64, 256, 3000, 8192):
+            cases.append(rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, n, endpoint=True).astype(dt))
+            cases.append(np.where(rng.random(n) < 0.8, 7, rng.integers(0, 120, n)).astype(dt))
     walk = np.cumsum(rng.integers(-1, 2, 8000)) + 70000; cases.append(walk.astype(np.int64))   # a random walk: near-duplicates next to each other
     cases.append(np.repeat(rng.integers(0, 9, 700), 9).astype(np.uint32))                       # runs
     cases.append((rng.integers(0, 40, 6554) * 3.0 + 1000.0).astype(np.float32))                 # floats through the classic mode: not screened unless close
     for nums in cases:
-        kw = dict(mode=1, delta=3)
+        kw = dict(mode=1, delta=3, enable_8_bit=True)
         want = O.simple_compress(nums, O.make_config(**kw))
         got = U.gpu_simple_compress(nums, G.make_config(**kw))
         assert got == want, (nums.dtype, nums.size, int(nums.min()), int(nums.max()))
@@ -135,6 +139,36 @@ def test_lookback_on_duplicate_heavy_pages(L):
     chunks, back = U.gpu_batched(batch, G.make_config(mode=1, delta=3))
     for x, ch, b in zip(batch, chunks, back):
         assert ch == U.chunk_of_file(O.simple_compress(x, O.make_config(mode=1, delta=3)), len(ch)) and U.bits_equal(x, b)
+
+
+def test_segmented_encode_walk_never_depends_on_luck(L):
+    """enc_walkseg_kernel (encode_walkseg.hip) starts every segment of a long page from the arc of ALL tANS states and emits only once the
+    arc's two ends have met; what it walked before is walked again from the true state.  Tables that forget their state at once (many
+    bins), slowly (a 0.999 / 0.001 pair: hundreds of symbols) and never (equal power-of-two weights: the state is a bijection of the
+    start state) must all give the reference's bytes, at page lengths with full and ragged last segments and batches."""
+    rng = np.random.default_rng(31)
+    cases = []
+    for n in (16384, 16385, 20000, 65536 + 255, 1 << 18, (1 << 18) + 1):
+        cases.append(rng.integers(0, 4, n).astype(np.uint32))                                   # four equal bins
+        cases.append(rng.integers(0, 2, n).astype(np.uint32) * 1000)                            # two equal bins
+        cases.append(np.where(rng.random(n) < 0.999, 5, 77).astype(np.int32))                   # one heavy bin: a rare symbol is the only thing that makes states meet
+        cases.append((rng.geometric(0.3, n) % 16).astype(np.uint16))                            # a skewed handful
+        cases.append(rng.integers(0, 1 << 20, n).astype(np.uint32))                             # 256 bins: meets within a few symbols
+    cases.append(np.where(np.arange(1 << 18) < 200000, 5, rng.integers(0, 3, 1 << 18)).astype(np.uint32))   # a constant stretch longer than several segments
+    cases.append(np.repeat(rng.integers(0, 8, 1 << 12), 64).astype(np.uint32))                  # runs
+    for nums in cases:
+        for kw in (dict(mode=1, delta=0), dict(mode=1, delta=2, delta_order=1)):
+            want = O.simple_compress(nums, O.make_config(**kw))
+            got = U.gpu_simple_compress(nums, G.make_config(**kw))
+            assert got == want, (nums.dtype, nums.size, kw)
+    for i in (20, 22, 29):   # the file cut into chunks of up to 50 000 numbers (simple_compress's paging)
+        kw = dict(mode=1, delta=0, max_page_n=50000)
+        assert U.gpu_simple_compress(cases[i], G.make_config(**kw)) == O.simple_compress(cases[i], O.make_config(**kw)), i
+    # several long chunks of different tables in one call
+    batch = [cases[i] for i in (0, 2, 7, 12, 24, 21)]   # (none longer than 2^18: simple_compress cuts those into two chunks)
+    chunks, back = U.gpu_batched(batch, G.make_config(mode=1, delta=0))
+    for x, ch, b in zip(batch, chunks, back):
+        assert ch == U.chunk_of_file(O.simple_compress(x, O.make_config(mode=1, delta=0)), len(ch)) and U.bits_equal(x, b)
 
 
 def test_lookback_with_two_variable_modes(L):
