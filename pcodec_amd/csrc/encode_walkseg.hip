@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t ws_step2(uint32_t& a, uint32_t& b, uint32_t&
 #ifdef PCO_WS_TRACE
 __device__ unsigned long long g_ws_trace[3 * 16384];   // per block: HW_ID, start, end (s_memrealtime: 100 MHz)
 #endif
-__global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkseg_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+__global__ __launch_bounds__(128) void enc_walkseg_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   uint8_t PCO_LDS* smem = enc_lds_base();
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -80,15 +80,19 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkseg_kernel(EncW
   }
   // the slack between the info words and the symbol buffers: offset bits u8[n_bins] | bins u8[range + 1] (as enc_walkd_kernel's slots)
   const uint32_t ob_off = info_off + 8u * pv.n_bins, vt_off = ob_off + ((pv.n_bins + 3u) & ~3u);
+#ifdef PCO_WS_NOLDSLUT
+  const bool all_lds = false;
+#else
   const bool all_lds = finds && pv.n_bins <= 256 && pv.range < 4096 && vt_off + (uint32_t)pv.range + 1u <= kWsSymBase;
+#endif
   if (all_lds && wave == 1) {
     for (uint32_t b = lane; b < pv.n_bins; b += 64) smem[ob_off + b] = (uint8_t)plan.bob()[b];
     const uint16_t PCO_GLOBAL* lut = vlut_ptr(ws, fx, t, v);
     const uint32_t base = (uint32_t)(pv.minv - pv.rel) + vlut_rot(t * ws.n_slots + ws.slot_of_var[v]);
     for (uint32_t i = lane; i <= (uint32_t)pv.range; i += 64) smem[vt_off + i] = (uint8_t)lut[(base + i) & (kDirectHistRange - 1)];
   }
-  // a walker lane keeps the segment of its quad (lane >> 2), a gathering lane the segment (wave - 1) * kWdH + (lane & (kWdH - 1))
-  const uint32_t my_q = wave == 0 ? lane >> 2 : (wave - 1) * kWdH + (lane & (kWdH - 1));
+  // a walker lane keeps the segment of its quad (lane >> 2), a gathering lane the segment lane & 15
+  const uint32_t my_q = wave == 0 ? lane >> 2 : lane & (kWsSegs - 1);
   const uint32_t my_first = my_q * nbs;                                                              // the segment's first batch
   const uint32_t my_n_lat = my_q < n_seg && (wave == 0 || finds) ? (pv.n_lat - my_first * kBatchN < nbs * kBatchN ? pv.n_lat - my_first * kBatchN : nbs * kBatchN) : 0u;
   const uint32_t my_nb = (my_n_lat + kBatchN - 1) / kBatchN, max_nb = nbs;
@@ -96,7 +100,10 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkseg_kernel(EncW
   const uint32_t my_m0 = (uint32_t)(pv.minv - pv.rel);
   wd_barrier();
   if (wave != 0) {
-    // ================= the gathering waves: enc_walkd_kernel's, with segments for items =================
+    // ================= the gathering wave: the batch of step `it` of all sixteen segments, four segments at a time =================
+    // One wave per block (enc_walkd_kernel has four): what bounds the kernel on a full chip is how many WALKERS a CU holds -- their steps are
+    // a chain of LDS round trips that the neighbours' traffic stretches from 145 to 400 cycles -- and a block of two waves fits twelve times
+    // (its 12.8 KB of LDS), where five waves fitted five times.  The latents of a group of four segments are requested two groups ahead.
     const bool mine = my_n_lat != 0;
     const uint64_t my_clat_p = mine ? (uint64_t)(uintptr_t)(clat_ptr(ws, t, v) + my_clat) : (uint64_t)(uintptr_t)fx.vlut;
     uint8_t PCO_GLOBAL* my_gsym = mine ? fsym_ptr(ws, fx, t, v) + my_at : (uint8_t PCO_GLOBAL*)nullptr;
@@ -107,95 +114,81 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkseg_kernel(EncW
     const uint32_t vt = lds0 + (all_lds ? vt_off : 0u), ot = lds0 + (all_lds ? ob_off : 0u), rg = all_lds ? (uint32_t)pv.range : 0u;
     auto bcast = [](uint32_t x, uint32_t q) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)q); };
     auto bcast64 = [&](uint64_t x, uint32_t q) { return ((uint64_t)bcast((uint32_t)(x >> 32), q) << 32) | bcast((uint32_t)x, q); };
-    auto batch_of = [&](uint32_t it) { return it < my_nb ? my_nb - 1 - it : 0u; };
-    auto load_batches = [&](uint32_t it, uint64_t (&w)[kWdH]) {
+    auto batch_of = [&](uint32_t it) { return it < my_nb ? my_nb - 1 - it : 0u; };   // (no batch at this step: batch 0 is read, and never used)
+    constexpr uint32_t kG = 4, kGroups = kWsSegs / kG;
+    auto load_group = [&](uint32_t step, uint64_t (&w)[kG]) {   // step = it * kGroups + group; the 4 latents a lane owns of each of the group's batches
+      const uint32_t it = step / kGroups, g = step % kGroups;
       const uint64_t my_src = my_clat_p + 2ull * batch_of(it) * kBatchN;
 #pragma unroll
-      for (uint32_t q = 0; q < kWdH; q++) w[q] = __builtin_nontemporal_load((const u64_align2 PCO_GLOBAL*)((const uint16_t PCO_GLOBAL*)(uintptr_t)bcast64(my_src, q) + 4 * lane));
+      for (uint32_t r = 0; r < kG; r++) w[r] = __builtin_nontemporal_load((const u64_align2 PCO_GLOBAL*)((const uint16_t PCO_GLOBAL*)(uintptr_t)bcast64(my_src, g * kG + r) + 4 * lane));
     };
-    auto gather = [&](const uint64_t (&w)[kWdH], uint32_t (&e)[kWdH][4]) {
+    auto gather = [&](const uint64_t (&w)[kG], uint32_t (&e)[kG][4]) {
 #pragma unroll
-      for (uint32_t q = 0; q < kWdH; q++) {
-        const uint32_t lo = (uint32_t)w[q] + rot2, hi = (uint32_t)(w[q] >> 32) + rot2;
-        e[q][0] = lut[lo & (kDirectHistRange - 1)]; e[q][1] = lut[(lo >> 16) & (kDirectHistRange - 1)];
-        e[q][2] = lut[hi & (kDirectHistRange - 1)]; e[q][3] = lut[(hi >> 16) & (kDirectHistRange - 1)];
+      for (uint32_t r = 0; r < kG; r++) {
+        const uint32_t lo = (uint32_t)w[r] + rot2, hi = (uint32_t)(w[r] >> 32) + rot2;
+        e[r][0] = lut[lo & (kDirectHistRange - 1)]; e[r][1] = lut[(lo >> 16) & (kDirectHistRange - 1)];
+        e[r][2] = lut[hi & (kDirectHistRange - 1)]; e[r][3] = lut[(hi >> 16) & (kDirectHistRange - 1)];
       }
     };
-    auto gather_lds = [&](const uint64_t (&w)[kWdH], uint32_t (&e)[kWdH][4]) {
+    auto gather_lds = [&](const uint64_t (&w)[kG], uint32_t (&e)[kG][4]) {
 #pragma unroll
-      for (uint32_t q = 0; q < kWdH; q++) {
-        const uint32_t lo = (uint32_t)w[q], hi = (uint32_t)(w[q] >> 32);
+      for (uint32_t r = 0; r < kG; r++) {
+        const uint32_t lo = (uint32_t)w[r], hi = (uint32_t)(w[r] >> 32);
         uint32_t idx[4] = {(lo & 0xffffu) - my_m0, (lo >> 16) - my_m0, (hi & 0xffffu) - my_m0, (hi >> 16) - my_m0};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           idx[k] = idx[k] > rg ? 0u : idx[k];
           const uint32_t bin = *(const uint8_t PCO_LDS*)(uintptr_t)(vt + idx[k]);
-          e[q][k] = bin | ((uint32_t)*(const uint8_t PCO_LDS*)(uintptr_t)(ot + bin) << 8);
+          e[r][k] = bin | ((uint32_t)*(const uint8_t PCO_LDS*)(uintptr_t)(ot + bin) << 8);
         }
       }
     };
-    uint64_t wnxt[kWdH]; uint32_t e[kWdH][4], enxt[kWdH][4];
-    if (finds) {
-      load_batches(0, wnxt);
-      if (all_lds) gather_lds(wnxt, enxt); else gather(wnxt, enxt);
-      if (1 < max_nb) load_batches(1, wnxt);
-    }
+    const uint32_t n_steps = finds ? max_nb * kGroups : 0u;
+    uint64_t w0[kG], w1[kG], w2[kG];   // the groups of steps s, s + 1, s + 2 (rotating)
+    if (0 < n_steps) load_group(0, w0);
+    if (1 < n_steps) load_group(1, w1);
     for (uint32_t it = 0; it <= max_nb; it++) {   // it == max_nb: nothing left to find, only the barrier
-#ifdef PCO_WS_NOHELP
-      if (false) {   // (timing experiments: wrong bytes)
-#else
       if (it < max_nb && finds) {
-#endif
-#pragma unroll
-        for (uint32_t q = 0; q < kWdH; q++) { e[q][0] = enxt[q][0]; e[q][1] = enxt[q][1]; e[q][2] = enxt[q][2]; e[q][3] = enxt[q][3]; }
-        __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < max_nb) { if (all_lds) gather_lds(wnxt, enxt); else gather(wnxt, enxt); }
-        __builtin_amdgcn_sched_barrier(0);
-        if (it + 2 < max_nb) load_batches(it + 2, wnxt);
-        __builtin_amdgcn_sched_barrier(0);
         const bool my_on = it < my_nb;
         const uint32_t my_hb = batch_of(it), my_base = my_hb * kBatchN;
         const uint32_t my_cnt = my_on ? (my_n_lat - my_base < kBatchN ? my_n_lat - my_base : kBatchN) : 0u;
         const uint32_t my_buf = lds0 + kWsSymBase + my_q * 512 + (my_hb & 1) * 256;
         uint32_t my_total = 0;
-        if (__all(my_cnt == kBatchN)) {
-          // every segment has a full batch at this step (all steps but the one with the page's last batch, and the tail of a page whose last
-          // segment is shorter): straight-line code, the segments' chains scheduled into one another (see enc_walkd_kernel)
 #pragma unroll
-          for (uint32_t q = 0; q < kWdH; q++) {
-            const uint32_t e01 = e[q][0] | (e[q][1] << 16), e23 = e[q][2] | (e[q][3] << 16);
+        for (uint32_t g = 0; g < kGroups; g++) {
+          const uint32_t step = it * kGroups + g;
+          if (step + 2 < n_steps) load_group(step + 2, w2);
+          uint32_t e[kG][4];
+          if (all_lds) gather_lds(w0, e); else gather(w0, e);
+#pragma unroll
+          for (uint32_t r = 0; r < kG; r++) {
+            const uint32_t q = g * kG + r, cnt = bcast(my_cnt, q);
+            if (cnt < kBatchN) {   // (the page's last batch: a latent beyond it is bin 0 with no bits; no batch at this step: nothing is kept)
+#pragma unroll
+              for (int k = 0; k < 4; k++) e[r][k] = 4 * lane + k < cnt ? e[r][k] : 0u;
+            }
+            const uint32_t e01 = e[r][0] | (e[r][1] << 16), e23 = e[r][2] | (e[r][3] << 16);
             const uint32_t packed = __builtin_amdgcn_perm(e23, e01, 0x06040200u);               // the four bin bytes
             const uint32_t obs4 = __builtin_amdgcn_perm(e23, e01, 0x07050301u);                 // the four offset-bit counts (<= 64 each)
             const uint32_t total = wave_sum(__builtin_amdgcn_sad_u8(obs4, 0u, 0u));
-            my_total = (lane & (kWdH - 1)) == q ? total : my_total;
-            *(uint32_t PCO_LDS*)(uintptr_t)(bcast(my_buf, q) + 4 * lane) = quad_transpose_u8(packed, lane & 3);
+            my_total = (lane & (kWsSegs - 1)) == q ? total : my_total;
+            const uint32_t tr = quad_transpose_u8(packed, lane & 3);
+            if (cnt != 0) *(uint32_t PCO_LDS*)(uintptr_t)(bcast(my_buf, q) + 4 * lane) = tr;
           }
-        } else {
 #pragma unroll
-          for (uint32_t q = 0; q < kWdH; q++) {
-            const uint32_t cnt = bcast(my_cnt, q);
-            if (cnt == 0) continue;
-            if (cnt < kBatchN) {   // (the page's last batch: a latent beyond it is bin 0 with no bits)
-#pragma unroll
-              for (int k = 0; k < 4; k++) e[q][k] = 4 * lane + k < cnt ? e[q][k] : 0u;
-            }
-            const uint32_t e01 = e[q][0] | (e[q][1] << 16), e23 = e[q][2] | (e[q][3] << 16);
-            const uint32_t packed = __builtin_amdgcn_perm(e23, e01, 0x06040200u);
-            const uint32_t obs4 = __builtin_amdgcn_perm(e23, e01, 0x07050301u);
-            const uint32_t total = wave_sum(__builtin_amdgcn_sad_u8(obs4, 0u, 0u));
-            my_total = (lane & (kWdH - 1)) == q ? total : my_total;
-            *(uint32_t PCO_LDS*)(uintptr_t)(bcast(my_buf, q) + 4 * lane) = quad_transpose_u8(packed, lane & 3);
-          }
+          for (uint32_t r = 0; r < kG; r++) { w0[r] = w1[r]; w1[r] = w2[r]; }
         }
+        // the symbols go on to enc_pack_kernel's scratch from the LDS buffers: a lane copies a quarter (64 bytes) of its own segment's batch,
+        // whole 16-latent blocks as enc_dissect_kernel writes them; lanes 0..15 leave the batch's offset-bit total
         if (my_on) {
-          constexpr uint32_t kParts = 64 / kWdH, kPer = 16 / kParts;   // lanes per segment, 16-byte blocks per lane
-          const uint32_t part = lane / kWdH, blocks = (my_cnt + 15u) >> 4;
+          constexpr uint32_t kParts = 64 / kWsSegs, kPer = 16 / kParts;   // lanes per segment, 16-byte blocks per lane
+          const uint32_t part = lane / kWsSegs, blocks = (my_cnt + 15u) >> 4;
 #pragma unroll
           for (uint32_t r = 0; r < kPer; r++) {
             const uint32_t blk = part * kPer + r;
             if (blk < blocks) *(u32x4_unaligned PCO_GLOBAL*)(my_gsym + my_base + 16 * blk) = *(const u32x4 PCO_LDS*)(uintptr_t)(my_buf + 16 * blk);
           }
-          if (lane < kWdH) my_gbat[(uint64_t)my_hb * 2] = my_total;
+          if (lane < kWsSegs) my_gbat[(uint64_t)my_hb * 2] = my_total;
         }
       }
       if (it == max_nb) __threadfence();   // (the walker reads the symbols back from the scratch for what it walks twice)
@@ -269,7 +262,11 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkseg_kernel(EncW
         const uint32_t o0 = ew_step(state, bits_acc, i0);
         const uint64_t n0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd & 0xffu));
         nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * nnblk + 4 * j);
+#ifndef PCO_WS_NOSTORE
         *(u64_align2 PCO_GLOBAL*)(ga + 16 * blk) = (uint64_t)(o0 | (o1 << 16)) | ((uint64_t)o23 << 32);
+#else
+        if (o0 == 0xdeadbeefu && o1 == 0x12345u && o23 == 77u) *(u64_align2 PCO_GLOBAL*)(ga + 16 * blk) = 1;   // (timing experiments: wrong bytes)
+#endif
         __builtin_amdgcn_sched_barrier(0);
         i0 = n0; i1 = n1; i2 = n2; i3 = n3;
       }
