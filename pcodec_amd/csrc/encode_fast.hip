@@ -82,7 +82,7 @@ __device__ __forceinline__ bool wd_walks(uint32_t fused, const PageVar& pv) {
 }
 // enc_walkseg_kernel (encode_walkseg.hip) walks the long items, sixteen segments side by side; the kernels here leave those alone
 constexpr uint32_t kFusedSegments = 0x200u;   // EncFast::fused flag
-constexpr uint32_t kWsSegs = 16, kWsMinBatches = 64, kWsMaxItems = 4608;           // segments per item; items shorter than 64 batches (16 384 latents) stay with the unsegmented kernels
+constexpr uint32_t kWsSegs = 16, kWsMinBatches = 64, kWsMaxItems = 4096;           // segments per item; items shorter than 64 batches (16 384 latents) stay with the unsegmented kernels
 __device__ __forceinline__ bool ws_walks(uint32_t fused, const PageVar& pv) {
   return (fused & 0xffu) != 0 && (fused & kFusedSegments) != 0 && pv.present && pv.n_bins > 1 && pv.n_lat >= kWsMinBatches * kBatchN;
 }
