@@ -18,10 +18,12 @@
 // Measured full-set meeting times (scripts/ans_merge_sim.py, the reference's spread + encoder on this repo's workloads): the headline's
 // 20-bin table median 2 steps, p99 125; float-mult decimals 10 / 161; the lookbacks of configs[3] (weights 1023 + 1) 732 / 4841.
 //
-// One block per (page, variable): the tables ONCE in LDS (enc_walkd_kernel kept sixteen copies, one per item: 72 KB a block, two blocks per
-// CU, 512 walking waves on the chip whatever the call's size), sixteen symbol buffers behind them -- 12.8 KB, six blocks per CU.  The walker
-// wave's quad q walks segment q; the gathering waves find the symbols of the segments' batches exactly as enc_walkd_kernel's do for its
-// sixteen items.
+// One block of two waves per (page, variable): the tables ONCE in LDS (enc_walkd_kernel keeps sixteen copies, one per item: 72 KB a block, two
+// blocks per CU, 512 walking waves on the chip whatever the call's size), sixteen symbol buffers behind them -- 12.8 KB, twelve blocks per CU.
+// The walker wave's quad q walks segment q; the gathering wave finds the symbols of the sixteen segments' batches as enc_walkd_kernel's four do
+// for its sixteen items, four segments at a time.  Used for calls of up to kWsMaxItems items: on a full chip the gathering is 3.1 ms of
+// instruction work by itself, which the unsegmented kernel hides under its 3.4 ms of latency (profiles/r05_walkseg_scaling.txt).
+// A second walk that does not arrive at the state the first one had where its ends met fails the chunk (it cannot happen; it is checked).
 namespace pcogfx {
 
 constexpr uint32_t kWsSymBase = 4096, kWsExOff = kWsSymBase + kWsSegs * 512, kWsLdsBytes = kWsExOff + 2 * kWsSegs * 4 * 4;   // tables | u8[16][2][256] symbols | u32[16][4] exit states | u32[16][4] exact?
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(128) void enc_walkseg_kernel(EncWorkspace ws, EncFa
     return;
   }
   // ================= the walker wave: quad q = segment q =================
-  __builtin_amdgcn_s_setprio(3);   // (its chain of dependent steps is the block's critical path; the gathering waves of five blocks share its SIMD)
+  __builtin_amdgcn_s_setprio(3);   // (its chain of dependent steps is the block's critical path; the gathering waves of the CU's other blocks share its SIMD)
   const uint32_t j = lane & 3;
   const uint32_t info_addr = lds0 + info_off, symbuf = lds0 + kWsSymBase + my_q * 512;
   uint16_t PCO_GLOBAL* gans = fansw_ptr(ws, fx, t, v) + my_at;
