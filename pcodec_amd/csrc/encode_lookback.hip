@@ -562,7 +562,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kProps ? 4 : 1) void enc_lookba
   for (uint32_t k = blockIdx.x; k < n_lb_pages; k += gridDim.x) {
     const uint32_t p = page_ids[k];
     EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
-    if (skip != nullptr && uni(skip[k]) != 0) { if (threadIdx.x == 0) redo[k] = 1; continue; }   // (the pre-pass's screen: a page of the one-wave kernel)
+    if (skip != nullptr && uni(skip[k]) != 0) { if (threadIdx.x == 0) redo[k] = 1; continue; }   // (the pre-pass's screen: a page of enc_lookback_seq_kernel, or -- without it -- of the one-wave kernel)
     if (threadIdx.x == 0) redo[k] = 0;
     if (uni(pg->flags) & kPageFlagMetaOnly) continue;
     const uint32_t t = uni(pg->chunk);
@@ -792,7 +792,7 @@ __device__ bool lookback_hash_page(const EncWorkspace& ws, uint32_t t, const Enc
 
 // grid = 2 x the lookback pages (item = 2 k + table), one block per CU (the table)
 __global__ __launch_bounds__(kLhThreads) void enc_lookback_hash_kernel(EncWorkspace ws, const uint32_t* page_ids, uint32_t n_lb_pages, uint16_t* props, uint64_t prop_stride, uint32_t queue_off /* lh_queue_off(the call's largest window_n_log) */,
-                                                                     uint32_t* skip /* [page]: 1 = left to the one-wave kernel (see the screen in lookback_hash_page) */) {
+                                                                     uint32_t* skip /* [page]: 1 = not the pipeline's (see the screen in lookback_hash_page) */) {
   const uint32_t k = blockIdx.x >> 1, c = blockIdx.x & 1u;
   if (k >= n_lb_pages) return;
   if (c == 0 && threadIdx.x == 0) skip[k] = 0u;   // (rewritten below for the pages the screen takes out)
