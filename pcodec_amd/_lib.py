@@ -47,9 +47,16 @@ class TaskResult(C.Structure):
     _fields_ = [("n_out", C.c_uint64), ("consumed", C.c_uint64), ("status", C.c_uint32), ("aux", C.c_uint32)]
 
 
+KIND_NAMES = {ST_CORRUPTION: "Corruption", ST_INSUFFICIENT_DATA: "InsufficientData", ST_INVALID_ARGUMENT: "InvalidArgument",
+              ST_UNSUPPORTED: "Unsupported", ST_DEVICE_ERROR: "DeviceError"}
+
+
 class PcoGfxError(RuntimeError):
+    """The reference's Python binding raises RuntimeError("pco error: pco <ErrorKind> error: <message>") (pco_python/src/utils.rs:78 over
+    errors.rs:52-60): the same text here, so that callers (and the reference's own tests) that match on the kind keep working."""
+
     def __init__(self, code, status, msg):
-        super().__init__(f"libpco_gfx error code={code} status={status}: {msg}")
+        super().__init__(f"pco error: pco {KIND_NAMES.get(status, status)} error: {msg} (libpco_gfx code={code} status={status})")
         self.code, self.status = code, status
 
 

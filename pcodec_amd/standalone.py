@@ -11,6 +11,9 @@ _FILE_DTYPES = {1: np.uint32, 2: np.uint64, 3: np.int32, 4: np.int64, 5: np.floa
                 7: np.uint16, 8: np.int16, 9: np.float16, 10: np.uint8, 11: np.int8}
 
 
+_TYPE_NAMES = {1: "U32", 2: "U64", 3: "I32", 4: "I64", 5: "F32", 6: "F64", 7: "U16", 8: "I16", 9: "F16", 10: "U8", 11: "I8"}
+
+
 def _dtype_byte(arr):
     try:
         return G.DTYPE_BYTE[arr.dtype.name]
@@ -20,9 +23,11 @@ def _dtype_byte(arr):
 
 def simple_compress(nums, config=None):
     """standalone::simple_compress (standalone/simple.rs:58-91): returns the .pco file as bytes."""
-    nums = np.ascontiguousarray(nums)
-    if nums.ndim != 1:
-        raise TypeError("nums must be a 1D array")
+    nums = np.asarray(nums)
+    if nums.ndim != 1:   # pco_python/src/utils.rs: the binding takes 1D contiguous arrays and says so (test_standalone.py:185-199)
+        raise TypeError(f"{nums.ndim}D {nums.dtype} numpy array could not be cast to 1D")
+    if not nums.flags["C_CONTIGUOUS"]:
+        raise TypeError("nums is not contiguous")
     config = config or ChunkConfig()
     cfg = config.to_c()
     L = G.lib()
@@ -47,23 +52,39 @@ def _peek_dtype_and_n_hint(data):
     """Enough of FileDecompressor::new + peek_number_type_or_termination (standalone/decompressor.rs:85-188)
     to size the output array: returns (dtype byte or 0 for an empty file, n_hint)."""
     b = bytes(data[:32])
-    if len(b) < 5 or b[:4] != b"pco!":
-        raise RuntimeError("magic header does not match")
+    short = RuntimeError("pco error: pco InsufficientData error: the file ends inside its header")   # (bit_reader.rs: what the reference says of any truncated read)
+    if len(b) < 4:
+        raise short
+    if b[:4] != b"pco!":
+        raise RuntimeError("pco error: pco Corruption error: magic header does not match")
+    if len(b) < 5:
+        raise short
     ver = b[4]
     if ver < 2:
         return (b[5] if len(b) > 5 else 0), 0  # wrapped version byte follows; dtype byte after it
     pos = 5
     uniform = 0
     if ver >= 3:
+        if pos >= len(b):
+            raise short
         uniform = b[pos]; pos += 1
     bits = int.from_bytes(b[pos:pos + 10], "little")
     power = 1 + (bits & 63)
     n_hint = (bits >> 6) & ((1 << power) - 1)
     pos += (6 + power + 7) // 8
+    if pos >= len(b):
+        raise short
     major = b[pos]; pos += 1
     if major >= 4:
         pos += 1
+        if pos > len(b):
+            raise short
+    if pos >= len(data):   # not even the terminator byte (standalone/decompressor.rs:190-200)
+        raise short
     first = b[pos] if pos < len(b) else 0
+    if uniform and first and first != uniform:   # standalone/decompressor.rs:200-210, with the reference's words
+        raise RuntimeError(f"pco error: pco Corruption error: chunk's number type of {first} does not match file's uniform number type of "
+                           f"{_TYPE_NAMES.get(uniform, uniform)}")
     return (uniform or first), n_hint
 
 

@@ -198,3 +198,32 @@ def test_argument_errors(P):   # test_standalone.py:185-199
     rng = np.random.default_rng(1)
     with pytest.raises(TypeError, match="1D"):
         P.standalone.simple_compress(rng.normal(size=[10, 11]), P.ChunkConfig())
+    with pytest.raises(TypeError, match="2D float64 numpy array could not be cast to 1D"):
+        P.standalone.simple_compress(rng.normal(size=[10, 11]), P.ChunkConfig())
+    with pytest.raises(TypeError, match="not contiguous"):   # test_standalone.py:201-203
+        P.standalone.simple_compress(rng.normal(size=20)[::2], P.ChunkConfig())
+
+
+def test_simple_decompress_errors_with_the_reference_words(P):   # test_standalone.py:81-114, on the reference's own asset
+    path = os.path.join(HERE, "golden", "ref_assets", "v0_4_5_uniform_type.pco")
+    compressed = bytearray(open(path, "rb").read())
+    # byte 5 is the uniform number type, byte 8 the first chunk's number type
+    with pytest.raises(RuntimeError, match="InsufficientData"):
+        P.standalone.simple_decompress(bytes(compressed[:8]))
+    compressed[8] = 99
+    with pytest.raises(RuntimeError, match="chunk's number type of 99 does not match file's uniform number type of U32"):
+        P.standalone.simple_decompress(bytes(compressed))
+    compressed[8] = 0   # a file with a uniform type and no chunks: an empty array of that type
+    out = P.standalone.simple_decompress(bytes(compressed))
+    assert out.dtype == np.uint32 and out.size == 0
+    compressed[5] = 0   # no uniform type, no chunk: None
+    assert P.standalone.simple_decompress(bytes(compressed)) is None
+    # every error of the library carries the reference's ErrorKind name in the reference's sentence (pco_python/src/utils.rs:78)
+    good = bytearray(open(path, "rb").read())
+    with pytest.raises(RuntimeError, match=r"pco error: pco (InsufficientData|Corruption) error"):
+        P.standalone.simple_decompress(bytes(good[:-3]))
+
+
+def test_decompress_without_n_hint(P):   # test_standalone.py:176-182: old files have no n_hint
+    compressed = open(os.path.join(HERE, "golden", "ref_assets", "v0_0_0_classic.pco"), "rb").read()
+    assert len(P.standalone.simple_decompress(compressed)) == 2000
