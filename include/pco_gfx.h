@@ -98,12 +98,16 @@ typedef struct PcoChunkConfigEx {
   uint32_t delta_order;
   uint64_t max_page_n;        /* PagingSpec::EqualPagesUpTo; 0 => 2^18 */
   uint32_t enable_8_bit;
-  uint32_t flags;             /* PCO_GFX_CFG_* bits; 0 = the reference's ChunkConfig and nothing else */
+  uint32_t flags;             /* PCO_GFX_CFG_* bits; 0 = the reference's ChunkConfig and nothing else.  ZERO-INITIALISE the struct: bits
+                                 this library does not know are rejected with PCO_GFX_INVALID_ARGUMENT (so that a later flag is never
+                                 silently ignored by an older library, and an uninitialised word never silently turns a mode on) */
 } PcoChunkConfigEx;
 /* Strict histograms: replay the reference's quickselect (histograms.rs:208-280, sort_utils.rs) pivot by pivot on the device, so that
  * the chunk's bytes equal the reference's even on input ORDERS that send its histogram into the heapsort branch (histograms.rs:248-258),
  * the one place where the default (sort-free, order-independent) histogram kernels can differ from it.  Costs several passes over a
- * private copy of every latent variable; see DESIGN.md section 2 for when it matters (an order built against the pivot rule). */
+ * private copy of every latent variable; see DESIGN.md section 2 for when it matters (an order built against the pivot rule).
+ * PCO_GFX_STRICT_HISTOGRAM=1 in the environment (read once, when the library is loaded) sets it for every call of the process -- for
+ * callers of the reference's own three-function ABI, whose PcoChunkConfig has no field for it. */
 #define PCO_GFX_CFG_STRICT_HISTOGRAM 1u
 
 /* Detailed status of the last failing call on this thread (errors.rs:8-24). */
@@ -216,7 +220,8 @@ void pco_gfx_release_workspace(void);
 size_t pco_gfx_workspace_bytes(void);
 /* How many (chunk, latent variable) histograms of this thread's PCO_GFX_CFG_STRICT_HISTOGRAM calls on the current device replayed the
  * reference's heapsort branch (histograms.rs:248-258) since the workspace was created: 0 on any data that was not ordered against the
- * pivot rule.  Waits for the thread's last call. */
+ * pivot rule.  Waits for the thread's last call.  (This counter and the two below are 64-bit totals kept on the host: they survive
+ * pco_gfx_release_workspace and the library's own re-allocations.) */
 unsigned long long pco_gfx_strict_histogram_fallbacks(void);
 /* How many chunks of this thread's decode calls on the current device were marked for the expander kernel that runs UNDER the tANS walk
  * (decode_trail.hip) and had to be expanded after it instead, because their expander wave saw no walker beside it for ~55 ms (a device shared with
@@ -275,6 +280,46 @@ enum PcoError pco_page_decompressor_new(PcoGfxChunkDecompressor*, const void* sr
 enum PcoError pco_page_decompressor_read(PcoGfxPageDecompressor*, void* dst, size_t dst_len, size_t* n_processed, int* finished);
 size_t pco_page_decompressor_consumed(const PcoGfxPageDecompressor*);
 void pco_page_decompressor_free(PcoGfxPageDecompressor*);
+
+/* ------------------------------------------------------------------------------------------
+ * 4b. The wrapped surface, BATCHED, on DEVICE buffers: what an embedding format (the reference's `pcopage` bench codec,
+ *     pco_cli/src/bench/codecs/pcopage.rs:33-113; a Parquet- or Zarr-style container) calls once per row group.  A chunk is cut into
+ *     pages by PagingSpec::EqualPagesUpTo(config->max_page_n) (chunk_config.rs:145-161); every page is an independent tANS stream
+ *     with its own delta state (wrapped/chunk_compressor.rs:164-213,659-705), so the pages of one chunk encode and decode side by side.
+ *     The bytes are exactly ChunkCompressor::write_meta's and write_page's.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct PcoGfxPageInfo {
+  uint64_t offset;   /* where the piece starts, in bytes from the chunk's dst */
+  uint64_t len;      /* bytes written */
+  uint64_t n;        /* numbers in the page (0 for the ChunkMeta entry) */
+  uint32_t status;   /* enum PcoGfxStatus */
+  uint32_t aux;      /* bit0 = the chunk fell back to the uncompressed-equivalent encoding */
+} PcoGfxPageInfo;
+/* number of pages EqualPagesUpTo(max_page_n) cuts n numbers into (0 => 2^18 per page), and the dst_cap a chunk of n numbers needs */
+size_t pco_gfx_wrapped_n_pages(size_t n, uint64_t max_page_n);
+size_t pco_gfx_wrapped_chunk_cap(size_t n, unsigned char dtype, const PcoChunkConfigEx* config);
+/* wrapped::FileCompressor::chunk_compressor + write_meta + write_page for every page, n_tasks chunks in one pass.  tasks[i].dst (DEVICE,
+ * 16-byte aligned, dst_cap >= pco_gfx_wrapped_chunk_cap) receives the ChunkMeta at offset 0 and the pages at the offsets reported.
+ * `infos` (HOST) gets 1 + pco_gfx_wrapped_n_pages(tasks[i].n, max_page_n) entries per chunk, chunk after chunk: the ChunkMeta's, then one
+ * per page.  Synchronous (the call returns when the bytes are there). */
+enum PcoError pco_gfx_compress_wrapped_chunks(size_t n_tasks, const PcoGfxEncodeTask* tasks, const PcoChunkConfigEx* config,
+                                              PcoGfxPageInfo* infos, void* stream);
+
+typedef struct PcoGfxPageTask {
+  const void* meta;      /* DEVICE: the chunk's ChunkMeta bytes (shared by the chunk's pages) */
+  uint64_t meta_len;
+  const void* page;      /* DEVICE: one page; 16 readable bytes past page_len */
+  uint64_t page_len;
+  void* dst;             /* DEVICE: room for page_n numbers */
+  uint64_t page_n;       /* the page's count of numbers: the wrapping format stores it (wrapped/chunk_decompressor.rs:74-80) */
+  uint32_t dtype;
+  uint32_t format_major; /* of the wrapped header (pco_wrapped_read_header); the current one is 4 */
+} PcoGfxPageTask;
+/* ChunkDecompressor::page_decompressor + PageDecompressor::read of the whole page, n_tasks pages in one pass (pages of one chunk or of
+ * many; each names its chunk's ChunkMeta).  results[i].n_out = page_n, .consumed = the page's bytes.  results / d_results as in
+ * pco_gfx_decompress_chunks. */
+enum PcoError pco_gfx_decompress_pages(size_t n_tasks, const PcoGfxPageTask* tasks, PcoGfxTaskResult* results,
+                                       PcoGfxTaskResult* d_results, void* stream);
 
 /* ChunkMeta accessors (wrapped/chunk_compressor.rs:549 ChunkCompressor::meta, wrapped/chunk_decompressor.rs:62 ChunkDecompressor::meta,
  * standalone/decompressor.rs:288): what the reference's `ChunkMeta` says about a chunk -- mode, delta encoding, and per latent variable the

@@ -51,6 +51,15 @@ KIND_NAMES = {ST_CORRUPTION: "Corruption", ST_INSUFFICIENT_DATA: "InsufficientDa
               ST_UNSUPPORTED: "Unsupported", ST_DEVICE_ERROR: "DeviceError"}
 
 
+class PageInfo(C.Structure):   # PcoGfxPageInfo: one piece (ChunkMeta or page) of a chunk written by pco_gfx_compress_wrapped_chunks
+    _fields_ = [("offset", C.c_uint64), ("len", C.c_uint64), ("n", C.c_uint64), ("status", C.c_uint32), ("aux", C.c_uint32)]
+
+
+class PageTask(C.Structure):   # PcoGfxPageTask: one wrapped page for pco_gfx_decompress_pages
+    _fields_ = [("meta", C.c_void_p), ("meta_len", C.c_uint64), ("page", C.c_void_p), ("page_len", C.c_uint64),
+                ("dst", C.c_void_p), ("page_n", C.c_uint64), ("dtype", C.c_uint32), ("format_major", C.c_uint32)]
+
+
 class PcoGfxError(RuntimeError):
     """The reference's Python binding raises RuntimeError("pco error: pco <ErrorKind> error: <message>") (pco_python/src/utils.rs:78 over
     errors.rs:52-60): the same text here, so that callers (and the reference's own tests) that match on the kind keep working."""
@@ -107,6 +116,12 @@ def lib():
         L.pco_gfx_write_standalone_footer.argtypes = [C.c_void_p, C.c_size_t]
         L.pco_wrapped_write_header.restype = C.c_size_t
         L.pco_wrapped_write_header.argtypes = [C.c_void_p, C.c_size_t]
+        L.pco_gfx_wrapped_n_pages.restype = C.c_size_t
+        L.pco_gfx_wrapped_n_pages.argtypes = [C.c_size_t, C.c_uint64]
+        L.pco_gfx_wrapped_chunk_cap.restype = C.c_size_t
+        L.pco_gfx_wrapped_chunk_cap.argtypes = [C.c_size_t, C.c_ubyte, C.c_void_p]
+        L.pco_gfx_compress_wrapped_chunks.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pco_gfx_decompress_pages.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

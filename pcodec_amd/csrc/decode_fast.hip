@@ -171,7 +171,8 @@ struct FrontOut {
 
 // Everything before the page body for one task, executed by the whole wave on behalf of group q.
 template <class L, uint32_t KQ, bool kInline>
-__device__ __forceinline__ void fast_front_impl(const PcoGfxDecodeTask& task, uint32_t q, DecPlan PCO_GLOBAL* plan, uint8_t PCO_GLOBAL* bins_out, FrontOut& out) {
+__device__ __forceinline__ void fast_front_impl(const PcoGfxDecodeTask& task, uint32_t q, DecPlan PCO_GLOBAL* plan, uint8_t PCO_GLOBAL* bins_out, FrontOut& out,
+                                                gcptr_u8 meta_p, uint64_t meta_len) {   // meta_p: a wrapped page whose ChunkMeta has a buffer of its own (MetaRef); else nullptr
   constexpr uint32_t kGrpBytes = WalkCfg<KQ>::kGrpBytes, kGrpTblBytes = WalkCfg<KQ>::kGrpTblBytes;
   const uint32_t lane = lane_id();
   gcptr_u8 src = (gcptr_u8)task.src;
@@ -179,16 +180,26 @@ __device__ __forceinline__ void fast_front_impl(const PcoGfxDecodeTask& task, ui
   const uint32_t dtype = uni(task.dtype), flags = uni(task.flags);
   const uint64_t dst_cap = uni((uint64_t)task.dst_cap);
   constexpr uint32_t LB = LBits<L>::v;
+  const bool wrapped = (flags & PCO_GFX_TASK_WRAPPED_PAGE) != 0;
   MetaReader mr{src, src_len, 0};
+  if (wrapped && meta_p != nullptr) mr = MetaReader{meta_p, meta_len, 0};
   uint32_t status = PCO_GFX_OK, format_major = 4, uniform_type = 0;
   out.status = PCO_GFX_OK; out.n = 0; out.bitpos = 0;
   for (int v = 0; v < 3; v++) for (int j = 0; j < 4; j++) out.states[v][j] = 0;
   out.mode_kind = kClassic;
   VarInfo PCO_LDS* vinfo = (VarInfo PCO_LDS*)(walk_lds<KQ>() + q * kGrpBytes + kGrpVarOff);
-  auto fail = [&](uint32_t s) { out.status = s; if (lane == 0) { plan->status = s; plan->consumed = mr.bit >> 3; plan->n = 0; plan->fused = 0; plan->more = 0; } };
+  // (a wrapped page that goes wrong -- here or in its body -- is handed to the single-kernel decoder, which also says how many batches came out
+  //  before the failure: PageDecompressor::read's error timing, wrapped/page_decompressor.rs:193-221)
+  auto fail = [&](uint32_t s) { if (wrapped && s != kStatusRetryK4) s = kStatusRetryLegacy; out.status = s; if (lane == 0) { plan->status = s; plan->consumed = mr.bit >> 3; plan->n = 0; plan->fused = 0; plan->more = 0; } };
   out.moments[0][0] = out.moments[0][1] = out.moments[1][0] = out.moments[1][1] = 0;
   if (dtype_bits(dtype) != (int)LB) { fail(PCO_GFX_INVALID_ARGUMENT); return; }
-  if (flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY)) { fail(kStatusRetryLegacy); return; }
+  if (flags & PCO_GFX_TASK_META_ONLY) { fail(kStatusRetryLegacy); return; }
+  uint32_t n = 0;
+  if (wrapped) {   // wrapped surface: ChunkMeta, then one page of exactly dst_cap numbers; the format version comes from the caller (wrapped/file_decompressor.rs:44-52)
+    format_major = (flags >> 8) & 0xffu;
+    if (dst_cap == 0 || dst_cap > kMaxEntries || format_major > 4) { fail(kStatusRetryLegacy); return; }
+    n = (uint32_t)dst_cap;
+  } else
   if (flags & PCO_GFX_TASK_HAS_FILE_HEADER) {  // standalone/decompressor.rs:85-137
     const uint32_t magic = (uint32_t)mr.read(32);
     if (!mr.in_bounds()) status = PCO_GFX_INSUFFICIENT_DATA; else if (magic != 0x216f6370u) status = PCO_GFX_CORRUPTION;
@@ -210,14 +221,15 @@ __device__ __forceinline__ void fast_front_impl(const PcoGfxDecodeTask& task, ui
     if (status) { fail(status); return; }
   } else if (src_len == 0) { fail(kStatusRetryLegacy); return; }  // empty stream: zero chunks
   else if ((flags & PCO_GFX_TASK_ONE_CHUNK) && ((flags >> 8) & 0xffu) != 0) format_major = (flags >> 8) & 0xffu;   // the caller read the file's header itself
-  // chunk preamble (standalone/decompressor.rs:190-231)
-  const uint32_t tb = (uint32_t)mr.read(8);
-  if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
-  if (tb == 0) { fail(kStatusRetryLegacy); return; }  // empty file: the general path reports it
-  if ((uniform_type && uniform_type != tb) || tb != dtype) { fail(PCO_GFX_CORRUPTION); return; }
-  const uint32_t n = (uint32_t)mr.read(kBitsNEntries) + 1;
-  if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
-  if (n > dst_cap) { fail(PCO_GFX_INVALID_ARGUMENT); return; }
+  if (!wrapped) {   // chunk preamble (standalone/decompressor.rs:190-231)
+    const uint32_t tb = (uint32_t)mr.read(8);
+    if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
+    if (tb == 0) { fail(kStatusRetryLegacy); return; }  // empty file: the general path reports it
+    if ((uniform_type && uniform_type != tb) || tb != dtype) { fail(PCO_GFX_CORRUPTION); return; }
+    n = (uint32_t)mr.read(kBitsNEntries) + 1;
+    if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
+    if (n > dst_cap) { fail(PCO_GFX_INVALID_ARGUMENT); return; }
+  }
   const uint32_t num_kind = dtype_kind(dtype);
   // ChunkMeta (metadata/chunk.rs:127-174), as in decode_kernel.hip::decode_chunk
   const uint32_t mode_kind = (uint32_t)mr.read(kBitsModeVariant);
@@ -278,6 +290,7 @@ __device__ __forceinline__ void fast_front_impl(const PcoGfxDecodeTask& task, ui
   }
   if (!mr.drain_empty_byte()) { if (mr.in_bounds()) { fail(PCO_GFX_CORRUPTION); return; } }
   if (!mr.in_bounds()) { fail(PCO_GFX_INSUFFICIENT_DATA); return; }
+  if (wrapped && meta_p != nullptr) mr = MetaReader{src, src_len, 0};   // the page has a buffer of its own: every bit position from here on is relative to task.src
   if (dkind == kDeltaLookback) {  // metadata/chunk.rs:38-57
     const uint32_t nb0 = uni(vinfo[0].n_bins);
     const uint64_t PCO_GLOBAL* lw = (const uint64_t PCO_GLOBAL*)bins_out;
@@ -336,7 +349,7 @@ __device__ __forceinline__ void fast_front_impl(const PcoGfxDecodeTask& task, ui
 }
 
 template <class L, uint32_t KQ>
-__device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q, DecPlan PCO_GLOBAL* plan, uint8_t PCO_GLOBAL* bins_out, FrontOut& out) { fast_front_impl<L, KQ, false>(task, q, plan, bins_out, out); }
+__device__ __noinline__ void fast_front(const PcoGfxDecodeTask& task, uint32_t q, DecPlan PCO_GLOBAL* plan, uint8_t PCO_GLOBAL* bins_out, FrontOut& out, gcptr_u8 meta_p, uint64_t meta_len) { fast_front_impl<L, KQ, false>(task, q, plan, bins_out, out, meta_p, meta_len); }
 
 // ---------------------------------------------------------------------------------------------------------
 // dec_walk_kernel: kWQ chunks per wave, four lanes per chunk (lane 4c+j walks tANS chain j of chunk slot c).
@@ -436,14 +449,19 @@ __device__ unsigned long long g_walk_timing[8];
 // that fit a wave's registers, delta order <= 2) is the publishing walker's, after it has parsed the metadata.
 // Returns bit 0: a one-variable candidate (classic mode), bit 1: a two-variable candidate (int-mult / float-mult / float-quant: the blocks
 // dec_trail_kernel<L, true> follows).
-__device__ __forceinline__ uint32_t block_trail_kinds(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, uint32_t wb) {
+__device__ __forceinline__ uint32_t block_trail_kinds(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, uint32_t wb, const MetaRef* metas) {
   const uint32_t lane = lane_id(), bi = wb * 8 + (lane & 7u);
   bool one = false, two = false;
   if (lane < 8 && bi < n_ids) {
-    const PcoGfxDecodeTask t = tasks[task_ids ? task_ids[bi] : bi];
-    const uint32_t fmt = (t.flags & PCO_GFX_TASK_ONE_CHUNK) && ((t.flags >> 8) & 0xffu) ? (t.flags >> 8) & 0xffu : 4u;
-    if ((t.flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY | PCO_GFX_TASK_HAS_FILE_HEADER)) == 0 && t.src_len >= 24 && fmt >= 3) {
-      const uint64_t w = load_u64_le((gcptr_u8)t.src + 4);   // mode (4 bits) | [base (the type's bits) or k (8)] | delta variant (4) | [order (3) | secondary uses delta (1)] | ans_size_log (4) | n_bins (15)
+    const uint32_t ti = task_ids ? task_ids[bi] : bi;
+    const PcoGfxDecodeTask t = tasks[ti];
+    const bool wrapped = (t.flags & PCO_GFX_TASK_WRAPPED_PAGE) != 0;
+    const uint32_t fmt = wrapped ? (t.flags >> 8) & 0xffu : ((t.flags & PCO_GFX_TASK_ONE_CHUNK) && ((t.flags >> 8) & 0xffu) ? (t.flags >> 8) & 0xffu : 4u);
+    // where the ChunkMeta starts: behind the 4-byte chunk preamble of a standalone chunk, at the first byte of a wrapped page's metadata
+    gcptr_u8 mp = (gcptr_u8)t.src + 4; uint64_t mlen = t.src_len >= 4 ? t.src_len - 4 : 0;
+    if (wrapped) { if (metas != nullptr && metas[ti].p != nullptr) { mp = (gcptr_u8)metas[ti].p; mlen = metas[ti].len; } else { mp = (gcptr_u8)t.src; mlen = t.src_len; } }
+    if ((t.flags & (PCO_GFX_TASK_META_ONLY | PCO_GFX_TASK_HAS_FILE_HEADER)) == 0 && mlen >= 20 && fmt >= 3 && fmt <= 4) {
+      const uint64_t w = load_u64_le(mp);   // mode (4 bits) | [base (the type's bits) or k (8)] | delta variant (4) | [order (3) | secondary uses delta (1)] | ans_size_log (4) | n_bins (15)
       const uint32_t mode = (uint32_t)w & 15u;
       if (mode == kClassic) {
         const uint32_t dv = (uint32_t)(w >> 4) & 15u;
@@ -451,7 +469,7 @@ __device__ __forceinline__ uint32_t block_trail_kinds(const PcoGfxDecodeTask* ta
         one = (dv == kDeltaNone || dv == kDeltaConsecutive) && n_bins > 1 && n_bins <= kTrailMaxBins;   // (one bin: nothing to walk, nothing to hide the expansion under)
       } else if (mode == kIntMult || mode == kFloatMult || mode == kFloatQuant) {
         const uint32_t at = 4u + (mode == kFloatQuant ? kBitsQuantK : (uint32_t)dtype_bits(t.dtype));   // where the delta variant starts, in bits from byte 4
-        const uint64_t w2 = load_u64_le((gcptr_u8)t.src + 4 + (at >> 3));
+        const uint64_t w2 = load_u64_le(mp + (at >> 3));
         const uint32_t dv = (uint32_t)(w2 >> (at & 7u)) & 15u;
         two = dv == kDeltaNone || dv == kDeltaConsecutive;
       }
@@ -459,8 +477,8 @@ __device__ __forceinline__ uint32_t block_trail_kinds(const PcoGfxDecodeTask* ta
   }
   return (uni((uint32_t)__any(one)) ? 1u : 0u) | (uni((uint32_t)__any(two)) ? 2u : 0u);
 }
-__device__ __forceinline__ bool block_has_trail_candidate(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, uint32_t wb) {
-  return block_trail_kinds(tasks, task_ids, n_ids, wb) != 0;
+__device__ __forceinline__ bool block_has_trail_candidate(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, uint32_t wb, const MetaRef* metas) {
+  return block_trail_kinds(tasks, task_ids, n_ids, wb, metas) != 0;
 }
 
 #ifdef PCO_TRAIL_TIMING   // (measurement builds: when every walker block and every expander block started and ended, on the device-wide 100 MHz clock)
@@ -473,7 +491,7 @@ __device__ unsigned long long g_trail_stamps[4][kTrailStampBlocks];   // walker 
 template <class L, uint32_t kWQ, bool kTrail>
 __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                               uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
-                                              uint32_t accept_status, PcoGfxTaskResult* results, uint32_t* progress) {
+                                              uint32_t accept_status, PcoGfxTaskResult* results, uint32_t* progress, const MetaRef* metas) {
   static_assert(!kTrail || kWQ == 8, "the trailing expanders follow the eight-chunk walker");
   const uint32_t wb = walk_block_id();   // (the wave's "block": blockIdx.x in the one-wave kernels)
   if ((uint64_t)wb * kWQ >= n_ids) return;   // (the spare waves of the last four-wave workgroup)
@@ -484,12 +502,12 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
   const uint32_t lane = lane_id();
   const uint32_t slot = lane >> 2, j = lane & 3;
   if constexpr (kTrail) {   // the blocks without a candidate belong to the ordinary walker (launched beside this one); their expanders are told at once
-    if (!block_has_trail_candidate(tasks, task_ids, n_ids, wb)) {
+    if (!block_has_trail_candidate(tasks, task_ids, n_ids, wb, metas)) {
       if (lane < 8) __hip_atomic_store(progress + (uint64_t)wb * kTrailProgressStride + lane, kTrailDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
   } else if constexpr (kWQ == 8) {
-    if (progress != nullptr && accept_status == 0 && block_has_trail_candidate(tasks, task_ids, n_ids, wb)) return;   // (progress != nullptr: the publishing walker runs too and takes this block)
+    if (progress != nullptr && accept_status == 0 && block_has_trail_candidate(tasks, task_ids, n_ids, wb, metas)) return;   // (progress != nullptr: the publishing walker runs too and takes this block)
   }
   if constexpr (kTrail) PCO_TRAIL_STAMP(0, wb);
   // ---- phase 0: metadata + tables, one task at a time with the whole wave; slot q belongs to lanes 4q..4q+3 ----
@@ -505,8 +523,10 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
     if (accept_status != 0 && uni(((const DecPlan PCO_GLOBAL*)plans + ti)->status) != accept_status) continue;   // an earlier stage dealt with this task
     const PcoGfxDecodeTask task = tasks[ti];
     FrontOut fo;
-    if constexpr (kTrail) fast_front_impl<L, kWQ, true>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);
-    else fast_front<L, kWQ>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo);
+    gcptr_u8 meta_p = metas != nullptr ? (gcptr_u8)metas[ti].p : (gcptr_u8) nullptr;
+    const uint64_t meta_len = metas != nullptr ? uni((uint64_t)metas[ti].len) : 0;
+    if constexpr (kTrail) fast_front_impl<L, kWQ, true>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo, meta_p, meta_len);
+    else fast_front<L, kWQ>(task, q, (DecPlan PCO_GLOBAL*)plans + ti, (uint8_t PCO_GLOBAL*)bins_area + (uint64_t)ti * kBinsAreaPerTask, fo, meta_p, meta_len);
     if (slot == q) {
       my_ti = ti; my_active = fo.status == PCO_GFX_OK ? 1u : 0u; my_front_ok = my_active; my_n = fo.n; my_bitpos = fo.bitpos; my_mode = fo.mode_kind;
       my_len = task.src_len; my_flags = task.flags; my_src = (gcptr_u8)task.src;
@@ -756,9 +776,11 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
         if (sh) { const uint64_t byte = bit >> 3; const uint32_t b = byte < my_len ? my_src[byte] : 0u; if ((b >> sh) != 0) status = PCO_GFX_CORRUPTION; bit += 8 - sh; }
         if (bit > my_len * 8) status = PCO_GFX_INSUFFICIENT_DATA;
       }
+      if ((my_flags & PCO_GFX_TASK_WRAPPED_PAGE) && status != PCO_GFX_OK) status = kStatusRetryLegacy;   // (the single-kernel decoder reports how far the page got: see fast_front_impl)
       if (status == PCO_GFX_OK) {
         uint64_t byte = bit >> 3;
-        if (my_flags & PCO_GFX_TASK_ONE_CHUNK) {   // this chunk only: say whether another follows (the caller comes back for it)
+        if (my_flags & PCO_GFX_TASK_WRAPPED_PAGE) { }   // a page ends where its last batch ends (+ padding); what follows is the caller's (PageDecompressor::into_src)
+        else if (my_flags & PCO_GFX_TASK_ONE_CHUNK) {   // this chunk only: say whether another follows (the caller comes back for it)
           if (byte < my_len && my_src[byte] != 0) plan->more = 1u;
           else if (byte < my_len) { byte += 1; plan->more = 2u; }     // the terminator (aux bit 1: it was there and is consumed)
           else if (my_flags & PCO_GFX_TASK_HAS_FILE_HEADER) status = PCO_GFX_INSUFFICIENT_DATA;
@@ -787,8 +809,8 @@ __device__ __forceinline__ void dec_walk_body(const PcoGfxDecodeTask* tasks, con
 template <class L, uint32_t kWQ>
 __global__ __launch_bounds__(256) void dec_walk_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                                       uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
-                                                      uint32_t accept_status, PcoGfxTaskResult* results, uint32_t* split) {
-  dec_walk_body<L, kWQ, false>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, accept_status, results, split);
+                                                      uint32_t accept_status, PcoGfxTaskResult* results, uint32_t* split, const MetaRef* metas) {
+  dec_walk_body<L, kWQ, false>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, accept_status, results, split, metas);
 }
 // The walker that publishes its progress to the trailing expanders: at most 128 VGPRs (four waves per SIMD's worth -- what the ordinary
 // walker takes), so that two expander waves of up to 192 fit beside it on every SIMD.  Tighter caps do not pay: at 80 or 96 the per-round
@@ -798,8 +820,8 @@ __global__ __launch_bounds__(256) void dec_walk_kernel(const PcoGfxDecodeTask* t
 template <class L>
 __global__ __launch_bounds__(256) PCO_TRAIL_WALK_ATTR void dec_walk_trail_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                                       uint8_t* bins_area, uint8_t* sym_area, uint64_t sym_stride, uint64_t* offpos_area, uint64_t offpos_stride,
-                                                      PcoGfxTaskResult* results, uint32_t* progress) {
-  dec_walk_body<L, 8, true>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, 0u, results, progress);
+                                                      PcoGfxTaskResult* results, uint32_t* progress, const MetaRef* metas) {
+  dec_walk_body<L, 8, true>(tasks, task_ids, n_ids, plans, bins_area, sym_area, sym_stride, offpos_area, offpos_stride, 0u, results, progress, metas);
 }
 
 // A full batch of 64-bit numbers, four per lane in element order, stored as two instructions that each cover one contiguous KB (lane l:

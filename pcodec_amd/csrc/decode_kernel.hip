@@ -25,6 +25,10 @@ namespace pcogfx {
 #define PCO_LDS __attribute__((address_space(3)))
 template <bool kLds, class T> using tptr = std::conditional_t<kLds, T PCO_LDS*, T PCO_GLOBAL*>;
 
+// Where a wrapped page's ChunkMeta lives when it is not in front of the page (pco_gfx_decompress_pages: one ChunkMeta, many pages); indexed
+// like the tasks.  p == nullptr: the task's src starts with the ChunkMeta (PCO_GFX_TASK_WRAPPED_PAGE as the host-buffer entry points use it).
+struct MetaRef { const void* p; uint64_t len; };
+
 struct VarInfo {
   uint32_t present, latent_bits, ans_size_log, n_bins, max_ob;
   uint32_t delta_kind, delta_order, window_n_log, state_n_log;  // LatentVarDeltaEncoding
@@ -297,9 +301,10 @@ __device__ __forceinline__ L join_one(uint32_t mode_kind, uint32_t num_kind, L b
 struct PageParams {
   uint32_t mode_kind, mode_k, num_kind, n;
   uint64_t mode_base;
-  uint64_t dict_byte; uint32_t dict_n;     // Dict mode: the dictionary's first byte in src and its length (metadata/mode.rs:138-165)
+  uint64_t dict_byte; uint32_t dict_n;     // Dict mode: the dictionary's first byte in the ChunkMeta's buffer and its length (metadata/mode.rs:138-165)
   uint32_t conv_order, conv_quant;         // Conv1 delta (metadata/delta_encoding.rs): weights and bias live in LDS (kLdsConvOff)
   void PCO_GLOBAL* sec_hist;               // lookback with a delta'd SECONDARY variable: n latents of scratch for its history (else null)
+  gcptr_u8 dict_src = nullptr;             // ... and that buffer (the page body may live in a buffer of its own: PcoGfxPageTask)
   uint32_t* progress = nullptr;            // (wrapped pages) where to say how far a page got that then failed: 1 + the numbers of the batches before the failing one, 0 = before its first batch was reached
 };
 // Conv1 parameters in LDS, in the lookback path's "parent" area (the two deltas exclude each other): i64 bias | i64 weights[32]
@@ -610,7 +615,7 @@ __device__ __noinline__ void decode_page_body_dict(gcptr_u8 src, uint64_t src_le
   constexpr uint32_t kBytes = sizeof(L);
   auto dict_value = [&](uint32_t index) -> L {
     L v = 0;
-    gcptr_u8 p = src + pp.dict_byte + (uint64_t)index * kBytes;
+    gcptr_u8 p = pp.dict_src + pp.dict_byte + (uint64_t)index * kBytes;
     for (uint32_t b = 0; b < kBytes; b++) v |= (L)((L)p[b] << (8 * b));   // (the dictionary sits at an arbitrary byte offset)
     return from_latent_ordered<L>(v, num_kind);
   };
@@ -700,7 +705,8 @@ __device__ __noinline__ void decode_page_body_dict(gcptr_u8 src, uint64_t src_le
 template <class L>
 __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaReader& mr, uint32_t lds_table_budget,
                                          gptr_u8 tbl_ws, uint32_t format_major, uint32_t dtype, uint32_t n, L PCO_GLOBAL* dst, uint32_t& status,
-                                         bool meta_only, void PCO_GLOBAL* sec_hist = nullptr, uint32_t need_hist_status = PCO_GFX_UNSUPPORTED, uint32_t* progress = nullptr) {
+                                         bool meta_only, void PCO_GLOBAL* sec_hist = nullptr, uint32_t need_hist_status = PCO_GFX_UNSUPPORTED, uint32_t* progress = nullptr,
+                                         gcptr_u8 page_src = nullptr, uint64_t page_len = 0) {   // page_src: the page lives in a buffer of its own (src holds the ChunkMeta only); mr is re-seated on it
   const uint32_t lane = lane_id();
   const uint32_t num_kind = dtype_kind(dtype);
   constexpr uint32_t LB = LBits<L>::v;
@@ -845,14 +851,16 @@ __device__ __noinline__ void decode_chunk(gcptr_u8 src, uint64_t src_len, MetaRe
   // (the only kind an encoder writes, mode/dict.rs:12-33) always does; a padded one on an 8- / 16-bit type is refused.
   if (dict && dkind == kDeltaLookback && LB < 32 && dict_n > (1u << LB)) { status = PCO_GFX_UNSUPPORTED; return; }
   if (meta_only) return;
-  PageParams pp{mode_kind, mode_k, num_kind, n, (uint64_t)mode_base, dict_byte, dict_n, dorder, conv_quant, sec_hist, progress};
+  PageParams pp{mode_kind, mode_k, num_kind, n, (uint64_t)mode_base, dict_byte, dict_n, dorder, conv_quant, sec_hist, src, progress};
+  gcptr_u8 body_src = src; uint64_t body_len = src_len;
+  if (page_src != nullptr) { body_src = page_src; body_len = page_len; mr = MetaReader{page_src, page_len, 0}; }   // wrapped/page_decompressor.rs:82-113: a page is read from its own source
   if (dict) {
-    if (lds_tables) decode_page_body_dict<L, true>(src, src_len, mr, tbl_lds, pp, dst, status);
-    else decode_page_body_dict<L, false>(src, src_len, mr, tbl_ws, pp, dst, status);
+    if (lds_tables) decode_page_body_dict<L, true>(body_src, body_len, mr, tbl_lds, pp, dst, status);
+    else decode_page_body_dict<L, false>(body_src, body_len, mr, tbl_ws, pp, dst, status);
     return;
   }
-  if (lds_tables) decode_page_body<L, true>(src, src_len, mr, tbl_lds, pp, dst, status);
-  else decode_page_body<L, false>(src, src_len, mr, tbl_ws, pp, dst, status);
+  if (lds_tables) decode_page_body<L, true>(body_src, body_len, mr, tbl_lds, pp, dst, status);
+  else decode_page_body<L, false>(body_src, body_len, mr, tbl_ws, pp, dst, status);
 }
 
 // One wave per task; a task is a stream of >= 1 standalone chunks of number width sizeof(L).
@@ -863,7 +871,7 @@ template <class L>
 __global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results, const uint32_t* task_ids,
                                                         uint32_t n_ids, uint32_t lds_table_budget, uint8_t* tbl_ws_base,
                                                         const uint32_t* only_if_status, uint32_t status_stride_u32, uint32_t status_value,
-                                                        uint8_t* hist_base, const uint64_t* hist_off, uint32_t need_hist_status) {
+                                                        uint8_t* hist_base, const uint64_t* hist_off, uint32_t need_hist_status, const MetaRef* metas) {
   const uint32_t lane = lane_id();
   for (uint32_t bi = blockIdx.x; bi < n_ids; bi += gridDim.x) {
     const uint32_t ti = task_ids ? task_ids[bi] : bi;
@@ -889,8 +897,13 @@ __global__ __launch_bounds__(64, PCO_DEC_MIN_WAVES) void pco_decode_kernel(const
       if (!status) {
         gptr_u8 tbl_ws = tbl_ws_base ? (gptr_u8)tbl_ws_base + (uint64_t)blockIdx.x * kTblWsBytes : (gptr_u8) nullptr;
         uint32_t progress = 0;
-        decode_chunk<L>(src, src_len, mr, lds_table_budget, tbl_ws, format_major, dtype, n, (L PCO_GLOBAL*)task.dst, status, meta_only,
-                        hist_base ? (void PCO_GLOBAL*)(hist_base + hist_off[bi]) : (void PCO_GLOBAL*)nullptr, need_hist_status, &progress);
+        // PcoGfxPageTask (pco_gfx_decompress_pages): the ChunkMeta in a buffer of its own, shared by the chunk's pages; src is the page alone
+        gcptr_u8 meta_p = metas != nullptr && !meta_only ? (gcptr_u8)metas[ti].p : (gcptr_u8) nullptr;
+        const uint64_t meta_len = meta_p != nullptr ? uni((uint64_t)metas[ti].len) : 0;
+        if (meta_p != nullptr) mr = MetaReader{meta_p, meta_len, 0};
+        decode_chunk<L>(meta_p != nullptr ? meta_p : src, meta_p != nullptr ? meta_len : src_len, mr, lds_table_budget, tbl_ws, format_major, dtype, n, (L PCO_GLOBAL*)task.dst, status, meta_only,
+                        hist_base ? (void PCO_GLOBAL*)(hist_base + hist_off[bi]) : (void PCO_GLOBAL*)nullptr, need_hist_status, &progress,
+                        meta_p != nullptr ? src : (gcptr_u8) nullptr, src_len);
         status = uni(status); progress = uni(progress);
         if (!status && !meta_only) n_out = n;
         // a page that failed inside its body: the batches before the failing one are in dst (page_decompressor.rs:115-221 hands them out

@@ -421,11 +421,11 @@ template <class L, bool kTwo>
 __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_eu(5, 5))) void dec_trail_kernel(const PcoGfxDecodeTask* tasks, const uint32_t* task_ids, uint32_t n_ids, DecPlan* plans,
                                                                      const uint8_t* bins_area, const uint8_t* sym_area, uint64_t sym_stride,
                                                                      const uint64_t* offpos_area, uint64_t offpos_stride, const uint32_t* progress,
-                                                                     uint32_t n_walk_blocks) {
+                                                                     uint32_t n_walk_blocks, const MetaRef* metas) {
   const uint32_t lane = lane_id(), wave = uni(threadIdx.x >> 6);
   const TrailAreas ar{sym_area, sym_stride, offpos_area, offpos_stride};
   for (uint32_t wb = blockIdx.x; wb < n_walk_blocks; wb += gridDim.x) {
-    if (((block_trail_kinds(tasks, task_ids, n_ids, wb) & 2u) != 0) != kTwo) continue;   // the other kernel's block
+    if (((block_trail_kinds(tasks, task_ids, n_ids, wb, metas) & 2u) != 0) != kTwo) continue;   // the other kernel's block
     if (wave == 0) PCO_TRAIL_STAMP(2, wb);
     TrailChunk<L> S[kTrailSlotsPerWave];
     const uint32_t* pline = progress + (uint64_t)wb * kTrailProgressStride + (lane & 7u);

@@ -310,7 +310,8 @@ __device__ void lit_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32
       L pivot, lhs_ubx, rhs_lbx; bool lhs_ubt, rhs_lbt;
       if (tentative > lbx) { pivot = tentative; lhs_ubx = (L)(tentative - 1); lhs_ubt = false; rhs_lbx = tentative; rhs_lbt = true; }
       else { pivot = (L)(tentative + 1); lhs_ubx = tentative; lhs_ubt = true; rhs_lbx = (L)(tentative + 1); rhs_lbt = false; }
-      const uint32_t lhs = lit_partition<K>(v, len, (K)(pivot - ref));   // (pivot - ref <= 2^15: tentative is a key of at most 15 bits)
+      static_assert(kC16KeyRange <= (1u << 15), "the 16-bit replay carries pivot - ref = key + 1 in a uint16_t: keys must stay below 2^15 (enc_split_kernel<c16>)");
+      const uint32_t lhs = lit_partition<K>(v, len, (K)(pivot - ref));   // (pivot - ref <= kC16KeyRange = 2^15: tentative is a key below it)
       const uint32_t smaller = lhs < len - lhs ? lhs : len - lhs;
       if (1 + smaller < len / 8) {   // was_bad_pivot (sort_utils.rs:124)
         limit -= 1;

@@ -21,6 +21,10 @@
 
 namespace pcogfx {
 
+// Speculative 16-bit latents (enc_split_kernel<c16>): a variable's stored keys are latent - ref, all below this bound.  The strict histogram's
+// 16-bit replay (encode_hist_literal.hip) carries `pivot - ref` = key + 1 in a uint16_t and static_asserts on this constant.
+constexpr uint32_t kC16KeyRange = 32768u;
+
 #ifndef PCO_LDS
 #define PCO_LDS __attribute__((address_space(3)))
 #endif
@@ -399,12 +403,12 @@ __device__ __forceinline__ void enc_split_body(const EncWorkspace& ws, const Pco
       const L t1 = (L)(d[k] - lo1);
       const uint32_t u1 = (uint32_t)t1;
       w1[k] = (uint16_t)u1;
-      if (i < n && i >= order) { if ((uint64_t)t1 >= 32768u) bad = 1; rmin1 = u1 < rmin1 ? u1 : rmin1; rmax1 = u1 > rmax1 ? u1 : rmax1; }
+      if (i < n && i >= order) { if ((uint64_t)t1 >= kC16KeyRange) bad = 1; rmin1 = u1 < rmin1 ? u1 : rmin1; rmax1 = u1 > rmax1 ? u1 : rmax1; }
       if (has_sec) {
         const L t2 = (L)(sec[k] - lo2);
         const uint32_t u2 = (uint32_t)t2;
         w2[k] = (uint16_t)u2;
-        if (i < n) { if ((uint64_t)t2 >= 32768u) bad = 1; rmin2 = u2 < rmin2 ? u2 : rmin2; rmax2 = u2 > rmax2 ? u2 : rmax2; }
+        if (i < n) { if ((uint64_t)t2 >= kC16KeyRange) bad = 1; rmin2 = u2 < rmin2 ? u2 : rmin2; rmax2 = u2 > rmax2 ? u2 : rmax2; }
       }
     }
     if (full) {   // one 16-byte store per variable (2-byte aligned: a page may start at an odd index)
@@ -566,8 +570,8 @@ __device__ __forceinline__ bool presample_bad(const PcoGfxEncodeTask& task, cons
 #pragma unroll
   for (uint32_t k = 0; k < 8; k++) if (k == order) d = a[k];
   d = (L)(d + (order > 0 ? lmid<L>() : (L)0));
-  bool bad = (uint64_t)(L)(d - (L)(ref1 - kBias)) >= 32768u;
-  if (has_sec) bad = bad || (uint64_t)(L)(sec_last - (L)(ref2 - kBias)) >= 32768u;
+  bool bad = (uint64_t)(L)(d - (L)(ref1 - kBias)) >= kC16KeyRange;
+  if (has_sec) bad = bad || (uint64_t)(L)(sec_last - (L)(ref2 - kBias)) >= kC16KeyRange;
   return __any(bad) != 0;
 }
 template <class L>

@@ -120,11 +120,11 @@ static uint32_t g_decode_lds_bytes = 16 * 1024;  // dynamic LDS per wave (fixed 
 static bool g_decode_fast = std::getenv("PCO_GFX_NO_FAST_DECODE") == nullptr;  // A/B switch for the two-kernel path
 // The expanders of the common chunks run on a second stream UNDER the walk (decode_trail.hip); PCO_GFX_DEC_TRAIL=0 keeps the two kernels
 // back to back (A/B switch).
-static bool g_decode_trail = [] { const char* e = std::getenv("PCO_GFX_DEC_TRAIL"); return !(e && e[0] == '0'); }();
+static bool g_decode_trail = env_not_zero("PCO_GFX_DEC_TRAIL");
 // measurement / test switches: 's' = the expanders on the walker's own stream (after it, nothing overlaps), 'n' = no expanders at all, 'd' = the expanders
 // BEFORE the walkers (they time out waiting): in the last two every chunk marked for the expanders is given back to dec_expand_kernel
-static char g_trail_debug = [] { const char* e = std::getenv("PCO_GFX_TRAIL_DEBUG"); return e ? e[0] : '\0'; }();
-static bool g_trail_always = [] { const char* e = std::getenv("PCO_GFX_DEC_TRAIL"); return e && e[0] == '2'; }();   // PCO_GFX_DEC_TRAIL=2: the expanders for calls of any size (tests)
+static char g_trail_debug = env_char("PCO_GFX_TRAIL_DEBUG");
+static bool g_trail_always = env_first_is("PCO_GFX_DEC_TRAIL", '2');   // PCO_GFX_DEC_TRAIL=2: the expanders for calls of any size (tests)
 
 // the workspace's second stream and the two events that fork it off the caller's stream and join it again
 static void ensure_side_stream(Workspace& ws) {
@@ -136,8 +136,9 @@ static void ensure_side_stream(Workspace& ws) {
   if (!ws.n_cus) { hipDeviceProp_t prop; PCO_HIP_CHECK(hipGetDeviceProperties(&prop, ws.device)); ws.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
 }
 
+// metas (HOST array of n_tasks entries, or nullptr): where each PCO_GFX_TASK_WRAPPED_PAGE task's ChunkMeta lives when it is not in front of the page
 static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxTaskResult* results,
-                          PcoGfxTaskResult* d_results_user, hipStream_t stream) {
+                          PcoGfxTaskResult* d_results_user, hipStream_t stream, const MetaRef* metas = nullptr) {
   if (n_tasks == 0) return;
   Workspace& ws = workspace();
   // group task ids by number width: one kernel instantiation per width present in the batch
@@ -149,9 +150,12 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
   }
   if (any_bad) throw HostError{PCO_GFX_INVALID_ARGUMENT, "decode: invalid number type"};
   const size_t task_bytes = n_tasks * sizeof(PcoGfxDecodeTask);
-  uint8_t* d_base = (uint8_t*)ws.tasks.ensure(task_bytes + n_tasks * sizeof(uint32_t) + 64);
+  const size_t ids_off = (task_bytes + 15) & ~(size_t)15, metas_off = (ids_off + n_tasks * sizeof(uint32_t) + 15) & ~(size_t)15;
+  uint8_t* d_base = (uint8_t*)ws.tasks.ensure(metas_off + (metas ? n_tasks * sizeof(MetaRef) : 0) + 64);
   PcoGfxDecodeTask* d_tasks = (PcoGfxDecodeTask*)d_base;
-  uint32_t* d_ids = (uint32_t*)(d_base + ((task_bytes + 15) & ~(size_t)15));
+  uint32_t* d_ids = (uint32_t*)(d_base + ids_off);
+  const MetaRef* d_metas = nullptr;
+  if (metas) { PCO_HIP_CHECK(hipMemcpyAsync(d_base + metas_off, metas, n_tasks * sizeof(MetaRef), hipMemcpyHostToDevice, stream)); d_metas = (const MetaRef*)(d_base + metas_off); }
   PcoGfxTaskResult* d_results = d_results_user ? d_results_user : (PcoGfxTaskResult*)ws.results.ensure(n_tasks * sizeof(PcoGfxTaskResult));
   PCO_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks, task_bytes, hipMemcpyHostToDevice, stream));
   const bool mixed = (ids[0].size() != n_tasks) && (ids[1].size() != n_tasks) && (ids[2].size() != n_tasks) && (ids[3].size() != n_tasks);
@@ -172,7 +176,7 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
   // Fast path (decode_fast.hip): walk 8 chunks per wave, then expand one chunk per wave; whatever it cannot take
   // (multi-chunk streams, big tANS tables, wrapped pages, ...) is finished by the single-kernel decoder.
   uint64_t max_cap = 0; bool plain = true;
-  for (size_t i = 0; i < n_tasks; i++) { max_cap = std::max<uint64_t>(max_cap, tasks[i].dst_cap); if (tasks[i].flags & (PCO_GFX_TASK_WRAPPED_PAGE | PCO_GFX_TASK_META_ONLY)) plain = false; }
+  for (size_t i = 0; i < n_tasks; i++) { max_cap = std::max<uint64_t>(max_cap, tasks[i].dst_cap); if (tasks[i].flags & PCO_GFX_TASK_META_ONLY) plain = false; }   // (wrapped pages walk and expand like chunks)
   const uint64_t sym_stride = ((max_cap + 255) & ~(uint64_t)255) + 256, offpos_stride = sym_stride / 256 + 2;
   const bool fast = g_decode_fast && plain && n_tasks * 3 * sym_stride <= ((size_t)48 << 30);
   DecPlan* d_plans = nullptr; uint8_t* d_bins = nullptr; uint8_t* d_sym = nullptr; uint64_t* d_offpos = nullptr;
@@ -203,7 +207,7 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
         ensure_side_stream(ws);
         d_progress = (uint32_t*)ws.dec_progress.ensure((size_t)n_wb * kTrailProgressStride * sizeof(uint32_t));
         PCO_HIP_CHECK(hipMemsetAsync(d_progress, 0, (size_t)n_wb * kTrailProgressStride * sizeof(uint32_t), stream));
-        if (!ws.dec_stats.p) { ws.dec_stats.ensure(256); PCO_HIP_CHECK(hipMemset(ws.dec_stats.p, 0, 256)); }
+        if (!ws.dec_stats.p) { ws.dec_stats.ensure(256); PCO_HIP_CHECK(hipMemsetAsync(ws.dec_stats.p, 0, 256, stream)); }   // (in stream order: nothing synchronous inside an asynchronous call)
         d_givebacks = (uint32_t*)ws.dec_stats.p;
       }
       // (persistent expander grid: at most four blocks of four waves per CU, so that every walker block finds its wave slot, registers and LDS
@@ -218,38 +222,38 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
       if (use_trail) {                                                                                                                                    \
         ScopedKernelTimer _span("dec_walk+trail<" name ">", stream);                                                                                      \
         if (g_trail_debug == 'd') {   /* test switch: the expanders BEFORE the walkers on the caller's stream -- every wave times out waiting for a walker that has not started */ \
-          hipLaunchKernelGGL((dec_trail_kernel<L, false>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb); \
-          hipLaunchKernelGGL((dec_trail_kernel<L, true>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);  \
+          hipLaunchKernelGGL((dec_trail_kernel<L, false>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb, d_metas); \
+          hipLaunchKernelGGL((dec_trail_kernel<L, true>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, stream, d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb, d_metas);  \
         }                                                                                                                                                 \
         PCO_HIP_CHECK(hipEventRecord(ws.fork_event, stream));                                                                                             \
         /* four walker waves per workgroup, the CU's whole LDS: one walker per SIMD by construction (decode_fast.hip, walk_lds) */                      \
         static const bool _quad_ok = hipFuncSetAttribute((const void*)dec_walk_trail_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * WalkCfg<8>::kWalkLdsBytes)) == hipSuccess; \
         if (!_quad_ok) throw HostError{PCO_GFX_DEVICE_ERROR, "cannot reserve LDS for dec_walk_trail_kernel"};                                             \
         PCO_TIMED_LAUNCH("~dec_walk_kernel<" name ">", stream, (dec_walk_trail_kernel<L>), dim3((n_wb + 3) / 4), dim3(256), 4 * WalkCfg<8>::kWalkLdsBytes, stream, \
-                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_results, d_progress);                          \
+                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_results, d_progress, d_metas);                 \
         /* the blocks without a candidate for the expanders: the ordinary walker, beside the two (every block runs in exactly one of the walkers).       \
            Launched second: where no block is a candidate the publishing walker's blocks say so and leave at once, and the expanders with them         \
            (launched first it held the LDS, they queued behind it: 1.8 instead of 1.3 ms per 16384 one-bin chunks).  Where every block is a        \
            candidate its own blocks queue behind the publishing walker's LDS and then leave at once: its time in a profile is that wait */          \
         PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream2, ws.fork_event, 0));                                                                             \
         PCO_TIMED_LAUNCH("~dec_walk_kernel(rest)<" name ">", ws.side_stream2, (dec_walk_kernel<L, 8>), dim3((n_wb + 3) / 4), dim3(256), 4 * WalkCfg<8>::kWalkLdsBytes, ws.side_stream2, \
-                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results, d_progress);                      \
+                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results, d_progress, d_metas);             \
         PCO_HIP_CHECK(hipEventRecord(ws.join_event2, ws.side_stream2));                                                                                   \
         hipStream_t ts = g_trail_debug == 's' ? stream : ws.side_stream;                                                                                  \
         PCO_HIP_CHECK(hipStreamWaitEvent(ws.side_stream, ws.fork_event, 0));                                                                              \
         /* one kernel per kind of walker block (classic chunks only / a chunk with two latent variables among them), one after the other on the    \
            expanders' stream: the blocks of the kind a call does not have leave at once */                                                         \
         if (g_trail_debug != 'n' && g_trail_debug != 'd') PCO_TIMED_LAUNCH("~dec_trail_kernel<" name ">", ts, (dec_trail_kernel<L, false>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
-                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);                               \
+                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb, d_metas);                               \
         if (g_trail_debug != 'n' && g_trail_debug != 'd') PCO_TIMED_LAUNCH("~dec_trail2_kernel<" name ">", ts, (dec_trail_kernel<L, true>), dim3(trail_grid), dim3(64 * kTrailWaves), 0, ts, \
-                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb);                               \
+                         d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, d_progress, n_wb, d_metas);                               \
         PCO_HIP_CHECK(hipEventRecord(ws.join_event, ws.side_stream));                                                                                     \
         PCO_HIP_CHECK(hipStreamWaitEvent(stream, ws.join_event, 0));                                                                                      \
         PCO_HIP_CHECK(hipStreamWaitEvent(stream, ws.join_event2, 0));                                                                                     \
       } else PCO_TIMED_LAUNCH("dec_walk_kernel<" name ">", stream, (dec_walk_kernel<L, 8>), dim3((n_wb + 3) / 4), dim3(256), 4 * WalkCfg<8>::kWalkLdsBytes, stream, \
-                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results, (uint32_t*)nullptr);                \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, 0u, d_results, (uint32_t*)nullptr, d_metas);       \
       PCO_TIMED_LAUNCH("dec_walk4_kernel<" name ">", stream, (dec_walk_kernel<L, 4>), dim3((cnt + 15) / 16), dim3(256), 4 * WalkCfg<4>::kWalkLdsBytes, stream, \
-                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4, d_results, (uint32_t*)nullptr);   \
+                       d_tasks, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, kStatusRetryK4, d_results, (uint32_t*)nullptr, d_metas); \
       PCO_TIMED_LAUNCH("dec_expand_kernel<" name ">", stream, (dec_expand_kernel<L, false>), dim3(grid), dim3(256), kExpLdsBytes, stream,               \
                        d_tasks, d_results, idp, cnt, d_plans, d_bins, d_sym, sym_stride, d_offpos, offpos_stride, (const uint32_t*)d_progress, d_givebacks);    \
       PCO_TIMED_LAUNCH("dec_expand_lb_kernel<" name ">", stream, (dec_expand_kernel<L, true>), dim3(grid), dim3(256), kExpLbLdsBytes, stream,           \
@@ -257,10 +261,10 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
       if (g == 0) { PCO_FAST_DECODE(uint64_t, "u64") } else if (g == 1) { PCO_FAST_DECODE(uint32_t, "u32") } else if (g == 2) { PCO_FAST_DECODE(uint16_t, "u16") } else { PCO_FAST_DECODE(uint8_t, "u8") }
 #undef PCO_FAST_DECODE
     }
-    if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist);
-    else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist);
-    else if (g == 2) PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist);
-    else PCO_TIMED_LAUNCH("pco_decode_kernel<u8>", stream, pco_decode_kernel<uint8_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist);
+    if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist, d_metas);
+    else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist, d_metas);
+    else if (g == 2) PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist, d_metas);
+    else PCO_TIMED_LAUNCH("pco_decode_kernel<u8>", stream, pco_decode_kernel<uint8_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl, filt, fstride, kStatusRetryLegacy, (uint8_t*)nullptr, (const uint64_t*)nullptr, need_hist, d_metas);
     PCO_HIP_CHECK(hipGetLastError());
   }
   if (results) {
@@ -287,10 +291,10 @@ static void launch_decode(size_t n_tasks, const PcoGfxDecodeTask* tasks, PcoGfxT
         if (again[g].empty()) continue;
         const uint32_t cnt = (uint32_t)again[g].size(), grid = (uint32_t)std::min<size_t>(cnt, kGeneralGrid);
         const uint32_t* idp = d_again + goff[g]; const uint64_t* hop = d_hoff + goff[g];
-        if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED);
-        else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED);
-        else if (g == 2) PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED);
-        else PCO_TIMED_LAUNCH("pco_decode_kernel<u8>", stream, pco_decode_kernel<uint8_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED);
+        if (g == 0) PCO_TIMED_LAUNCH("pco_decode_kernel<u64>", stream, pco_decode_kernel<uint64_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED, d_metas);
+        else if (g == 1) PCO_TIMED_LAUNCH("pco_decode_kernel<u32>", stream, pco_decode_kernel<uint32_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED, d_metas);
+        else if (g == 2) PCO_TIMED_LAUNCH("pco_decode_kernel<u16>", stream, pco_decode_kernel<uint16_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED, d_metas);
+        else PCO_TIMED_LAUNCH("pco_decode_kernel<u8>", stream, pco_decode_kernel<uint8_t>, dim3(grid), dim3(64), g_decode_lds_bytes, stream, d_tasks, d_results, idp, cnt, budget, tbl2, (const uint32_t*)nullptr, 0u, 0u, d_hist, hop, (uint32_t)PCO_GFX_UNSUPPORTED, d_metas);
       }
       PCO_HIP_CHECK(hipGetLastError());
       PCO_HIP_CHECK(hipMemcpyAsync(results, d_results, n_tasks * sizeof(PcoGfxTaskResult), hipMemcpyDeviceToHost, stream));
@@ -323,11 +327,12 @@ size_t pco_gfx_workspace_bytes(void) {
 static unsigned long long trail_stat(int which) {
   try {
     Workspace& w = workspace();
-    if (!w.dec_stats.p) return 0;
+    const unsigned long long acc = which == 0 ? w.acc_givebacks : w.acc_marked;
+    if (!w.dec_stats.p) return acc;
     if (w.has_last && w.last_event) (void)hipEventSynchronize(w.last_event);
     uint32_t v[2] = {0, 0};
-    if (hipMemcpy(v, w.dec_stats.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    return v[which];
+    if (hipMemcpy(v, w.dec_stats.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return acc;
+    return acc + v[which];
   } catch (...) { return 0; }
 }
 unsigned long long pco_gfx_trail_givebacks(void) { return trail_stat(0); }
@@ -335,11 +340,11 @@ unsigned long long pco_gfx_trail_marked(void) { return trail_stat(1); }
 unsigned long long pco_gfx_strict_histogram_fallbacks(void) {
   try {
     Workspace& w = workspace();
-    if (!w.enc_strict.p) return 0;
+    if (!w.enc_strict.p) return w.acc_strict;
     if (w.has_last && w.last_event) (void)hipEventSynchronize(w.last_event);
     uint32_t v = 0;
-    if (hipMemcpy(&v, w.enc_strict.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    return v;
+    if (hipMemcpy(&v, w.enc_strict.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return w.acc_strict;
+    return w.acc_strict + v;
   } catch (...) { return 0; }
 }
 
@@ -423,6 +428,27 @@ enum PcoError pco_gfx_decompress_chunks(size_t n_tasks, const PcoGfxDecodeTask* 
     { WorkspaceUse use(workspace(), (hipStream_t)stream); launch_decode(n_tasks, tasks, results, d_results, (hipStream_t)stream); }
     if (results) for (size_t i = 0; i < n_tasks; i++) if (results[i].status != PCO_GFX_OK) {
       set_error((int)results[i].status, "decode task " + std::to_string(i) + " failed");
+      return PcoDecompressionError;
+    }
+    return PcoSuccess;
+  } catch (const HostError& e) { return fail_with(e, PcoDecompressionError); }
+}
+
+enum PcoError pco_gfx_decompress_pages(size_t n_tasks, const PcoGfxPageTask* tasks, PcoGfxTaskResult* results, PcoGfxTaskResult* d_results, void* stream) {
+  clear_error();
+  try {
+    require_device();
+    std::vector<PcoGfxDecodeTask> dt(n_tasks); std::vector<MetaRef> refs(n_tasks);
+    for (size_t i = 0; i < n_tasks; i++) {
+      const PcoGfxPageTask& t = tasks[i];
+      if (t.format_major > 4) throw HostError{PCO_GFX_CORRUPTION, "page task " + std::to_string(i) + ": the file's format version definitely cannot be decompressed"};   // wrapped/file_decompressor.rs:31-36
+      if (t.meta == nullptr || t.page == nullptr) throw HostError{PCO_GFX_INVALID_ARGUMENT, "page task " + std::to_string(i) + ": null ChunkMeta or page"};
+      dt[i] = PcoGfxDecodeTask{t.page, t.page_len, t.dst, t.page_n, t.dtype, PCO_GFX_TASK_WRAPPED_PAGE | (t.format_major << 8)};
+      refs[i] = MetaRef{t.meta, t.meta_len};
+    }
+    { WorkspaceUse use(workspace(), (hipStream_t)stream); launch_decode(n_tasks, dt.data(), results, d_results, (hipStream_t)stream, refs.data()); }
+    if (results) for (size_t i = 0; i < n_tasks; i++) if (results[i].status != PCO_GFX_OK) {
+      set_error((int)results[i].status, "page task " + std::to_string(i) + " failed");
       return PcoDecompressionError;
     }
     return PcoSuccess;

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,16 @@ struct HostError {
 
 void set_error(int status, const std::string& msg);
 void clear_error();
+
+// Environment switches (A/B runs, tests) are read through these NAMED functions, never through a lambda in an initialiser: hipcc numbers the
+// lambdas of the host and device passes of this translation unit differently, and a namespace-scope `static const bool x = [] {...}();` was
+// once compiled with ANOTHER lambda's body (round 5: every call silently ran strict histograms).  tests/test_gpu_switch_defaults.py asserts
+// every switch's default with a clean environment.
+inline bool env_is_one(const char* name) { const char* e = std::getenv(name); return e != nullptr && e[0] == '1'; }
+inline bool env_not_zero(const char* name) { const char* e = std::getenv(name); return !(e != nullptr && e[0] == '0'); }   // default ON, "0..." switches off
+inline char env_char(const char* name) { const char* e = std::getenv(name); return e != nullptr ? e[0] : '\0'; }
+inline bool env_first_is(const char* name, char c) { const char* e = std::getenv(name); return e != nullptr && e[0] == c; }
+inline int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e != nullptr ? std::atoi(e) : dflt; }
 
 #define PCO_HIP_CHECK(expr)                                                                   \
   do {                                                                                        \
@@ -99,7 +110,17 @@ struct Workspace {
 #undef PCO_WS_REP
     return r;
   }
+  // The two device counters (pco_gfx_trail_givebacks / _marked, pco_gfx_strict_histogram_fallbacks) count since the workspace was CREATED: what
+  // they held is folded into 64-bit host totals before their buffers go (release_all also runs on the out-of-memory retry path of a call).
+  unsigned long long acc_givebacks = 0, acc_marked = 0, acc_strict = 0;
+  void fold_counters() {
+    uint32_t v[2] = {0, 0};
+    if (dec_stats.p && hipMemcpy(v, dec_stats.p, 8, hipMemcpyDeviceToHost) == hipSuccess) { acc_givebacks += v[0]; acc_marked += v[1]; }
+    uint32_t f = 0;
+    if (enc_strict.p && hipMemcpy(&f, enc_strict.p, 4, hipMemcpyDeviceToHost) == hipSuccess) acc_strict += f;
+  }
   void release_all() {
+    fold_counters();
     // (the side streams and their events belong to the workspace too: a worker thread that decoded >= 1024 chunks once must not leak them)
     if (side_stream) { (void)hipStreamSynchronize(side_stream); (void)hipStreamDestroy(side_stream); side_stream = nullptr; }
     if (side_stream2) { (void)hipStreamSynchronize(side_stream2); (void)hipStreamDestroy(side_stream2); side_stream2 = nullptr; }
