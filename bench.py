@@ -40,6 +40,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 N18 = 1 << 18
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+PAGE_INFO = np.dtype([("offset", "<u8"), ("len", "<u8"), ("n", "<u8"), ("status", "<u4"), ("aux", "<u4")])
+PAGE_TASK = np.dtype([("meta", "<u8"), ("meta_len", "<u8"), ("page", "<u8"), ("page_len", "<u8"), ("dst", "<u8"), ("page_n", "<u8"), ("dtype", "<u4"), ("format_major", "<u4")])
 ENC_TASK = np.dtype([("src", "<u8"), ("n", "<u8"), ("dst", "<u8"), ("dst_cap", "<u8"), ("dtype", "<u4"), ("reserved", "<u4")])
 DEC_TASK = np.dtype([("src", "<u8"), ("src_len", "<u8"), ("dst", "<u8"), ("dst_cap", "<u8"), ("dtype", "<u4"), ("flags", "<u4")])
 RESULT = np.dtype([("n_out", "<u8"), ("consumed", "<u8"), ("status", "<u4"), ("aux", "<u4")])
@@ -67,6 +69,10 @@ WORKLOADS = {
     # adversarial input ORDERS costs) and at compression level 12 (a published data point of the reference: 4096 histogram bins per chunk)
     "c2strict": (["u64ramp"], dict(mode=1, delta=2, delta_order=1, strict_histogram=True), "u64", "u64 classic delta-1 noisy ramp, strict (literal) histograms, 2^18-element chunks"),
     "c2l12": (["u64ramp"], dict(mode=1, delta=2, delta_order=1, level=12), "u64", "u64 classic delta-1 noisy ramp, compression level 12, 2^18-element chunks"),
+    # the headline's data through the WRAPPED surface, batched (include/pco_gfx.h section 4b): 2^18-number chunks cut into pages of 16384 numbers
+    # (PagingSpec::EqualPagesUpTo(16384): sixteen independent tANS streams per chunk), pco_gfx_compress_wrapped_chunks + pco_gfx_decompress_pages --
+    # what the reference's `pcopage` bench codec does chunk by chunk (pco_cli/src/bench/codecs/pcopage.rs:33-113)
+    "c2paged": (["u64ramp"], dict(mode=1, delta=2, delta_order=1, max_page_n=16384), "u64", "u64 classic delta-1 noisy ramp, 2^18-element chunks in pages of 16384 (wrapped surface, batched)"),
     "c5auto": (["u64ramp", "f32normal", "i32lomax"], dict(), "u64/f32/i32",
                "mixed u64 ramp / f32 normal / i32 lomax chunks of 2^18, one call per rank, default ChunkConfig (BASELINE configs[4], Auto/Auto)"),
 }
@@ -317,6 +323,10 @@ class Bench:
         kinds, cfg_kw, dtype_label, desc = WORKLOADS[workload]
         gcfg = G.make_config(**cfg_kw)
         elem = [np.dtype(KINDS[k][0]).itemsize for k in kinds]
+        if self.args.total_gib and chunks is None:   # STRONG scaling: `--total-gib G` of numbers over ALL ranks (BASELINE configs[4]: "~64 GiB total" at 1/2/4/8 GPUs)
+            per_cycle = sum(N18 * e for e in elem)
+            total_chunks = max(len(kinds) * world, int((self.args.total_gib * (1 << 30)) // per_cycle) * len(kinds))
+            chunks = -(-total_chunks // (world * len(kinds))) * len(kinds)
         if chunks is None:   # 16 GiB of numbers per GPU
             per_cycle = sum(N18 * e for e in elem)
             chunks = max(len(kinds), int((16 << 30) // per_cycle) * len(kinds))
@@ -334,7 +344,13 @@ class Bench:
         out = {k: torch.empty_like(v) for k, v in data.items()}
         chunk_bytes = np.array([N18 * elem[k] for k in kind_of], dtype=np.uint64)
         dtb = np.array([KINDS[kinds[k]][1] for k in kind_of], dtype=np.uint32)
-        caps = np.array([(L.pco_gfx_guarantee_chunk_size(N18, int(b)) + 64 + 15) // 16 * 16 for b in dtb], dtype=np.uint64)
+        paged = "max_page_n" in cfg_kw
+        if paged:   # room for the ChunkMeta and every page of a chunk (pco_gfx_wrapped_chunk_cap)
+            L.pco_gfx_wrapped_chunk_cap.restype = C.c_size_t; L.pco_gfx_wrapped_chunk_cap.argtypes = [C.c_size_t, C.c_ubyte, C.c_void_p]
+            L.pco_gfx_wrapped_n_pages.restype = C.c_size_t; L.pco_gfx_wrapped_n_pages.argtypes = [C.c_size_t, C.c_uint64]
+            caps = np.array([(L.pco_gfx_wrapped_chunk_cap(N18, int(b), C.addressof(gcfg)) + 64 + 15) // 16 * 16 for b in dtb], dtype=np.uint64)
+        else:
+            caps = np.array([(L.pco_gfx_guarantee_chunk_size(N18, int(b)) + 64 + 15) // 16 * 16 for b in dtb], dtype=np.uint64)
         cap_off = np.concatenate([[0], np.cumsum(caps)]).astype(np.uint64)
         comp = torch.zeros(int(cap_off[-1]), dtype=torch.uint8, device=device)
         src_ptr = np.array([data[k].data_ptr() + int(r) * N18 * elem[k] for k, r in zip(kind_of, row_of)], dtype=np.uint64)
@@ -360,8 +376,29 @@ class Bench:
             comm = self.c_abi_comm() if use_cabi else None
         gather_ms = []
         state = {"n_bytes": 0, "offs": None}
+        if paged:
+            assert len(kinds) == 1 and not gather
+            npg = int(L.pco_gfx_wrapped_n_pages(N18, cfg_kw["max_page_n"]))
+            infos = np.zeros((nch, 1 + npg), PAGE_INFO)
+            ptasks = np.zeros((nch, npg), PAGE_TASK)
+            pres = np.zeros(nch * npg, RESULT)
+            ptasks["dtype"] = dtb[:, None]; ptasks["format_major"] = 4; ptasks["meta"] = enc_tasks["dst"][:, None]
+
+        def encode_paged():
+            G.check(L.pco_gfx_compress_wrapped_chunks(nch, enc_tasks.ctypes.data, C.addressof(gcfg), infos.ctypes.data, None))
+            enc_res["n_out"] = infos["len"].sum(axis=1)   # a chunk's bytes: its ChunkMeta + its pages
+
+        def decode_paged():   # one task per page: the chunk's ChunkMeta + the page's own bytes -> the page's slice of the chunk's numbers
+            ptasks["meta_len"] = infos["len"][:, 0:1]
+            ptasks["page"] = enc_tasks["dst"][:, None] + infos["offset"][:, 1:]
+            ptasks["page_len"] = infos["len"][:, 1:]; ptasks["page_n"] = infos["n"][:, 1:]
+            first = np.cumsum(infos["n"][:, 1:], axis=1) - infos["n"][:, 1:]
+            ptasks["dst"] = out_ptr[:, None] + first * np.uint64(elem[0])
+            G.check(L.pco_gfx_decompress_pages(nch * npg, ptasks.ctypes.data, pres.ctypes.data, None, None))
 
         def encode():
+            if paged:
+                return encode_paged()
             G.check(L.pco_gfx_compress_chunks(nch, enc_tasks.ctypes.data, C.byref(gcfg), enc_res.ctypes.data, d_res.data_ptr() if gather else None, None))
             if gather:   # device-side compaction (no Python loop), then the exact-size gather-v to rank 0
                 t = time.perf_counter()
@@ -378,6 +415,8 @@ class Bench:
                 gather_ms.append((time.perf_counter() - t) * 1e3)
 
         def decode():
+            if paged:
+                return decode_paged()
             if gather:   # decoders read the byte ranges the root hands out
                 if use_cabi:
                     comm.scatter(file_body.data_ptr(), state["offs"], recv.data_ptr(), stream_cap - 16, 0, root=0)
@@ -403,7 +442,18 @@ class Bench:
         for k in data:
             assert no_verify or torch.equal(out[k].view(torch.uint8), data[k].view(torch.uint8)), "decode(encode(x)) != x"
         verified = 0
-        if rank == 0 and verify_chunks > 0 and not no_verify:   # parity spot check against the oracle's bytes (native threads)
+        if rank == 0 and verify_chunks > 0 and not no_verify and paged:   # the oracle's wrapped::ChunkCompressor on a few chunks: ChunkMeta and every page, byte for byte
+            import oracle_lib as O
+            ocfg = O.make_config(**oracle_kw(cfg_kw))
+            for i in np.sort(np.random.default_rng(99).choice(nch, size=min(verify_chunks, 48, nch), replace=False)):
+                host = data[0][int(row_of[i])].cpu().numpy().view(KINDS[kinds[0]][0])
+                want_meta, want_pages, want_ns = O.wrapped_compress(host, ocfg)
+                blob = comp[int(cap_off[i]): int(cap_off[i]) + int(caps[i])].cpu().numpy()
+                got_meta = bytes(blob[: int(infos[i, 0]["len"])])
+                got_pages = [bytes(blob[int(e["offset"]): int(e["offset"]) + int(e["len"])]) for e in infos[i, 1:]]
+                assert got_meta == want_meta and got_pages == want_pages and [int(e["n"]) for e in infos[i, 1:]] == want_ns, f"wrapped chunk {i} differs from the oracle's bytes"
+                verified += 1
+        elif rank == 0 and verify_chunks > 0 and not no_verify:   # parity spot check against the oracle's bytes (native threads)
             verified = self.verify_against_oracle(kinds, cfg_kw, kind_of, row_of, data, comp, cap_off, enc_res["n_out"], verify_chunks)
 
         # timed region: exactly K steps, bracketed by barrier + synchronize
@@ -480,6 +530,8 @@ class Bench:
                 "config": {"workload": desc, "chunks_per_gpu": nch, "chunk_n": N18, "compression_level": cfg_kw.get("level", 8), **({"strict_histogram": True} if cfg_kw.get("strict_histogram") else {}),
                            "mode_spec": MODE_NAMES[cfg_kw.get("mode", 0)] + (f"({cfg_kw['mode_f64']})" if "mode_f64" in cfg_kw else ""),
                            "delta_spec": DELTA_NAMES[cfg_kw.get("delta", 0)] + (f"({cfg_kw['delta_order']})" if "delta_order" in cfg_kw else ""),
+                           **({"paging_spec": f"EqualPagesUpTo({cfg_kw['max_page_n']})", "pages_per_chunk": npg, "api": "pco_gfx_compress_wrapped_chunks / pco_gfx_decompress_pages"} if paged else {}),
+                           **({"total_GiB_all_ranks": round(world * rank_bytes / (1 << 30), 2)} if self.args.total_gib else {}),
                            "parallelism": f"chunk-sharded x{world}, contiguous chunk blocks" + ((f", device compaction + RCCL gather-v / scatter of the chunk bytes ({'C ABI pco_gfx_gather_chunks / _scatter_chunks' if carrier == 'cabi' else 'torch.distributed carrier'})" if gather else ", no data-path collective")),
                            "compressed_bytes_per_chunk": comp_bytes // nch,
                            "encode_GBps": round(total_bytes * steps / t_enc / 1e9, 2),
@@ -517,8 +569,27 @@ OTHER_WORKLOADS = [("c3", "c3", None, 4, False), ("c4", "c4", 4096, 3, False), (
                    ("c2strict", "c2strict", 4096, 2, False), ("c2l12", "c2l12", 2048, 2, False),
                    # the headline's dependence on the call size (the walkers' flat cost: profiles/r04_c2_chunk_scaling.txt); 4096 chunks per GPU is
                    # what configs[4]'s "~64 GiB over 8 GPUs" comes to
-                   ("c2_1k", "c2", 1024, 3, False), ("c2_4k", "c2", 4096, 3, False), ("c2_12k", "c2", 12288, 3, False)]
-LIGHT_WORKLOADS = ("c5auto", "c2strict", "c2l12", "c2_1k", "c2_4k", "c2_12k")   # no CPU leg of their own (the headline's / c2's applies), fewer verified chunks
+                   ("c2_1k", "c2", 1024, 3, False), ("c2_4k", "c2", 4096, 3, False), ("c2_12k", "c2", 12288, 3, False),
+                   # the same 1024 chunks through the wrapped surface in pages of 16384 numbers: sixteen independent tANS streams per chunk, the honest
+                   # answer to the walkers' flat cost in small calls (compare c2_1k)
+                   ("c2paged", "c2paged", 1024, 3, False)]
+LIGHT_WORKLOADS = ("c5auto", "c2strict", "c2l12", "c2_1k", "c2_4k", "c2_12k", "c2paged")   # no CPU leg of their own (the headline's / c2's applies), fewer verified chunks
+# The driver's record keeps the FIRST 24 keys of `config` and of `roofline`: one scalar pair per BASELINE config and per default-ChunkConfig
+# variant goes there, everything else behind
+CONFIG_FIRST = ["workload", "chunks_per_gpu", "encode_GBps", "decode_GBps", "compressed_bytes_per_chunk",
+                "c3_value", "c3_frac_step", "c4_value", "c4_frac_step", "c4_x_socket_extrapolated", "c5_value", "c5_frac_step", "c5gather_value", "c5gather_frac_step",
+                "c2auto_value", "c2auto_frac_step", "c3auto_value", "c3auto_frac_step", "c1_value", "c1_frac_step", "c5auto_value", "c5auto_frac_step", "c2_4k_value", "c2paged_value"]
+ROOFLINE_FIRST = ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_encode", "frac_decode", "frac_step", "kernel_ms_encode", "kernel_ms_decode",
+                  "traffic_over_algorithmic_encode", "traffic_over_algorithmic_decode", "avg_launch_ms", "algorithmic_bytes_per_launch",
+                  "ms.enc_split_kernel<c16>", "ms.enc_hist_kernel", "ms.enc_train_kernel", "ms.enc_walkd_kernel", "ms.enc_pack_kernel", "ms.dec_walk+trail<u64>", "ms.dec_expand_kernel<u64>",
+                  "traffic_source"]
+
+
+def ordered(d, first):
+    """`d` with the keys of `first` (those present) in front, the rest in their own order."""
+    out = {k: d[k] for k in first if k in d}
+    out.update({k: v for k, v in d.items() if k not in out})
+    return out
 
 
 def flat_workload(name, r):
@@ -537,7 +608,7 @@ def flat_workload(name, r):
         if cb["linear_extrapolation_one_socket"]:
             out["x_socket_extrapolated"] = round(r["value"] / cb["linear_extrapolation_one_socket"], 1)
     if name in LIGHT_WORKLOADS:   # (the line must stay well inside what the driver keeps of it: the headline's variants carry their rates only)
-        out = {k: out[k] for k in ("value", "chunks", "encode_GBps", "decode_GBps", "top_kernel", "verified")}
+        out = {k: out[k] for k in ("value", "frac_step", "chunks", "encode_GBps", "decode_GBps", "top_kernel", "verified")}
     return {f"{name}_{k}": v for k, v in out.items()}
 
 
@@ -552,6 +623,8 @@ def main():
     ap.add_argument("--gather-carrier", default="cabi", choices=["cabi", "torch"], help="cabi: pco_gfx_gather_chunks / pco_gfx_scatter_chunks (the library calls RCCL itself); torch: pcodec_amd.sharding over torch.distributed")
     ap.add_argument("--verify-chunks", type=int, default=1024, help="chunks (drawn at random) whose bytes rank 0 compares with the oracle during warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--total-gib", type=float, default=0.0, help="STRONG scaling: this many GiB of numbers in total, split over the ranks in contiguous chunk blocks "
+                    "(BASELINE configs[4]: --workload c5 --total-gib 64 --gather at 1/2/4/8 GPUs); default: 16 GiB per GPU, weak scaling")
     ap.add_argument("--no-others", action="store_true", help="only the headline workload (default: BASELINE's other configs are timed after it and attached as config.<name>_*)")
     args = ap.parse_args()
 
@@ -561,7 +634,7 @@ def main():
     B = Bench(args)
     head = B.run(args.workload, args.chunks, args.steps, args.warmup, args.gather, args.verify_chunks, not args.no_cpu_baseline, carrier=args.gather_carrier)
     others = []
-    if args.workload == "c2" and args.chunks is None and not args.no_others and not args.gather:
+    if args.workload == "c2" and args.chunks is None and not args.no_others and not args.gather and not args.total_gib:
         for name, wl, chunks, steps, gather in OTHER_WORKLOADS:
             try:
                 light = name in LIGHT_WORKLOADS
@@ -579,7 +652,7 @@ def main():
                 roof[f"ms.{k}"] = v
         line = {"metric": "encode+decode GB/s (uncompressed) per chunk, u64/f64 2^18-elem", "value": head["value"], "unit": "GB/s",
                 "n_gpus": B.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+                "higher_is_better": True, "scaling": "strong" if args.total_gib else "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
                 "config": dict(head["config"]), "roofline": roof}
         full = dict(line); full["config"] = dict(head["config"]); full["roofline"] = dict(head["roofline"])
         if others:
@@ -599,6 +672,7 @@ def main():
                                          "cgroup_cpu_quota": cb["cpu"].get("cgroup_cpu_quota"), "cores_per_socket": cb["cpu"].get("cores_per_socket")})
             if cb.get("linear_extrapolation_one_socket"):
                 line["cpu_baseline"]["gpu_over_socket_extrapolated"] = round(head["value"] / B.world / cb["linear_extrapolation_one_socket"], 1)
+        line["config"] = ordered(line["config"], CONFIG_FIRST); line["roofline"] = ordered(line["roofline"], ROOFLINE_FIRST)
         full_s = json.dumps(full)
         print("BENCH_FULL " + full_s, file=sys.stderr, flush=True)
         try:

@@ -30,6 +30,7 @@ struct EncFast {
   uint32_t* fstate;     // [page][3][4] final tANS states
   uint16_t* vlut;       // [task][slot][kDirectHistRange] value -> bin | offset bits << 8 of the variables enc_walkd_kernel takes (enc_vlut_kernel)
   uint32_t bat_stride, run_stride;
+  uint32_t pack1;       // enc_pack1_kernel takes the pages it can (pack1_takes)
   uint32_t runs_per_page, fused; // 1-D grids of dissect / pack: block = page * runs_per_page + run.  fused: which variables enc_walkd_kernel takes (wd_takes)
   uint64_t stride;               // elements per (task, slot) in sym / answ: n_stride + 16 per page, so that the 16-latent
                                  // blocks of neighbouring pages never overlap (see fast_at)
@@ -59,6 +60,13 @@ __device__ __forceinline__ PageVar page_var(const EncChunk PCO_GLOBAL* ch, uint3
   // compact latents: the histogram's copy relative to the minimum, or -- when the split speculated on 16-bit latents and held -- the split's own, relative to c16_ref
   r.rel = v != 0 && uni(ch->c16_ok) == 1 ? uni(ch->c16_ref[v == 2 ? 1 : 0]) : r.minv;
   return r;
+}
+
+// The pages of the lean pack kernel (enc_pack1_kernel): ONE latent variable that writes anything, held as 16-bit latents, with tANS fields and
+// offsets of at most 16 bits -- classic-mode chunks of smooth data (BASELINE configs[1], the u64 / i32 chunks of configs[4]).
+__device__ __forceinline__ bool pack1_takes(const PageVar (&pv)[3]) {
+  const bool on0 = pv[0].present && !pv[0].trivial, on2 = pv[2].present && !pv[2].trivial;
+  return !on0 && !on2 && pv[1].present && !pv[1].trivial && pv[1].compact && pv[1].needs_ans && pv[1].n_bins > 1 && pv[1].n_bins <= 256 && pv[1].max_ob <= 16;
 }
 
 // Q (page, variable) items per wave: 8 (slot 4608 B: any table of the fast path) or 16 (slot 2304 B, all 64 lanes busy).
@@ -1015,6 +1023,8 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
   PageVar pv[3];
 #pragma unroll
   for (int v = 0; v < 3; v++) pv[v] = page_var(ch, v, page_n);
+  const bool lean = fx.pack1 != 0 && pack1_takes(pv);   // enc_pack1_kernel packs this page's batches; what is left here is the head of run 0 (preamble, ChunkMeta, page meta)
+  if (lean && run != 0) return;
   PackSink sink;
   sink.init_at((uint32_t PCO_LDS*)(smem + kPageLdsStg), (uint32_t PCO_GLOBAL*)pg->dst, run == 0 ? 0ull : uni(fx.run_start[(uint64_t)p * fx.run_stride + run]));
   if (run == 0) {
@@ -1066,6 +1076,7 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
     }
     sink.finish_byte();
   }
+  if (lean) { sink.close(); return; }   // (the head ends on a byte, at run_start[0]: enc_scan_kernel zeroed that dword, both writers OR into it)
   // tables for the offsets: lowers widened to u64 (differences wrap the same way once masked to offset_bits)
   bool on[3];
 #pragma unroll
@@ -1150,6 +1161,90 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
     }
 #pragma unroll
     for (int v = 0; v < 3; v++) cur[v] = nxt[v];
+  }
+  if ((uint64_t)(run + 1) * kRunBatches * kBatchN >= page_n) sink.finish_byte();
+  sink.close();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// enc_pack1_kernel: the batches of the pages with ONE 16-bit latent variable (pack1_takes), nothing else.  The general kernel above carries
+// three variables' worth of per-batch state (two PackItems of eleven registers each per variable, ~124 VGPRs: four waves per SIMD) and decides
+// per batch and variable what to do; it runs at 2.7 TB/s of its own traffic, about half VALU-bound, two thirds of its wave cycles waiting
+// (profiles/r04_c2_pmc_instruction_mix.txt).  Here a batch is five registers of loads, ONE wave scan for both sections (the lane's tANS bits in
+// the low half of a dword, its offset bits in the high half: a batch holds at most 256 x 16 of either) and two puts; the head of the page
+// (preamble, ChunkMeta, page meta) stays with the general kernel, which stops behind it for these pages.  Same bytes
+// (chunk_latent_compressor.rs:272-329), same run structure and joins (enc_scan_kernel).
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kPack1LdsBytes = kStgDwords * 4 + 1024;   // bit sink staging | lower | offset bits << 16 per bin, u32[256]
+
+template <bool kFull>
+__device__ __forceinline__ void pack1_item(PackSink& sink, const uint32_t PCO_LDS* cpk, const PackItem& it, uint32_t cnt) {
+  const uint32_t lane = lane_id();
+  const uint32_t syms = quad_transpose_u8(it.syms, lane & 3);
+  uint32_t a = it.a, b = it.b;
+  quad_transpose_u16(a, b, lane & 3);
+  const uint32_t f[4] = {a & 0xffffu, a >> 16, b & 0xffffu, b >> 16};
+  uint64_t acc = 0, off = 0; uint32_t abits = 0, obits = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const bool act = kFull || 4 * lane + k < cnt;
+    const uint32_t nb = act ? f[k] >> 12 : 0u;
+    acc |= (uint64_t)(act ? f[k] & 0xfffu : 0u) << abits; abits += nb;                     // <= 4 x 10 bits
+    const uint32_t e = cpk[(syms >> (8 * k)) & 0xffu];
+    const uint32_t o = act ? e >> 16 : 0u;
+    off |= (uint64_t)__builtin_amdgcn_ubfe(((uint32_t)(it.x[0] >> (16 * k)) & 0xffffu) - (e & 0xffffu), 0u, o) << obits; obits += o;   // <= 4 x 16 bits
+  }
+  const uint32_t both = abits | (obits << 16);
+  const uint32_t incl = wave_incl_scan(both), total = wave_last(incl), excl = incl - both;
+  const uint32_t ans_total = total & 0xffffu, all = ans_total + (total >> 16);
+  sink.reserve(all);
+  sink.put(excl & 0xffffu, acc, abits);
+  sink.put(ans_total + (excl >> 16), off, obits);
+  sink.commit(all);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void enc_pack1_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+  const uint32_t p = blockIdx.x / fx.runs_per_page, run = blockIdx.x % fx.runs_per_page;
+  if (p >= n_pages) return;
+  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+  const uint32_t t = uni(pg->chunk);
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+  if (!page_is_fast(ch, pg) || uni(pg->pad) != 0) return;
+  const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
+  if ((uint64_t)run * kRunBatches * kBatchN >= page_n) return;
+  PageVar pv[3];
+#pragma unroll
+  for (int v = 0; v < 3; v++) pv[v] = page_var(ch, v, page_n);
+  if (!pack1_takes(pv)) return;
+  const uint32_t lane = lane_id();
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  uint32_t PCO_LDS* cpk = (uint32_t PCO_LDS*)(smem + kStgDwords * 4);
+  {
+    const PlanRef plan = plan_ref(ws, t, 1);
+    const uint64_t rel0 = pv[1].rel;   // the 16-bit latents are relative to it
+    for (uint32_t b = lane; b < pv[1].n_bins; b += 64) cpk[b] = ((uint32_t)(plan.blower()[b] - rel0) & 0xffffu) | ((uint32_t)plan.bob()[b] << 16);
+  }
+  PackSink sink;
+  sink.init_at((uint32_t PCO_LDS*)smem, (uint32_t PCO_GLOBAL*)pg->dst, uni(fx.run_start[(uint64_t)p * fx.run_stride + run]));   // (run 0 starts behind the head; init_at ends with a wave sync: cpk is visible)
+  const uint32_t n_lat = pv[1].n_lat, first = run * kRunBatches * kBatchN;
+  const uint64_t at = uni((uint64_t)pg->start) + pv[1].skip + first, fat = fast_at(pg, pv[1].skip) + first;
+  const uint16_t PCO_GLOBAL* lat = clat_ptr(ws, t, 1) + at;
+  const uint8_t PCO_GLOBAL* sym = fsym_ptr(ws, fx, t, 1) + fat;
+  const uint16_t PCO_GLOBAL* answ = fansw_ptr(ws, fx, t, 1) + fat;
+  PackItem cur, nxt;
+  auto load = [&](uint32_t bb, PackItem& it) {
+    const uint32_t base = first + bb * kBatchN;
+    if (base >= n_lat) return;
+    pack_load<uint16_t, true>(it, lat + bb * kBatchN, sym + bb * kBatchN, answ + bb * kBatchN, n_lat - base < kBatchN ? n_lat - base : kBatchN, true, false, true);
+  };
+  load(0, cur);
+  for (uint32_t bb = 0; bb < kRunBatches; bb++) {
+    const uint32_t base = first + bb * kBatchN;
+    if (base >= n_lat) break;
+    if (bb + 1 < kRunBatches) load(bb + 1, nxt);
+    const uint32_t cnt = n_lat - base < kBatchN ? n_lat - base : kBatchN;
+    if (cnt == kBatchN) pack1_item<true>(sink, cpk, cur, cnt); else pack1_item<false>(sink, cpk, cur, cnt);
+    cur = nxt;
   }
   if ((uint64_t)(run + 1) * kRunBatches * kBatchN >= page_n) sink.finish_byte();
   sink.close();

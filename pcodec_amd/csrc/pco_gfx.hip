@@ -549,6 +549,7 @@ enum PcoError pco_standalone_simple_decompress_into(const void* compressed, size
     } else {
       for (;;) {
         if (off >= compressed_len) { set_error(PCO_GFX_INSUFFICIENT_DATA, "decompression failed: the file ends without its terminator"); return PcoDecompressionError; }
+        if (((const uint8_t*)compressed)[off] == 0) break;   // the terminator where a chunk's type byte would be: a file without (further) chunks (standalone/decompressor.rs:190-200)
         // (a chunk holds at most 2^24 numbers: the scratch launch_decode sizes from dst_cap stays a chunk's, whatever the caller's buffer)
         PcoGfxDecodeTask task{d_in + off, compressed_len - off, d_out + done * esz, std::min<size_t>(dst_cap - done, kMaxEntries), dtype, PCO_GFX_TASK_ONE_CHUNK | (fmt_major << 8)};
         PcoGfxTaskResult res{};

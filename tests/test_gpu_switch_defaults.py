@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 CHILD = r'''
 import ctypes as C, json, sys
 import numpy as np
-sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+sys.path.insert(0, '@ROOT@'); sys.path.insert(0, '@HERE@')
 import torch
 from pcodec_amd import _lib as G
 import gpu_util as U
@@ -61,7 +61,7 @@ print("REPORT " + json.dumps(rep))
 
 def test_switch_defaults_in_a_clean_environment():
     env = {k: v for k, v in os.environ.items() if not k.startswith("PCO_GFX_")}
-    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "here": HERE}], capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run([sys.executable, "-c", CHILD.replace("@ROOT@", ROOT).replace("@HERE@", HERE)], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("REPORT ")][-1][7:])
     every = set().union(*[set(rep[k]) for k in ("few_long", "many_short", "over_4096_items", "lookback")])

@@ -227,3 +227,15 @@ def test_simple_decompress_errors_with_the_reference_words(P):   # test_standalo
 def test_decompress_without_n_hint(P):   # test_standalone.py:176-182: old files have no n_hint
     compressed = open(os.path.join(HERE, "golden", "ref_assets", "v0_0_0_classic.pco"), "rb").read()
     assert len(P.standalone.simple_decompress(compressed)) == 2000
+
+
+def test_c_abi_round_trip_of_an_empty_array(P):   # standalone/simple.rs:22-48 with n = 0: header + terminator, and back (uniform type set, no chunk)
+    import ctypes as C
+    from pcodec_amd import _lib as G
+    L = G.lib()
+    dst = np.zeros(64, np.uint8); n = C.c_size_t(0)
+    x = np.zeros(1, np.float64)
+    assert L.pco_standalone_simple_compress_into(x.ctypes.data_as(C.c_void_p), 0, 6, None, dst.ctypes.data_as(C.c_void_p), 64, C.byref(n)) == G.PcoSuccess
+    k = n.value; assert 0 < k <= 16 and dst[k - 1] == 0
+    out = np.zeros(4, np.float64); m = C.c_size_t(99)
+    assert L.pco_standalone_simple_decompress_into(dst.ctypes.data_as(C.c_void_p), k, 6, out.ctypes.data_as(C.c_void_p), 4, C.byref(m)) == G.PcoSuccess and m.value == 0
