@@ -62,12 +62,24 @@ __device__ __forceinline__ PageVar page_var(const EncChunk PCO_GLOBAL* ch, uint3
   return r;
 }
 
-// The pages of the lean pack kernel (enc_pack1_kernel): ONE latent variable that writes anything, held as 16-bit latents, with tANS fields and
-// offsets of at most 16 bits -- classic-mode chunks of smooth data (BASELINE configs[1], the u64 / i32 chunks of configs[4]).
-__device__ __forceinline__ bool pack1_takes(const PageVar (&pv)[3]) {
-  const bool on0 = pv[0].present && !pv[0].trivial, on2 = pv[2].present && !pv[2].trivial;
-  return !on0 && !on2 && pv[1].present && !pv[1].trivial && pv[1].compact && pv[1].needs_ans && pv[1].n_bins > 1 && pv[1].n_bins <= 256 && pv[1].max_ob <= 16;
+// The pages of the lean pack kernel (enc_pack1_kernel): ONE or TWO latent variables that write anything (the primary alone: classic mode
+// without lookback; primary + secondary: int-mult / float-mult / float-quant; lookback variable + primary), each with at most 256 bins and held
+// either as 16-bit latents or at a full width of 32 / 64 bits.  Left to the general kernel: three variables, levels 9-12, full-width latents of
+// the 8- / 16-bit types, and the one-bin / full-width-offsets page that is a shifted copy (pack_run).  Returns 0 or the mask of the variables on.
+__device__ __forceinline__ uint32_t pack1_mask(const PageVar (&pv)[3], uint32_t latent_bits) {
+  uint32_t mask = 0, n_on = 0;
+#pragma unroll
+  for (int v = 0; v < 3; v++) {
+    if (!pv[v].present || pv[v].trivial) continue;
+    mask |= 1u << v; n_on++;
+    if (pv[v].n_bins > 256 || pv[v].n_bins == 0) return 0;
+    if (!pv[v].compact && latent_bits < 32) return 0;   // (full-width latents of the 8- / 16-bit types: no lean instantiation)
+  }
+  if (!(mask & 2u) || n_on > 2) return 0;
+  if (n_on == 1 && pv[1].n_bins == 1 && !pv[1].needs_ans && pv[1].max_ob == latent_bits && !pv[1].compact) return 0;   // the shifted copy
+  return mask;
 }
+__device__ __forceinline__ bool pack1_takes(const PageVar (&pv)[3], uint32_t latent_bits) { return pack1_mask(pv, latent_bits) != 0; }
 
 // Q (page, variable) items per wave: 8 (slot 4608 B: any table of the fast path) or 16 (slot 2304 B, all 64 lanes busy).
 // The walk is latency-bound, so what matters is that every item is resident at once: with more than 8192 items the launch
@@ -830,7 +842,11 @@ __global__ __launch_bounds__(64) void enc_scan_kernel(EncWorkspace ws, EncFast f
     if (pass == 0) {
       const uint64_t total = (carry + 7) & ~(uint64_t)7;
       const bool overflow = total + 64 > cap_bits;
-      if (lane == 0) { pg->pad = overflow ? 1u : 0u; store_result((PcoGfxTaskResult PCO_GLOBAL*)results + p, overflow ? 0 : total >> 3, overflow ? PCO_GFX_INVALID_ARGUMENT : PCO_GFX_OK, 0); }
+      // (pad: bit 0 = the page does not fit its dst; else bit 8 and, in bits 4-7, the lean pack kernel's shape for this page -- pack1_mask | full-width << 3,
+      //  0 = the general kernel's -- so that the pack kernels of the other shapes leave after one load)
+      uint32_t shape = 0;
+      if (fx.pack1) { shape = pack1_mask(pv, LB); if (shape) { bool wide = false; for (int v = 0; v < 3; v++) if ((shape >> v) & 1u) wide = wide || !pv[v].compact; shape |= wide ? 8u : 0u; } }
+      if (lane == 0) { pg->pad = overflow ? 1u : (0x100u | (shape << 4)); store_result((PcoGfxTaskResult PCO_GLOBAL*)results + p, overflow ? 0 : total >> 3, overflow ? PCO_GFX_INVALID_ARGUMENT : PCO_GFX_OK, 0); }
       if (overflow) return;
       if (lane == 0) { dst32[0] = 0; dst32[total >> 5] = 0; dst32[carry >> 5] = 0; }
     }
@@ -1012,7 +1028,7 @@ __device__ __forceinline__ void pack_item(PackSink& sink, const uint8_t PCO_LDS*
 }
 
 template <class L>
-__device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run, EncPage PCO_GLOBAL* pg, EncChunk PCO_GLOBAL* ch) {
+__device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run, EncPage PCO_GLOBAL* pg, EncChunk PCO_GLOBAL* ch, bool lean) {
   const uint32_t t = uni(pg->chunk);
   const uint32_t lane = lane_id();
   constexpr uint32_t LB = LBits<L>::v;
@@ -1023,8 +1039,7 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
   PageVar pv[3];
 #pragma unroll
   for (int v = 0; v < 3; v++) pv[v] = page_var(ch, v, page_n);
-  const bool lean = fx.pack1 != 0 && pack1_takes(pv);   // enc_pack1_kernel packs this page's batches; what is left here is the head of run 0 (preamble, ChunkMeta, page meta)
-  if (lean && run != 0) return;
+  // lean: enc_pack1_kernel packs this page's batches; what is left here is the head of run 0 (preamble, ChunkMeta, page meta)
   PackSink sink;
   sink.init_at((uint32_t PCO_LDS*)(smem + kPageLdsStg), (uint32_t PCO_GLOBAL*)pg->dst, run == 0 ? 0ull : uni(fx.run_start[(uint64_t)p * fx.run_stride + run]));
   if (run == 0) {
@@ -1167,87 +1182,165 @@ __device__ __forceinline__ void pack_run(const EncWorkspace& ws, const EncFast& 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// enc_pack1_kernel: the batches of the pages with ONE 16-bit latent variable (pack1_takes), nothing else.  The general kernel above carries
+// enc_pack1_kernel: the batches of the pages with one or two latent variables (pack1_mask), nothing else.  The general kernel above carries
 // three variables' worth of per-batch state (two PackItems of eleven registers each per variable, ~124 VGPRs: four waves per SIMD) and decides
-// per batch and variable what to do; it runs at 2.7 TB/s of its own traffic, about half VALU-bound, two thirds of its wave cycles waiting
-// (profiles/r04_c2_pmc_instruction_mix.txt).  Here a batch is five registers of loads, ONE wave scan for both sections (the lane's tANS bits in
-// the low half of a dword, its offset bits in the high half: a batch holds at most 256 x 16 of either) and two puts; the head of the page
-// (preamble, ChunkMeta, page meta) stays with the general kernel, which stops behind it for these pages.  Same bytes
-// (chunk_latent_compressor.rs:272-329), same run structure and joins (enc_scan_kernel).
+// per batch and variable what to do; it ran at 2.7 TB/s of its own traffic, about half VALU-bound, two thirds of its wave cycles waiting
+// (profiles/r04_c2_pmc_instruction_mix.txt).  Here the kernel is instantiated per shape -- which variables, 16-bit latents only or also
+// full-width ones -- a variable's batch is ONE wave scan for both of its sections (the lane's tANS bits in the low half of a dword, its
+// offset bits in the high half: a batch holds at most 256 x 15 of the one and 256 x 64 of the other) and one to five puts; the head of the page (preamble,
+// ChunkMeta, page meta) stays with the general kernel, which stops behind it for these pages.  Same bytes
+// (chunk_latent_compressor.rs:272-329), same run structure and joins (enc_scan_kernel).  BASELINE configs[1]: 5.03 -> 2.92 + 0.28 ms.
 // ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t kPack1LdsBytes = kStgDwords * 4 + 1024;   // bit sink staging | lower | offset bits << 16 per bin, u32[256]
+// LDS: the bit sink's staging, then per variable on -- kWide: lowers u64[256] | offset bits u8[256] | lower | offset bits << 16, u32[256]; else the last table alone
+__host__ __device__ constexpr uint32_t pack1_var_bytes(bool wide) { return wide ? 2048u + 256u + 1024u : 1024u; }
+__host__ __device__ constexpr uint32_t pack1_cpk_off(bool wide) { return wide ? 2304u : 0u; }
+__host__ __device__ constexpr uint32_t pack1_lds_bytes(uint32_t mask, bool wide) { return kStgDwords * 4 + (mask == 2u ? 1u : 2u) * pack1_var_bytes(wide); }
 
-template <bool kFull>
-__device__ __forceinline__ void pack1_item(PackSink& sink, const uint32_t PCO_LDS* cpk, const PackItem& it, uint32_t cnt) {
+// one variable's batch: its tANS fields, then its offset fields (chunk_latent_compressor.rs:134-169)
+template <bool kFull, bool kWide>
+__device__ __forceinline__ void pack1_item(PackSink& sink, const uint8_t PCO_LDS* vt, const PackItem& it, uint32_t cnt, bool needs_ans, bool single_bin, uint32_t max_ob, bool compact) {
   const uint32_t lane = lane_id();
-  const uint32_t syms = quad_transpose_u8(it.syms, lane & 3);
-  uint32_t a = it.a, b = it.b;
-  quad_transpose_u16(a, b, lane & 3);
-  const uint32_t f[4] = {a & 0xffffu, a >> 16, b & 0xffffu, b >> 16};
-  uint64_t acc = 0, off = 0; uint32_t abits = 0, obits = 0;
+  const uint32_t syms = single_bin ? 0u : quad_transpose_u8(it.syms, lane & 3);
+  uint64_t acc = 0; uint32_t abits = 0;
+  if (needs_ans) {
+    uint32_t a = it.a, b = it.b;
+    quad_transpose_u16(a, b, lane & 3);
+    const uint32_t f[4] = {a & 0xffffu, a >> 16, b & 0xffffu, b >> 16};
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const bool act = kFull || 4 * lane + k < cnt;
-    const uint32_t nb = act ? f[k] >> 12 : 0u;
-    acc |= (uint64_t)(act ? f[k] & 0xfffu : 0u) << abits; abits += nb;                     // <= 4 x 10 bits
-    const uint32_t e = cpk[(syms >> (8 * k)) & 0xffu];
-    const uint32_t o = act ? e >> 16 : 0u;
-    off |= (uint64_t)__builtin_amdgcn_ubfe(((uint32_t)(it.x[0] >> (16 * k)) & 0xffffu) - (e & 0xffffu), 0u, o) << obits; obits += o;   // <= 4 x 16 bits
+    for (int k = 0; k < 4; k++) {
+      const bool act = kFull || 4 * lane + k < cnt;
+      const uint32_t nb = act ? f[k] >> 12 : 0u;
+      acc |= (uint64_t)(act ? f[k] & 0xfffu : 0u) << abits; abits += nb;      // <= 4 x 15 bits
+    }
   }
-  const uint32_t both = abits | (obits << 16);
+  uint32_t ob[4] = {0, 0, 0, 0}, obits = 0; uint64_t x[4] = {0, 0, 0, 0};
+  if (max_ob != 0) {
+    if (!kWide || compact) {   // 16-bit latents relative to rel: one packed table word per symbol, 32-bit arithmetic
+      const uint32_t PCO_LDS* cpk = (const uint32_t PCO_LDS*)(vt + pack1_cpk_off(kWide));
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t e = cpk[(syms >> (8 * k)) & 0xffu];
+        ob[k] = (kFull || 4 * lane + k < cnt) ? e >> 16 : 0u;
+        x[k] = (uint64_t)__builtin_amdgcn_ubfe(((uint32_t)(it.x[0] >> (16 * k)) & 0xffffu) - (e & 0xffffu), 0u, ob[k]);   // (compact latents arrive packed, four in x[0])
+        obits += ob[k];
+      }
+    } else {
+      const uint64_t PCO_LDS* low = (const uint64_t PCO_LDS*)vt;
+      const uint8_t PCO_LDS* obs = vt + 2048;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t sy = (syms >> (8 * k)) & 0xffu;
+        ob[k] = (kFull || 4 * lane + k < cnt) ? (uint32_t)obs[sy] : 0u;
+        const uint64_t d = it.x[k] - low[sy];
+        x[k] = ob[k] >= 64 ? d : d & (((uint64_t)1 << ob[k]) - 1);
+        obits += ob[k];
+      }
+    }
+  }
+  const uint32_t both = abits | (obits << 16);                                  // (obits <= 256 per lane, 16384 per batch)
   const uint32_t incl = wave_incl_scan(both), total = wave_last(incl), excl = incl - both;
   const uint32_t ans_total = total & 0xffffu, all = ans_total + (total >> 16);
   sink.reserve(all);
-  sink.put(excl & 0xffffu, acc, abits);
-  sink.put(ans_total + (excl >> 16), off, obits);
+  if (needs_ans) sink.put(excl & 0xffffu, acc, abits);
+  if (max_ob != 0) {
+    uint32_t rel = ans_total + (excl >> 16);
+    // the widest offset of THIS batch decides how many puts it takes (as pack_item_t)
+    uint32_t bmax = max_ob;
+    if (kWide && max_ob > 16) { const uint32_t o01 = ob[0] > ob[1] ? ob[0] : ob[1], o23 = ob[2] > ob[3] ? ob[2] : ob[3]; bmax = wave_max_u32(o01 > o23 ? o01 : o23); }
+    if (!kWide || bmax <= 16) {   // the lane's four fields fit one 64-bit word
+      uint64_t w = 0; uint32_t sh = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { w |= x[k] << sh; sh += ob[k]; }
+      sink.put(rel, w, obits);
+    } else if (bmax <= 32) {
+#pragma unroll
+      for (int k = 0; k < 4; k += 2) { sink.put(rel, x[k] | (x[k + 1] << ob[k]), ob[k] + ob[k + 1]); rel += ob[k] + ob[k + 1]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) { sink.put(rel, x[k], ob[k]); rel += ob[k]; }
+    }
+  }
   sink.commit(all);
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void enc_pack1_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+// kMask: the variables on (2: primary; 6: primary + secondary; 3: lookback variable + primary).  kWide: a variable may hold full-width latents
+// (L = uint32_t / uint64_t; the lookback variable's are uint32_t) -- otherwise every variable on has 16-bit latents and L plays no part.
+template <class L, uint32_t kMask, bool kWide>
+__device__ __forceinline__ void pack1_run(const EncWorkspace& ws, const EncFast& fx, uint32_t p, uint32_t run, EncPage PCO_GLOBAL* pg, uint32_t t, const PageVar (&pv)[3], uint32_t page_n) {
+  const uint32_t lane = lane_id();
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  constexpr int kV0 = (kMask & 1u) ? 0 : 1, kV1 = (kMask & 4u) ? 2 : 1;   // the one or two variables, in stream order (kV0 == kV1: one)
+  constexpr int kN = kV0 == kV1 ? 1 : 2;
+  const int vs[2] = {kV0, kV1};
+#pragma unroll
+  for (int i = 0; i < kN; i++) {
+    const int v = vs[i];
+    const PlanRef plan = plan_ref(ws, t, v);
+    uint8_t PCO_LDS* vt = smem + kStgDwords * 4 + i * pack1_var_bytes(kWide);
+    const uint64_t rel0 = pv[v].compact ? pv[v].rel : 0ull;   // 16-bit latents are relative to it
+    for (uint32_t b = lane; b < pv[v].n_bins; b += 64) {
+      const uint64_t lw = plan.blower()[b] - rel0; const uint32_t ob = plan.bob()[b];
+      if (kWide) { ((uint64_t PCO_LDS*)vt)[b] = lw; (vt + 2048)[b] = (uint8_t)ob; }
+      ((uint32_t PCO_LDS*)(vt + pack1_cpk_off(kWide)))[b] = ((uint32_t)lw & 0xffffu) | (ob << 16);
+    }
+  }
+  PackSink sink;
+  sink.init_at((uint32_t PCO_LDS*)smem, (uint32_t PCO_GLOBAL*)pg->dst, uni(fx.run_start[(uint64_t)p * fx.run_stride + run]));   // (run 0 starts behind the head; init_at ends with a wave sync: the tables are visible)
+  const uint32_t first = run * kRunBatches * kBatchN;
+  const uint64_t pstart = uni((uint64_t)pg->start);
+  PackItem cur[kN], nxt[kN];
+  auto load = [&](uint32_t bb, PackItem (&dstv)[kN]) {
+    const uint32_t base = first + bb * kBatchN;
+#pragma unroll
+    for (int i = 0; i < kN; i++) {
+      const int v = vs[i];
+      if (base >= pv[v].n_lat) continue;
+      const uint32_t cnt = pv[v].n_lat - base < kBatchN ? pv[v].n_lat - base : kBatchN;
+      const uint64_t at = pstart + pv[v].skip + base, fat = fast_at(pg, pv[v].skip) + base;
+      const uint8_t PCO_GLOBAL* sy = fsym_ptr(ws, fx, t, v) + fat; const uint16_t PCO_GLOBAL* an = fansw_ptr(ws, fx, t, v) + fat;
+      if (!kWide || pv[v].compact) pack_load<uint16_t, true>(dstv[i], clat_ptr(ws, t, v) + at, sy, an, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
+      else if (v == 0) pack_load<uint32_t>(dstv[i], lat_ptr<uint32_t>(ws, t, 0) + at, sy, an, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
+      else pack_load<L>(dstv[i], lat_ptr<L>(ws, t, v) + at, sy, an, cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob != 0);
+    }
+  };
+  load(0, cur);
+  for (uint32_t bb = 0; bb < kRunBatches; bb++) {
+    const uint32_t base = first + bb * kBatchN;
+    if (base >= page_n) break;
+    if (bb + 1 < kRunBatches && base + kBatchN < page_n) load(bb + 1, nxt);
+#pragma unroll
+    for (int i = 0; i < kN; i++) {
+      const int v = vs[i];
+      if (base >= pv[v].n_lat) continue;
+      const uint32_t cnt = pv[v].n_lat - base < kBatchN ? pv[v].n_lat - base : kBatchN;
+      const uint8_t PCO_LDS* vt = smem + kStgDwords * 4 + i * pack1_var_bytes(kWide);
+      if (cnt == kBatchN) pack1_item<true, kWide>(sink, vt, cur[i], cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob, pv[v].compact != 0);
+      else pack1_item<false, kWide>(sink, vt, cur[i], cnt, pv[v].needs_ans != 0, pv[v].n_bins <= 1, pv[v].max_ob, pv[v].compact != 0);
+    }
+#pragma unroll
+    for (int i = 0; i < kN; i++) cur[i] = nxt[i];
+  }
+  if ((uint64_t)(run + 1) * kRunBatches * kBatchN >= page_n) sink.finish_byte();
+  sink.close();
+}
+
+// grid pages * runs_per_page, 64 threads; one instantiation per shape (launched only for the shapes a call can have: `shape` = kMask | kWide << 3 | 64-bit << 4)
+template <class L, uint32_t kMask, bool kWide>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kWide ? 5 : 8, kWide ? 5 : 8))) void enc_pack1_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
   const uint32_t p = blockIdx.x / fx.runs_per_page, run = blockIdx.x % fx.runs_per_page;
   if (p >= n_pages) return;
   EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
   const uint32_t t = uni(pg->chunk);
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
-  if (!page_is_fast(ch, pg) || uni(pg->pad) != 0) return;
+  const uint32_t pad = uni(pg->pad);   // enc_scan_kernel: bit 0 = does not fit, bits 4-7 = this page's shape
+  if ((pad & 1u) != 0 || ((pad >> 4) & 0xfu) != (kMask | (kWide ? 8u : 0u))) return;
   const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
   if ((uint64_t)run * kRunBatches * kBatchN >= page_n) return;
+  if (kWide && (uint32_t)dtype_bits(uni(ch->dtype)) != LBits<L>::v) return;
   PageVar pv[3];
 #pragma unroll
   for (int v = 0; v < 3; v++) pv[v] = page_var(ch, v, page_n);
-  if (!pack1_takes(pv)) return;
-  const uint32_t lane = lane_id();
-  uint8_t PCO_LDS* smem = enc_lds_base();
-  uint32_t PCO_LDS* cpk = (uint32_t PCO_LDS*)(smem + kStgDwords * 4);
-  {
-    const PlanRef plan = plan_ref(ws, t, 1);
-    const uint64_t rel0 = pv[1].rel;   // the 16-bit latents are relative to it
-    for (uint32_t b = lane; b < pv[1].n_bins; b += 64) cpk[b] = ((uint32_t)(plan.blower()[b] - rel0) & 0xffffu) | ((uint32_t)plan.bob()[b] << 16);
-  }
-  PackSink sink;
-  sink.init_at((uint32_t PCO_LDS*)smem, (uint32_t PCO_GLOBAL*)pg->dst, uni(fx.run_start[(uint64_t)p * fx.run_stride + run]));   // (run 0 starts behind the head; init_at ends with a wave sync: cpk is visible)
-  const uint32_t n_lat = pv[1].n_lat, first = run * kRunBatches * kBatchN;
-  const uint64_t at = uni((uint64_t)pg->start) + pv[1].skip + first, fat = fast_at(pg, pv[1].skip) + first;
-  const uint16_t PCO_GLOBAL* lat = clat_ptr(ws, t, 1) + at;
-  const uint8_t PCO_GLOBAL* sym = fsym_ptr(ws, fx, t, 1) + fat;
-  const uint16_t PCO_GLOBAL* answ = fansw_ptr(ws, fx, t, 1) + fat;
-  PackItem cur, nxt;
-  auto load = [&](uint32_t bb, PackItem& it) {
-    const uint32_t base = first + bb * kBatchN;
-    if (base >= n_lat) return;
-    pack_load<uint16_t, true>(it, lat + bb * kBatchN, sym + bb * kBatchN, answ + bb * kBatchN, n_lat - base < kBatchN ? n_lat - base : kBatchN, true, false, true);
-  };
-  load(0, cur);
-  for (uint32_t bb = 0; bb < kRunBatches; bb++) {
-    const uint32_t base = first + bb * kBatchN;
-    if (base >= n_lat) break;
-    if (bb + 1 < kRunBatches) load(bb + 1, nxt);
-    const uint32_t cnt = n_lat - base < kBatchN ? n_lat - base : kBatchN;
-    if (cnt == kBatchN) pack1_item<true>(sink, cpk, cur, cnt); else pack1_item<false>(sink, cpk, cur, cnt);
-    cur = nxt;
-  }
-  if ((uint64_t)(run + 1) * kRunBatches * kBatchN >= page_n) sink.finish_byte();
-  sink.close();
+  pack1_run<L, kMask, kWide>(ws, fx, p, run, pg, t, pv, page_n);
 }
 
 // grid pages * runs_per_page, 64 threads
@@ -1257,12 +1350,15 @@ __global__ __launch_bounds__(64) void enc_pack_kernel(EncWorkspace ws, EncFast f
   if (p >= n_pages) return;
   EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + uni(pg->chunk);
-  if (!page_is_fast(ch, pg) || uni(pg->pad) != 0) return;
+  const uint32_t pad = uni(pg->pad);   // enc_scan_kernel: bit 0 = does not fit, bits 4-7 = the lean kernel's shape (0: this kernel packs the page)
+  if (!page_is_fast(ch, pg) || (pad & 1u) != 0) return;
+  const bool lean = ((pad >> 4) & 0xfu) != 0;
+  if (lean && run != 0) return;   // (what is left here of a lean page is the head of run 0: preamble, ChunkMeta, page meta)
   const int bits = dtype_bits(uni(ch->dtype));
-  if (bits == 64) pack_run<uint64_t>(ws, fx, p, run, pg, ch);
-  else if (bits == 32) pack_run<uint32_t>(ws, fx, p, run, pg, ch);
-  else if (bits == 16) pack_run<uint16_t>(ws, fx, p, run, pg, ch);
-  else pack_run<uint8_t>(ws, fx, p, run, pg, ch);
+  if (bits == 64) pack_run<uint64_t>(ws, fx, p, run, pg, ch, lean);
+  else if (bits == 32) pack_run<uint32_t>(ws, fx, p, run, pg, ch, lean);
+  else if (bits == 16) pack_run<uint16_t>(ws, fx, p, run, pg, ch, lean);
+  else pack_run<uint8_t>(ws, fx, p, run, pg, ch, lean);
 }
 
 }  // namespace pcogfx
