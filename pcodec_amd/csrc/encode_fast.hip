@@ -34,6 +34,8 @@ struct EncFast {
   uint32_t runs_per_page, fused; // 1-D grids of dissect / pack: block = page * runs_per_page + run.  fused: which variables enc_walkd_kernel takes (wd_takes)
   uint64_t stride;               // elements per (task, slot) in sym / answ: n_stride + 16 per page, so that the 16-latent
                                  // blocks of neighbouring pages never overlap (see fast_at)
+  uint64_t* body;       // [page][2] enc_walkp_kernel (encode_walkpack.hip): bits of the page's packed body | 1 << 63, its first bit in `answ`; null: that kernel is off
+  uint32_t* wp_block;   // [walk block] 1: enc_walkp_kernel took the block (enc_walkd_kernel leaves it alone)
 };
 // first scratch index of a page variable: its latent index plus 16 slots per preceding page
 __device__ __forceinline__ uint64_t fast_at(const EncPage PCO_GLOBAL* pg, uint32_t skip) { return uni((uint64_t)pg->start) + skip + 16ull * uni(pg->page_idx); }
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(64 * (1 + kWdHelpers)) void enc_walkd_kernel(EncWor
   uint8_t PCO_LDS* smem = enc_lds_base();
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t n_items = n_pages * ws.n_slots;
+  if (fx.wp_block != nullptr && uni(fx.wp_block[blockIdx.x]) != 0) return;   // walked AND packed by enc_walkp_kernel
   typedef uint64_t __attribute__((aligned(2))) u64_align2;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
@@ -814,6 +817,19 @@ __global__ __launch_bounds__(64) void enc_scan_kernel(EncWorkspace ws, EncFast f
   uint32_t PCO_GLOBAL* dst32 = (uint32_t PCO_GLOBAL*)pg->dst;
   const uint64_t cap_bits = uni((uint64_t)pg->dst_cap) * 8;
   const uint32_t n_batches = (page_n + kBatchN - 1) / kBatchN;
+  if (fx.body != nullptr) {   // a page enc_walkp_kernel packed: its body is one bit string of known length behind the head (shape 15: no pack kernel but the head's and enc_place_kernel)
+    const uint64_t rec = uni(fx.body[2ull * p]);
+    if (rec >> 63) {
+      const uint64_t end = head + (rec & ~(1ull << 63)), total = (end + 7) & ~(uint64_t)7;
+      const bool overflow = total + 64 > cap_bits;
+      if (lane == 0) {
+        pg->pad = overflow ? 1u : (0x100u | (15u << 4));
+        store_result((PcoGfxTaskResult PCO_GLOBAL*)results + p, overflow ? 0 : total >> 3, overflow ? PCO_GFX_INVALID_ARGUMENT : PCO_GFX_OK, 0);
+        if (!overflow) { dst32[0] = 0; dst32[total >> 5] = 0; dst32[end >> 5] = 0; dst32[head >> 5] = 0; fx.run_start[(uint64_t)p * fx.run_stride] = head; }
+      }
+      return;
+    }
+  }
   uint64_t carry = head;
   // first pass: total size (so that nothing is written to a dst that is too small)
   for (int pass = 0; pass < 2; pass++) {

@@ -1,0 +1,429 @@
+// encode_walkpack.hip -- the reverse tANS walk AND the bit-packing of a page in one block (round 6).
+//
+// enc_walkd_kernel's walker is a chain of n / 4 dependent LDS round trips per page (3.4 ms per 2^18 latents whatever the call holds); its
+// gathering waves find the symbols beside it and the SIMDs are otherwise idle.  Until round 6 the page was then packed by a second kernel
+// (enc_pack1_kernel, 3.2 ms per 8192 chunks of BASELINE configs[1]) that read the 16-bit latents a second time plus what the walk had left in
+// HBM for it -- a symbol byte and a 16-bit tANS field per latent -- 5 bytes per latent to write 1.2.  Here the gathering waves of a block pack
+// every batch themselves, two barriers behind the walker: the walker leaves a batch's tANS fields in LDS, the gathering wave that found the
+// batch's symbols still holds its latents and bins in registers, looks the bins' lower bounds and offset-bit counts up in an LDS table, and
+// writes the batch's bits -- tANS fields, then offsets: chunk_latent_compressor.rs:134-169 -- through a small LDS bit stage.
+//
+// Where?  The walk runs from the page's last batch to its first (ans/encoding.rs: the decoder reads forwards), so when a batch is packed the
+// bits of the batches BEFORE it are not known.  The batches are therefore written downwards from the end of the page's tANS-field scratch
+// (which these pages no longer need): batch b ends where batch b + 1 begins, bit-exactly, and when the walk is over the page's body is one
+// contiguous, right-aligned bit string of known length.  enc_scan_kernel sizes the page from it, the general pack kernel writes the head
+// (preamble, ChunkMeta, page meta with the final tANS states), and enc_place_kernel moves the body behind the head with one funnel shift per
+// dword -- 1.2 bytes per latent read and written instead of 5 + 1.2.
+//
+// Which pages: every walked item of the block is the ONLY variable of its page that writes anything (classic mode without lookback, or
+// a two-variable mode whose other variable is trivial), has 16-bit latents spanning fewer than 4096 values (the value -> bin tables of
+// enc_vlut_kernel), tables that fit the slot below, and bins whose tANS bits + offset bits never exceed 16 per latent (so that the body fits
+// the 2 bytes per latent of the field scratch).  A block with any other item leaves everything to enc_walkd_kernel and the pack kernels.
+// Same bytes either way (tests: every encode test runs through here when its pages qualify; PCO_GFX_WALKP=0 switches it off).
+#pragma once
+
+namespace pcogfx {
+
+constexpr uint32_t kWpQ = 16, kWpHelpers = 4, kWpH = kWpQ / kWpHelpers;   // items per block, gathering / packing waves, items per such wave
+constexpr uint32_t kWpSlot = 5120;                                         // LDS per item: two blocks per CU take all 160 KB
+constexpr uint32_t kWpStgDwords = 132;                                     // bit stage: one batch (<= 4096 bits) + the carried dword + the reach of a 64-bit put
+constexpr uint32_t kWpStgOff = kWpSlot - 16 - kWpStgDwords * 4;            // 4576
+constexpr uint32_t kWpAnsOff = kWpStgOff - 1024;                           // tANS fields u16[2][256], quad-transposed (as the walker produces them)
+constexpr uint32_t kWpSymOff = kWpAnsOff - 512;                            // symbols u8[2][256], quad-transposed
+constexpr uint32_t kWpLdsBytes = kWpQ * kWpSlot;                           // 81920
+static_assert(kWpStgOff % 16 == 0 && kWpAnsOff % 16 == 0 && kWpSymOff % 16 == 0, "aligned sections");
+static_assert(2 * kWpLdsBytes <= 160 * 1024, "two blocks per CU");
+constexpr uint64_t kWpBodyFlag = 1ull << 63;
+// slot: next states u16[T] | info u64[n_bins] (ew_step) | lower (16 bits, relative) | offset bits << 16, u32[n_bins] | ... | symbols | fields | stage
+__device__ __forceinline__ bool wp_fits(uint32_t asl, uint32_t n_bins) { return ew_info_off(asl) + 12u * n_bins <= kWpSymOff; }
+
+// one field of <= 64 bits OR-ed into the stage at bit `pos` (val has no bits beyond its width); three dwords, the third zero for narrow fields
+__device__ __forceinline__ void wp_put(uint32_t stg_addr, uint32_t pos, uint64_t val) {
+  const uint32_t dw = pos >> 5, sh = pos & 31;
+  const uint64_t lo = val << sh;
+  uint32_t PCO_LDS* s = (uint32_t PCO_LDS*)(uintptr_t)(stg_addr + 4u * dw);
+  atomicOr((uint32_t*)&s[0], (uint32_t)lo);
+  atomicOr((uint32_t*)&s[1], (uint32_t)(lo >> 32));
+  atomicOr((uint32_t*)&s[2], (uint32_t)((val >> 1) >> (63 - sh)));   // val >> (64 - sh), 0 when sh == 0
+}
+
+// LDS accesses of one wave execute in program order: between a wave's own stage atomics, reads and stores nothing has to be waited for -- the compiler
+// only must not move them across each other (enc_wave_sync's release fence would also wait for the wave's loads in flight: a round trip to HBM per batch)
+__device__ __forceinline__ void wp_lds_order() { __asm__ volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+// grid = ceil(items / 16), 320 threads: wave 0 walks, waves 1..4 find the symbols and pack
+// (at most 128 registers: a block's five waves land on the SIMDs as 2-1-1-1, two blocks may put four waves on one)
+__global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_per_eu(4, 4))) void enc_walkp_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  uint8_t PCO_LDS* smem = enc_lds_base();
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t n_items = n_pages * ws.n_slots;
+  typedef uint64_t __attribute__((aligned(2))) u64_align2;
+  // ---- pass 1: does the block qualify?  (uniform; every wave computes the same answer) ----
+  bool ok = (fx.fused & kFusedLookups) != 0;
+  for (uint32_t q = 0; q < kWpQ && ok; q++) {
+    const uint32_t item = blockIdx.x * kWpQ + q;
+    if (item >= n_items) break;
+    const uint32_t p = item / ws.n_slots, sl = item % ws.n_slots;
+    const uint32_t v = ws.slot_of_var[0] == sl ? 0u : (ws.slot_of_var[1] == sl ? 1u : 2u);
+    EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+    const uint32_t t = uni(pg->chunk);
+    EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+    if (!page_is_fast(ch, pg)) continue;
+    const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
+    const PageVar pv = page_var(ch, v, page_n);
+    if (!pv.present || pv.trivial) continue;                          // nothing of this item reaches the page body
+    // it writes something: it must be the page's primary variable, walked here, looked up here, and alone
+    if (v != 1 || !wd_walks(fx.fused, pv) || ws_walks(fx.fused, pv) || !wd_takes(fx.fused, pv) || !pv.needs_ans || pv.n_bins > 256 || !wp_fits(pv.asl, pv.n_bins)) { ok = false; break; }
+    const PageVar p0 = page_var(ch, 0, page_n), p2 = page_var(ch, 2, page_n);
+    if ((p0.present && !p0.trivial) || (p2.present && !p2.trivial)) { ok = false; break; }
+    // tANS bits + offset bits of a latent: at most min_renorm_bits + 1 + the bin's offset bits
+    const PlanRef plan = plan_ref(ws, t, v);
+    uint32_t worst = 0;
+    for (uint32_t b = lane; b < pv.n_bins; b += 64) { const uint32_t w = ((plan.syminfo()[b] >> 14) & 15u) + 1u + plan.bob()[b]; worst = w > worst ? w : worst; }
+    if (wave_max_u32(worst) > 16u) { ok = false; break; }
+  }
+  if (threadIdx.x == 0) fx.wp_block[blockIdx.x] = ok ? 1u : 0u;
+  if (!ok) {   // enc_walkd_kernel takes the block; the pages whose primary variable sits here are marked "no body"
+    if (threadIdx.x < kWpQ) {
+      const uint32_t item = blockIdx.x * kWpQ + threadIdx.x;
+      if (item < n_items && ws.slot_of_var[1] == item % ws.n_slots) fx.body[2ull * (item / ws.n_slots)] = 0;
+    }
+    return;
+  }
+  // ---- pass 2: the items' tables (wave 0), and what a lane keeps of its item: a walker lane the item of its quad (lane >> 2), a helper
+  //      lane of wave w the item (w - 1) * 4 + (lane & 3) ----
+  const uint32_t my_q = wave == 0 ? lane >> 2 : (wave - 1) * kWpH + (lane & (kWpH - 1));
+  uint32_t my_n_lat = 0, my_T = 0, my_p = 0, my_task = 0, my_info_off = 0, my_cpk_off = 0;
+  uint64_t my_at = 0, my_clat = 0;
+  uint32_t max_nb = 0;
+  for (uint32_t q = 0; q < kWpQ; q++) {
+    const uint32_t item = blockIdx.x * kWpQ + q;
+    if (item >= n_items) break;
+    const uint32_t p = item / ws.n_slots, sl = item % ws.n_slots;
+    const uint32_t v = ws.slot_of_var[0] == sl ? 0u : (ws.slot_of_var[1] == sl ? 1u : 2u);
+    EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+    const uint32_t t = uni(pg->chunk);
+    EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
+    if (!page_is_fast(ch, pg)) continue;
+    const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
+    const PageVar pv = page_var(ch, v, page_n);
+    if (!pv.present || pv.trivial) {
+      // (as enc_walkd_kernel: nobody else writes the states of a variable that needs no walk; a page whose primary variable is trivial has no body of ours)
+      if (pv.present && (pv.n_bins <= 1 || pv.n_lat == 0) && wave == 0 && lane < 4) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
+      if (v == 1 && threadIdx.x == 0) fx.body[2ull * p] = 0;
+      continue;
+    }
+    const uint32_t info_off = ew_info_off(pv.asl), cpk_off = info_off + 8u * pv.n_bins;
+    { const uint32_t nbq = (pv.n_lat + kBatchN - 1) / kBatchN; max_nb = nbq > max_nb ? nbq : max_nb; }
+    if (wave == 0) {
+      const PlanRef plan = plan_ref(ws, t, v);
+      uint8_t PCO_LDS* slot = smem + q * kWpSlot;
+      const uint32_t T = 1u << pv.asl;
+      for (uint32_t i = lane; i < T; i += 64) ((uint16_t PCO_LDS*)slot)[i] = plan.next_states()[i];
+      for (uint32_t b = lane; b < pv.n_bins; b += 64) {
+        const uint32_t si = plan.syminfo()[b];   // cutoff(14) | min_renorm_bits(4) << 14 | (row + 8192)(14) << 18
+        const uint32_t cutoff = si & 0x3fffu, minb = (si >> 14) & 15u, row = (si >> 18) - 8192u;
+        const uint32_t row_addr = lds0 + q * kWpSlot + 2u * row;
+        ((uint64_t PCO_LDS*)(slot + info_off))[b] = (uint64_t)(((minb + 1u) << 16) - cutoff) | ((uint64_t)row_addr << 32);
+        ((uint32_t PCO_LDS*)(slot + cpk_off))[b] = ((uint32_t)(plan.blower()[b] - pv.rel) & 0xffffu) | ((uint32_t)plan.bob()[b] << 16);   // (16-bit latents are relative to rel)
+      }
+      for (uint32_t i = lane; i < kWpStgDwords; i += 64) ((uint32_t PCO_LDS*)(slot + kWpStgOff))[i] = 0;
+    }
+    if (my_q == q) {
+      my_n_lat = pv.n_lat; my_T = 1u << pv.asl; my_p = p; my_task = t; my_info_off = info_off; my_cpk_off = cpk_off;
+      my_at = fast_at(pg, pv.skip); my_clat = uni((uint64_t)pg->start) + pv.skip;
+    }
+  }
+  const uint32_t my_nb = (my_n_lat + kBatchN - 1) / kBatchN;
+  if (max_nb == 0) return;
+  wd_barrier();
+  if (wave != 0) {
+    // ================= a gathering + packing wave: four items =================
+    // Everything that depends on the item alone is wave-uniform and lives in SGPRs (the item loops are unrolled): the kernel is bound by the
+    // VALU instructions of these waves -- two walkers and eight of them share a CU's four SIMDs, ~7100 issue cycles per batch of the walk --
+    // so nothing is fetched from an owner lane per step, the loads take scalar bases, and full batches (all but a page's last) take a
+    // path without per-latent predicates.
+    const bool mine = my_n_lat != 0;
+    const uint64_t my_clat_p = mine ? (uint64_t)(uintptr_t)(clat_ptr(ws, my_task, 1) + my_clat) : (uint64_t)(uintptr_t)fx.vlut;
+    const uint32_t my_lut_off = mine ? (my_task * ws.n_slots + ws.slot_of_var[1]) * kDirectHistRange : 0u;   // (u16 elements)
+    // the page's body region: the dwords of its tANS-field scratch (and of the 32-byte gap behind it), written downwards from the end
+    const uint64_t my_reg = ((uint64_t)(uintptr_t)(fansw_ptr(ws, fx, my_task, 1) + my_at) + 3ull) & ~3ull;
+    const uint32_t my_reg_bits = mine ? (uint32_t)(((2ull * my_n_lat + 8ull) & ~3ull) * 8ull) : 0u;
+    auto bcast = [](uint32_t x, uint32_t q) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)q); };
+    auto bcast64 = [&](uint64_t x, uint32_t q) { return ((uint64_t)bcast((uint32_t)(x >> 32), q) << 32) | bcast((uint32_t)x, q); };
+    const uint32_t q0 = (wave - 1) * kWpH;
+    uint32_t s_nlat[kWpH], s_nb[kWpH], s_cpk[kWpH], s_rot2[kWpH], s_low[kWpH], s_carry[kWpH], s_slot[kWpH];
+    uint64_t s_clat[kWpH], s_lut[kWpH], s_reg[kWpH];
+#pragma unroll
+    for (uint32_t q = 0; q < kWpH; q++) {
+      s_nlat[q] = bcast(my_n_lat, q); s_nb[q] = (s_nlat[q] + kBatchN - 1) / kBatchN;
+      s_slot[q] = lds0 + (q0 + q) * kWpSlot; s_cpk[q] = s_slot[q] + bcast(my_cpk_off, q);
+      const uint32_t lo = bcast(my_lut_off, q);
+      s_lut[q] = (uint64_t)(uintptr_t)fx.vlut + 2ull * lo; s_rot2[q] = vlut_rot(lo / kDirectHistRange) * 0x10001u;   // the table's rotation, for both 16-bit halves of a dword (no carry: latents < 2^15)
+      s_clat[q] = bcast64(my_clat_p, q); s_reg[q] = bcast64(my_reg, q); s_low[q] = bcast(my_reg_bits, q); s_carry[q] = 0;
+    }
+    auto batch_at = [&](uint32_t q, uint32_t it) { return it < s_nb[q] ? s_nb[q] - 1 - it : 0u; };   // (no batch at this step: batch 0 is read, and never used)
+    auto count_at = [&](uint32_t q, uint32_t it) { const uint32_t base = batch_at(q, it) * kBatchN; return it < s_nb[q] ? (s_nlat[q] - base < kBatchN ? s_nlat[q] - base : kBatchN) : 0u; };
+    // (branch-free on purpose, as in enc_walkd_kernel.  The 8 bytes of a page's last, partial batch may run into the scratch behind the page: those latents count for nothing)
+    auto load_batches = [&](uint32_t it, uint64_t (&w)[kWpH]) {   // the 4 latents a lane owns of every item's batch
+#pragma unroll
+      for (uint32_t q = 0; q < kWpH; q++) w[q] = __builtin_nontemporal_load((const u64_align2 PCO_GLOBAL*)((const uint8_t PCO_GLOBAL*)(uintptr_t)(s_clat[q] + 2ull * batch_at(q, it) * kBatchN) + 8 * lane));
+    };
+    auto gather = [&](const uint64_t (&w)[kWpH], uint32_t (&e)[kWpH][4]) {   // value -> bin | offset bits << 8 through enc_vlut_kernel's tables
+#pragma unroll
+      for (uint32_t q = 0; q < kWpH; q++) {
+        const uint16_t PCO_GLOBAL* lut = (const uint16_t PCO_GLOBAL*)(uintptr_t)s_lut[q];
+        const uint32_t lo = (uint32_t)w[q] + s_rot2[q], hi = (uint32_t)(w[q] >> 32) + s_rot2[q];
+        e[q][0] = lut[lo & (kDirectHistRange - 1)]; e[q][1] = lut[(lo >> 16) & (kDirectHistRange - 1)];
+        e[q][2] = lut[hi & (kDirectHistRange - 1)]; e[q][3] = lut[(hi >> 16) & (kDirectHistRange - 1)];
+      }
+    };
+    // pipeline at step s: latents of step s + 2 requested, table entries of step s + 1 gathered; symbols of step s made and its offsets put together
+    // (they do not depend on the walk); the tANS fields of step s - 2 put together and the batch written
+    uint64_t xl[kWpH], xg[kWpH], xs[kWpH];      // latents: loaded for s + 2 | gathered for s + 1 | this step's
+    uint32_t e1[kWpH][4];                        // entries: gathered (during step s - 1) for step s, then (during step s) for s + 1
+    uint64_t o0[kWpH], oa[kWpH], ob[kWpH];      // a lane's four offsets, concatenated: steps s, s - 1, s - 2
+    uint32_t n0[kWpH], na[kWpH], nb2[kWpH];     // ... and how many bits that is
+#pragma unroll
+    for (uint32_t q = 0; q < kWpH; q++) { xl[q] = xg[q] = xs[q] = 0; o0[q] = oa[q] = ob[q] = 0; n0[q] = na[q] = nb2[q] = 0; e1[q][0] = e1[q][1] = e1[q][2] = e1[q][3] = 0; }
+    load_batches(0, xg);
+    gather(xg, e1);
+    if (1 < max_nb) load_batches(1, xl);
+    const uint32_t lane_sym = 16u * (lane >> 2) + (lane & 3u), lane_ans = 32u * (lane >> 2) + 2u * (lane & 3u);
+    // symbols and offsets of one batch of one item (entries in e1[q], latents in xs[q])
+    auto find_item = [&](auto full_tag, uint32_t q, uint32_t hb, uint32_t cnt) {
+      constexpr bool kFull = decltype(full_tag)::value;
+      uint32_t e[4] = {e1[q][0], e1[q][1], e1[q][2], e1[q][3]};
+      if (!kFull) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = 4 * lane + k < cnt ? e[k] : 0u;
+      }
+      // the walker's chain k reads byte k of the dwords at 16 blk + 4 k; latent 4 l + k sits in block l >> 2, step l & 3
+      const uint32_t buf = s_slot[q] + kWpSymOff + (hb & 1) * 256 + lane_sym;
+#pragma unroll
+      for (int k = 0; k < 4; k++) *(uint8_t PCO_LDS*)(uintptr_t)(buf + 4 * k) = (uint8_t)e[k];
+      uint32_t c[4], w[4], dv[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) c[k] = *(const uint32_t PCO_LDS*)(uintptr_t)(s_cpk[q] + 4u * (e[k] & 0xffu));   // lower (16 bits, relative) | offset bits << 16
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        w[k] = (kFull || 4 * lane + k < cnt) ? c[k] >> 16 : 0u;
+        const uint32_t xk = (uint32_t)(xs[q] >> (16 * k)) & 0xffffu;
+        dv[k] = __builtin_amdgcn_ubfe(xk - c[k], 0u, w[k]);   // (w <= 15; c's high half only disturbs bits 16 and up)
+      }
+      const uint32_t o01 = w[0] + w[1];
+      o0[q] = (uint64_t)(dv[0] | (dv[1] << w[0])) | ((uint64_t)(dv[2] | (dv[3] << w[2])) << o01);   // <= 60 bits, two fields at a time in 32
+      n0[q] = o01 + w[2] + w[3];
+    };
+    // one batch of one item: its tANS fields (left by the walker), then its offsets (ob / nb2), at bits [low - all, low) of the page's body region
+    auto pack_item = [&](auto full_tag, uint32_t q, uint32_t pb, uint32_t cnt) {
+      constexpr bool kFull = decltype(full_tag)::value;
+      const uint32_t fa = s_slot[q] + kWpAnsOff + (pb & 1) * 512 + lane_ans, stg = s_slot[q] + kWpStgOff;
+      uint32_t f[4], nb[4], fv[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) f[k] = *(const uint16_t PCO_LDS*)(uintptr_t)(fa + 8 * k);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        nb[k] = (kFull || 4 * lane + k < cnt) ? f[k] >> 12 : 0u;
+        fv[k] = __builtin_amdgcn_ubfe(f[k], 0u, nb[k]);                                                            // <= 12 bits
+      }
+      const uint32_t a01 = nb[0] + nb[1], abits = a01 + nb[2] + nb[3], obits = nb2[q];
+      const uint64_t acc = (uint64_t)(fv[0] | (fv[1] << nb[0])) | ((uint64_t)(fv[2] | (fv[3] << nb[2])) << a01);   // <= 48 bits
+      const uint32_t both = abits | (obits << 16);
+      const uint32_t incl = wave_incl_scan(both), total = wave_last(incl), excl = incl - both;
+      const uint32_t ans_total = total & 0xffffu, all = ans_total + (total >> 16);
+      const uint32_t low = s_low[q], new_low = low - all, sh0 = new_low & 31u, lo_dw = new_low >> 5;
+#ifdef PCO_WP_NOPUT   // (timing experiments: wrong bytes)
+      if (all == 0xdeadbeefu) {
+#else
+      if (all != 0) {
+#endif
+        wp_put(stg, sh0 + (excl & 0xffffu), acc);
+        wp_put(stg, sh0 + ans_total + (excl >> 16), ob[q]);
+        wp_lds_order();
+        // the dwords the batch completes go out -- the highest with what the batch above left of it; the lowest stays as the carry unless the batch starts on a dword
+        const uint32_t n_dw = ((low - 1u) >> 5) - lo_dw + 1u, i0 = sh0 ? 1u : 0u, top = (low & 31u) ? n_dw - 1u : 0xffffffffu;
+        uint32_t PCO_GLOBAL* g = (uint32_t PCO_GLOBAL*)(uintptr_t)s_reg[q] + lo_dw;
+#ifndef PCO_WP_NOFLUSH
+        for (uint32_t r = 0; r < n_dw; r += 64) {
+          const uint32_t i = r + lane;
+          if (i >= i0 && i < n_dw) {
+            uint32_t PCO_LDS* sp = (uint32_t PCO_LDS*)(uintptr_t)stg + i;
+            g[i] = *sp | (i == top ? s_carry[q] : 0u); *sp = 0;
+          }
+        }
+#endif
+        uint32_t nc = 0;
+        if (sh0) { nc = uni(*(const uint32_t PCO_LDS*)(uintptr_t)stg) | (top == 0u ? s_carry[q] : 0u); wp_lds_order(); *(uint32_t PCO_LDS*)(uintptr_t)stg = 0; }   // (a batch inside one dword: the carry stays where it is)
+        s_low[q] = new_low; s_carry[q] = nc;
+        wp_lds_order();
+      }
+    };
+    for (uint32_t it = 0; it < max_nb + 2; it++) {
+      // ---- rotate the pipeline ----
+#pragma unroll
+      for (uint32_t q = 0; q < kWpH; q++) { ob[q] = oa[q]; nb2[q] = na[q]; oa[q] = o0[q]; na[q] = n0[q]; xs[q] = xg[q]; xg[q] = xl[q]; }
+      // ---- symbols and offsets of step `it` ----
+      if (it < max_nb) {
+        uint32_t cn[kWpH]; bool all_full = true;
+#pragma unroll
+        for (uint32_t q = 0; q < kWpH; q++) { cn[q] = count_at(q, it); all_full = all_full && cn[q] == kBatchN; }
+        if (all_full) {   // straight-line: the four items' LDS round trips overlap
+#pragma unroll
+          for (uint32_t q = 0; q < kWpH; q++) find_item(std::true_type{}, q, batch_at(q, it), kBatchN);
+        } else {
+#pragma unroll
+          for (uint32_t q = 0; q < kWpH; q++) { if (cn[q] != 0) find_item(std::false_type{}, q, batch_at(q, it), cn[q]); else { o0[q] = 0; n0[q] = 0; } }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < max_nb) gather(xg, e1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 2 < max_nb) load_batches(it + 2, xl);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- pack the batch of step it - 2 ----
+#ifndef PCO_WP_NOPACK
+      if (it >= 2) {
+        uint32_t cn[kWpH]; bool all_full = true;
+#pragma unroll
+        for (uint32_t q = 0; q < kWpH; q++) { cn[q] = count_at(q, it - 2); all_full = all_full && cn[q] == kBatchN; }
+        if (all_full) {
+#pragma unroll
+          for (uint32_t q = 0; q < kWpH; q++) pack_item(std::true_type{}, q, batch_at(q, it - 2), kBatchN);
+        } else {
+#pragma unroll
+          for (uint32_t q = 0; q < kWpH; q++) if (cn[q] != 0) pack_item(std::false_type{}, q, batch_at(q, it - 2), cn[q]);
+        }
+      }
+#endif
+      wd_barrier();
+    }
+    // the body's lowest, partial dword, and the page's record: bits | flag, first bit (counted from fx.answ)
+#pragma unroll
+    for (uint32_t q = 0; q < kWpH; q++) {
+      if (s_nlat[q] == 0) continue;
+      const uint32_t pq = bcast(my_p, q), rb = bcast(my_reg_bits, q);
+      if (lane == 0) {
+        if (s_low[q] & 31u) ((uint32_t PCO_GLOBAL*)(uintptr_t)s_reg[q])[s_low[q] >> 5] = s_carry[q];
+        fx.body[2ull * pq] = (uint64_t)(rb - s_low[q]) | kWpBodyFlag;
+        fx.body[2ull * pq + 1] = (s_reg[q] - (uint64_t)(uintptr_t)fx.answ) * 8ull + s_low[q];
+      }
+    }
+    return;
+  }
+  // ================= the walker wave (enc_walkd_kernel's walk; the fields stay in LDS) =================
+  const uint32_t j = lane & 3;
+  const uint32_t slice = lds0 + my_q * kWpSlot;
+  const uint32_t info_addr = slice + my_info_off, symbuf = slice + kWpSymOff, ansbuf = slice + kWpAnsOff;
+  uint32_t state = my_T;
+  wd_barrier();   // (the gathering waves' it = 0)
+  for (uint32_t it = 0; it < max_nb; it++) {
+    if (it < my_nb) {
+      const uint32_t b = my_nb - 1 - it, base = b * kBatchN, cnt = my_n_lat - base < kBatchN ? my_n_lat - base : kBatchN;
+      const uint32_t buf = symbuf + (b & 1) * 256, abuf = ansbuf + (b & 1) * 512 + 8 * j;
+      uint32_t bits_acc = 0;
+      if (cnt < kBatchN) {   // the last (partial) batch: per-step predicates
+        const uint32_t steps = (cnt + 3) >> 2;
+        for (uint32_t blk = (steps + 3) >> 2; blk-- > 0;) {
+          const uint32_t sd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * blk + 4 * j);
+          uint64_t out = 0;
+#pragma unroll
+          for (int k = 3; k >= 0; k--) {
+            const uint32_t g = 4 * blk + k;
+            if (4 * g + j < cnt) {
+              const uint64_t info = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> (8 * k)) & 0xffu));
+              out |= (uint64_t)ew_step(state, bits_acc, info) << (16 * k);
+            }
+          }
+          *(uint64_t PCO_LDS*)(uintptr_t)(abuf + 32 * blk) = out;
+        }
+      } else {               // a full batch, software-pipelined as in enc_walk_kernel
+        uint32_t sd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * 15 + 4 * j);
+        uint32_t nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * 14 + 4 * j);
+        uint64_t i0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (sd & 0xffu));
+        uint64_t i1 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> 8) & 0xffu));
+        uint64_t i2 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> 16) & 0xffu));
+        uint64_t i3 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (sd >> 24));
+        for (uint32_t blk = 16; blk-- > 0;) {
+          const uint32_t nnblk = blk > 1 ? blk - 2 : 0;
+          const uint32_t o3 = ew_step(state, bits_acc, i3);
+          const uint64_t n3 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd >> 24));
+          __builtin_amdgcn_sched_barrier(0);
+          const uint32_t o2 = ew_step(state, bits_acc, i2);
+          const uint64_t n2 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((nsd >> 16) & 0xffu));
+          const uint32_t o23 = o2 | (o3 << 16);
+          __builtin_amdgcn_sched_barrier(0);
+          const uint32_t o1 = ew_step(state, bits_acc, i1);
+          const uint64_t n1 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((nsd >> 8) & 0xffu));
+          __builtin_amdgcn_sched_barrier(0);
+          const uint32_t o0 = ew_step(state, bits_acc, i0);
+          const uint64_t n0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd & 0xffu));
+          nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * nnblk + 4 * j);
+          *(uint64_t PCO_LDS*)(uintptr_t)(abuf + 32 * blk) = (uint64_t)(o0 | (o1 << 16)) | ((uint64_t)o23 << 32);
+          __builtin_amdgcn_sched_barrier(0);
+          i0 = n0; i1 = n1; i2 = n2; i3 = n3;
+        }
+      }
+    }
+    wd_barrier();
+  }
+  wd_barrier();   // (the packing waves' last step)
+  if (my_n_lat > 0) fx.fstate[((uint64_t)my_p * 3 + 1) * 4 + j] = state;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// enc_place_kernel: the bodies enc_walkp_kernel left right-aligned in the field scratch, moved behind their pages' heads.  The head ends on
+// a byte (enc_scan_kernel: run_start[0]), the body starts at any bit of the scratch: every dst dword is one v_alignbit of two source dwords.
+// The first and the last dword of the body in dst are shared (with the head; with the padding) and are OR-ed into what enc_scan_kernel zeroed.
+// grid pages * kPlacePieces, 256 threads: 16 bytes of dst per thread and step.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kPlacePieces = 16;
+__global__ __launch_bounds__(256) void enc_place_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
+  const uint32_t p = blockIdx.x / kPlacePieces, piece = blockIdx.x % kPlacePieces;
+  if (p >= n_pages) return;
+  EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
+  EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + uni(pg->chunk);
+  if (!page_is_fast(ch, pg)) return;
+  const uint64_t rec = uni(fx.body[2ull * p]);
+  if (!(rec & kWpBodyFlag) || (uni(pg->pad) & 1u) != 0) return;
+  const uint64_t bits = rec & ~kWpBodyFlag, sbit = uni(fx.body[2ull * p + 1]);
+  if (bits == 0) return;
+  const uint64_t head = uni(fx.run_start[(uint64_t)p * fx.run_stride]), end = head + bits;   // dst bits [head, end)
+  uint32_t PCO_GLOBAL* dst32 = (uint32_t PCO_GLOBAL*)pg->dst;
+  const uint32_t PCO_GLOBAL* src32 = (const uint32_t PCO_GLOBAL*)fx.answ;
+  const uint64_t d_first = head >> 5, d_last = (end - 1) >> 5;
+  // src bit of dst bit x: sbit + (x - head)
+  const uint64_t g0 = d_first >> 2, g1 = d_last >> 2;   // 16-byte groups of dst touched
+  for (uint64_t g = g0 + (uint64_t)piece * 256 + threadIdx.x; g <= g1; g += (uint64_t)kPlacePieces * 256) {
+    const uint64_t d0 = 4 * g;
+    if (d0 > d_first && d0 + 3 < d_last) {   // four interior dwords
+      const uint64_t s = sbit + (32 * d0 - head);
+      const uint32_t PCO_GLOBAL* sp = src32 + (s >> 5);
+      const u32x4 a = *(const u32x4_a4 PCO_GLOBAL*)sp; const uint32_t a4 = sp[4];
+      const uint32_t r = (uint32_t)s & 31u;
+      u32x4 o;
+      o.x = __builtin_amdgcn_alignbit(a.y, a.x, r); o.y = __builtin_amdgcn_alignbit(a.z, a.y, r);
+      o.z = __builtin_amdgcn_alignbit(a.w, a.z, r); o.w = __builtin_amdgcn_alignbit(a4, a.w, r);
+      *(u32x4 PCO_GLOBAL*)(dst32 + d0) = o;
+    } else {
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint64_t d = d0 + k;
+        if (d < d_first || d > d_last) continue;
+        const uint64_t lo = 32 * d > head ? 32 * d : head, hi = 32 * d + 32 < end ? 32 * d + 32 : end;
+        const uint32_t nb = (uint32_t)(hi - lo);
+        const uint64_t s = sbit + (lo - head);
+        const uint32_t PCO_GLOBAL* sp = src32 + (s >> 5);
+        const uint64_t w = (uint64_t)sp[0] | ((uint64_t)sp[1] << 32);
+        uint32_t val = (uint32_t)(w >> (s & 31));
+        if (nb < 32) val &= (1u << nb) - 1u;
+        val <<= (uint32_t)(lo - 32 * d);
+        if (nb < 32 || d == d_first) atomicOr((uint32_t*)(dst32 + d), val); else dst32[d] = val;
+      }
+    }
+  }
+}
+
+}  // namespace pcogfx

@@ -30,6 +30,7 @@
 #include "auto_mode_kernels.hip"
 #include "encode_fast.hip"
 #include "encode_walkseg.hip"
+#include "encode_walkpack.hip"
 #include "stream_kernels.hip"
 
 namespace pcogfx {
