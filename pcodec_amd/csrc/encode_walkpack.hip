@@ -24,14 +24,30 @@
 
 namespace pcogfx {
 
-constexpr uint32_t kWpQ = 16, kWpHelpers = 4, kWpH = kWpQ / kWpHelpers;   // items per block, gathering / packing waves, items per such wave
+// Eight packing waves of two items each, at most 80 registers (measured, 8192 chunks of BASELINE configs[1]: four waves of four items 5.4 ms -- a
+// packing wave's own chain of LDS round trips, scans and flushes takes 8500 cycles per batch step where the walker takes 7100; eight waves at 96
+// registers 6.6 ms -- a block's nine waves land on the SIMDs as 3-2-2-2, two blocks may put six on one: the second block did not fit; eight at 80: 4.4 ms)
+#ifndef PCO_WP_HELPERS
+#define PCO_WP_HELPERS 8
+#endif
+#ifndef PCO_WP_WAVES
+#define PCO_WP_WAVES 6
+#endif
+constexpr uint32_t kWpQ = 16, kWpHelpers = PCO_WP_HELPERS, kWpH = kWpQ / kWpHelpers;   // items per block, gathering / packing waves, items per such wave
 constexpr uint32_t kWpSlot = 5120;                                         // LDS per item: two blocks per CU take all 160 KB
 constexpr uint32_t kWpStgDwords = 132;                                     // bit stage: one batch (<= 4096 bits) + the carried dword + the reach of a 64-bit put
-constexpr uint32_t kWpStgOff = kWpSlot - 16 - kWpStgDwords * 4;            // 4576
+// Slot q starts 8 q bytes into its 5120: the slots' strides are a multiple of the 128 bytes the LDS banks repeat after, and sixteen quads (or four
+// waves) that read the same offset of sixteen slots -- the same step's symbols, the info word of the most frequent bin -- would all hit one bank.
+#ifndef PCO_WP_SKEW
+#define PCO_WP_SKEW 8
+#endif
+constexpr uint32_t kWpSkew = PCO_WP_SKEW, kWpSlotUse = kWpSlot - kWpSkew * (16 - 1);   // 5000 usable bytes
+__device__ __forceinline__ uint32_t wp_slot(uint32_t q) { return q * (kWpSlot + kWpSkew); }
+constexpr uint32_t kWpStgOff = (kWpSlotUse - kWpStgDwords * 4) & ~15u;     // 4464
 constexpr uint32_t kWpAnsOff = kWpStgOff - 1024;                           // tANS fields u16[2][256], quad-transposed (as the walker produces them)
 constexpr uint32_t kWpSymOff = kWpAnsOff - 512;                            // symbols u8[2][256], quad-transposed
 constexpr uint32_t kWpLdsBytes = kWpQ * kWpSlot;                           // 81920
-static_assert(kWpStgOff % 16 == 0 && kWpAnsOff % 16 == 0 && kWpSymOff % 16 == 0, "aligned sections");
+static_assert(kWpStgOff % 16 == 0 && kWpAnsOff % 16 == 0 && kWpSymOff % 16 == 0 && kWpStgOff + kWpStgDwords * 4 <= kWpSlotUse, "aligned sections");
 static_assert(2 * kWpLdsBytes <= 160 * 1024, "two blocks per CU");
 constexpr uint64_t kWpBodyFlag = 1ull << 63;
 // slot: next states u16[T] | info u64[n_bins] (ew_step) | lower (16 bits, relative) | offset bits << 16, u32[n_bins] | ... | symbols | fields | stage
@@ -42,18 +58,41 @@ __device__ __forceinline__ void wp_put(uint32_t stg_addr, uint32_t pos, uint64_t
   const uint32_t dw = pos >> 5, sh = pos & 31;
   const uint64_t lo = val << sh;
   uint32_t PCO_LDS* s = (uint32_t PCO_LDS*)(uintptr_t)(stg_addr + 4u * dw);
+  const uint32_t hi = (uint32_t)((val >> 1) >> (63 - sh));   // val >> (64 - sh), 0 when sh == 0
+#ifdef PCO_WP_PLAINST   // (timing experiments: wrong bytes)
+  s[0] = (uint32_t)lo; s[1] = (uint32_t)(lo >> 32);
+  if (__any(hi != 0)) s[2] = hi;
+#else
   atomicOr((uint32_t*)&s[0], (uint32_t)lo);
   atomicOr((uint32_t*)&s[1], (uint32_t)(lo >> 32));
-  atomicOr((uint32_t*)&s[2], (uint32_t)((val >> 1) >> (63 - sh)));   // val >> (64 - sh), 0 when sh == 0
+  atomicOr((uint32_t*)&s[2], hi);   // (unconditionally: a wave-uniform branch around it -- v_cmp, s_cbranch_vccz right behind the ds_or pair -- was one of the two
+                                      //  forms with which, at 80 registers, a batch in a few came out garbled in its tANS section; see the note at the kernel)
+#endif
 }
 
 // LDS accesses of one wave execute in program order: between a wave's own stage atomics, reads and stores nothing has to be waited for -- the compiler
 // only must not move them across each other (enc_wave_sync's release fence would also wait for the wave's loads in flight: a round trip to HBM per batch)
+#ifdef PCO_WP_FULLORDER
+__device__ __forceinline__ void wp_lds_order() { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+#else
 __device__ __forceinline__ void wp_lds_order() { __asm__ volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+#endif
 
+#ifdef PCO_WP_TIMING
+__device__ unsigned long long g_wp_timing[16];   // block 7: helper wave 1: find, gather+load, puts, flush, barrier, iterations; walker: walk, barrier
+#define WPT_NOW() __builtin_readcyclecounter()
+#endif
+#ifdef PCO_WP_ASSERT
+__device__ uint32_t g_wp_err[8];   // scan mismatch, fields changed under the reader, stage not clean, ...
+#endif
+#ifdef PCO_WP_DEBUGSUM
+__device__ uint32_t g_wp_dbg[16 * 1100 * 4];   // block 0: [item][step]: walker field sum, walker symbol sum, helper field sum, helper symbol sum (each: sum of value * (latent index + 1))
+#endif
+#ifdef PCO_WP_FULLSYNC
+#define wd_barrier() __syncthreads()
+#endif
 // grid = ceil(items / 16), 320 threads: wave 0 walks, waves 1..4 find the symbols and pack
-// (at most 128 registers: a block's five waves land on the SIMDs as 2-1-1-1, two blocks may put four waves on one)
-__global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_per_eu(4, 4))) void enc_walkp_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+__global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_per_eu(PCO_WP_WAVES, PCO_WP_WAVES))) void enc_walkp_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   uint8_t PCO_LDS* smem = enc_lds_base();
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -118,13 +157,13 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
     { const uint32_t nbq = (pv.n_lat + kBatchN - 1) / kBatchN; max_nb = nbq > max_nb ? nbq : max_nb; }
     if (wave == 0) {
       const PlanRef plan = plan_ref(ws, t, v);
-      uint8_t PCO_LDS* slot = smem + q * kWpSlot;
+      uint8_t PCO_LDS* slot = smem + wp_slot(q);
       const uint32_t T = 1u << pv.asl;
       for (uint32_t i = lane; i < T; i += 64) ((uint16_t PCO_LDS*)slot)[i] = plan.next_states()[i];
       for (uint32_t b = lane; b < pv.n_bins; b += 64) {
         const uint32_t si = plan.syminfo()[b];   // cutoff(14) | min_renorm_bits(4) << 14 | (row + 8192)(14) << 18
         const uint32_t cutoff = si & 0x3fffu, minb = (si >> 14) & 15u, row = (si >> 18) - 8192u;
-        const uint32_t row_addr = lds0 + q * kWpSlot + 2u * row;
+        const uint32_t row_addr = lds0 + wp_slot(q) + 2u * row;
         ((uint64_t PCO_LDS*)(slot + info_off))[b] = (uint64_t)(((minb + 1u) << 16) - cutoff) | ((uint64_t)row_addr << 32);
         ((uint32_t PCO_LDS*)(slot + cpk_off))[b] = ((uint32_t)(plan.blower()[b] - pv.rel) & 0xffffu) | ((uint32_t)plan.bob()[b] << 16);   // (16-bit latents are relative to rel)
       }
@@ -149,7 +188,7 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
     const uint32_t my_lut_off = mine ? (my_task * ws.n_slots + ws.slot_of_var[1]) * kDirectHistRange : 0u;   // (u16 elements)
     // the page's body region: the dwords of its tANS-field scratch (and of the 32-byte gap behind it), written downwards from the end
     const uint64_t my_reg = ((uint64_t)(uintptr_t)(fansw_ptr(ws, fx, my_task, 1) + my_at) + 3ull) & ~3ull;
-    const uint32_t my_reg_bits = mine ? (uint32_t)(((2ull * my_n_lat + 8ull) & ~3ull) * 8ull) : 0u;
+    auto reg_bits_of = [](uint32_t n_lat) { return n_lat != 0 ? (uint32_t)(((2ull * n_lat + 8ull) & ~3ull) * 8ull) : 0u; };
     auto bcast = [](uint32_t x, uint32_t q) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)q); };
     auto bcast64 = [&](uint64_t x, uint32_t q) { return ((uint64_t)bcast((uint32_t)(x >> 32), q) << 32) | bcast((uint32_t)x, q); };
     const uint32_t q0 = (wave - 1) * kWpH;
@@ -158,10 +197,10 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
 #pragma unroll
     for (uint32_t q = 0; q < kWpH; q++) {
       s_nlat[q] = bcast(my_n_lat, q); s_nb[q] = (s_nlat[q] + kBatchN - 1) / kBatchN;
-      s_slot[q] = lds0 + (q0 + q) * kWpSlot; s_cpk[q] = s_slot[q] + bcast(my_cpk_off, q);
+      s_slot[q] = lds0 + wp_slot(q0 + q); s_cpk[q] = s_slot[q] + bcast(my_cpk_off, q);
       const uint32_t lo = bcast(my_lut_off, q);
       s_lut[q] = (uint64_t)(uintptr_t)fx.vlut + 2ull * lo; s_rot2[q] = vlut_rot(lo / kDirectHistRange) * 0x10001u;   // the table's rotation, for both 16-bit halves of a dword (no carry: latents < 2^15)
-      s_clat[q] = bcast64(my_clat_p, q); s_reg[q] = bcast64(my_reg, q); s_low[q] = bcast(my_reg_bits, q); s_carry[q] = 0;
+      s_clat[q] = bcast64(my_clat_p, q); s_reg[q] = bcast64(my_reg, q); s_low[q] = reg_bits_of(s_nlat[q]); s_carry[q] = 0;
     }
     auto batch_at = [&](uint32_t q, uint32_t it) { return it < s_nb[q] ? s_nb[q] - 1 - it : 0u; };   // (no batch at this step: batch 0 is read, and never used)
     auto count_at = [&](uint32_t q, uint32_t it) { const uint32_t base = batch_at(q, it) * kBatchN; return it < s_nb[q] ? (s_nlat[q] - base < kBatchN ? s_nlat[q] - base : kBatchN) : 0u; };
@@ -190,8 +229,8 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
     load_batches(0, xg);
     gather(xg, e1);
     if (1 < max_nb) load_batches(1, xl);
-    const uint32_t lane_sym = 16u * (lane >> 2) + (lane & 3u), lane_ans = 32u * (lane >> 2) + 2u * (lane & 3u);
     // symbols and offsets of one batch of one item (entries in e1[q], latents in xs[q])
+    uint32_t dbg_it = 0; (void)dbg_it;
     auto find_item = [&](auto full_tag, uint32_t q, uint32_t hb, uint32_t cnt) {
       constexpr bool kFull = decltype(full_tag)::value;
       uint32_t e[4] = {e1[q][0], e1[q][1], e1[q][2], e1[q][3]};
@@ -199,10 +238,20 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
 #pragma unroll
         for (int k = 0; k < 4; k++) e[k] = 4 * lane + k < cnt ? e[k] : 0u;
       }
-      // the walker's chain k reads byte k of the dwords at 16 blk + 4 k; latent 4 l + k sits in block l >> 2, step l & 3
-      const uint32_t buf = s_slot[q] + kWpSymOff + (hb & 1) * 256 + lane_sym;
-#pragma unroll
-      for (int k = 0; k < 4; k++) *(uint8_t PCO_LDS*)(uintptr_t)(buf + 4 * k) = (uint8_t)e[k];
+      // the walker's chain j reads byte k of the dword at 16 blk + 4 j for its step 4 blk + k: a 4 x 4 byte transpose inside the quad (in registers:
+      // the LDS pipe, not the VALU, is what this kernel runs out of), then one conflict-free dword per lane
+#ifdef PCO_WP_V3
+      { const uint32_t buf = s_slot[q] + kWpSymOff + (hb & 1) * 256 + 16u * (lane >> 2) + (lane & 3u);
+        for (int k = 0; k < 4; k++) *(uint8_t PCO_LDS*)(uintptr_t)(buf + 4 * k) = (uint8_t)e[k]; }
+      const uint32_t e01 = e[0] | (e[1] << 16), e23 = e[2] | (e[3] << 16);
+      if (false)
+#else
+      const uint32_t e01 = e[0] | (e[1] << 16), e23 = e[2] | (e[3] << 16);
+#endif
+      *(uint32_t PCO_LDS*)(uintptr_t)(s_slot[q] + kWpSymOff + (hb & 1) * 256 + 4 * lane) = quad_transpose_u8(__builtin_amdgcn_perm(e23, e01, 0x06040200u), lane & 3);
+#ifdef PCO_WP_DEBUGSUM
+      { uint32_t sm = 0; for (int k = 0; k < 4; k++) sm += (e[k] & 0xffu) * (4 * lane + k + 1); sm = wave_sum(sm); if (blockIdx.x == 0 && lane == 0) g_wp_dbg[((q0 + q) * 1100 + dbg_it) * 4 + 3] = sm; }
+#endif
       uint32_t c[4], w[4], dv[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) c[k] = *(const uint32_t PCO_LDS*)(uintptr_t)(s_cpk[q] + 4u * (e[k] & 0xffu));   // lower (16 bits, relative) | offset bits << 16
@@ -216,13 +265,31 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
       o0[q] = (uint64_t)(dv[0] | (dv[1] << w[0])) | ((uint64_t)(dv[2] | (dv[3] << w[2])) << o01);   // <= 60 bits, two fields at a time in 32
       n0[q] = o01 + w[2] + w[3];
     };
-    // one batch of one item: its tANS fields (left by the walker), then its offsets (ob / nb2), at bits [low - all, low) of the page's body region
-    auto pack_item = [&](auto full_tag, uint32_t q, uint32_t pb, uint32_t cnt) {
+    // one batch of one item: its tANS fields (left by the walker), then its offsets (ob / nb2), at bits [low - all, low) of the page's body region.
+    // In two parts, so that the four items' field reads, scans and stage atomics are scheduled into one another (no branch between them; a
+    // batch without bits ORs nothing and flushes nothing) before the four flushes, which are loops.
+    uint32_t p_new[kWpH];   // (uniform) where each item's batch starts
+#ifdef PCO_WP_ASSERT
+    uint64_t dbg_f64[kWpH]; uint32_t dbg_pb[kWpH];
+#endif
+    auto pack_puts = [&](auto full_tag, uint32_t q, uint32_t pb, uint32_t cnt) {
       constexpr bool kFull = decltype(full_tag)::value;
-      const uint32_t fa = s_slot[q] + kWpAnsOff + (pb & 1) * 512 + lane_ans, stg = s_slot[q] + kWpStgOff;
+      const uint32_t stg = s_slot[q] + kWpStgOff;
       uint32_t f[4], nb[4], fv[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) f[k] = *(const uint16_t PCO_LDS*)(uintptr_t)(fa + 8 * k);
+#ifdef PCO_WP_V2
+      { const uint32_t fa = s_slot[q] + kWpAnsOff + (pb & 1) * 512 + 32u * (lane >> 2) + 2u * (lane & 3u);
+        for (int k = 0; k < 4; k++) f[k] = *(const uint16_t PCO_LDS*)(uintptr_t)(fa + 8 * k); }
+      if (false)
+#endif
+      {   // the walker left (block, chain) units of four steps: lane 4 blk + j reads unit (blk, j), the quad transposes
+        const uint64_t w = *(const uint64_t PCO_LDS*)(uintptr_t)(s_slot[q] + kWpAnsOff + (pb & 1) * 512 + 8 * lane);
+        uint32_t a = (uint32_t)w, b = (uint32_t)(w >> 32);
+        quad_transpose_u16(a, b, lane & 3);
+        f[0] = a & 0xffffu; f[1] = a >> 16; f[2] = b & 0xffffu; f[3] = b >> 16;
+      }
+#ifdef PCO_WP_DEBUGSUM
+      { uint32_t sm = 0; for (int k = 0; k < 4; k++) sm += ((kFull || 4 * lane + k < cnt) ? f[k] : 0u) * (4 * lane + k + 1); sm = wave_sum(sm); if (blockIdx.x == 0 && lane == 0) g_wp_dbg[((q0 + q) * 1100 + dbg_it - 2) * 4 + 2] = sm; }
+#endif
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         nb[k] = (kFull || 4 * lane + k < cnt) ? f[k] >> 12 : 0u;
@@ -233,39 +300,73 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
       const uint32_t both = abits | (obits << 16);
       const uint32_t incl = wave_incl_scan(both), total = wave_last(incl), excl = incl - both;
       const uint32_t ans_total = total & 0xffffu, all = ans_total + (total >> 16);
-      const uint32_t low = s_low[q], new_low = low - all, sh0 = new_low & 31u, lo_dw = new_low >> 5;
-#ifdef PCO_WP_NOPUT   // (timing experiments: wrong bytes)
-      if (all == 0xdeadbeefu) {
-#else
-      if (all != 0) {
-#endif
-        wp_put(stg, sh0 + (excl & 0xffffu), acc);
-        wp_put(stg, sh0 + ans_total + (excl >> 16), ob[q]);
-        wp_lds_order();
-        // the dwords the batch completes go out -- the highest with what the batch above left of it; the lowest stays as the carry unless the batch starts on a dword
-        const uint32_t n_dw = ((low - 1u) >> 5) - lo_dw + 1u, i0 = sh0 ? 1u : 0u, top = (low & 31u) ? n_dw - 1u : 0xffffffffu;
-        uint32_t PCO_GLOBAL* g = (uint32_t PCO_GLOBAL*)(uintptr_t)s_reg[q] + lo_dw;
-#ifndef PCO_WP_NOFLUSH
-        for (uint32_t r = 0; r < n_dw; r += 64) {
-          const uint32_t i = r + lane;
-          if (i >= i0 && i < n_dw) {
-            uint32_t PCO_LDS* sp = (uint32_t PCO_LDS*)(uintptr_t)stg + i;
-            g[i] = *sp | (i == top ? s_carry[q] : 0u); *sp = 0;
-          }
-        }
-#endif
-        uint32_t nc = 0;
-        if (sh0) { nc = uni(*(const uint32_t PCO_LDS*)(uintptr_t)stg) | (top == 0u ? s_carry[q] : 0u); wp_lds_order(); *(uint32_t PCO_LDS*)(uintptr_t)stg = 0; }   // (a batch inside one dword: the carry stays where it is)
-        s_low[q] = new_low; s_carry[q] = nc;
-        wp_lds_order();
+      const uint32_t new_low = s_low[q] - all, sh0 = new_low & 31u;
+      p_new[q] = new_low;
+#ifdef PCO_WP_ASSERT
+      {
+        const uint32_t prev = __shfl_up(incl, 1, 64);
+        if (excl != (lane == 0 ? 0u : prev)) atomicAdd(&g_wp_err[0], 1u);
+        const uint64_t z = *(const uint64_t PCO_LDS*)(uintptr_t)(stg + 8 * lane);
+        if (z != 0) atomicAdd(&g_wp_err[2], 1u);
+        if (lane < 2 && *(const uint32_t PCO_LDS*)(uintptr_t)(stg + 512 + 4 * lane) != 0) atomicAdd(&g_wp_err[2], 1u);
+        dbg_f64[q] = (uint64_t)f[0] | ((uint64_t)f[1] << 16) | ((uint64_t)f[2] << 32) | ((uint64_t)f[3] << 48); dbg_pb[q] = pb;
       }
+#endif
+#ifndef PCO_WP_NOPUT   // (timing experiments: wrong bytes)
+      wp_put(stg, sh0 + (excl & 0xffffu), acc);
+      wp_put(stg, sh0 + ans_total + (excl >> 16), ob[q]);
+#endif
     };
+    // the dwords the batch completes go out -- the highest with what the batch above left of it; the lowest stays as the carry unless the batch starts on a dword
+    auto pack_flush = [&](uint32_t q) {
+      const uint32_t stg = s_slot[q] + kWpStgOff;
+#ifdef PCO_WP_ASSERT
+      {
+        const uint64_t w = *(const uint64_t PCO_LDS*)(uintptr_t)(s_slot[q] + kWpAnsOff + (dbg_pb[q] & 1) * 512 + 8 * lane);
+        uint32_t a = (uint32_t)w, b = (uint32_t)(w >> 32);
+        quad_transpose_u16(a, b, lane & 3);
+        if ((((uint64_t)b << 32) | a) != dbg_f64[q] && s_nlat[q] - dbg_pb[q] * kBatchN >= kBatchN) atomicAdd(&g_wp_err[1], 1u);
+      }
+#endif
+      const uint32_t low = s_low[q], new_low = p_new[q], sh0 = new_low & 31u, lo_dw = new_low >> 5;
+      const uint32_t n_dw = ((low - 1u) >> 5) - lo_dw + 1u, i0 = sh0 ? 1u : 0u, top = (low & 31u) ? n_dw - 1u : 0xffffffffu;   // (no bits: n_dw is 0, or 1 with the carry staying where it is)
+      uint32_t nc = 0;   // what stays behind of the lowest dword (read before the flush zeroes the stage)
+      if (sh0) nc = uni(*(const uint32_t PCO_LDS*)(uintptr_t)stg) | (top == 0u ? s_carry[q] : 0u);   // (a batch inside one dword: the carry stays where it is)
+      wp_lds_order();
+      uint32_t PCO_GLOBAL* g = (uint32_t PCO_GLOBAL*)(uintptr_t)s_reg[q] + lo_dw;
+#ifndef PCO_WP_NOFLUSH
+      typedef uint64_t __attribute__((aligned(4))) u64_align4;
+      for (uint32_t r = 0; r < n_dw; r += 128) {   // two dwords per lane
+        const uint32_t i = r + 2 * lane;
+        if (i < n_dw) {
+          uint64_t PCO_LDS* sp = (uint64_t PCO_LDS*)((uint32_t PCO_LDS*)(uintptr_t)stg + i);
+          uint64_t v = *sp; *sp = 0;
+          v |= i == top ? (uint64_t)s_carry[q] : (i + 1 == top ? (uint64_t)s_carry[q] << 32 : 0ull);
+          if (i >= i0 && i + 1 < n_dw) *(u64_align4 PCO_GLOBAL*)(g + i) = v;
+          else if (i >= i0) g[i] = (uint32_t)v;                       // (the batch's last dword alone)
+          else if (i + 1 < n_dw) g[i + 1] = (uint32_t)(v >> 32);      // (dword 0 stays behind as the carry)
+        }
+      }
+#endif
+      s_low[q] = new_low; s_carry[q] = nc;
+      wp_lds_order();
+    };
+#ifdef PCO_WP_TIMING
+    unsigned long long t_find = 0, t_gath = 0, t_puts = 0, t_flush = 0, t_bar = 0, t0 = WPT_NOW(), t1;
+#define WPT_ACC(x) do { __builtin_amdgcn_sched_barrier(0); t1 = WPT_NOW(); x += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WPT_ACC(x) do { } while (0)
+#endif
     for (uint32_t it = 0; it < max_nb + 2; it++) {
       // ---- rotate the pipeline ----
 #pragma unroll
       for (uint32_t q = 0; q < kWpH; q++) { ob[q] = oa[q]; nb2[q] = na[q]; oa[q] = o0[q]; na[q] = n0[q]; xs[q] = xg[q]; xg[q] = xl[q]; }
       // ---- symbols and offsets of step `it` ----
+#ifdef PCO_WP_NOHELP   // (timing experiments: wrong bytes)
+      if (it > 1000000u) {
+#else
       if (it < max_nb) {
+#endif
         uint32_t cn[kWpH]; bool all_full = true;
 #pragma unroll
         for (uint32_t q = 0; q < kWpH; q++) { cn[q] = count_at(q, it); all_full = all_full && cn[q] == kBatchN; }
@@ -277,33 +378,48 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
           for (uint32_t q = 0; q < kWpH; q++) { if (cn[q] != 0) find_item(std::false_type{}, q, batch_at(q, it), cn[q]); else { o0[q] = 0; n0[q] = 0; } }
         }
       }
+      WPT_ACC(t_find);
       __builtin_amdgcn_sched_barrier(0);
       if (it + 1 < max_nb) gather(xg, e1);
       __builtin_amdgcn_sched_barrier(0);
       if (it + 2 < max_nb) load_batches(it + 2, xl);
       __builtin_amdgcn_sched_barrier(0);
+      WPT_ACC(t_gath);
       // ---- pack the batch of step it - 2 ----
 #ifndef PCO_WP_NOPACK
       if (it >= 2) {
         uint32_t cn[kWpH]; bool all_full = true;
 #pragma unroll
         for (uint32_t q = 0; q < kWpH; q++) { cn[q] = count_at(q, it - 2); all_full = all_full && cn[q] == kBatchN; }
+#ifdef PCO_WP_V4
+        all_full = false;
+#endif
         if (all_full) {
 #pragma unroll
-          for (uint32_t q = 0; q < kWpH; q++) pack_item(std::true_type{}, q, batch_at(q, it - 2), kBatchN);
+          for (uint32_t q = 0; q < kWpH; q++) pack_puts(std::true_type{}, q, batch_at(q, it - 2), kBatchN);
+          wp_lds_order();
+          WPT_ACC(t_puts);
+#pragma unroll
+          for (uint32_t q = 0; q < kWpH; q++) pack_flush(q);
+          WPT_ACC(t_flush);
         } else {
 #pragma unroll
-          for (uint32_t q = 0; q < kWpH; q++) if (cn[q] != 0) pack_item(std::false_type{}, q, batch_at(q, it - 2), cn[q]);
+          for (uint32_t q = 0; q < kWpH; q++) if (cn[q] != 0) { pack_puts(std::false_type{}, q, batch_at(q, it - 2), cn[q]); wp_lds_order(); pack_flush(q); }
         }
       }
 #endif
+      WPT_ACC(t_flush);
       wd_barrier();
+      WPT_ACC(t_bar);
     }
+#ifdef PCO_WP_TIMING
+    if (blockIdx.x == 7 && wave == 1 && lane == 0) { g_wp_timing[0] = t_find; g_wp_timing[1] = t_gath; g_wp_timing[2] = t_puts; g_wp_timing[3] = t_flush; g_wp_timing[4] = t_bar; g_wp_timing[5] = max_nb; }
+#endif
     // the body's lowest, partial dword, and the page's record: bits | flag, first bit (counted from fx.answ)
 #pragma unroll
     for (uint32_t q = 0; q < kWpH; q++) {
       if (s_nlat[q] == 0) continue;
-      const uint32_t pq = bcast(my_p, q), rb = bcast(my_reg_bits, q);
+      const uint32_t pq = bcast(my_p, q), rb = reg_bits_of(s_nlat[q]);
       if (lane == 0) {
         if (s_low[q] & 31u) ((uint32_t PCO_GLOBAL*)(uintptr_t)s_reg[q])[s_low[q] >> 5] = s_carry[q];
         fx.body[2ull * pq] = (uint64_t)(rb - s_low[q]) | kWpBodyFlag;
@@ -313,16 +429,29 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
     return;
   }
   // ================= the walker wave (enc_walkd_kernel's walk; the fields stay in LDS) =================
+#ifndef PCO_WP_NOPRIO
+  __builtin_amdgcn_s_setprio(3);   // (the walker's chain of dependent steps sets the block's pace; the packing waves of both blocks share its SIMD)
+#endif
   const uint32_t j = lane & 3;
-  const uint32_t slice = lds0 + my_q * kWpSlot;
+  const uint32_t slice = lds0 + wp_slot(my_q);
   const uint32_t info_addr = slice + my_info_off, symbuf = slice + kWpSymOff, ansbuf = slice + kWpAnsOff;
   uint32_t state = my_T;
   wd_barrier();   // (the gathering waves' it = 0)
+#ifdef PCO_WP_TIMING
+  unsigned long long w_walk = 0, w_bar = 0, w0 = WPT_NOW(), w1;
+#endif
   for (uint32_t it = 0; it < max_nb; it++) {
+#ifdef PCO_WP_NOWALK   // (timing experiments: wrong bytes)
+    if (it > 1000000u) {
+#else
     if (it < my_nb) {
+#endif
       const uint32_t b = my_nb - 1 - it, base = b * kBatchN, cnt = my_n_lat - base < kBatchN ? my_n_lat - base : kBatchN;
       const uint32_t buf = symbuf + (b & 1) * 256, abuf = ansbuf + (b & 1) * 512 + 8 * j;
       uint32_t bits_acc = 0;
+#ifdef PCO_WP_DEBUGSUM
+      uint32_t dbg_f = 0, dbg_s = 0;
+#endif
       if (cnt < kBatchN) {   // the last (partial) batch: per-step predicates
         const uint32_t steps = (cnt + 3) >> 2;
         for (uint32_t blk = (steps + 3) >> 2; blk-- > 0;) {
@@ -334,13 +463,22 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
             if (4 * g + j < cnt) {
               const uint64_t info = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> (8 * k)) & 0xffu));
               out |= (uint64_t)ew_step(state, bits_acc, info) << (16 * k);
+#ifdef PCO_WP_DEBUGSUM
+              dbg_s += ((sd >> (8 * k)) & 0xffu) * (16 * blk + 4 * k + j + 1);
+#endif
             }
           }
+#ifdef PCO_WP_DEBUGSUM
+          for (int k = 0; k < 4; k++) dbg_f += (uint32_t)((out >> (16 * k)) & 0xffffu) * (16 * blk + 4 * k + j + 1);
+#endif
           *(uint64_t PCO_LDS*)(uintptr_t)(abuf + 32 * blk) = out;
         }
       } else {               // a full batch, software-pipelined as in enc_walk_kernel
         uint32_t sd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * 15 + 4 * j);
         uint32_t nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * 14 + 4 * j);
+#ifdef PCO_WP_DEBUGSUM
+        uint32_t nsd_prev = nsd;
+#endif
         uint64_t i0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (sd & 0xffu));
         uint64_t i1 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> 8) & 0xffu));
         uint64_t i2 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * ((sd >> 16) & 0xffu));
@@ -361,13 +499,31 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
           const uint64_t n0 = *(const uint64_t PCO_LDS*)(uintptr_t)(info_addr + 8u * (nsd & 0xffu));
           nsd = *(const uint32_t PCO_LDS*)(uintptr_t)(buf + 16 * nnblk + 4 * j);
           *(uint64_t PCO_LDS*)(uintptr_t)(abuf + 32 * blk) = (uint64_t)(o0 | (o1 << 16)) | ((uint64_t)o23 << 32);
+#ifdef PCO_WP_DEBUGSUM
+          dbg_f += o0 * (16 * blk + j + 1) + o1 * (16 * blk + 4 + j + 1) + o2 * (16 * blk + 8 + j + 1) + o3 * (16 * blk + 12 + j + 1);
+          for (int k = 0; k < 4; k++) dbg_s += ((sd >> (8 * k)) & 0xffu) * (16 * blk + 4 * k + j + 1);
+          sd = nsd_prev; nsd_prev = nsd;
+#endif
           __builtin_amdgcn_sched_barrier(0);
           i0 = n0; i1 = n1; i2 = n2; i3 = n3;
         }
       }
+#ifdef PCO_WP_DEBUGSUM
+      dbg_f += quad_dpp<0xB1>(dbg_f); dbg_f += quad_dpp<0x4E>(dbg_f); dbg_s += quad_dpp<0xB1>(dbg_s); dbg_s += quad_dpp<0x4E>(dbg_s);
+      if (blockIdx.x == 0 && j == 0) { g_wp_dbg[(my_q * 1100 + it) * 4 + 0] = dbg_f; g_wp_dbg[(my_q * 1100 + it) * 4 + 1] = dbg_s; }
+#endif
     }
+#ifdef PCO_WP_TIMING
+    w1 = WPT_NOW(); w_walk += w1 - w0; w0 = w1;
+#endif
     wd_barrier();
+#ifdef PCO_WP_TIMING
+    w1 = WPT_NOW(); w_bar += w1 - w0; w0 = w1;
+#endif
   }
+#ifdef PCO_WP_TIMING
+  if (blockIdx.x == 7 && lane == 0) { g_wp_timing[8] = w_walk; g_wp_timing[9] = w_bar; }
+#endif
   wd_barrier();   // (the packing waves' last step)
   if (my_n_lat > 0) fx.fstate[((uint64_t)my_p * 3 + 1) * 4 + j] = state;
 }

@@ -583,6 +583,15 @@ extern "C" int pco_gfx_debug_trail_stamps(unsigned long long* out) {   // [4][kT
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_trail_stamps), sizeof(unsigned long long) * 4 * pcogfx::kTrailStampBlocks);
 }
 #endif
+#ifdef PCO_WP_ASSERT
+extern "C" int pco_gfx_debug_wp_err(uint32_t* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_wp_err), 32); }
+#endif
+#ifdef PCO_WP_DEBUGSUM
+extern "C" int pco_gfx_debug_wp_sums(uint32_t* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_wp_dbg), 16 * 1100 * 16); }
+#endif
+#ifdef PCO_WP_TIMING
+extern "C" int pco_gfx_debug_wp_timing(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_wp_timing), 128); }
+#endif
 #ifdef PCO_WALK_TIMING
 extern "C" int pco_gfx_debug_walk_timing(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcogfx::g_walk_timing), 64);
