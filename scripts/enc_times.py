@@ -8,7 +8,8 @@ from pcodec_amd import _lib as G
 
 kind, k = sys.argv[1], int(sys.argv[2]); flt = sys.argv[3] if len(sys.argv) > 3 else ""
 L = G.lib()
-nums = U.synth(kind); gcfg, _ = U.cfg_pair(kind)
+data_kind, cfg_kind = (kind.split("+") + [kind])[:2] if "+" in kind else (kind, kind)   # e.g. c2+auto: the c2 data under the default ChunkConfig
+nums = U.synth(data_kind); gcfg, _ = U.cfg_pair(cfg_kind)
 src = torch.from_numpy(nums.view(np.uint8).reshape(-1).copy()).cuda()
 srcs = src.repeat(k).contiguous()
 cap = (L.pco_gfx_guarantee_chunk_size(nums.size, G.DTYPE_BYTE[nums.dtype.name]) + 64 + 15) // 16 * 16
