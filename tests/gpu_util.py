@@ -18,6 +18,7 @@ def cfg_pair(kind):
         "c3d": dict(mode=2, mode_f64=0.01, delta=2, delta_order=1),
         "c4": dict(mode=1, delta=3),                                    # Classic, TryLookback
         "auto": dict(),
+        "c2l12": dict(mode=1, delta=2, delta_order=1, level=12),   # BASELINE configs[1] at compression level 12 (up to 4096 bins)
     }[kind]
     return G.make_config(enable_8_bit=True, **table), O.make_config(**table)
 

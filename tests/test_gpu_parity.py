@@ -1052,3 +1052,27 @@ def test_many_short_chunks_keep_the_dissect_kernel(L):
     for i in range(0, len(arrays), 50):
         want = O.simple_compress(arrays[i], O.make_config(**kw))
         assert chunks[i] == U.chunk_of_file(want, len(chunks[i])), (i, arrays[i].size)
+
+
+@pytest.mark.parametrize("kind", ["c2", "c3", "periodic8", "geometric32"])
+def test_identical_chunks_in_one_call_give_identical_bytes(L, kind):
+    """Hundreds of copies of one chunk in ONE call: every copy's bytes are the oracle's.  The copies sit in different walk blocks, at different
+    LDS slots and on different CUs, and run at slightly different times -- a fault that depends on timing or placement (round 6 had one: a build
+    of enc_walkp_kernel garbled a batch's tANS section in some blocks only) shows up as copies that differ from each other."""
+    rng = np.random.default_rng(5)
+    if kind in ("c2", "c3"):
+        nums = U.synth(kind, 1 << 16); gcfg, ocfg = U.cfg_pair(kind)
+    elif kind == "periodic8":
+        base = rng.integers(0, 250, 37); n = 50000
+        nums = ((base[np.arange(n) % 37] + rng.integers(0, 3, n)) % 256).astype(np.uint8)
+        kw = dict(level=7, mode=1, delta=1, enable_8_bit=True); gcfg, ocfg = G.make_config(**kw), O.make_config(**kw)
+    else:
+        nums = (rng.geometric(0.02, 40000) % 100000).astype(np.uint32)
+        kw = dict(mode=1, delta=1); gcfg, ocfg = G.make_config(enable_8_bit=True, **kw), O.make_config(**kw)
+    k = 384
+    chunks, back = U.gpu_batched([nums] * k, gcfg)
+    ref = O.simple_compress(nums, ocfg)
+    want = U.chunk_of_file(ref, len(chunks[0]))
+    bad = [i for i, c in enumerate(chunks) if c != want]
+    assert not bad, (kind, len(bad), bad[:8])
+    assert all(U.bits_equal(b, nums) for b in back[:16])
