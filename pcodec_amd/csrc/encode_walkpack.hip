@@ -254,7 +254,11 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
 #endif
       uint32_t c[4], w[4], dv[4];
 #pragma unroll
+#ifdef PCO_WP_NOCPK   // (timing experiments: wrong bytes)
+      for (int k = 0; k < 4; k++) c[k] = ((e[k] >> 8) << 16) | (e[k] & 0xffu);
+#else
       for (int k = 0; k < 4; k++) c[k] = *(const uint32_t PCO_LDS*)(uintptr_t)(s_cpk[q] + 4u * (e[k] & 0xffu));   // lower (16 bits, relative) | offset bits << 16
+#endif
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         w[k] = (kFull || 4 * lane + k < cnt) ? c[k] >> 16 : 0u;
