@@ -581,7 +581,7 @@ CONFIG_FIRST = ["workload", "chunks_per_gpu", "encode_GBps", "decode_GBps", "com
                 "c2auto_value", "c2auto_frac_step", "c3auto_value", "c3auto_frac_step", "c1_value", "c1_frac_step", "c5auto_value", "c5auto_frac_step", "c2_4k_value", "c2paged_value"]
 ROOFLINE_FIRST = ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_encode", "frac_decode", "frac_step", "kernel_ms_encode", "kernel_ms_decode",
                   "traffic_over_algorithmic_encode", "traffic_over_algorithmic_decode", "avg_launch_ms", "algorithmic_bytes_per_launch",
-                  "ms.enc_split_kernel<c16>", "ms.enc_hist_kernel", "ms.enc_train_kernel", "ms.enc_walkp_kernel", "ms.enc_place_kernel", "ms.enc_pack_kernel", "ms.dec_walk+trail<u64>",
+                  "ms.enc_split_kernel<c16>", "ms.enc_hist_kernel", "ms.enc_train_kernel", "ms.enc_walkp_kernel", "ms.enc_place+pack", "ms.enc_place_kernel", "ms.~enc_place_kernel", "ms.dec_walk+trail<u64>",
                   "traffic_source"]
 
 

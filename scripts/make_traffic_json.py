@@ -64,6 +64,10 @@ def label(name):
         return {"<true, false>": "enc_split_kernel<c16>", "<false, true>": "enc_split_kernel(redo)"}.get(name[len("enc_split_kernel"):], "enc_split_kernel")
     if name.startswith("enc_hist_select_kernel"):
         return "enc_hist_select_kernel"
+    m = re.match(r"enc_pack1_kernel<([^,>]*), (\d)u, (t|f)", name)   # <L, mask, wide>: the launch-timer labels of pco_gfx_encode_api.inc (PCO_PACK1)
+    if m:
+        tags = ([{"6": "sec", "3": "lb"}[m.group(2)]] if m.group(2) in "63" else []) + (["wide"] if m.group(3) == "t" else [])
+        return "enc_pack1_kernel" + ("<" + ",".join(tags) + ">" if tags else "")
     m = re.match(r"enc_hist_wide_kernel<(\d+)u>", name)
     if m:
         return f"enc_hist_wide_kernel<{m.group(1)}>"
