@@ -73,6 +73,9 @@ def test_switch_defaults_in_a_clean_environment():
     assert "enc_walkseg_kernel" in rep["few_long"]
     assert "enc_walkseg_kernel" not in rep["many_short"] and "enc_walkseg_kernel" not in rep["over_4096_items"]
     assert "enc_walkd_kernel" in rep["over_4096_items"]
+    # PCO_GFX_WALKP / PCO_GFX_PLACE_FORK default on: walk + pack in one block where the walk is not segmented, its bodies moved into place on the second stream
+    assert "enc_walkp_kernel" in rep["over_4096_items"] and "~enc_place_kernel" in rep["over_4096_items"] and "enc_place+pack" in rep["over_4096_items"]
+    assert "enc_walkp_kernel" not in rep["few_long"]
     # PCO_GFX_DEC_TRAIL default 1 (not 2): the expanders under the walk from 1024 chunks of one width on, not below
     assert any(k.startswith("dec_walk+trail") for k in rep["many_short"]) and any(k.startswith("~dec_trail_kernel") for k in rep["many_short"])
     assert not any("trail" in k for k in rep["few_long"])
