@@ -91,6 +91,21 @@ __device__ uint32_t g_wp_dbg[16 * 1100 * 4];   // block 0: [item][step]: walker 
 #ifdef PCO_WP_FULLSYNC
 #define wd_barrier() __syncthreads()
 #endif
+// page_var (encode_fast.hip) for ONE lane's item: the same fields without the wave-uniform loads
+__device__ __forceinline__ PageVar page_var_lane(const EncChunk PCO_GLOBAL* ch, uint32_t v, uint32_t page_n) {
+  PageVar r;
+  r.present = ch->v[v].present; r.n_bins = ch->v[v].n_bins; r.asl = ch->v[v].ans_size_log; r.max_ob = ch->v[v].max_ob;
+  r.needs_ans = ch->v[v].needs_ans; r.trivial = ch->v[v].is_trivial;
+  r.skip = v == 2 ? 0u : ch->v[v].lat_start;
+  if (r.skip > page_n) r.skip = page_n;
+  r.n_lat = page_n - r.skip;
+  r.compact = ch->v[v].hist_path == 0 ? 1u : 0u;
+  r.minv = (uint64_t)ch->v[v].minv;
+  r.range = (uint64_t)ch->v[v].maxv - r.minv;
+  r.rel = v != 0 && ch->c16_ok == 1 ? ch->c16_ref[v == 2 ? 1 : 0] : r.minv;
+  return r;
+}
+
 // grid = ceil(items / 16), 320 threads: wave 0 walks, waves 1..4 find the symbols and pack
 __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_per_eu(PCO_WP_WAVES, PCO_WP_WAVES))) void enc_walkp_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -98,30 +113,39 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t n_items = n_pages * ws.n_slots;
   typedef uint64_t __attribute__((aligned(2))) u64_align2;
-  // ---- pass 1: does the block qualify?  (uniform; every wave computes the same answer) ----
-  bool ok = (fx.fused & kFusedLookups) != 0;
-  for (uint32_t q = 0; q < kWpQ && ok; q++) {
-    const uint32_t item = blockIdx.x * kWpQ + q;
-    if (item >= n_items) break;
-    const uint32_t p = item / ws.n_slots, sl = item % ws.n_slots;
-    const uint32_t v = ws.slot_of_var[0] == sl ? 0u : (ws.slot_of_var[1] == sl ? 1u : 2u);
-    EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
-    const uint32_t t = uni(pg->chunk);
-    EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
-    if (!page_is_fast(ch, pg)) continue;
-    const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
-    const PageVar pv = page_var(ch, v, page_n);
-    if (!pv.present || pv.trivial) continue;                          // nothing of this item reaches the page body
-    // it writes something: it must be the page's primary variable, walked here, looked up here, and alone
-    if (v != 1 || !wd_walks(fx.fused, pv) || ws_walks(fx.fused, pv) || !wd_takes(fx.fused, pv) || !pv.needs_ans || pv.n_bins > 256 || !wp_fits(pv.asl, pv.n_bins)) { ok = false; break; }
-    const PageVar p0 = page_var(ch, 0, page_n), p2 = page_var(ch, 2, page_n);
-    if ((p0.present && !p0.trivial) || (p2.present && !p2.trivial)) { ok = false; break; }
-    // tANS bits + offset bits of a latent: at most min_renorm_bits + 1 + the bin's offset bits
-    const PlanRef plan = plan_ref(ws, t, v);
-    uint32_t worst = 0;
-    for (uint32_t b = lane; b < pv.n_bins; b += 64) { const uint32_t w = ((plan.syminfo()[b] >> 14) & 15u) + 1u + plan.bob()[b]; worst = w > worst ? w : worst; }
-    if (wave_max_u32(worst) > 16u) { ok = false; break; }
+  // ---- pass 1: does the block qualify?  Lane L of EVERY wave inspects item L & 15 (the four lanes L, L + 16, L + 32, L + 48 share an item's bins):
+  //      sixteen items' facts in one round of dependent loads.  (Item after item with wave-uniform loads, the set-up of a block was 0.2-0.4 ms --
+  //      a tenth of the kernel on BASELINE configs[1], half of it on pages of 16 384 numbers, whose walk is 64 steps.)  Every wave computes the
+  //      same verdict. ----
+  const uint32_t iq = lane & 15u, sub = lane >> 4;
+  const uint32_t l_item = blockIdx.x * kWpQ + iq;
+  const bool l_exists = l_item < n_items;
+  const uint32_t l_p = l_exists ? l_item / ws.n_slots : 0u, l_sl = l_exists ? l_item % ws.n_slots : 0u;
+  const uint32_t l_v = ws.slot_of_var[0] == l_sl ? 0u : (ws.slot_of_var[1] == l_sl ? 1u : 2u);
+  const EncPage PCO_GLOBAL* l_pg = (const EncPage PCO_GLOBAL*)ws.pages + l_p;
+  const uint32_t l_t = l_pg->chunk;
+  const EncChunk PCO_GLOBAL* l_ch = (const EncChunk PCO_GLOBAL*)ws.chunks + l_t;
+  const bool l_fast = l_exists && l_ch->status == PCO_GFX_OK && l_ch->fast_ok != 0 && !(l_pg->flags & kPageFlagMetaOnly);   // (page_is_fast, per lane)
+  const uint32_t l_page_n = (uint32_t)l_pg->n;
+  const PageVar l_pv = page_var_lane(l_ch, l_v, l_page_n);
+  const bool l_writes = l_fast && l_pv.present && !l_pv.trivial;   // something of this item reaches the page body
+  bool l_bad = false;
+  if (l_writes) {
+    // it must be the page's primary variable, walked here, looked up here, and alone
+    if (l_v != 1 || !wd_walks(fx.fused, l_pv) || ws_walks(fx.fused, l_pv) || !wd_takes(fx.fused, l_pv) || !l_pv.needs_ans || l_pv.n_bins > 256 || !wp_fits(l_pv.asl, l_pv.n_bins)) l_bad = true;
+    else if ((l_ch->v[0].present && !l_ch->v[0].is_trivial) || (l_ch->v[2].present && !l_ch->v[2].is_trivial)) l_bad = true;
   }
+  {   // tANS bits + offset bits of a latent: at most min_renorm_bits + 1 + the bin's offset bits
+    uint32_t worst = 0;
+    if (l_writes && !l_bad) {
+      const PlanRef plan = plan_ref(ws, l_t, l_v);
+      for (uint32_t b = sub; b < l_pv.n_bins; b += 4) { const uint32_t w = ((plan.syminfo()[b] >> 14) & 15u) + 1u + plan.bob()[b]; worst = w > worst ? w : worst; }
+    }
+    { const uint32_t o = (uint32_t)__shfl_xor((int)worst, 16, 64); worst = worst > o ? worst : o; }
+    { const uint32_t o = (uint32_t)__shfl_xor((int)worst, 32, 64); worst = worst > o ? worst : o; }
+    if (worst > 16u) l_bad = true;
+  }
+  const bool ok = (fx.fused & kFusedLookups) != 0 && !__any(l_bad);
   if (threadIdx.x == 0) fx.wp_block[blockIdx.x] = ok ? 1u : 0u;
   if (!ok) {   // enc_walkd_kernel takes the block; the pages whose primary variable sits here are marked "no body"
     if (threadIdx.x < kWpQ) {
@@ -130,50 +154,43 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
     }
     return;
   }
-  // ---- pass 2: the items' tables (wave 0), and what a lane keeps of its item: a walker lane the item of its quad (lane >> 2), a helper
-  //      lane of wave w the item (w - 1) * 4 + (lane & 3) ----
-  const uint32_t my_q = wave == 0 ? lane >> 2 : (wave - 1) * kWpH + (lane & (kWpH - 1));
-  uint32_t my_n_lat = 0, my_T = 0, my_p = 0, my_task = 0, my_info_off = 0, my_cpk_off = 0;
-  uint64_t my_at = 0, my_clat = 0;
-  uint32_t max_nb = 0;
-  for (uint32_t q = 0; q < kWpQ; q++) {
-    const uint32_t item = blockIdx.x * kWpQ + q;
-    if (item >= n_items) break;
-    const uint32_t p = item / ws.n_slots, sl = item % ws.n_slots;
-    const uint32_t v = ws.slot_of_var[0] == sl ? 0u : (ws.slot_of_var[1] == sl ? 1u : 2u);
-    EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
-    const uint32_t t = uni(pg->chunk);
-    EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
-    if (!page_is_fast(ch, pg)) continue;
-    const uint32_t page_n = (uint32_t)uni((uint64_t)pg->n);
-    const PageVar pv = page_var(ch, v, page_n);
-    if (!pv.present || pv.trivial) {
-      // (as enc_walkd_kernel: nobody else writes the states of a variable that needs no walk; a page whose primary variable is trivial has no body of ours)
-      if (pv.present && (pv.n_bins <= 1 || pv.n_lat == 0) && wave == 0 && lane < 4) fx.fstate[((uint64_t)p * 3 + v) * 4 + lane] = 1u << pv.asl;
-      if (v == 1 && threadIdx.x == 0) fx.body[2ull * p] = 0;
-      continue;
-    }
-    const uint32_t info_off = ew_info_off(pv.asl), cpk_off = info_off + 8u * pv.n_bins;
-    { const uint32_t nbq = (pv.n_lat + kBatchN - 1) / kBatchN; max_nb = nbq > max_nb ? nbq : max_nb; }
-    if (wave == 0) {
-      const PlanRef plan = plan_ref(ws, t, v);
-      uint8_t PCO_LDS* slot = smem + wp_slot(q);
-      const uint32_t T = 1u << pv.asl;
-      for (uint32_t i = lane; i < T; i += 64) ((uint16_t PCO_LDS*)slot)[i] = plan.next_states()[i];
-      for (uint32_t b = lane; b < pv.n_bins; b += 64) {
-        const uint32_t si = plan.syminfo()[b];   // cutoff(14) | min_renorm_bits(4) << 14 | (row + 8192)(14) << 18
-        const uint32_t cutoff = si & 0x3fffu, minb = (si >> 14) & 15u, row = (si >> 18) - 8192u;
-        const uint32_t row_addr = lds0 + wp_slot(q) + 2u * row;
-        ((uint64_t PCO_LDS*)(slot + info_off))[b] = (uint64_t)(((minb + 1u) << 16) - cutoff) | ((uint64_t)row_addr << 32);
-        ((uint32_t PCO_LDS*)(slot + cpk_off))[b] = ((uint32_t)(plan.blower()[b] - pv.rel) & 0xffffu) | ((uint32_t)plan.bob()[b] << 16);   // (16-bit latents are relative to rel)
-      }
-      for (uint32_t i = lane; i < kWpStgDwords; i += 64) ((uint32_t PCO_LDS*)(slot + kWpStgOff))[i] = 0;
-    }
-    if (my_q == q) {
-      my_n_lat = pv.n_lat; my_T = 1u << pv.asl; my_p = p; my_task = t; my_info_off = info_off; my_cpk_off = cpk_off;
-      my_at = fast_at(pg, pv.skip); my_clat = uni((uint64_t)pg->start) + pv.skip;
-    }
+  // ---- pass 2: the items' tables (item q by wave q mod 9), and what a lane keeps of its item: a walker lane the item of its quad (lane >> 2), a
+  //      lane of packing wave w the item (w - 1) * kWpH + (lane & (kWpH - 1)) -- fetched from the lane that inspected the item ----
+  const uint32_t l_nb = l_writes ? (l_pv.n_lat + kBatchN - 1) / kBatchN : 0u;
+  const uint32_t max_nb = wave_max_u32(l_nb);
+  if (l_fast && !l_writes && sub == 0 && wave == 0) {
+    // (as enc_walkd_kernel: nobody else writes the states of a variable that needs no walk; a page whose primary variable is trivial has no body of ours)
+    if (l_pv.present && (l_pv.n_bins <= 1 || l_pv.n_lat == 0)) for (uint32_t jj = 0; jj < 4; jj++) fx.fstate[((uint64_t)l_p * 3 + l_v) * 4 + jj] = 1u << l_pv.asl;
+    if (l_v == 1) fx.body[2ull * l_p] = 0;
   }
+  const uint32_t l_info_off = ew_info_off(l_pv.asl), l_cpk_off = l_info_off + 8u * l_pv.n_bins;
+  const uint64_t l_start = (uint64_t)l_pg->start;
+  const uint64_t l_at = l_start + l_pv.skip + 16ull * l_pg->page_idx, l_clat = l_start + l_pv.skip;   // (fast_at, per lane)
+  auto rl = [](uint32_t x, uint32_t q) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)q); };
+  for (uint32_t q = wave; q < kWpQ; q += 1 + kWpHelpers) {   // (uniform per wave) this wave's share of the tables
+    if (rl(l_writes ? 1u : 0u, q) == 0) continue;
+    const uint32_t t = rl(l_t, q), n_bins = rl(l_pv.n_bins, q), asl = rl(l_pv.asl, q);
+    const uint64_t rel = ((uint64_t)rl((uint32_t)(l_pv.rel >> 32), q) << 32) | rl((uint32_t)l_pv.rel, q);
+    const uint32_t info_off = ew_info_off(asl), cpk_off = info_off + 8u * n_bins;
+    const PlanRef plan = plan_ref(ws, t, 1);
+    uint8_t PCO_LDS* slot = smem + wp_slot(q);
+    const uint32_t T = 1u << asl;
+    for (uint32_t i = lane; i < T; i += 64) ((uint16_t PCO_LDS*)slot)[i] = plan.next_states()[i];
+    for (uint32_t b = lane; b < n_bins; b += 64) {
+      const uint32_t si = plan.syminfo()[b];   // cutoff(14) | min_renorm_bits(4) << 14 | (row + 8192)(14) << 18
+      const uint32_t cutoff = si & 0x3fffu, minb = (si >> 14) & 15u, row = (si >> 18) - 8192u;
+      const uint32_t row_addr = lds0 + wp_slot(q) + 2u * row;
+      ((uint64_t PCO_LDS*)(slot + info_off))[b] = (uint64_t)(((minb + 1u) << 16) - cutoff) | ((uint64_t)row_addr << 32);
+      ((uint32_t PCO_LDS*)(slot + cpk_off))[b] = ((uint32_t)(plan.blower()[b] - rel) & 0xffffu) | ((uint32_t)plan.bob()[b] << 16);   // (16-bit latents are relative to rel)
+    }
+    for (uint32_t i = lane; i < kWpStgDwords; i += 64) ((uint32_t PCO_LDS*)(slot + kWpStgOff))[i] = 0;
+  }
+  const uint32_t my_q = wave == 0 ? lane >> 2 : (wave - 1) * kWpH + (lane & (kWpH - 1));
+  auto from_item = [&](uint32_t x) { return (uint32_t)__shfl((int)x, (int)my_q, 64); };   // (lane q < 16 inspected item q)
+  const uint32_t my_n_lat = from_item(l_writes ? l_pv.n_lat : 0u), my_T = 1u << from_item(l_pv.asl), my_p = from_item(l_p), my_task = from_item(l_t);
+  const uint32_t my_info_off = from_item(l_info_off), my_cpk_off = from_item(l_cpk_off);
+  const uint64_t my_at = ((uint64_t)from_item((uint32_t)(l_at >> 32)) << 32) | from_item((uint32_t)l_at);
+  const uint64_t my_clat = ((uint64_t)from_item((uint32_t)(l_clat >> 32)) << 32) | from_item((uint32_t)l_clat);
   const uint32_t my_nb = (my_n_lat + kBatchN - 1) / kBatchN;
   if (max_nb == 0) return;
   wd_barrier();
@@ -536,13 +553,15 @@ __global__ __launch_bounds__(64 * (1 + kWpHelpers)) __attribute__((amdgpu_waves_
 // enc_place_kernel: the bodies enc_walkp_kernel left right-aligned in the field scratch, moved behind their pages' heads.  The head ends on
 // a byte (enc_scan_kernel: run_start[0]), the body starts at any bit of the scratch: every dst dword is one v_alignbit of two source dwords.
 // The first and the last dword of the body in dst are shared (with the head; with the padding) and are OR-ed into what enc_scan_kernel zeroed.
-// grid pages * kPlacePieces, 256 threads: 16 bytes of dst per thread and step.
+// grid pages * pieces, 256 threads: 16 bytes of dst per thread and step; `pieces` (1 .. 16) from the longest page of the call, so that a block has
+// eight steps' worth to move (sixteen blocks per page of 16 384 numbers were mostly launch overhead: 3.4 ms per 131 072 pages, 1.2 with one).
 // ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t kPlacePieces = 16;
-__global__ __launch_bounds__(256) void enc_place_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages) {
+constexpr uint32_t kPlaceMaxPieces = 16;
+__host__ __device__ constexpr uint32_t place_pieces(uint64_t page_max) { return (uint32_t)(2 * page_max / 32768 < 1 ? 1 : (2 * page_max / 32768 > kPlaceMaxPieces ? kPlaceMaxPieces : 2 * page_max / 32768)); }
+__global__ __launch_bounds__(256) void enc_place_kernel(EncWorkspace ws, EncFast fx, uint32_t n_pages, uint32_t pieces) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
-  const uint32_t p = blockIdx.x / kPlacePieces, piece = blockIdx.x % kPlacePieces;
+  const uint32_t p = blockIdx.x / pieces, piece = blockIdx.x % pieces;
   if (p >= n_pages) return;
   EncPage PCO_GLOBAL* pg = (EncPage PCO_GLOBAL*)ws.pages + p;
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + uni(pg->chunk);
@@ -557,7 +576,7 @@ __global__ __launch_bounds__(256) void enc_place_kernel(EncWorkspace ws, EncFast
   const uint64_t d_first = head >> 5, d_last = (end - 1) >> 5;
   // src bit of dst bit x: sbit + (x - head)
   const uint64_t g0 = d_first >> 2, g1 = d_last >> 2;   // 16-byte groups of dst touched
-  for (uint64_t g = g0 + (uint64_t)piece * 256 + threadIdx.x; g <= g1; g += (uint64_t)kPlacePieces * 256) {
+  for (uint64_t g = g0 + (uint64_t)piece * 256 + threadIdx.x; g <= g1; g += (uint64_t)pieces * 256) {
     const uint64_t d0 = 4 * g;
     if (d0 > d_first && d0 + 3 < d_last) {   // four interior dwords
       const uint64_t s = sbit + (32 * d0 - head);
