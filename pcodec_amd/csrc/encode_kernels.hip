@@ -1706,12 +1706,16 @@ template <uint32_t CAP> struct TrainLds {
   static constexpr uint32_t up = low + CAP * 8;                       // u64[CAP]
   static constexpr uint32_t bj = up + CAP * 8;                        // u16[CAP]
   static constexpr uint32_t part = bj + CAP * 2;                      // u16[CAP][2] partition
-  static constexpr uint32_t w = part + CAP * 4;                       // u32[CAP] weights
-  static constexpr uint32_t fw = kAlias ? best : w + CAP * 4;         // f32[CAP] float weights
-  static constexpr uint32_t sym = kAlias ? bj : fw + CAP * 4;         // u16[4096] state symbols
-  static constexpr uint32_t cum = kAlias ? cc : sym + 8192;           // u32[CAP + 1]
+  static constexpr uint32_t fw = kAlias ? best : part + CAP * 4;      // f32[CAP] float weights
+  static constexpr uint32_t w = kAlias ? part + CAP * 4 : fw + CAP * 4;   // u32[CAP] weights
+  // u16[4096] state symbols.  CAP 256 (round 6): over everything in front of the weights -- the histogram, the DP's arrays and the float weights are
+  // dead once thread 0 has quantised the weights (a block_sync away from the table build, which reads w, cum and sym only): 19.2 -> 11 KB a wave,
+  // fourteen waves on a CU instead of eight for a kernel that is one latency chain per wave
+  static constexpr uint32_t sym = kAlias ? bj : 0;
+  static constexpr uint32_t cum = kAlias ? cc : w + CAP * 4;          // u32[CAP + 1]
   static constexpr uint32_t red = kAlias ? w + CAP * 4 : cum + (CAP + 4) * 4;   // block reduction scratch: f32[16] u32[16]
   static constexpr uint32_t bytes = red + 256;
+  static_assert(kAlias || w >= 8192, "the state symbols end in front of the weights");
 };
 constexpr uint32_t kTrainLdsBytes = TrainLds<256>::bytes;
 constexpr uint32_t kTrainBigLdsBytes = TrainLds<kBigBins>::bytes;

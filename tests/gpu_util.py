@@ -98,3 +98,17 @@ def gpu_batched(arrays, cfg):
 def chunk_of_file(file_bytes, chunk_len):
     """The single chunk inside an oracle-written one-chunk standalone file (header | chunk | 0x00)."""
     return file_bytes[len(file_bytes) - 1 - chunk_len:-1]
+
+
+def profile_names(L):
+    """Names of the kernels / spans timed since pco_gfx_profile_begin() (pco_gfx_profile_end), as a sorted list without repeats."""
+    import ctypes as C
+    import torch
+    torch.cuda.synchronize()
+    names = C.create_string_buffer(1 << 16); ms = (C.c_float * 4096)()
+    nk = L.pco_gfx_profile_end(names, len(names), ms, 4096)
+    raw = names.raw; out = []; pos = 0
+    for _ in range(nk):
+        e = raw.index(b"\0", pos); out.append(raw[pos:e].decode()); pos = e + 1
+    return sorted(set(out))
+

@@ -1040,6 +1040,33 @@ def test_walk_arrangements_of_small_and_large_launches(L):
             assert chunks[i] == U.chunk_of_file(want, len(chunks[i])), (count, kw, i, arrays[i].size)
 
 
+def test_one_variable_launch_beyond_8192_items_stays_with_the_fused_walk(L):
+    """More than 8192 one-variable items whose value -> bin tables are allocated (chunks of 2 k+ numbers): every item stays with the fused kernels
+    (enc_walkp_kernel's blocks where all sixteen items qualify, enc_walkd_kernel for the rest -- wide, constant and many-bin chunks break blocks
+    up on purpose), enc_walk_kernel<16> is not launched; bytes equal the oracle's on a spread of chunks, all of them round-trip."""
+    rng = np.random.default_rng(79)
+
+    def make(i):
+        n = int([2049, 2304, 2560, 2817, 3000, 4097][i % 6])
+        kind = (i // 40) % 5 if (i // 200) % 2 else 0   # runs of 200 narrow chunks (whole walkp blocks), then 200 in runs of 40 of each kind
+        if kind == 0: return (np.uint64(1 << 40) + np.uint64(1000) * np.arange(n, dtype=np.uint64) + rng.integers(0, 512, n).astype(np.uint64))
+        if kind == 1: return rng.integers(0, 1 << 62, n, dtype=np.uint64)
+        if kind == 2: return np.full(n, 12345, np.uint64)
+        if kind == 3: return np.cumsum(rng.integers(0, 3000, n)).astype(np.uint64)
+        return (np.uint64(7) * np.arange(n, dtype=np.uint64) + (rng.integers(0, 2, n) * 5000).astype(np.uint64))
+    count, kw = 8300, dict(mode=1, delta=2, delta_order=1)
+    arrays = [make(i) for i in range(count)]
+    L.pco_gfx_profile_begin()
+    chunks, back = U.gpu_batched(arrays, G.make_config(**kw))
+    names = U.profile_names(L)
+    assert "enc_walkp_kernel" in names and "enc_walk16_kernel" not in names, names
+    for i in range(count):
+        assert U.bits_equal(back[i], arrays[i]), i
+    for i in list(range(0, count, 60)) + list(range(190, 260)):
+        want = O.simple_compress(arrays[i], O.make_config(**kw))
+        assert chunks[i] == U.chunk_of_file(want, len(chunks[i])), (i, arrays[i].size)
+
+
 def test_many_short_chunks_keep_the_dissect_kernel(L):
     """The value -> bin tables of enc_walkd_kernel are 8 KB per (chunk, variable): a call whose chunks are much shorter than that does not
     allocate them (the symbols come from enc_dissect_kernel, the walk from the same kernel) -- same bytes either way."""
