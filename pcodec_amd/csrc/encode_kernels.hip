@@ -1176,6 +1176,7 @@ constexpr uint32_t kHistLdsBytes = hist_lds_bytes(kDirectHistRange);
 // enc_hist_sort_kernel: radix counters u32[2048] | bucket prefix u32[8200] | marks u32[256] | marked-bucket list u32[2][1600 + 1]
 constexpr uint32_t kHistSortLdsBytes = kHistLdsCounts + (2048 + kSelBuckets + 8 + kSelBuckets / 32 + 2 * (kSelMaxNeeded + 1)) * 4;
 
+template <bool B> struct BoolC { static constexpr bool value = B; };   // (a compile-time flag handed to a generic lambda)
 // counts[c] += 1 for the lanes with `on`; the lanes that share the first active lane's value are added with one atomic
 // (secondary latents and residuals are often dominated by one value: 64 same-address LDS atomics would serialise)
 __device__ __forceinline__ void hist_count(uint32_t PCO_LDS* counts, uint32_t c, bool on, bool aggregate) {
@@ -1250,7 +1251,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     constexpr uint32_t PER = R / T;   // counters per thread in the prefix pass
     for (uint32_t i = tid; i < R + 8; i += T) counts[i] = 0;
     __syncthreads();
-    {  // counting: 8 loads in flight per thread; the compact copy (x - min, u16) is written on the way
+    {  // counting; the compact copy (x - min, u16) is written on the way
       uint16_t PCO_GLOBAL* clat = clat_ptr(ws, t, var);
       // (wave-uniform) few distinct values: same-address atomics would serialise, aggregate per wave.  The lookbacks of a lookback delta
       // (variable 0) are thousands of distances of which nearly all decisions take ONE, the period: aggregated whatever their range
@@ -1258,37 +1259,72 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
       const bool agg = uni((uint32_t)(((uint64_t)range < 256 || var == 0) ? 1u : 0u)) != 0;
       const bool c16 = uni(ch->c16_ok) == 1 && var != 0;   // the split left 16-bit latents relative to c16_ref (in the compact copy's place)
       const uint16_t c16_off = (uint16_t)((uint64_t)minv - (uint64_t)ch->c16_ref[var == 2 ? 1 : 0]);
-      uint32_t base = 0;
-      if (c16) {   // (the 16-bit latents stay as the split wrote them, relative to c16_ref: the page kernels take that as their reference)
-        for (; base + 8 * T <= n_all; base += 8 * T) {
-          uint16_t x[8];
+      // A block's time IS the kernel's time (a block takes what it takes alone, five of them on a CU or two: scripts/hist_timing.py), and the count
+      // was 70 % of it.  Round 6: (1) EVERY position is counted and the unstored ones -- the first `skip` of each page -- are taken out again
+      // afterwards (a few atomics per page): the per-latent "is it stored" (page arithmetic, a binary search under PagingSpec::Exact) and the
+      // aggregate-or-not branch sat INSIDE the loop, some forty instructions and six branches per latent; an unstored position may hold anything,
+      // hence the range check.  (2) 16-bit latents: a thread takes eight CONSECUTIVE ones with one 16-byte load, two rounds ahead of the one it
+      // counts (the eight 2-byte loads of a round were waited for before its first atomic).  Which thread counts a latent changes no count.
+      auto count_all = [&](auto agg_c) {
+        constexpr bool kAgg = decltype(agg_c)::value;
+        uint32_t base = 0;
+        if (c16) {   // (the 16-bit latents stay as the split wrote them, relative to c16_ref: the page kernels take that as their reference)
+          if (((uint64_t)(uintptr_t)clat & 15u) == 0 && n_all >= 8 * T) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 PCO_GLOBAL* c4 = (const u32x4 PCO_GLOBAL*)clat;
+            const uint32_t n_it = n_all / (8 * T);
+            auto fetch = [&](uint32_t it) { return c4[(uint64_t)(it < n_it ? it : n_it - 1) * T + tid]; };   // (unconditional: past the end the last round again, unused)
+            u32x4 cur = fetch(0), nx1 = fetch(1);
+            for (uint32_t it = 0; it < n_it; it++) {
+              const u32x4 nx2 = fetch(it + 2);
+              const uint32_t w[4] = {cur[0], cur[1], cur[2], cur[3]};
 #pragma unroll
-          for (int k = 0; k < 8; k++) x[k] = clat[base + k * T + tid];
+              for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t c = (uint32_t)(uint16_t)(((k & 1u) ? w[k >> 1] >> 16 : w[k >> 1]) - c16_off);
+                hist_count(counts, c, c < R, kAgg);
+              }
+              cur = nx1; nx1 = nx2;
+            }
+            base = n_it * 8 * T;
+          }
+          for (; base + 8 * T <= n_all; base += 8 * T) {
+            uint16_t x[8];
 #pragma unroll
-          for (int k = 0; k < 8; k++) {
-            const uint32_t i = base + k * T + tid;
-            hist_count(counts, (uint32_t)(uint16_t)(x[k] - c16_off), stored(i), agg);
+            for (int k = 0; k < 8; k++) x[k] = clat[base + k * T + tid];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const uint32_t c = (uint32_t)(uint16_t)(x[k] - c16_off); hist_count(counts, c, c < R, kAgg); }
+          }
+        } else {
+          for (; base + 8 * T <= n_all; base += 8 * T) {
+            L x[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = lat[base + k * T + tid];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+              const L d = (L)(x[k] - minv);
+              clat[base + k * T + tid] = (uint16_t)d;
+              hist_count(counts, (uint32_t)d, (uint64_t)d < R, kAgg);
+            }
           }
         }
-      } else {
-        for (; base + 8 * T <= n_all; base += 8 * T) {
-          L x[8];
-#pragma unroll
-          for (int k = 0; k < 8; k++) x[k] = lat[base + k * T + tid];
-#pragma unroll
-          for (int k = 0; k < 8; k++) {
-            const uint32_t i = base + k * T + tid;
-            const uint32_t c = (uint32_t)(x[k] - minv);
-            clat[i] = (uint16_t)c;
-            hist_count(counts, c, stored(i), agg);
+        for (uint32_t i0 = base; i0 < n_all; i0 += T) {   // whole waves enter hist_count
+          const uint32_t i = i0 + tid;
+          const uint64_t d = i < n_all ? (c16 ? (uint64_t)(uint16_t)(clat[i] - c16_off) : (uint64_t)(L)(lat[i] - minv)) : 0ull;
+          if (i < n_all && !c16) clat[i] = (uint16_t)d;
+          hist_count(counts, (uint32_t)d, i < n_all && d < R, kAgg);
+        }
+      };
+      if (agg) count_all(BoolC<true>{}); else count_all(BoolC<false>{});
+      if (skip != 0) {   // (delta state positions: wrapped/chunk_compressor.rs:129-140)
+        __syncthreads();
+        for (uint32_t q = tid; q < n_pg * skip; q += T) {
+          const uint32_t pi = q / skip, j = q - pi * skip;
+          const uint64_t pst = pgl[pi].start;
+          if (j < (uint64_t)pgl[pi].n) {
+            const uint64_t d = c16 ? (uint64_t)(uint16_t)(clat[pst + j] - c16_off) : (uint64_t)(L)(lat[pst + j] - minv);
+            if (d < R) atomicSub((uint32_t*)&counts[(uint32_t)d], 1u);
           }
         }
-      }
-      for (uint32_t i0 = base; i0 < n_all; i0 += T) {   // whole waves enter hist_count
-        const uint32_t i = i0 + tid;
-        const uint32_t c = i < n_all ? (c16 ? (uint32_t)(uint16_t)(clat[i] - c16_off) : (uint32_t)(lat[i] - minv)) : 0u;
-        if (i < n_all && !c16) clat[i] = (uint16_t)c;
-        hist_count(counts, c, i < n_all && stored(i), agg);
       }
     }
     __syncthreads();
