@@ -679,7 +679,7 @@ __global__ __launch_bounds__(kSelThr, 4) void enc_hist_select_kernel(EncWorkspac
 // place by block_radix_sort_inplace, and the <= 256 rank queries read the sorted array directly.  LDS = the record area +
 // n keys (launcher: small_lds_bytes), so two to four blocks share a CU and hide each other's barriers and loads.
 // ---------------------------------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr uint32_t small_lds_bytes(uint32_t n, uint32_t key_bytes) { return kHistLdsCounts + (n * key_bytes > 11280u ? ((n * key_bytes + 15u) & ~15u) : 11280u); }   // (at least hist_emit's 11 KB of scratch)
+__host__ __device__ constexpr uint32_t small_lds_bytes(uint32_t n, uint32_t key_bytes) { return kHistLdsCounts + (n * key_bytes > kWalkScratchBytes + 16u ? ((n * key_bytes + 15u) & ~15u) : kWalkScratchBytes + 16u); }   // (at least hist_emit's scratch)
 
 template <class L, class K>
 __device__ __forceinline__ void small_body(const EncWorkspace& ws, uint32_t t, uint32_t var, uint32_t bins_log, EncChunk PCO_GLOBAL* ch, EncVar PCO_GLOBAL* ev,

@@ -1070,31 +1070,46 @@ __device__ __forceinline__ void hist_state_machine(uint32_t n_lat, uint32_t bins
 // before the walk:  pre[0][b] = c_count(b);  pre[1][b] = bin_idx(c_count(b)), the bin the walk stands in after completing bin b;
 // pre[2][b] = bin_idx(en_b), ... after a constant run;  pre[3][b] = bin_idx(middle of the run);  pre[4][b] = c_count(pre[3][b]);
 // pre[5][b] = c_count(pre[3][b] - 1).
-template <class L>
-__device__ __forceinline__ void hist_precompute(uint32_t b, uint32_t n_lat, uint32_t bins_log, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren, uint32_t PCO_LDS* pre) {
+// pre[0] = c_count(b); pre[1] = bin_idx(c_count(b)); pre[2] = bin_idx(en_b); pre[3] = bin_idx(middle of the run); pre[4] = c_count(pre[3]); pre[5] = c_count(pre[3] - 1)
+__device__ __forceinline__ void hist_precompute(uint32_t b, uint32_t n_lat, uint32_t bins_log, uint32_t st, uint32_t en, uint32_t (&pre)[6]) {
   const uint64_t n = n_lat, B = (uint64_t)1 << bins_log;
   const uint64_t magic = n > 1 ? (~0ull / n) + 1 : 0ull;
   auto bin_idx = [&](uint64_t pos) { return n > 1 ? (uint32_t)__umul64hi(pos << bins_log, magic) : (uint32_t)(pos << bins_log); };
   auto c_count = [&](uint32_t bb) { return (uint32_t)((((uint64_t)bb + 1) * n + B - 1) >> bins_log); };
-  const uint32_t c = c_count(b), st = rst[b], en = ren[b];
+  const uint32_t c = c_count(b);
   const uint32_t bm = bin_idx(st + (en - st) / 2);
-  pre[b] = c; pre[B + b] = bin_idx(c); pre[2 * B + b] = bin_idx(en); pre[3 * B + b] = bm; pre[4 * B + b] = c_count(bm); pre[5 * B + b] = bm > 0 ? c_count(bm - 1) : 0u;
+  pre[0] = c; pre[1] = bin_idx(c); pre[2] = bin_idx(en); pre[3] = bm; pre[4] = c_count(bm); pre[5] = bm > 0 ? c_count(bm - 1) : 0u;
 }
+// Everything a step of the walk may need about bin b, as ONE 64-byte record (round 6): the six tables above, the run [st, en) and the four
+// values (at the bin's last rank, the one after it, the run's predecessor and successor; 64-bit whatever the latent type).  A step used to
+// read twelve LDS words from twelve arrays -- twelve DS instructions issued by a lone lane, some 16 cycles each that nothing hides, before
+// the round trip itself; now it is four 16-byte reads.
+constexpr uint32_t kWalkRecDwords = 16;
+constexpr uint32_t kWalkScratchBytes = 256 * kWalkRecDwords * 4;   // what hist_emit needs of its scratch area when it walks itself
+__device__ __forceinline__ void hist_pack_record(uint32_t PCO_LDS* rec, uint32_t b, const uint32_t (&pre)[6], uint32_t st, uint32_t en, uint64_t v, uint64_t vnext, uint64_t vpred, uint64_t vsucc) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 PCO_LDS* r4 = (u32x4 PCO_LDS*)(rec + b * kWalkRecDwords);
+  u32x4 a, c, d, e;
+  a[0] = pre[0]; a[1] = pre[1]; a[2] = pre[2]; a[3] = pre[3];
+  c[0] = pre[4]; c[1] = pre[5]; c[2] = st; c[3] = en;
+  d[0] = (uint32_t)v; d[1] = (uint32_t)(v >> 32); d[2] = (uint32_t)vnext; d[3] = (uint32_t)(vnext >> 32);
+  e[0] = (uint32_t)vpred; e[1] = (uint32_t)(vpred >> 32); e[2] = (uint32_t)vsucc; e[3] = (uint32_t)(vsucc >> 32);
+  r4[0] = a; r4[1] = c; r4[2] = d; r4[3] = e;
+}
+// The walk of hist_walk above for one window covering every bin, by one lane, over the records; bins go straight to the plan (stores nobody waits for)
 template <class L>
-__device__ __forceinline__ uint32_t hist_walk_pre(uint32_t n_lat, uint32_t bins_log, L first_value, const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
-                                                  const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc, const uint32_t PCO_LDS* pre, const PlanRef& plan) {
-  const uint32_t B = 1u << bins_log;
-  uint32_t pos = 0, target = 0; L pos_value = first_value;
-  bool pending = false; uint32_t pending_start = 0; L pending_lower = 0;
+__device__ __forceinline__ uint32_t hist_walk_rec(uint32_t n_lat, L first_value, const uint32_t PCO_LDS* rec, const PlanRef& plan) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  uint32_t pos = 0, target = 0; uint64_t pos_value = (uint64_t)first_value;
+  bool pending = false; uint32_t pending_start = 0; uint64_t pending_lower = 0;
   uint32_t next_avail = 0, n_hist = 0;
-  // (bins are emitted into LDS -- u32 counts after the six tables, then u64 lowers and uppers -- and copied out by the block afterwards)
-  uint32_t PCO_LDS* o_cnt = (uint32_t PCO_LDS*)(pre + 6 * B); uint64_t PCO_LDS* o_lo = (uint64_t PCO_LDS*)(pre + 7 * B); uint64_t PCO_LDS* o_hi = o_lo + B;
-  auto emit = [&](uint32_t start, uint32_t end, L lower, L upper) { o_cnt[n_hist] = end - start; o_lo[n_hist] = (uint64_t)lower; o_hi[n_hist] = (uint64_t)upper; n_hist++; };
+  auto emit = [&](uint32_t start, uint32_t end, uint64_t lower, uint64_t upper) { plan.hcount()[n_hist] = end - start; plan.hlower()[n_hist] = lower; plan.hupper()[n_hist] = upper; n_hist++; };
   while (pos < n_lat) {
-    // everything this step may need, read at once (one LDS round trip per step instead of one per dependent use)
-    const uint32_t c = pre[target], nb_c = pre[B + target], nb_en = pre[2 * B + target], bm = pre[3 * B + target], c_bm = pre[4 * B + target], c_bm1 = pre[5 * B + target];
-    const L v = rv[target], vnext = rnext[target], vpred = rpred[target], vsucc = rsucc[target];
-    const uint32_t st = rst[target], en = ren[target];
+    const u32x4 PCO_LDS* r4 = (const u32x4 PCO_LDS*)(rec + target * kWalkRecDwords);
+    const u32x4 ra = r4[0], rb = r4[1], rc = r4[2], rd = r4[3];
+    const uint32_t c = ra[0], nb_c = ra[1], nb_en = ra[2], bm = ra[3], c_bm = rb[0], c_bm1 = rb[1], st = rb[2], en = rb[3];
+    const uint64_t v = (uint64_t)rc[0] | ((uint64_t)rc[1] << 32), vnext = (uint64_t)rc[2] | ((uint64_t)rc[3] << 32);
+    const uint64_t vpred = (uint64_t)rd[0] | ((uint64_t)rd[1] << 32), vsucc = (uint64_t)rd[2] | ((uint64_t)rd[3] << 32);
     if (en <= c) {  // every run in [pos, c) fits: absorb and complete at c
       if (!pending) { pending_start = pos; pending_lower = pos_value; }
       emit(pending_start, c, pending_lower, v);
@@ -1127,7 +1142,7 @@ __device__ __forceinline__ uint32_t hist_walk_pre(uint32_t n_lat, uint32_t bins_
 template <class L>
 __device__ __forceinline__ void hist_emit(uint32_t n_lat, uint32_t bins_log, L first_value, const L PCO_LDS* rv, const uint32_t PCO_LDS* rst, const uint32_t PCO_LDS* ren,
                                           const L PCO_LDS* rnext, const L PCO_LDS* rpred, const L PCO_LDS* rsucc, const PlanRef& plan, EncVar PCO_GLOBAL* ev, uint32_t path,
-                                          uint32_t PCO_LDS* pre /* u32[11 << bins_log + 1] of scratch (the counters / sort area: done with by now) */,
+                                          uint32_t PCO_LDS* pre /* kWalkScratchBytes of 16-byte aligned scratch (the counters / sort area: done with by now) */,
                                           uint8_t PCO_GLOBAL* defer = nullptr /* where to leave records + tables for enc_hist_walk_kernel instead of walking here */) {
   const uint32_t tid = threadIdx.x, B = 1u << bins_log;
   const uint64_t n64 = n_lat;
@@ -1141,14 +1156,13 @@ __device__ __forceinline__ void hist_emit(uint32_t n_lat, uint32_t bins_log, L f
     }
     if (tid == 0) { ev->n_hist = B; ev->hist_path = path; }
   } else {
-    if (tid < B) hist_precompute<L>(tid, n_lat, bins_log, rst, ren, pre);
-    if (tid == 0) pre[11 * B] = 0;
-    __syncthreads();
+    uint32_t p6[6] = {0, 0, 0, 0, 0, 0};
+    if (tid < B) hist_precompute(tid, n_lat, bins_log, rst[tid], ren[tid], p6);
     if (defer != nullptr) {   // the walk is one thread's work: with two 1024-thread blocks per CU it was most of the kernel's time; it gets a wave of its own later
       if (tid < B) {
         uint32_t PCO_GLOBAL* g32 = (uint32_t PCO_GLOBAL*)defer;
 #pragma unroll
-        for (uint32_t k = 0; k < 6; k++) g32[k * 256 + tid] = pre[k * B + tid];
+        for (uint32_t k = 0; k < 6; k++) g32[k * 256 + tid] = p6[k];
         g32[6 * 256 + tid] = rst[tid]; g32[7 * 256 + tid] = ren[tid];
         uint64_t PCO_GLOBAL* g64 = (uint64_t PCO_GLOBAL*)(defer + 8192);
         g64[tid] = (uint64_t)rv[tid]; g64[256 + tid] = (uint64_t)rnext[tid]; g64[512 + tid] = (uint64_t)rpred[tid]; g64[768 + tid] = (uint64_t)rsucc[tid];
@@ -1156,10 +1170,9 @@ __device__ __forceinline__ void hist_emit(uint32_t n_lat, uint32_t bins_log, L f
       if (tid == 0) { ev->hist_path = path; ev->walk_pending = 1u; }
       return;
     }
-    if (tid == 0) { const uint32_t nh = hist_walk_pre<L>(n_lat, bins_log, first_value, rv, rst, ren, rnext, rpred, rsucc, pre, plan); ev->n_hist = nh; ev->hist_path = path; pre[11 * B] = nh; }
+    if (tid < B) hist_pack_record(pre, tid, p6, rst[tid], ren[tid], (uint64_t)rv[tid], (uint64_t)rnext[tid], (uint64_t)rpred[tid], (uint64_t)rsucc[tid]);
     __syncthreads();
-    const uint32_t nh = pre[11 * B];
-    if (tid < nh) { plan.hcount()[tid] = pre[6 * B + tid]; plan.hlower()[tid] = ((const uint64_t PCO_LDS*)(pre + 7 * B))[tid]; plan.hupper()[tid] = ((const uint64_t PCO_LDS*)(pre + 7 * B))[B + tid]; }
+    if (tid == 0) { const uint32_t nh = hist_walk_rec<L>(n_lat, first_value, pre, plan); ev->n_hist = nh; ev->hist_path = path; }
   }
 }
 
@@ -1358,7 +1371,7 @@ __device__ void hist_var(const EncWorkspace& ws, uint32_t t, uint32_t var, uint3
     __syncthreads();
     HIST_STAMP(2);
     hist_emit<L>(n_lat, bins_log, minv, rv, rst, ren, rnext, rpred, rsucc, plan, ev, 0u, (uint32_t PCO_LDS*)(smem + kHistLdsCounts),
-                 kWide && ws.walk != nullptr ? (uint8_t PCO_GLOBAL*)ws.walk + ((uint64_t)t * 3 + var) * kWalkRecBytes : (uint8_t PCO_GLOBAL*)nullptr);   // (five 256-thread blocks per CU hide their own walks: measured, no gain from deferring)
+                 ws.walk != nullptr ? (uint8_t PCO_GLOBAL*)ws.walk + ((uint64_t)t * 3 + var) * kWalkRecBytes : (uint8_t PCO_GLOBAL*)nullptr);   // (enc_hist_kernel is launched without the record buffer unless PCO_GFX_HIST_DEFER=1: its five blocks per CU hide their own walks)
     __syncthreads();
     HIST_STAMP(3);
 #ifdef PCO_HIST_TIMING
@@ -1667,16 +1680,13 @@ __global__ __launch_bounds__(1024) void enc_hist_wide_kernel(EncWorkspace ws, ui
 
 // The bin walks the 1024-thread histogram kernels left behind (EncVar::walk_pending): one wave per chunk, records and tables from HBM
 // into LDS, the walk by one lane, the bins copied out by the wave.  Thousands of walks at once instead of one per resident block.
-constexpr uint32_t kWalkLdsBytes = (11 * 256 + 4) * 4 + 2 * 1024 + 4 * 2048;   // hist_walk_pre's tables + emit area | run starts, ends | four value arrays
+constexpr uint32_t kWalkLdsBytes = kWalkScratchBytes;   // the records (round 6: 21.5 -> 16 KB, nine walks on a CU instead of seven; the bins go straight to the plan)
 __global__ __launch_bounds__(64) void enc_hist_walk_kernel(EncWorkspace ws, uint32_t n_tasks) {
   const uint32_t t = blockIdx.x;
   if (t >= n_tasks) return;
   EncChunk PCO_GLOBAL* ch = (EncChunk PCO_GLOBAL*)ws.chunks + t;
   if (uni(ch->status) != PCO_GFX_OK) return;
-  uint8_t PCO_LDS* smem = enc_lds_base();
-  uint32_t PCO_LDS* pre = (uint32_t PCO_LDS*)smem;
-  uint32_t PCO_LDS* rst = (uint32_t PCO_LDS*)(smem + (11 * 256 + 4) * 4); uint32_t PCO_LDS* ren = rst + 256;
-  uint64_t PCO_LDS* rv = (uint64_t PCO_LDS*)(ren + 256);
+  uint32_t PCO_LDS* rec = (uint32_t PCO_LDS*)enc_lds_base();
   const uint32_t lane = lane_id(), ubl = uni(ch->unopt_bins_log);
   for (uint32_t var = 0; var < 3; var++) {
     EncVar PCO_GLOBAL* ev = &ch->v[var];
@@ -1685,19 +1695,14 @@ __global__ __launch_bounds__(64) void enc_hist_walk_kernel(EncWorkspace ws, uint
     const uint8_t PCO_GLOBAL* src = (const uint8_t PCO_GLOBAL*)ws.walk + ((uint64_t)t * 3 + var) * kWalkRecBytes;
     const uint32_t PCO_GLOBAL* g32 = (const uint32_t PCO_GLOBAL*)src; const uint64_t PCO_GLOBAL* g64 = (const uint64_t PCO_GLOBAL*)(src + 8192);
     for (uint32_t i = lane; i < B; i += 64) {
+      uint32_t p6[6];
 #pragma unroll
-      for (uint32_t k = 0; k < 6; k++) pre[k * B + i] = g32[k * 256 + i];
-      rst[i] = g32[6 * 256 + i]; ren[i] = g32[7 * 256 + i];
-      rv[i] = g64[i]; rv[256 + i] = g64[256 + i]; rv[512 + i] = g64[512 + i]; rv[768 + i] = g64[768 + i];
+      for (uint32_t k = 0; k < 6; k++) p6[k] = g32[k * 256 + i];
+      hist_pack_record(rec, i, p6, g32[6 * 256 + i], g32[7 * 256 + i], g64[i], g64[256 + i], g64[512 + i], g64[768 + i]);
     }
     enc_wave_sync();
     const PlanRef plan = plan_ref(ws, t, var);
-    uint32_t nh = 0;
-    if (lane == 0) nh = hist_walk_pre<uint64_t>(uni(ev->n_lat), bins_log, (uint64_t)ev->minv, rv, rst, ren, rv + 256, rv + 512, rv + 768, pre, plan);
-    nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)nh);
-    enc_wave_sync();
-    for (uint32_t i = lane; i < nh; i += 64) { plan.hcount()[i] = pre[6 * B + i]; plan.hlower()[i] = ((const uint64_t PCO_LDS*)(pre + 7 * B))[i]; plan.hupper()[i] = ((const uint64_t PCO_LDS*)(pre + 7 * B))[B + i]; }
-    if (lane == 0) { ev->n_hist = nh; ev->walk_pending = 0u; }
+    if (lane == 0) { const uint32_t nh = hist_walk_rec<uint64_t>(uni(ev->n_lat), (uint64_t)ev->minv, rec, plan); ev->n_hist = nh; ev->walk_pending = 0u; }
     enc_wave_sync();
   }
 }
