@@ -299,6 +299,34 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
     big[kSelBigCap + 2] = ns;
   }
   __syncthreads();
+  // ---- (B') data that is spread evenly over its range (incompressible columns: BASELINE configs[0], ids, hashes) needs no quantile map: 64-128
+  //      EQUAL power-of-two segments put 30-60 latents into every bucket, and a latent's bucket is one shift -- no cell table, no search, no
+  //      segment record: the count pass was bound by those random LDS reads (scripts/sel_timing.py: 377 k of 1.18 M cycles a variable).  Taken when
+  //      the sorted sample says so: no heavy value, and no power-of-two segment holds more than three times its share of the sample.  The segment
+  //      table is rewritten in the same form, so everything behind the count pass (and its tail loop) goes through the tables as before. ----
+  const uint32_t flat_w = range_bl >= 15 ? range_bl - 7 : 8u;   // (ranges here are >= 32768: range_bl >= 16)
+  const uint32_t flat_segs = (uint32_t)((uint64_t)(L)(maxv - minv) >> flat_w) + 1u;   // 64 .. 128
+  {
+    bool bad = false;
+    if (tid < flat_segs) {
+      const L lo = (L)(minv + ((L)tid << flat_w));
+      L hi = (L)(lo + (L)(((L)1 << flat_w) - 1)); if (hi > maxv || hi < lo) hi = maxv;
+      uint32_t a = 0, b = kSelSample;   // first sample >= lo
+      while (a < b) { const uint32_t mid = (a + b) >> 1; if (srt[mid] < lo) a = mid + 1; else b = mid; }
+      uint32_t c = a, e = kSelSample;   // first sample > hi
+      while (c < e) { const uint32_t mid = (c + e) >> 1; if (srt[mid] <= hi) c = mid + 1; else e = mid; }
+      bad = (c - a) * flat_segs > 3u * kSelSample;
+    }
+    if (tid < uni(big[kSelBigCap + 2]) && seg[tid].par == 1) bad = true;   // a heavy value
+    // (a range just above a power of two makes 64 segments of twice the population: windows beyond the 64 latents a wave orders in registers -- the quantile map keeps those)
+    const bool flat_now = __syncthreads_or(bad ? 1 : 0) == 0 && range_bl >= 16 && flat_segs >= 90;
+    if (flat_now) {
+      if (tid < flat_segs) { seg[tid].lo = (L)(minv + ((L)tid << flat_w)); seg[tid].par = 0; }
+      if (tid == 0) { big[kSelBigCap + 2] = flat_segs; big[kSelBigCap + 3] = 1; }
+    }
+    __syncthreads();
+  }
+  const bool flat = uni(big[kSelBigCap + 3]) != 0;
   const uint32_t n_seg = uni(big[kSelBigCap + 2]);
   // A bound that is alone in its value cell moves down to the cell's first value (any monotone map will do): the cell then lies in ONE
   // segment and its latents need no search in the count pass.  On smooth data that is nearly every cell; where the data is dense
@@ -318,7 +346,7 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
     __syncthreads();
     if (tid < n_seg) {
       const L last = tid + 1 < n_seg ? (L)(seg[tid + 1].lo - 1) : maxv;     // last value of the segment
-      const L w1 = (L)(last - lo);                                             // width - 1
+      const L w1 = flat ? (L)(((L)1 << flat_w) - 1) : (L)(last - lo);         // width - 1 (flat: every segment scales as a full one, the last included)
       // sub-bucket = ((x - lo) >> pre) * m >> 16, monotone and < 64: segments of at most 64 values get one bucket per value
       // (pre 0, m 65536: "exact"), the others spread their (pre-shifted, < 2^16) width over all 64 sub-buckets
       uint32_t pre = 0, m = 65536;
@@ -364,7 +392,9 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
   constexpr uint32_t kE = sizeof(L) == 8 ? 8u : 16u, kV = kE * sizeof(L) / 16;   // latents / 16-byte vectors per thread and round
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   union VecL { u32x4 v[kV]; L x[kE]; };
-  {
+  auto count_pass = [&](auto flat_c) {
+    constexpr bool kFlat = decltype(flat_c)::value;
+    const uint32_t fsh = flat_w - kSelSubLog;
     uint32_t base = 0;
     VecL nxt;   // the next round's latents are fetched before this round's are worked on (the block's waves run in step: without it
                 // they all wait for HBM together, then all compute together)
@@ -373,39 +403,46 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
       for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + tid * kE))[q];
     }
     for (; base + kE * kSelThr <= n_all; base += kE * kSelThr) {
-      VecL d = nxt; uint32_t j[kE], jn[kE];
+      VecL d = nxt; uint32_t bb[kE];
       const uint32_t i0 = base + tid * kE;
       if (base + 2 * kE * kSelThr <= n_all) {
 #pragma unroll
         for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + i0 + kE * kSelThr))[q];
       }
 #pragma unroll
-      for (uint32_t k = 0; k < kE; k++) {
-        d.x[k] = d.x[k] < minv ? minv : (d.x[k] > maxv ? maxv : d.x[k]);   // (positions that are not stored may hold anything)
-        const uint32_t e = lut[(uint32_t)((L)(d.x[k] - minv) >> cell_sh)];
-        j[k] = e & 0xffu; jn[k] = e >> 8;
-      }
-      for (;;) {
-        bool more = false;
+      for (uint32_t k = 0; k < kE; k++) d.x[k] = d.x[k] < minv ? minv : (d.x[k] > maxv ? maxv : d.x[k]);   // (positions that are not stored may hold anything)
+      if constexpr (kFlat) {   // segment = (x - min) >> w, sub-bucket = the next six bits: what the tables say, without reading them
 #pragma unroll
-        for (uint32_t k = 0; k < kE; k++) more = more || j[k] < jn[k];
-        if (!__any(more)) break;
+        for (uint32_t k = 0; k < kE; k++) bb[k] = (uint32_t)((L)(d.x[k] - minv) >> fsh);
+      } else {
+        uint32_t j[kE], jn[kE];
 #pragma unroll
         for (uint32_t k = 0; k < kE; k++) {
-          const uint32_t mid = (j[k] + jn[k] + 1) >> 1;
-          const bool ge = seg[mid].lo <= d.x[k];
-          j[k] = ge ? mid : j[k]; jn[k] = ge ? jn[k] : mid - 1;
+          const uint32_t e = lut[(uint32_t)((L)(d.x[k] - minv) >> cell_sh)];
+          j[k] = e & 0xffu; jn[k] = e >> 8;
         }
-      }
-      // (staged: all segment records, then all buckets, then the stored-or-not flags, then the counter bumps -- one loop over the
-      //  latents made every LDS round trip wait for the one before it)
-      L rlo[kE]; uint32_t par[kE], bb[kE];
+        for (;;) {
+          bool more = false;
 #pragma unroll
-      for (uint32_t k = 0; k < kE; k++) { rlo[k] = seg[j[k]].lo; par[k] = seg[j[k]].par; }
+          for (uint32_t k = 0; k < kE; k++) more = more || j[k] < jn[k];
+          if (!__any(more)) break;
 #pragma unroll
-      for (uint32_t k = 0; k < kE; k++) {
-        const uint32_t v = (uint32_t)((L)(d.x[k] - rlo[k]) >> (par[k] >> 24));
-        bb[k] = (j[k] << kSelSubLog) + ((v * (par[k] & 0x1ffffu)) >> 16);
+          for (uint32_t k = 0; k < kE; k++) {
+            const uint32_t mid = (j[k] + jn[k] + 1) >> 1;
+            const bool ge = seg[mid].lo <= d.x[k];
+            j[k] = ge ? mid : j[k]; jn[k] = ge ? jn[k] : mid - 1;
+          }
+        }
+        // (staged: all segment records, then all buckets, then the stored-or-not flags, then the counter bumps -- one loop over the
+        //  latents made every LDS round trip wait for the one before it)
+        L rlo[kE]; uint32_t par[kE];
+#pragma unroll
+        for (uint32_t k = 0; k < kE; k++) { rlo[k] = seg[j[k]].lo; par[k] = seg[j[k]].par; }
+#pragma unroll
+        for (uint32_t k = 0; k < kE; k++) {
+          const uint32_t v = (uint32_t)((L)(d.x[k] - rlo[k]) >> (par[k] >> 24));
+          bb[k] = (j[k] << kSelSubLog) + ((v * (par[k] & 0x1ffffu)) >> 16);
+        }
       }
       if (skip != 0) {   // (block-uniform)
 #pragma unroll
@@ -413,10 +450,12 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
       }
 #pragma unroll
       for (uint32_t k = 0; k < kE; k++) if (bb[k] != 0xffffu) atomicAdd((uint32_t*)&P[bb[k]], 1u);
+      if constexpr (!kFlat) {   // (a flat map's gather pass shifts again instead of reading the id back: half a MB less each way per variable)
 #pragma unroll
-      for (uint32_t q = 0; q < kE / 8; q++) {   // eight u16 ids per 16-byte store
-        u32x4 w; w.x = bb[8 * q] | (bb[8 * q + 1] << 16); w.y = bb[8 * q + 2] | (bb[8 * q + 3] << 16); w.z = bb[8 * q + 4] | (bb[8 * q + 5] << 16); w.w = bb[8 * q + 6] | (bb[8 * q + 7] << 16);
-        ((u32x4 PCO_GLOBAL*)(ids + i0))[q] = w;
+        for (uint32_t q = 0; q < kE / 8; q++) {   // eight u16 ids per 16-byte store
+          u32x4 w; w.x = bb[8 * q] | (bb[8 * q + 1] << 16); w.y = bb[8 * q + 2] | (bb[8 * q + 3] << 16); w.z = bb[8 * q + 4] | (bb[8 * q + 5] << 16); w.w = bb[8 * q + 6] | (bb[8 * q + 7] << 16);
+          ((u32x4 PCO_GLOBAL*)(ids + i0))[q] = w;
+        }
       }
     }
     for (uint32_t i0 = base; i0 < n_all; i0 += kSelThr) {   // (whole waves run bucket_of: its search loop votes)
@@ -424,10 +463,11 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
       const bool on = i < n_all && stored(i);
       L xv = i < n_all ? lat[i] : minv; xv = xv < minv ? minv : (xv > maxv ? maxv : xv);
       const uint32_t b = bucket_of(xv);
-      if (i < n_all) ids[i] = on ? (uint16_t)b : (uint16_t)0xffffu;
+      if (!kFlat && i < n_all) ids[i] = on ? (uint16_t)b : (uint16_t)0xffffu;
       if (on) atomicAdd((uint32_t*)&P[b], 1u);
     }
-  }
+  };
+  if (flat) count_pass(BoolC<true>{}); else count_pass(BoolC<false>{});
   __threadfence_block();
   __syncthreads();
   SEL_STAMP(1);
@@ -498,33 +538,51 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
   // ---- (G) gather: every latent of a marked bucket goes into its bucket's window, in any order.  Same thread-to-latent mapping
   //      and load width as the count pass; staged (window lookups, then cursor atomics, then stores) so that the LDS round trips
   //      of a thread's latents overlap ----
-  {
+  auto gather_pass = [&](auto flat_c) {
+    constexpr bool kFlat = decltype(flat_c)::value;
+    const uint32_t fsh = flat_w - kSelSubLog;
+    auto flat_id = [&](L x, bool on) { x = x < minv ? minv : (x > maxv ? maxv : x); return on ? (uint32_t)((L)(x - minv) >> fsh) : 0xffffu; };   // (as the count pass counted it)
     uint32_t base = 0;
     union IdV { u32x4 v[kE / 8]; uint16_t k[kE]; };
     VecL nxt; IdV nid;
     if (kE * kSelThr <= n_all) {
 #pragma unroll
       for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + tid * kE))[q];
+      if constexpr (!kFlat) {
 #pragma unroll
-      for (uint32_t q = 0; q < kE / 8; q++) nid.v[q] = ((const u32x4 PCO_GLOBAL*)(ids + tid * kE))[q];
+        for (uint32_t q = 0; q < kE / 8; q++) nid.v[q] = ((const u32x4 PCO_GLOBAL*)(ids + tid * kE))[q];
+      }
     }
     for (; base + kE * kSelThr <= n_all; base += kE * kSelThr) {
-      VecL d = nxt; IdV id = nid; uint32_t sl[kE], at[kE];
+      VecL d = nxt; IdV id = nid; uint32_t sl[kE], at[kE], kid[kE];
       const uint32_t i0 = base + tid * kE;
       if (base + 2 * kE * kSelThr <= n_all) {
 #pragma unroll
         for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + i0 + kE * kSelThr))[q];
+        if constexpr (!kFlat) {
 #pragma unroll
-        for (uint32_t q = 0; q < kE / 8; q++) nid.v[q] = ((const u32x4 PCO_GLOBAL*)(ids + i0 + kE * kSelThr))[q];
+          for (uint32_t q = 0; q < kE / 8; q++) nid.v[q] = ((const u32x4 PCO_GLOBAL*)(ids + i0 + kE * kSelThr))[q];
+        }
+      }
+      if constexpr (kFlat) {
+#pragma unroll
+        for (uint32_t k = 0; k < kE; k++) kid[k] = flat_id(d.x[k], true);
+        if (skip != 0) {   // (block-uniform)
+#pragma unroll
+          for (uint32_t k = 0; k < kE; k++) kid[k] = stored(i0 + k) ? kid[k] : 0xffffu;
+        }
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < kE; k++) kid[k] = id.k[k];
       }
 #pragma unroll
-      for (uint32_t k = 0; k < kE; k++) at[k] = ((uint32_t)id.k[k] & (kSelBuckets - 1)) >> 5;   // bitmap word (an id of 0xffff -- not stored -- reads the last one)
+      for (uint32_t k = 0; k < kE; k++) at[k] = (kid[k] & (kSelBuckets - 1)) >> 5;   // bitmap word (an id of 0xffff -- not stored -- reads the last one)
       uint32_t wd[kE];
 #pragma unroll
       for (uint32_t k = 0; k < kE; k++) { wd[k] = need[at[k]]; sl[k] = wpre[at[k]]; }   // unconditional reads, all in flight together
 #pragma unroll
       for (uint32_t k = 0; k < kE; k++) {
-        const uint32_t kk = id.k[k];
+        const uint32_t kk = kid[k];
         const uint32_t hit = (uint32_t)(kk != 0xffffu) & (wd[k] >> (kk & 31)) & 1u;   // (bitwise: no short-circuit branch per latent)
         const uint32_t slot = sl[k] + (uint32_t)__popc(wd[k] & ((1u << (kk & 31)) - 1u));
         sl[k] = hit ? slot : 0xffffu;
@@ -535,10 +593,11 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
       for (uint32_t k = 0; k < kE; k++) if (sl[k] != 0xffffu) S[at[k]] = d.x[k];
     }
     for (uint32_t i = base + tid; i < n_all; i += kSelThr) {
-      const uint32_t k = ids[i];
+      const uint32_t k = kFlat ? flat_id(lat[i], stored(i)) : (uint32_t)ids[i];
       if (k != 0xffffu && ((need[k >> 5] >> (k & 31)) & 1u)) S[atomicAdd((uint32_t*)&nl_oc[slot_of(k) + 1], 1u)] = lat[i];
     }
-  }
+  };
+  if (flat) gather_pass(BoolC<true>{}); else gather_pass(BoolC<false>{});
   __threadfence_block();
   __syncthreads();
   SEL_STAMP(3);
