@@ -17,8 +17,9 @@
 // the first bucket of the last segment, which the block orders in LDS (up to 8192 latents).  Anything beyond that (never
 // seen in practice) is handed to round 1's radix-sort kernel, which stays as the fallback (EncVar::hist_path == 2).
 //
-// Per chunk and variable: two streaming passes over the latents (count, gather), both bound by LDS traffic (7 reads + 1
-// atomic per latent) at about the rate HBM delivers them; one block of 1024 threads per chunk, one block per CU.
+// Per chunk and variable: two streaming passes over the latents (count, gather); two blocks of 512 threads per CU.  Round 6: data
+// that is spread evenly over its range needs none of the above -- 64-128 equal power-of-two segments do (stage (B') below), a latent's
+// bucket is one shift, and its id does not have to be kept for the gather pass.
 #pragma once
 
 namespace pcogfx {

@@ -472,6 +472,39 @@ def test_histogram_range_boundaries_and_skew(L):
             assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, n), nums), name
 
 
+def test_flat_bucket_map_of_the_select_histogram(L):
+    """enc_hist_select_kernel takes equal power-of-two segments instead of sample quantiles when the sorted sample says the data is spread
+    evenly (no heavy value, no segment above three times its share, at least 90 segments): the decision's edges -- ranges that make 89 / 90 /
+    127 / 128 segments, 16-bit and 64-bit types --, unstored positions (delta, several pages), and data that only LOOKS flat to the sample (a
+    heavy value at positions the 2048 evenly spaced sample positions miss: one bucket holds thousands of latents) all give the oracle's bytes."""
+    rng = np.random.default_rng(2206)
+    n = 70000
+    cases = {}
+    for bl, segs in ((20, 89), (20, 90), (20, 127), (20, 128), (40, 100), (63, 128)):
+        r = (segs << (bl - 7)) - 1 if segs < 128 else (1 << bl) - 1     # range with bit length bl whose top seven bits + 1 make `segs` segments
+        x = rng.integers(0, r + 1, n, dtype=np.uint64); x[0] = 0; x[1] = r
+        cases[f"u64_bl{bl}_segs{segs}"] = x + np.uint64(12345)
+    cases["u16_full"] = rng.integers(0, 1 << 16, n, dtype=np.uint64).astype(np.uint16)
+    cases["i16_most"] = rng.integers(-30000, 30000, n).astype(np.int16)
+    cases["u32_full"] = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    hidden = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    pos = np.arange(n); sampled = set(((np.arange(2048, dtype=np.uint64) * np.uint64(n)) // np.uint64(2048)).tolist())
+    free = np.array([p for p in pos if p not in sampled])
+    hidden[rng.choice(free, 6000, replace=False)] = 0x12345678
+    cases["heavy_value_the_sample_misses"] = hidden
+    for name, nums in cases.items():
+        for kw in (dict(mode=1, delta=1), dict(mode=1, delta=2, delta_order=2), dict(mode=1, delta=2, delta_order=1, max_page_n=9000)):
+            ocfg = O.make_config(**kw)
+            want = O.simple_compress(nums, ocfg)
+            _, _, fb = O.chunk_plan(nums, ocfg)
+            got = U.gpu_simple_compress(nums, G.make_config(**kw))
+            if fb:  # the reference's order-dependent heapsort fallback ran (DESIGN.md section 2)
+                assert U.bits_equal(O.simple_decompress(got, nums.dtype, cap=n + 8), nums), (name, kw)
+            else:
+                assert got == want, (name, kw)
+            assert U.bits_equal(U.gpu_simple_decompress(got, nums.dtype, n), nums), (name, kw)
+
+
 def test_multi_page_chunks_match_the_oracle_bytes(L):
     """PagingSpec::EqualPagesUpTo (chunk_config.rs:134-182): a standalone file is always one page per chunk, so the
     wrapped surface is compared page by page with the oracle's wrapped chunk (meta + pages)."""
