@@ -410,12 +410,13 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
 #pragma unroll
         for (uint32_t q = 0; q < kV; q++) nxt.v[q] = ((const u32x4 PCO_GLOBAL*)(lat + i0 + kE * kSelThr))[q];
       }
-#pragma unroll
-      for (uint32_t k = 0; k < kE; k++) d.x[k] = d.x[k] < minv ? minv : (d.x[k] > maxv ? maxv : d.x[k]);   // (positions that are not stored may hold anything)
       if constexpr (kFlat) {   // segment = (x - min) >> w, sub-bucket = the next six bits: what the tables say, without reading them
+        // (no clamp: a stored latent lies in [min, max], and what an unstored position makes of this is replaced below)
 #pragma unroll
         for (uint32_t k = 0; k < kE; k++) bb[k] = (uint32_t)((L)(d.x[k] - minv) >> fsh);
       } else {
+#pragma unroll
+        for (uint32_t k = 0; k < kE; k++) d.x[k] = d.x[k] < minv ? minv : (d.x[k] > maxv ? maxv : d.x[k]);   // (positions that are not stored may hold anything, and the tables are indexed with it)
         uint32_t j[kE], jn[kE];
 #pragma unroll
         for (uint32_t k = 0; k < kE; k++) {
@@ -539,10 +540,13 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
   // ---- (G) gather: every latent of a marked bucket goes into its bucket's window, in any order.  Same thread-to-latent mapping
   //      and load width as the count pass; staged (window lookups, then cursor atomics, then stores) so that the LDS round trips
   //      of a thread's latents overlap ----
-  auto gather_pass = [&](auto flat_c) {
-    constexpr bool kFlat = decltype(flat_c)::value;
+  // (kMasked: some id may be 0xffff, "not stored" -- always with the ids of the quantile map, with a flat map only when the variable has unstored
+  //  positions.  The gather pass is bound by its VALU instructions, ~30 per latent at sixteen waves a CU: the flat map's do without the clamp and,
+  //  unmasked, without the test)
+  auto gather_pass = [&](auto flat_c, auto masked_c) {
+    constexpr bool kFlat = decltype(flat_c)::value, kMasked = decltype(masked_c)::value;
     const uint32_t fsh = flat_w - kSelSubLog;
-    auto flat_id = [&](L x, bool on) { x = x < minv ? minv : (x > maxv ? maxv : x); return on ? (uint32_t)((L)(x - minv) >> fsh) : 0xffffu; };   // (as the count pass counted it)
+    auto flat_id = [&](L x, bool on) { return on ? (uint32_t)((L)(x - minv) >> fsh) : 0xffffu; };   // (as the count pass counted it: a stored latent lies in [min, max])
     uint32_t base = 0;
     union IdV { u32x4 v[kE / 8]; uint16_t k[kE]; };
     VecL nxt; IdV nid;
@@ -584,7 +588,7 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
 #pragma unroll
       for (uint32_t k = 0; k < kE; k++) {
         const uint32_t kk = kid[k];
-        const uint32_t hit = (uint32_t)(kk != 0xffffu) & (wd[k] >> (kk & 31)) & 1u;   // (bitwise: no short-circuit branch per latent)
+        const uint32_t hit = (kMasked ? (uint32_t)(kk != 0xffffu) : 1u) & (wd[k] >> (kk & 31)) & 1u;   // (bitwise: no short-circuit branch per latent)
         const uint32_t slot = sl[k] + (uint32_t)__popc(wd[k] & ((1u << (kk & 31)) - 1u));
         sl[k] = hit ? slot : 0xffffu;
       }
@@ -598,7 +602,7 @@ __device__ __forceinline__ void select_var(const EncWorkspace& ws, uint32_t t, u
       if (k != 0xffffu && ((need[k >> 5] >> (k & 31)) & 1u)) S[atomicAdd((uint32_t*)&nl_oc[slot_of(k) + 1], 1u)] = lat[i];
     }
   };
-  if (flat) gather_pass(BoolC<true>{}); else gather_pass(BoolC<false>{});
+  if (!flat) gather_pass(BoolC<false>{}, BoolC<true>{}); else if (skip != 0) gather_pass(BoolC<true>{}, BoolC<true>{}); else gather_pass(BoolC<true>{}, BoolC<false>{});
   __threadfence_block();
   __syncthreads();
   SEL_STAMP(3);
