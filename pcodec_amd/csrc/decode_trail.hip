@@ -61,7 +61,7 @@ template <class T> __device__ __forceinline__ T bperm_t(uint32_t byte_index, T v
 
 // (kept narrow on purpose: two chunks' worth of this live in a wave's scalar registers across the whole loop -- the flags are bits of one word
 //  and the small fields one packed word; a bool each is a register pair, and the overflow went through v_readlane / scratch in the hot loop)
-constexpr uint32_t kFlLive = 1, kFlHave = 2, kFlFast = 4, kFlSecValid = 8, kFlTwo = 16, kFlFast2 = 32;
+constexpr uint32_t kFlLive = 1, kFlHave = 2, kFlFast = 4, kFlSecValid = 8, kFlTwo = 16, kFlFast2 = 32, kFlTriv2 = 64;
 template <class L> struct TrailChunk {
   uint32_t fl;                         // kFlLive; kFlHave: pf_* hold batch `next`; kFlFast: the common shape -- several bins, offsets of 1..7 bits (a full batch's section fits
                                        // one register across the wave), aligned output; kFlSecValid: batch `next`'s section(s) were requested at the end of the batch before;
@@ -85,6 +85,7 @@ template <class L> struct TrailChunk {
   __device__ __forceinline__ bool sec_valid() const { return (fl & kFlSecValid) != 0; }
   __device__ __forceinline__ bool two() const { return (fl & kFlTwo) != 0; }
   __device__ __forceinline__ bool fast2_ok() const { return (fl & kFlFast2) != 0; }
+  __device__ __forceinline__ bool triv2_ok() const { return (fl & kFlTriv2) != 0; }   // kFlTriv2: two variables in the common shape whose secondary is ONE bin without offset bits (a constant: exact decimals under float-mult)
   __device__ __forceinline__ void set(uint32_t bit, bool v) { fl = v ? (fl | bit) : (fl & ~bit); }
   __device__ __forceinline__ uint32_t num_kind() const { return shape & 3u; }
   __device__ __forceinline__ uint32_t n_bins() const { return (shape >> 2) & 127u; }
@@ -125,7 +126,7 @@ template <class L, bool kTwo = false> __device__ __forceinline__ void trail_requ
   const uint8_t* syms = c.syms(ar.sym_area, ar.sym_stride); const uint64_t* starts = c.starts(ar.offpos_area, ar.offpos_stride);
   c.pf_syms = ld_agent((const uint32_t*)(syms + (uint64_t)b * kBatchN) + lane_id());
   c.pf_start = ld_agent((const uint32_t*)(starts + b));
-  if constexpr (kTwo) {   // (the secondary variable's slots are the next ones of the task: stale bytes for a chunk without one, never used)
+  if (kTwo && !c.triv2_ok()) {   // (the secondary variable's slots are the next ones of the task: stale bytes for a chunk without one, never used; a constant secondary has nothing to fetch)
     c.pf_syms2 = ld_agent((const uint32_t*)(syms + ar.sym_stride + (uint64_t)b * kBatchN) + lane_id());
     c.pf_start2 = ld_agent((const uint32_t*)(starts + ar.offpos_stride + b));
   }
@@ -406,6 +407,79 @@ __device__ __forceinline__ uint32_t trail_fast_pair2(TrailChunk<L> (&S)[kTrailSl
   return pv_next;
 }
 
+// trail_fast_pair2 for chunks whose secondary variable is a CONSTANT (one bin, no offset bits: the adjustments of exact decimals under float-mult,
+// BASELINE configs[2]) -- round 6.  Such a batch is ONE unpacking and a join, so the wave's two chunks go through it interleaved like
+// trail_fast_pair's (trail_fast_pair2 takes them one after the other: four unpackings do not fit the registers, and its expanders finished
+// 2.6 ms behind the walker), the primary's section in two registers (offsets of up to 15 bits), nothing of the secondary fetched at all.
+template <class L>
+__device__ __forceinline__ uint32_t trail_fast_pair2t(TrailChunk<L> (&S)[kTrailSlotsPerWave], const uint32_t (&ready)[kTrailSlotsPerWave], const uint32_t* pline, const TrailAreas& ar) {
+  static_assert(kTrailSlotsPerWave == 2, "written for two chunks per wave");
+  const uint32_t lane = lane_id();
+  const uint32_t layout = 4u * ((lane & 48u) + 4u * (lane & 3u) + ((lane >> 2) & 3u));
+  uint32_t syms[2], obs[2], excl[2];
+  auto request_section = [&](TrailChunk<L>& c) {   // two registers: at most 120 + 3 dwords; reads clamped into the buffer's 16 bytes of slack
+    c.start_live = uni(c.pf_start);
+    const uint32_t last = (uint32_t)((c.src_len + 12) >> 2);
+    const uint32_t d0 = (c.start_live >> 5) + lane, d1 = d0 + 64;
+    c.sec = load_u32_le(c.src + 4ull * (d0 < last ? d0 : last));
+    c.sec_hi = load_u32_le(c.src + 4ull * (d1 < last ? d1 : last));
+  };
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    TrailChunk<L>& c = S[q];
+    if (!c.sec_valid()) request_section(c);
+    syms[q] = quad_transpose_u8(bperm(layout, c.pf_syms), lane & 3);
+    uint32_t t = 0, o4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t o = bperm(4u * ((syms[q] >> (8 * k)) & 63u), c.tbl_ob); o4 |= o << (8 * k); t += o; }
+    obs[q] = o4; excl[q] = wave_incl_scan(t) - t;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    TrailChunk<L>& c = S[q];
+    c.set(kFlHave, false);
+    if (c.next + 1 < c.n_batches && ready[q] > c.next + 1) trail_request<L, true>(c, c.next + 1, ar);
+  }
+  const uint32_t pv_next = ld_agent(pline);
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    TrailChunk<L>& c = S[q];
+    L x[4], y2[4], outv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = bperm_t<L>(4u * ((syms[q] >> (8 * k)) & 63u), c.tbl_low);
+    const uint32_t rel = (c.start_live & 31u) + excl[q], di = rel >> 5, sh = rel & 31u;
+    auto fetch = [&](uint32_t i) -> uint32_t { const uint32_t a = bperm(4u * (i & 63u), c.sec), b = bperm(4u * (i & 63u), c.sec_hi); return i < 64 ? a : b; };
+    const uint32_t w0 = fetch(di), w1 = fetch(di + 1), w2 = fetch(di + 2);
+    uint64_t v64 = ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t o = (obs[q] >> (8 * k)) & 0xffu;
+      x[k] = (L)(x[k] + (L)__builtin_amdgcn_ubfe((uint32_t)v64, 0u, o));
+      v64 >>= o;
+    }
+    if (c.dord()) trail_delta<L>(x, c.dord(), c.mom);
+    const L y2c = bperm_t<L>(0u, c.tbl_low2);   // bin 0's lower: the secondary latent of every number (lane 0 holds it; zero without a bin)
+#pragma unroll
+    for (int k = 0; k < 4; k++) y2[k] = y2c;
+    trail_join4<L>(c.mode_kind(), c.num_kind(), c.mode_base, c.mode_k, x, y2, outv);
+    L PCO_GLOBAL* o = c.dst + (uint64_t)c.next * kBatchN + 4 * lane;
+    c.set(kFlSecValid, false);
+    if (c.have() && c.n - (c.next + 1) * kBatchN >= kBatchN + c.nlps()) { request_section(c); c.set(kFlSecValid, true); }   // (a full batch follows and its start has been asked for; before the stores: trail_fast_pair)
+    if constexpr (sizeof(L) == 8) {
+      const unsigned long long y[4] = {outv[0], outv[1], outv[2], outv[3]};
+      store_u64_batch((unsigned long long PCO_GLOBAL*)(c.dst + (uint64_t)c.next * kBatchN), y);
+    } else if constexpr (sizeof(L) == 4) {
+      trail_u32x4 a; a.x = outv[0]; a.y = outv[1]; a.z = outv[2]; a.w = outv[3];
+      __builtin_nontemporal_store(a, (trail_u32x4 PCO_GLOBAL*)o);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) o[k] = outv[k];
+    }
+    c.next++;
+  }
+  return pv_next;
+}
+
 #ifdef PCO_TRAIL_TIMING
 __device__ unsigned long long g_trail_timing[8];   // block 0, wave 0: iterations, poll, stage A, requests, stage B (s_memtime units), idle polls
 #define TT_NOW() __builtin_readcyclecounter()
@@ -474,6 +548,7 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
       if (ok && two) fl |= kFlTwo;
       if (ok && !two && nb1 > 1 && mo1 >= 1 && mo1 <= 7 && aligned) fl |= kFlFast;
       if (ok && two && mo1 <= 15 && mo2 <= 7 && aligned) fl |= kFlFast2;
+      if (ok && two && nb1 > 1 && mo1 >= 1 && mo1 <= 15 && nb2 <= 1 && mo2 == 0 && aligned) fl |= kFlTriv2;
       c.fl = uni(fl);
       if constexpr (kTwo) {
         c.mode_k = word(kPlanModeK); c.mode_base = (L)word64(kPlanModeBase);
@@ -535,6 +610,15 @@ __global__ __launch_bounds__(64 * kTrailWaves) __attribute__((amdgpu_waves_per_e
         continue;
       }
       if constexpr (kTwo) {
+        if (ready[0] && ready[1] && S[0].triv2_ok() && S[1].triv2_ok() && S[0].n - S[0].next * kBatchN >= kBatchN + S[0].nlps() && S[1].n - S[1].next * kBatchN >= kBatchN + S[1].nlps()) {
+          pv = trail_fast_pair2t<L>(S, ready, pline, ar);
+          idle = 0;
+          TT_ADD(4, tt0);
+#ifdef PCO_TRAIL_TIMING
+          tt[0]++; tt[6]++;
+#endif
+          continue;
+        }
         if (ready[0] && ready[1] && S[0].fast2_ok() && S[1].fast2_ok() && S[0].n - S[0].next * kBatchN >= kBatchN + S[0].nlps() && S[1].n - S[1].next * kBatchN >= kBatchN + S[1].nlps()) {
           pv = trail_fast_pair2<L>(S, ready, pline, ar);
           idle = 0;
