@@ -746,6 +746,37 @@ def O_header_len(f):
     return 6 + (6 + 1 + (bits & 63) + 7) // 8 + 2
 
 
+def test_expanders_of_two_variable_chunks_with_a_constant_secondary(L):
+    """dec_trail_kernel<L, true>: walker blocks full of chunks whose secondary variable is one bin without offset bits (exact decimals under
+    float-mult, multiples under int-mult) take the interleaved pair path with nothing of the secondary fetched (trail_fast_pair2t); chunks
+    with a real secondary in the same call take the two-unpacking path.  1100+ chunks of one width (the expanders run from 1024 on), ragged
+    lengths (partial last batches, fewer than two batches, delta state in the tail), delta orders 0..2: every number comes back, the chunks
+    equal the oracle's on a spread."""
+    rng = np.random.default_rng(661)
+    sizes = [4096, 1, 4097, 300, 70000, 511, 8192, 257, 1024, 12289]
+    arrays = []
+    def make(i, n):
+        k = (i // 16) % 4    # runs of sixteen chunks of a kind: walker blocks (eight slots) and expander waves (two) of one kind, and mixed ones at the seams
+        if k == 0: return rng.integers(1000, 900000, n) / 100.0                                   # decimals: constant adjustment
+        if k == 1: return (np.cumsum(rng.integers(-50, 60, n)) + 100000) / 100.0                  # a walk in cents
+        if k == 2: return rng.integers(1000, 900000, n) / 100.0 + (rng.integers(0, 3, n) - 1) * 1e-9   # a real secondary
+        return rng.integers(1, 1 << 20, n) * 0.01
+    for i in range(1152):
+        arrays.append(np.ascontiguousarray(make(i, sizes[i % len(sizes)]), dtype=np.float64))
+    for kw in (dict(mode=2, mode_f64=0.01, delta=1), dict(mode=2, mode_f64=0.01, delta=2, delta_order=1), dict(mode=2, mode_f64=0.01, delta=2, delta_order=2)):
+        chunks, back = U.gpu_batched(arrays, G.make_config(**kw))
+        for i, a in enumerate(arrays):
+            assert U.bits_equal(back[i], a), (kw, i, a.size)
+        for i in range(0, len(arrays), 37):
+            want = O.simple_compress(arrays[i], O.make_config(**kw))
+            assert chunks[i] == U.chunk_of_file(want, len(chunks[i])), (kw, i)
+    ints = [np.ascontiguousarray((rng.integers(-3000, 3000, sizes[i % len(sizes)]) * 7).astype(np.int64)) for i in range(1100)]
+    kw = dict(mode=4, mode_u64=7, delta=2, delta_order=1)
+    chunks, back = U.gpu_batched(ints, G.make_config(**kw))
+    for i, a in enumerate(ints):
+        assert U.bits_equal(back[i], a), (kw, i, a.size)
+
+
 def test_the_heapsort_branch_of_the_reference_histogram(L):
     """The one documented divergence, pinned by an input (histograms.rs:248-258).  On the two adversarial orders of
     tests/golden/hist_fallback.npz the reference's histogram heapsorts and applies apply_sorted's tie rule; the GPU computes the quickselect
